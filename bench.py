@@ -1,0 +1,203 @@
+#!/usr/bin/env python
+"""Sonar front-end throughput on MI355X: keyframes/s for CFAR -> cloud -> ICP.
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over a batch of B synthetic keyframes resident in HBM:
+B sonar pings (1024 range bins x 512 beams, uint8) through SOCA-CFAR + intensity gate +
+polar->Cartesian point extraction, and B scan pairs (5000 x 5000 points) through the 30-iteration
+2-D point-to-plane ICP (BASELINE.json configs[1]).  Every rank owns one GPU and its own B jobs
+(weak scaling, no data-path collective; torch.distributed/gloo is control plane only: barrier
+and the max-over-ranks time).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP32_VALU_PEAK_TFLOPS = 157.3
+ROWS, COLS = 1024, 512     # range bins x beams
+N_PTS = 5000
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=512, help="keyframes per step per GPU")
+    ap.add_argument("--cfar-frames", type=int, default=1024, help="frames per launch for the CFAR roofline leg")
+    ap.add_argument("--cfar-launches", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-keyframes", type=int, default=8)
+    ap.add_argument("--icp-mode", choices=["p2plane30", "reference"], default="p2plane30")
+    return ap.parse_args()
+
+
+def make_inputs(rank, batch):
+    from sonar_slam_amd import synth
+    n_distinct = min(batch, 32)
+    base = [synth.sonar_frame(seed=1000 * rank + s) for s in range(n_distinct)]
+    frames = np.stack([base[j % n_distinct] for j in range(batch)])
+    srcs, tgts, guesses = [], [], []
+    for j in range(batch):
+        s, t, g, _ = synth.scan_pair(seed=100000 * rank + j, n_src=N_PTS, n_tgt=N_PTS)
+        srcs.append(s)
+        tgts.append(t)
+        guesses.append(g)
+    return frames, srcs, tgts, np.stack(guesses)
+
+
+def cpu_baseline(frames, srcs, tgts, guesses, n_kf, det, fe, icp_mode):
+    """The oracle (a single-threaded C port of the reference path) on a bounded sample."""
+    import oracle
+    th, gh, tau = det.params["SOCA"]
+    if icp_mode == "p2plane30":
+        prm = oracle.shipped_icp_params(minimizer=1, use_diff_checker=0, max_iter=30, precision=0)
+    else:
+        prm = oracle.shipped_icp_params(precision=0)
+    t0 = time.perf_counter()
+    t_cfar = 0.0
+    for j in range(n_kf):
+        a = time.perf_counter()
+        m = oracle.gate(frames[j], oracle.cfar(frames[j], "SOCA", th, gh, tau), 65)
+        t_cfar += time.perf_counter() - a
+        rc = oracle.nonzero(oracle.remap_u8(m, fe.map_x, fe.map_y))
+        oracle.px_to_m(rc, fe.rows, fe.cols, fe.width, fe.height)
+        oracle.icp(srcs[j], tgts[j], guesses[j], prm)
+    dt = time.perf_counter() - t0
+    return {"value": n_kf / dt, "unit": "keyframes/s", "cores": 1, "kind": "port",
+            "sample": "%d keyframes (1024x512 SOCA-CFAR+gate+remap+nonzero, 5000x5000 ICP %s, brute-force NN) "
+                      "in %.1f s on 1 host core; CFAR alone %.1f ms/frame"
+                      % (n_kf, icp_mode, dt, 1e3 * t_cfar / n_kf)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")  # control plane only; the data path has no collective
+
+    from sonar_slam_amd import _lib, icp_config
+    from sonar_slam_amd.CFAR import CFAR
+    from sonar_slam_amd.feature_extraction import FeatureExtraction, SonarPing, oculus_bearings
+    from sonar_slam_amd.pipeline import KeyframeBatch
+
+    ctx = _lib.Context(local_rank)
+    det = CFAR(40, 10, 0.1, 10)                      # feature.yaml:3-7
+    fe = FeatureExtraction(ctx)
+    fe.Ntc, fe.Ngc, fe.Pfa, fe.rank, fe.alg, fe.threshold = 40, 10, 0.1, 10, "SOCA", 65
+    fe.configure()
+    frames, srcs, tgts, guesses = make_inputs(rank, args.batch)
+    fe.generate_map_xy(SonarPing(frames[0], oculus_bearings(COLS), 30.0 / ROWS))
+    if args.icp_mode == "p2plane30":
+        icp_p = icp_config.shipped_params(minimizer=1, use_diff_checker=0, max_iter=30)
+    else:
+        icp_p = icp_config.shipped_params()
+
+    kb = KeyframeBatch(ctx, fe.geometry, det.params["SOCA"], "SOCA", 65, icp_p, args.batch)
+    kb.upload_frames(frames)
+    kb.upload_scan_pairs(srcs, tgts, guesses)
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        kb.run()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        kb.run()
+    ctx.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    res = kb.results()
+    ok = int((res["status"] == 0).sum())
+
+    out = None
+    if rank == 0:
+        # ---- per-stage time and rooflines, HIP events on the stream the kernels run on ----
+        def timed(fn, reps):
+            fn()
+            ctx.sync()
+            ctx.timer_start()
+            for _ in range(reps):
+                fn()
+            return ctx.timer_stop() / reps
+        ms_cfar_b = timed(kb.run_cfar, 5)
+        ms_extract_b = timed(kb.run_extract, 5)
+        ms_icp_b = timed(kb.run_icp, 2)
+        iters_total = int(res["iters"].sum())
+        icp_flops = 8.0 * N_PTS * N_PTS * iters_total      # 8 flop per pair evaluation
+        if args.icp_mode == "p2plane30":
+            icp_flops += 8.0 * N_PTS * N_PTS * args.batch   # the k-NN pass of the PCA normals
+        icp_tflops = icp_flops / (ms_icp_b * 1e-3) / 1e12
+
+        # CFAR roofline leg: a batch larger than the 256 MiB Infinity Cache, one kernel per launch
+        nf = args.cfar_frames
+        big = ctx.alloc(nf * ROWS * COLS)
+        bigm = ctx.alloc(nf * ROWS * COLS)
+        for f0 in range(0, nf, args.batch):
+            n = min(args.batch, nf - f0)
+            big.upload(frames[:n], offset=f0 * ROWS * COLS)
+        th, gh, tau = det.params["SOCA"]
+        def cfar_big():
+            ctx._check(ctx.lib.sfe_cfar_u8_batch_dev(ctx.handle, big.ptr, nf, ROWS, COLS, 1, th, gh, 0, float(tau), 65,
+                                                     bigm.ptr, None))
+        ms_cfar = timed(cfar_big, args.cfar_launches)
+        cfar_bytes = 2.0 * ROWS * COLS * nf                 # 1 B read + 1 B written per pixel
+        cfar_gbs = cfar_bytes / (ms_cfar * 1e-3) / 1e9
+        big.free()
+        bigm.free()
+
+        value = args.batch * args.steps * world / dt
+        out = {
+            "metric": "keyframes/sec (CFAR+ICP) on 512x1024 sonar, 5k-pt pairs",
+            "value": value, "unit": "keyframes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8 (CFAR, integer-exact) + f32/f64-accumulate (ICP)", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: %d keyframes/step/GPU = 1024x512 SOCA-CFAR(Ntc40,Ngc10)+gate65"
+                                   " -> remap+nonzero+px2m -> 5000x5000-pt ICP (%s)" % (args.batch, args.icp_mode),
+                       "batch_per_gpu": args.batch, "icp_mode": args.icp_mode, "parallelism": "job farm x%d" % world,
+                       "icp_converged_jobs": ok, "mean_icp_iters": iters_total / float(args.batch),
+                       "mean_points_per_frame": float(res["counts"].mean())},
+            "roofline": {"kernel": "cfar_u8_ring<20,5,SOCA>", "bound": "hbm", "achieved": cfar_gbs,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cfar_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "bytes_per_launch": cfar_bytes, "ms_per_launch": ms_cfar, "frames_per_launch": nf},
+            "roofline_icp": {"kernel": "icp_job_kernel", "bound": "valu", "achieved": icp_tflops,
+                             "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": icp_tflops / FP32_VALU_PEAK_TFLOPS,
+                             "flops_per_launch": icp_flops, "ms_per_launch": ms_icp_b},
+            "stage_ms_per_step": {"cfar": ms_cfar_b, "extract": ms_extract_b, "icp": ms_icp_b},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(frames, srcs, tgts, guesses, min(args.cpu_keyframes, args.batch), det,
+                                               fe, args.icp_mode)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

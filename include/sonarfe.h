@@ -1,0 +1,176 @@
+/*
+ * sonarfe.h -- C ABI of libsonarfe.so, the MI355X (gfx950) sonar front-end.
+ *
+ * This is the drop-in boundary for the two pybind11 modules of the reference
+ * (there is no C ABI in the reference; these entry points are what a ctypes /
+ * cgo / JNI binding of that path binds instead):
+ *
+ *   bruce_slam.cfar  (bruce_slam/src/bruce_slam/cpp/cfar.cpp:194-204)
+ *       ca/soca/goca/os, ca2/soca2/goca2/os2        -> sfe_cfar_u8 / sfe_cfar_f32
+ *   bruce_slam.pcl   (bruce_slam/src/bruce_slam/cpp/pcl.cpp:176-214)
+ *       match                                       -> sfe_match
+ *       remove_outlier                              -> sfe_remove_outlier
+ *       ICP.loadFromYaml / compute / getCovariance  -> sfe_icp_* (params parsed host-side)
+ *   feature_extraction.py:223-238 (CFAR gate, cv2.remap, nonzero, px->m)
+ *                                                   -> sfe_geom_*, sfe_remap_u8, sfe_extract_points
+ *
+ * Conventions
+ *   - plain pointers and sizes only; images are row-major (C order, numpy default):
+ *     rows = range bins, cols = beams.  Point clouds are N x 2 float32 row-major.
+ *     Transforms are 3 x 3 float32 row-major (Pose2 matrix).
+ *   - entry points without a _dev suffix take HOST pointers (they copy in, run the
+ *     HIP kernels, copy out) and are what the Python shims call.  *_dev entry points
+ *     take DEVICE pointers obtained from sfe_malloc and only enqueue work on the
+ *     context's stream (call sfe_sync to wait).
+ *   - return value: 0 = success; > 0 = ICP convergence-class status (see
+ *     SFE_ICP_*; the reference turns these into (what(), guess)); < 0 = hard error
+ *     (bad argument, HIP failure) with text in sfe_last_error().  There is no CPU
+ *     fallback anywhere: without a gfx950 device every compute entry point fails.
+ *   - one sfe_ctx = one device + one HIP stream + its scratch; a ctx is not
+ *     re-entrant (the reference's pybind calls hold the GIL and its ICP object is
+ *     stateful, SURVEY 8b "Threading"); use one ctx per worker thread/process.
+ */
+#ifndef SONARFE_H
+#define SONARFE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sfe_ctx sfe_ctx;
+typedef struct sfe_geom sfe_geom;
+
+/* hard-error codes (negative) */
+#define SFE_ERR_ARG (-1)
+#define SFE_ERR_HIP (-2)
+#define SFE_ERR_NODEV (-3)
+#define SFE_ERR_CAP (-4) /* caller-provided output capacity too small */
+
+/* CFAR variants (cfar.cpp:10,30,53,76) */
+#define SFE_CFAR_CA 0
+#define SFE_CFAR_SOCA 1
+#define SFE_CFAR_GOCA 2
+#define SFE_CFAR_OS 3
+
+/* ICP convergence-class statuses; messages are libpointmatcher's what() strings */
+#define SFE_ICP_OK 0
+#define SFE_ICP_NO_OUTLIER 1 /* "no outlier to filter" */
+#define SFE_ICP_NO_POINT 2   /* "ErrorMnimizer: no point to minimize" */
+#define SFE_ICP_NAN_ROT 3    /* "abs rotation norm not a number" */
+#define SFE_ICP_NAN_TRANS 4  /* "abs translation norm not a number" */
+#define SFE_ICP_SINGULAR 5   /* point-to-plane normal system not positive definite */
+
+/* ---- library / context ------------------------------------------------- */
+const char *sfe_version(void);
+int sfe_device_count(int *count);
+int sfe_ctx_create(int device, sfe_ctx **out);
+void sfe_ctx_destroy(sfe_ctx *ctx);
+const char *sfe_last_error(sfe_ctx *ctx); /* ctx may be NULL: error of the last failed create */
+int sfe_sync(sfe_ctx *ctx);
+int sfe_device_name(sfe_ctx *ctx, char *buf, int cap);
+
+/* device memory on the ctx's device, for resident pipelines (*_dev entry points) */
+int sfe_malloc(sfe_ctx *ctx, size_t bytes, void **dptr);
+int sfe_free(sfe_ctx *ctx, void *dptr);
+int sfe_memcpy_h2d(sfe_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int sfe_memcpy_d2h(sfe_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+int sfe_memset(sfe_ctx *ctx, void *dst_dev, int value, size_t bytes);
+
+/* HIP-event stopwatch on the ctx's stream (used by bench.py for per-kernel time) */
+int sfe_timer_start(sfe_ctx *ctx);
+int sfe_timer_stop(sfe_ctx *ctx, float *elapsed_ms); /* records, syncs, returns ms */
+
+/* ---- CFAR: replaces bruce_slam.cfar (cfar.cpp:10-192) ------------------- */
+/*
+ * img: rows x cols.  train_hs/guard_hs/tau/k as passed by CFAR.detect
+ * (CFAR.py:35-40,123-127).  intensity_thr >= 0 fuses feature_extraction.py:224
+ * (mask &= img > thr); pass -1 for the plain cfar.* result.  thr_out (nullable)
+ * receives the float threshold map of the *2 variants (cfar.cpp:98-192).
+ * k is only read for SFE_CFAR_OS and must satisfy 0 <= k < 2*train_hs.
+ */
+int sfe_cfar_u8(sfe_ctx *ctx, const uint8_t *img, int rows, int cols, int alg, int train_hs,
+                int guard_hs, int k, double tau, int intensity_thr, uint8_t *mask_out,
+                float *thr_out);
+/* float images (the pybind caster accepts any numeric dtype): exact float-sum semantics */
+int sfe_cfar_f32(sfe_ctx *ctx, const float *img, int rows, int cols, int alg, int train_hs,
+                 int guard_hs, int k, double tau, uint8_t *mask_out, float *thr_out);
+/* batched, device-resident: n_frames images of rows x cols back to back */
+int sfe_cfar_u8_batch_dev(sfe_ctx *ctx, const uint8_t *d_img, int n_frames, int rows, int cols,
+                          int alg, int train_hs, int guard_hs, int k, double tau,
+                          int intensity_thr, uint8_t *d_mask, float *d_thr);
+/* tuning / A-B knob for the ring kernel: output rows per thread (0 = default) and
+ * variant (0 = auto, 1 = force generic kernel, 2 = force ring kernel with prefetch depth 4, 3 = ring kernel depth 13) */
+int sfe_cfar_set_tuning(sfe_ctx *ctx, int tile_rows, int variant);
+
+/* ---- polar -> Cartesian: feature_extraction.py:134-173,226-238 --------- */
+/*
+ * A geometry = the (map_x, map_y) pair generate_map_xy builds (float32,
+ * cart_rows x cart_cols, host pointers) for a polar image of polar_rows x
+ * polar_cols, plus the metric extent used by the px->m step (width, height in m).
+ * Creation uploads the maps and pre-decodes OpenCV's fixed-point coordinates.
+ */
+int sfe_geom_create(sfe_ctx *ctx, const float *map_x, const float *map_y, int cart_rows,
+                    int cart_cols, int polar_rows, int polar_cols, double width, double height,
+                    sfe_geom **out);
+void sfe_geom_destroy(sfe_geom *g);
+/* cv2.remap(src, map_x, map_y, cv2.INTER_LINEAR) for a uint8 image (BORDER_CONSTANT 0) */
+int sfe_remap_u8(sfe_ctx *ctx, sfe_geom *g, const uint8_t *src, uint8_t *dst);
+/*
+ * remap(mask) -> np.nonzero -> px->m in one call (feature_extraction.py:231-238).
+ * mask: polar_rows x polar_cols uint8 0/1 (host).  Outputs (host, nullable):
+ * rc_out int64 [cap x 2] = (row, col) in row-major order, pts_out float64 [cap x 2] =
+ * (y_forward, x_lateral) in metres.  *n_out = number of points (may exceed cap -> SFE_ERR_CAP).
+ */
+int sfe_extract_points(sfe_ctx *ctx, sfe_geom *g, const uint8_t *mask, int64_t cap,
+                       int64_t *rc_out, double *pts_out, int64_t *n_out);
+/* device-resident batch: per frame f, points go to d_pts + f*cap*2 (float64), count to d_counts[f]
+ * (count is the true number even if it exceeds cap; only the first cap points are stored) */
+int sfe_extract_points_batch_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_frames,
+                                 int64_t cap, double *d_pts, int32_t *d_counts);
+
+/* ---- point clouds: replaces bruce_slam.pcl (pcl.cpp:54-74,161-212) ------ */
+typedef struct sfe_icp_params {
+    float matcher_max_dist;  /* KDTreeMatcher.maxDist (icp.yaml:9) */
+    int use_max_dist_filter; /* MaxDistOutlierFilter listed (icp.yaml:12) */
+    float max_dist_filter;   /*   .maxDist (icp.yaml:13) */
+    int use_trimmed_filter;  /* TrimmedDistOutlierFilter listed (icp.yaml:14) */
+    float trim_ratio;        /*   .ratio (icp.yaml:15) */
+    int minimizer;           /* 0 PointToPointErrorMinimizer (icp.yaml:20), 1 2-D PointToPlane (icp.yaml:18-19) */
+    int max_iter;            /* CounterTransformationChecker.maxIterationCount (icp.yaml:24) */
+    int use_diff_checker;    /* DifferentialTransformationChecker listed (icp.yaml:25) */
+    float min_diff_rot;      /*   .minDiffRotErr (icp.yaml:26) */
+    float min_diff_trans;    /*   .minDiffTransErr (icp.yaml:27) */
+    int smooth_len;          /*   .smoothLength (icp.yaml:28) */
+    int normals_knn;         /* point-to-plane only: neighbours (incl. self) for PCA normals */
+} sfe_icp_params;
+
+/* pcl.match(ref, in, knn=1, max_dist) (pcl.cpp:161-174): ids int32 [n_in] (-1 = none),
+ * d2 float [n_in] squared distance (inf = none).  Ties -> lowest reference index. */
+int sfe_match(sfe_ctx *ctx, const float *ref, int n_ref, const float *in, int n_in, float max_dist,
+              int32_t *ids, float *d2);
+/* pcl.remove_outlier(points, radius, min_points) (pcl.cpp:54-74): order preserved */
+int sfe_remove_outlier(sfe_ctx *ctx, const float *pts, int n, double radius, int min_points,
+                       float *out, int *n_out);
+/* pcl.ICP.compute(source, target, guess) (pcl.cpp:198-212).  Returns SFE_ICP_* (>= 0) or a
+ * hard error (< 0).  On a nonzero status T_out = guess (pcl.cpp:203,207-210). */
+int sfe_icp_compute(sfe_ctx *ctx, const sfe_icp_params *p, const float *src, int n_src,
+                    const float *tgt, int n_tgt, const float *guess9, float *T_out9, int *iters);
+/* many guesses on one cloud pair: the loop of SLAM.compute_icp_with_cov (slam.py:346-358) */
+int sfe_icp_compute_guesses(sfe_ctx *ctx, const sfe_icp_params *p, const float *src, int n_src,
+                            const float *tgt, int n_tgt, const float *guesses9, int n_guesses,
+                            float *T_out9, int32_t *status, int32_t *iters);
+/* independent jobs, device-resident: clouds concatenated, job j uses
+ * src[src_off[j]..src_off[j+1]) and tgt[tgt_off[j]..tgt_off[j+1]) (offsets in points, host
+ * arrays of n_jobs+1), guess d_guess9 + 9*j; outputs d_T9 (9 floats), d_status, d_iters per job */
+int sfe_icp_batch_dev(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_src,
+                      const int32_t *src_off, const float *d_tgt, const int32_t *tgt_off,
+                      const float *d_guess9, int n_jobs, float *d_T9, int32_t *d_status,
+                      int32_t *d_iters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SONARFE_H */

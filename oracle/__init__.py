@@ -1,0 +1,199 @@
+"""ctypes front-end of the CPU oracle (``sonar_oracle.c``).
+
+TEST INFRASTRUCTURE ONLY -- the product package ``sonar_slam_amd`` never imports
+this module.  Allowed importers: ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py``.
+
+Every function cites the reference lines it restates in ``sonar_oracle.c``.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libsonar_oracle.so")
+
+ALG = {"CA": 0, "SOCA": 1, "GOCA": 2, "OS": 3}
+
+ICP_STATUS_MESSAGES = {
+    0: "success",
+    1: "no outlier to filter",
+    2: "ErrorMnimizer: no point to minimize",
+    3: "abs rotation norm not a number",
+    4: "abs translation norm not a number",
+    5: "point-to-plane system not positive definite",
+}
+
+
+def build(force=False):
+    """Compile the oracle with the committed Makefile (gcc, -O3, single thread)."""
+    src = os.path.join(_HERE, "sonar_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+class IcpParams(C.Structure):
+    _fields_ = [
+        ("matcher_max_dist", C.c_float),
+        ("use_max_dist_filter", C.c_int),
+        ("max_dist_filter", C.c_float),
+        ("use_trimmed_filter", C.c_int),
+        ("trim_ratio", C.c_float),
+        ("minimizer", C.c_int),
+        ("max_iter", C.c_int),
+        ("use_diff_checker", C.c_int),
+        ("min_diff_rot", C.c_float),
+        ("min_diff_trans", C.c_float),
+        ("smooth_len", C.c_int),
+        ("normals_knn", C.c_int),
+        ("precision", C.c_int),
+    ]
+
+
+def shipped_icp_params(minimizer=0, precision=1, **over):
+    """The chain of bruce_slam/config/icp.yaml:1-31."""
+    p = dict(matcher_max_dist=10.0, use_max_dist_filter=1, max_dist_filter=3.0,
+             use_trimmed_filter=1, trim_ratio=0.8, minimizer=minimizer, max_iter=40,
+             use_diff_checker=1, min_diff_rot=0.01, min_diff_trans=0.1, smooth_len=4,
+             normals_knn=10, precision=precision)
+    p.update(over)
+    return IcpParams(**p)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        u8p, f32p, f64p, i64p, i32p = (C.POINTER(C.c_uint8), C.POINTER(C.c_float),
+                                       C.POINTER(C.c_double), C.POINTER(C.c_int64),
+                                       C.POINTER(C.c_int32))
+        L.orc_cfar_f32.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_double, u8p, f32p]
+        L.orc_cfar_u8.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_double, u8p, f32p]
+        L.orc_gate_u8.argtypes = [u8p, C.c_size_t, C.c_int, u8p]
+        L.orc_remap_u8.argtypes = [u8p, C.c_int, C.c_int, f32p, f32p, C.c_int, C.c_int, u8p]
+        L.orc_nonzero.argtypes = [u8p, C.c_int, C.c_int, i64p, C.c_int64]
+        L.orc_nonzero.restype = C.c_int64
+        L.orc_px_to_m.argtypes = [i64p, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_double, f64p]
+        L.orc_match.argtypes = [f32p, C.c_int, f32p, C.c_int, C.c_float, i32p, f32p]
+        L.orc_normals2d.argtypes = [f32p, C.c_int, C.c_int, f32p]
+        L.orc_icp.argtypes = [C.POINTER(IcpParams), f32p, C.c_int, f32p, C.c_int, f32p, f32p,
+                              C.POINTER(C.c_int)]
+        L.orc_remove_outlier.argtypes = [f32p, C.c_int, C.c_double, C.c_int, f32p]
+        L.orc_bilinear_tab.argtypes = [C.POINTER(C.c_int16)]
+        _lib = L
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def cfar(img, alg, train_hs, guard_hs, tau, k=0, want_threshold=False):
+    """cfar.cpp:10-192 on a 2-D image (uint8 -> cast to float like pybind, else float32)."""
+    img = np.asarray(img)
+    rows, cols = img.shape
+    mask = np.zeros((rows, cols), np.uint8)
+    thr = np.zeros((rows, cols), np.float32) if want_threshold else None
+    tp = _p(thr, C.c_float) if want_threshold else None
+    if img.dtype == np.uint8:
+        a = np.ascontiguousarray(img)
+        rc = lib().orc_cfar_u8(_p(a, C.c_uint8), rows, cols, ALG[alg], train_hs, guard_hs, int(k),
+                               float(tau), _p(mask, C.c_uint8), tp)
+    else:
+        a = np.ascontiguousarray(img, np.float32)
+        rc = lib().orc_cfar_f32(_p(a, C.c_float), rows, cols, ALG[alg], train_hs, guard_hs, int(k),
+                                float(tau), _p(mask, C.c_uint8), tp)
+    if rc:
+        raise ValueError("oracle cfar rc=%d" % rc)
+    return (mask, thr) if want_threshold else mask
+
+
+def gate(img, mask, threshold):
+    """feature_extraction.py:224."""
+    img = np.ascontiguousarray(img, np.uint8)
+    m = np.ascontiguousarray(mask, np.uint8).copy()
+    lib().orc_gate_u8(_p(img, C.c_uint8), img.size, int(threshold), _p(m, C.c_uint8))
+    return m
+
+
+def remap_u8(src, map_x, map_y):
+    """cv2.remap(src, map_x, map_y, INTER_LINEAR) on uint8 (feature_extraction.py:226,231)."""
+    src = np.ascontiguousarray(src, np.uint8)
+    mx = np.ascontiguousarray(map_x, np.float32)
+    my = np.ascontiguousarray(map_y, np.float32)
+    dst = np.zeros(mx.shape, np.uint8)
+    lib().orc_remap_u8(_p(src, C.c_uint8), src.shape[0], src.shape[1], _p(mx, C.c_float),
+                       _p(my, C.c_float), mx.shape[0], mx.shape[1], _p(dst, C.c_uint8))
+    return dst
+
+
+def nonzero(img):
+    """np.c_[np.nonzero(img)] (feature_extraction.py:232)."""
+    img = np.ascontiguousarray(img, np.uint8)
+    cap = int(img.size)
+    rc = np.zeros((max(cap, 1), 2), np.int64)
+    n = lib().orc_nonzero(_p(img, C.c_uint8), img.shape[0], img.shape[1], _p(rc, C.c_int64), cap)
+    return rc[:n].copy()
+
+
+def px_to_m(rc, rows, cols, width, height):
+    """feature_extraction.py:235-238 -> points [y_fwd, x_lat] float64."""
+    rc = np.ascontiguousarray(rc, np.int64).reshape(-1, 2)
+    pts = np.zeros((len(rc), 2), np.float64)
+    lib().orc_px_to_m(_p(rc, C.c_int64), len(rc), rows, cols, float(width), float(height),
+                      _p(pts, C.c_double))
+    return pts
+
+
+def match(ref, pts, max_dist):
+    """pcl.match(ref, in, 1, max_dist) (pcl.cpp:161-174) -> (ids [1xN] int32, d2 [1xN] f32)."""
+    ref = np.ascontiguousarray(ref, np.float32).reshape(-1, 2)
+    pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+    ids = np.zeros(len(pts), np.int32)
+    d2 = np.zeros(len(pts), np.float32)
+    lib().orc_match(_p(ref, C.c_float), len(ref), _p(pts, C.c_float), len(pts), float(max_dist),
+                    _p(ids, C.c_int32), _p(d2, C.c_float))
+    return ids[None, :], d2[None, :]
+
+
+def normals2d(tgt, k):
+    tgt = np.ascontiguousarray(tgt, np.float32).reshape(-1, 2)
+    out = np.zeros_like(tgt)
+    lib().orc_normals2d(_p(tgt, C.c_float), len(tgt), int(k), _p(out, C.c_float))
+    return out
+
+
+def icp(src, tgt, guess, params=None):
+    """pcl.ICP.compute (pcl.cpp:198-212) -> (status:int, T 3x3 f32, iterations)."""
+    params = params or shipped_icp_params()
+    src = np.ascontiguousarray(src, np.float32).reshape(-1, 2)
+    tgt = np.ascontiguousarray(tgt, np.float32).reshape(-1, 2)
+    g = np.ascontiguousarray(guess, np.float32).reshape(3, 3)
+    T = np.zeros((3, 3), np.float32)
+    it = C.c_int(0)
+    st = lib().orc_icp(C.byref(params), _p(src, C.c_float), len(src), _p(tgt, C.c_float), len(tgt),
+                       _p(g, C.c_float), _p(T, C.c_float), C.byref(it))
+    return st, T, it.value
+
+
+def remove_outlier(pts, radius, min_points):
+    pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+    out = np.zeros_like(pts)
+    m = lib().orc_remove_outlier(_p(pts, C.c_float), len(pts), float(radius), int(min_points),
+                                 _p(out, C.c_float))
+    return out[:m].copy()
+
+
+def bilinear_tab():
+    t = np.zeros((1024, 4), np.int16)
+    lib().orc_bilinear_tab(_p(t, C.c_int16))
+    return t

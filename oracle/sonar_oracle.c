@@ -1,0 +1,703 @@
+/*
+ * sonar_oracle.c -- CPU restatement of the bruce_slam sonar front-end hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under sonar_slam_amd/ (the product) may
+ * import, link or call this file; only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py use it, and only as the checker / CPU baseline.
+ *
+ * Parity status (see DESIGN.md "Oracle"):
+ *   - CFAR (ca/soca/goca/os and the *2 variants): arithmetic is fully given by
+ *     bruce_slam/src/bruce_slam/cpp/cfar.cpp:10-192, restated line by line
+ *     below (Eigen accessors replaced by row-major indexing).  The reference
+ *     ships no tests/golden vectors; the module cannot be compiled here (no
+ *     Eigen), so the pin is "restated from in-tree source".
+ *   - cv2.remap / libpointmatcher ICP / libnabo NN live in un-vendored third
+ *     parties (OpenCV unpinned; libpointmatcher@d478ef2 + libnabo HEAD,
+ *     reference README.md:50-55).  Their published algorithms are restated
+ *     here; PARITY UNPINNED against the real libraries.
+ *
+ * Build: see oracle/Makefile (gcc -std=c99 -O3, no -march=native, no OpenMP --
+ * mirrors bruce_slam/CMakeLists.txt:4 "-std=c++11 -O3", single thread).
+ * -ffp-contract=off so float arithmetic is plain IEEE (x86-64 baseline has no
+ * FMA anyway).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_ALG_CA 0
+#define ORC_ALG_SOCA 1
+#define ORC_ALG_GOCA 2
+#define ORC_ALG_OS 3
+
+/* ------------------------------------------------------------------------- */
+/* CFAR: cfar.cpp:10-192.  img is row-major rows x cols float (the pybind     */
+/* Eigen caster hands cfar.cpp a float matrix whatever the numpy dtype was).  */
+/* mask row-major uint8 0/1, thr (nullable) row-major float = the *2 map.     */
+/* ------------------------------------------------------------------------- */
+static int cmp_float(const void *a, const void *b)
+{
+    float x = *(const float *)a, y = *(const float *)b;
+    return (x > y) - (x < y);
+}
+
+int orc_cfar_f32(const float *img, int rows, int cols, int alg, int train_hs, int guard_hs, int k,
+                 double tau, uint8_t *mask, float *thr)
+{
+    const int half = train_hs + guard_hs;
+    float *train = NULL;
+    if (alg < 0 || alg > 3)
+        return -1;
+    memset(mask, 0, (size_t)rows * cols); /* MatrixXb::Zero, cfar.cpp:12,32,55,78 */
+    if (thr)
+        memset(thr, 0, sizeof(float) * (size_t)rows * cols); /* cfar.cpp:101 */
+    if (alg == ORC_ALG_OS) {
+        if (k < 0 || k >= 2 * train_hs) /* cfar.cpp:91 would read out of bounds */
+            return -2;
+        train = (float *)malloc(sizeof(float) * 2 * (size_t)train_hs);
+    }
+    for (int col = 0; col < cols; ++col) {                    /* cfar.cpp:14 */
+        for (int row = half; row < rows - half; ++row) {      /* cfar.cpp:16 */
+            const float x = img[(size_t)row * cols + col];
+            double t;
+            if (alg == ORC_ALG_CA) {
+                float sum_train = 0; /* cfar.cpp:18-23 */
+                for (int i = row - half; i < row + half + 1; ++i)
+                    if (abs(i - row) > guard_hs)
+                        sum_train += img[(size_t)i * cols + col];
+                t = tau * sum_train / (2.0 * train_hs); /* cfar.cpp:24 */
+            } else if (alg == ORC_ALG_SOCA || alg == ORC_ALG_GOCA) {
+                float leading_sum = 0.0f, lagging_sum = 0.0f; /* cfar.cpp:38-45 */
+                for (int i = row - half; i < row + half + 1; ++i) {
+                    if ((i - row) > guard_hs)
+                        lagging_sum += img[(size_t)i * cols + col];
+                    else if ((i - row) < -guard_hs)
+                        leading_sum += img[(size_t)i * cols + col];
+                }
+                float sum_train = (alg == ORC_ALG_SOCA)
+                                      ? (lagging_sum < leading_sum ? lagging_sum : leading_sum) /* std::min :46 */
+                                      : (leading_sum < lagging_sum ? lagging_sum : leading_sum); /* std::max :69 */
+                t = tau * sum_train / train_hs; /* cfar.cpp:47,70 */
+            } else {
+                int n = 0; /* cfar.cpp:84-92 */
+                for (int i = row - half; i < row + half + 1; ++i)
+                    if (abs(i - row) > guard_hs)
+                        train[n++] = img[(size_t)i * cols + col];
+                qsort(train, (size_t)n, sizeof(float), cmp_float); /* nth_element(k) value */
+                t = tau * train[k];
+            }
+            mask[(size_t)row * cols + col] = (double)x > t;
+            if (thr)
+                thr[(size_t)row * cols + col] = (float)t; /* cfar.cpp:111,139,164,188 */
+        }
+    }
+    free(train);
+    return 0;
+}
+
+/* uint8 entry: what pybind does to a uint8 numpy image (cast-copy to float). */
+int orc_cfar_u8(const uint8_t *img, int rows, int cols, int alg, int train_hs, int guard_hs, int k,
+                double tau, uint8_t *mask, float *thr)
+{
+    size_t n = (size_t)rows * cols;
+    float *f = (float *)malloc(sizeof(float) * (n ? n : 1));
+    for (size_t i = 0; i < n; ++i)
+        f[i] = (float)img[i];
+    int rc = orc_cfar_f32(f, rows, cols, alg, train_hs, guard_hs, k, tau, mask, thr);
+    free(f);
+    return rc;
+}
+
+/* feature_extraction.py:224  peaks &= img > threshold */
+void orc_gate_u8(const uint8_t *img, size_t n, int threshold, uint8_t *mask)
+{
+    for (size_t i = 0; i < n; ++i)
+        mask[i] = (uint8_t)(mask[i] & (img[i] > threshold));
+}
+
+/* ------------------------------------------------------------------------- */
+/* cv2.remap(src_u8, map_x, map_y, INTER_LINEAR), BORDER_CONSTANT 0           */
+/* (feature_extraction.py:226,231).  OpenCV imgproc restated:                 */
+/*   sx = cvRound(map_x*32), sy = cvRound(map_y*32)  (round-half-even)        */
+/*   ix = sx>>5, iy = sy>>5, table index (sy&31)*32 + (sx&31)                 */
+/*   weights = BilinearTab_i (short, scale 32768, initInterTab2D fix-up)      */
+/*   dst = (sum w_i v_i + 16384) >> 15, out-of-image neighbours read 0.       */
+/* PARITY UNPINNED (OpenCV not installed, version unpinned in the reference). */
+/* ------------------------------------------------------------------------- */
+void orc_bilinear_tab(int16_t tab[1024][4])
+{
+    /* initInterTab2D(INTER_LINEAR, fixpt=true): w = (1-fy|fy)*(1-fx|fx)*32768, */
+    /* saturate_cast<short>; entry (0,0) saturates to 32767 and the fix-up puts  */
+    /* the missing 1 on the last (largest-index max==min==0) tap -> {32767,0,0,1}*/
+    for (int i = 0; i < 32; ++i)
+        for (int j = 0; j < 32; ++j) {
+            float ty[2] = {1.0f - i / 32.0f, i / 32.0f};
+            float tx[2] = {1.0f - j / 32.0f, j / 32.0f};
+            int16_t *w = tab[i * 32 + j];
+            int isum = 0;
+            for (int k1 = 0; k1 < 2; ++k1)
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    float v = ty[k1] * tx[k2] * 32768.0f;
+                    long r = lrintf(v);
+                    if (r > 32767)
+                        r = 32767;
+                    w[k1 * 2 + k2] = (int16_t)r;
+                    isum += (int)r;
+                }
+            if (isum != 32768) { /* only (0,0): diff = -1 */
+                int diff = isum - 32768;
+                /* Mk/mk search starts at tap (1,1); other probed taps are the  */
+                /* not-yet-written (zero) next entries, so M = m = tap (1,1).   */
+                w[3] = (int16_t)(w[3] - diff);
+            }
+        }
+}
+
+static inline int orc_cvround(float v)
+{
+    return (int)lrintf(v); /* default rounding mode = nearest-even, like cvRound */
+}
+
+void orc_remap_u8(const uint8_t *src, int srows, int scols, const float *map_x, const float *map_y,
+                  int drows, int dcols, uint8_t *dst)
+{
+    static int16_t tab[1024][4];
+    static int tab_ready = 0;
+    if (!tab_ready) {
+        orc_bilinear_tab(tab);
+        tab_ready = 1;
+    }
+    for (int y = 0; y < drows; ++y)
+        for (int x = 0; x < dcols; ++x) {
+            size_t o = (size_t)y * dcols + x;
+            int sx = orc_cvround(map_x[o] * 32.0f);
+            int sy = orc_cvround(map_y[o] * 32.0f);
+            int ix = sx >> 5, iy = sy >> 5;
+            const int16_t *w = tab[(sy & 31) * 32 + (sx & 31)];
+            int acc = 0;
+            for (int k1 = 0; k1 < 2; ++k1)
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    int yy = iy + k1, xx = ix + k2;
+                    int v = (yy >= 0 && yy < srows && xx >= 0 && xx < scols)
+                                ? src[(size_t)yy * scols + xx]
+                                : 0;
+                    acc += w[k1 * 2 + k2] * v;
+                }
+            int r = (acc + 16384) >> 15;
+            dst[o] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+        }
+}
+
+/* np.c_[np.nonzero(peaks)] (feature_extraction.py:232): row-major (row, col) */
+int64_t orc_nonzero(const uint8_t *img, int rows, int cols, int64_t *rc, int64_t cap)
+{
+    int64_t n = 0;
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c)
+            if (img[(size_t)r * cols + c]) {
+                if (n < cap) {
+                    rc[2 * n] = r;
+                    rc[2 * n + 1] = c;
+                }
+                ++n;
+            }
+    return n;
+}
+
+/* feature_extraction.py:235-238: pixel -> metres, points = [y_fwd, x_lat] fp64 */
+void orc_px_to_m(const int64_t *rc, int64_t n, int rows, int cols, double width, double height,
+                 double *pts)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        double x = (double)rc[2 * i + 1] - cols / 2.;
+        x = (-1 * ((x / (double)(cols / 2.)) * (width / 2.)));
+        double y = (-1 * ((double)rc[2 * i] / (double)rows) * height) + height;
+        pts[2 * i] = y;
+        pts[2 * i + 1] = x;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* pcl.match (pcl.cpp:161-174): KDTreeMatcher knn=1 -> exact NN (epsilon 0),   */
+/* squared distance (libnabo convention), id -1 / dist inf beyond maxDist.    */
+/* Brute force; ties -> lowest reference index (documented choice).           */
+/* d2 = fl(fl(dx*dx) + fl(dy*dy)) in float (libnabo accumulates per dim).     */
+/* ------------------------------------------------------------------------- */
+static inline void nn1(const float *ref, int nref, float px, float py, int *id, float *d2)
+{
+    float best = INFINITY;
+    int bi = -1;
+    for (int j = 0; j < nref; ++j) {
+        float dx = px - ref[2 * j], dy = py - ref[2 * j + 1];
+        float a = dx * dx, b = dy * dy;
+        float d = a + b;
+        if (d < best) {
+            best = d;
+            bi = j;
+        }
+    }
+    *id = bi;
+    *d2 = best;
+}
+
+void orc_match(const float *ref, int nref, const float *in, int nin, float max_dist, int32_t *ids,
+               float *d2)
+{
+    const float r2 = max_dist * max_dist;
+    for (int i = 0; i < nin; ++i) {
+        int id;
+        float d;
+        nn1(ref, nref, in[2 * i], in[2 * i + 1], &id, &d);
+        if (id < 0 || !(d <= r2)) {
+            id = -1;
+            d = INFINITY;
+        }
+        ids[i] = id;
+        d2[i] = d;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* ICP: pcl.cpp:198-212 -> libpointmatcher PM::ICP::operator() configured by   */
+/* config/icp.yaml:1-31.  See DESIGN.md for the restated chain.               */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    float matcher_max_dist;  /* KDTreeMatcher maxDist (icp.yaml:9), linear metres      */
+    int use_max_dist_filter; /* MaxDistOutlierFilter present (icp.yaml:12)             */
+    float max_dist_filter;   /* its maxDist, linear; compared squared against d2       */
+    int use_trimmed_filter;  /* TrimmedDistOutlierFilter present (icp.yaml:14)         */
+    float trim_ratio;        /* ratio 0.8                                              */
+    int minimizer;           /* 0 PointToPoint (icp.yaml:20), 1 2-D PointToPlane        */
+    int max_iter;            /* CounterTransformationChecker maxIterationCount          */
+    int use_diff_checker;    /* DifferentialTransformationChecker present              */
+    float min_diff_rot;      /* rad                                                    */
+    float min_diff_trans;    /* m                                                      */
+    int smooth_len;          /* smoothLength                                           */
+    int normals_knn;         /* p2plane only: k (incl. self) for PCA normals            */
+    int precision;           /* 0 float accumulations (reference-like), 1 double        */
+} orc_icp_params;
+
+#define ORC_ICP_OK 0
+#define ORC_ICP_NO_OUTLIER 1 /* "no outlier to filter" (Matches::getDistsQuantile)        */
+#define ORC_ICP_NO_POINT 2   /* "ErrorMnimizer: no point to minimize" (getMatchedPoints)  */
+#define ORC_ICP_NAN_ROT 3    /* "abs rotation norm not a number"                           */
+#define ORC_ICP_NAN_TRANS 4  /* "abs translation norm not a number"                        */
+#define ORC_ICP_SINGULAR 5   /* p2plane normal system not positive definite                */
+
+static void mat3_mul_f(const float *a, const float *b, float *c)
+{
+    float r[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            float s = a[i * 3] * b[j];
+            s = s + a[i * 3 + 1] * b[3 + j];
+            s = s + a[i * 3 + 2] * b[6 + j];
+            r[i * 3 + j] = s;
+        }
+    memcpy(c, r, sizeof r);
+}
+
+/* 2-D PCA normals of the (mean-centred) target, k nearest incl. self, ties -> */
+/* lowest index.  normal = unit eigenvector of the smaller eigenvalue.         */
+void orc_normals2d(const float *tgt, int nt, int k, float *nrm)
+{
+    if (k > nt)
+        k = nt;
+    int *bi = (int *)malloc(sizeof(int) * (size_t)(k > 0 ? k : 1));
+    float *bd = (float *)malloc(sizeof(float) * (size_t)(k > 0 ? k : 1));
+    for (int i = 0; i < nt; ++i) {
+        int m = 0;
+        for (int j = 0; j < nt; ++j) {
+            float dx = tgt[2 * i] - tgt[2 * j], dy = tgt[2 * i + 1] - tgt[2 * j + 1];
+            float a = dx * dx, b = dy * dy;
+            float d = a + b;
+            if (m < k || d < bd[m - 1]) { /* strict <: equal distance keeps earlier index */
+                int p = (m < k) ? m++ : k - 1;
+                while (p > 0 && bd[p - 1] > d) {
+                    bd[p] = bd[p - 1];
+                    bi[p] = bi[p - 1];
+                    --p;
+                }
+                bd[p] = d;
+                bi[p] = j;
+            }
+        }
+        double mx = 0, my = 0;
+        for (int q = 0; q < m; ++q) {
+            mx += tgt[2 * bi[q]];
+            my += tgt[2 * bi[q] + 1];
+        }
+        mx /= m;
+        my /= m;
+        double a = 0, b = 0, d = 0;
+        for (int q = 0; q < m; ++q) {
+            double ux = tgt[2 * bi[q]] - mx, uy = tgt[2 * bi[q] + 1] - my;
+            a += ux * ux;
+            b += ux * uy;
+            d += uy * uy;
+        }
+        /* principal (tangent) direction of [[a,b],[b,d]] without trig */
+        double u = a - d, v = 2 * b, h = sqrt(u * u + v * v);
+        double tx, ty;
+        if (h == 0) {
+            tx = 1;
+            ty = 0;
+        } else if (u >= 0) {
+            tx = u + h;
+            ty = v;
+        } else {
+            tx = v;
+            ty = h - u;
+        }
+        double nn = sqrt(tx * tx + ty * ty);
+        if (nn == 0) {
+            tx = 1;
+            ty = 0;
+            nn = 1;
+        }
+        nrm[2 * i] = (float)(-ty / nn);
+        nrm[2 * i + 1] = (float)(tx / nn);
+    }
+    free(bi);
+    free(bd);
+}
+
+int orc_icp(const orc_icp_params *P, const float *src, int ns, const float *tgt_in, int nt,
+            const float *guess /*3x3 row-major*/, float *T_out, int *iters_out)
+{
+    int status = ORC_ICP_OK;
+    int iters = 0;
+    float *tgt = (float *)malloc(sizeof(float) * 2 * (size_t)(nt > 0 ? nt : 1));
+    float *rd = (float *)malloc(sizeof(float) * 2 * (size_t)(ns > 0 ? ns : 1));
+    float *cur = (float *)malloc(sizeof(float) * 2 * (size_t)(ns > 0 ? ns : 1));
+    float *d2 = (float *)malloc(sizeof(float) * (size_t)(ns > 0 ? ns : 1));
+    float *fin = (float *)malloc(sizeof(float) * (size_t)(ns > 0 ? ns : 1));
+    int *ids = (int *)malloc(sizeof(int) * (size_t)(ns > 0 ? ns : 1));
+    float *nrm = NULL;
+    float *hist = (float *)malloc(sizeof(float) * 3 * (size_t)(P->max_iter + 2));
+    int nhist = 0;
+
+    /* ICP.cpp operator(): reference mean (frame refMean), centre the reference */
+    float mean[2];
+    if (P->precision == 0) {
+        float sx = 0, sy = 0;
+        for (int j = 0; j < nt; ++j) {
+            sx += tgt_in[2 * j];
+            sy += tgt_in[2 * j + 1];
+        }
+        mean[0] = sx / (float)nt;
+        mean[1] = sy / (float)nt;
+    } else {
+        double sx = 0, sy = 0;
+        for (int j = 0; j < nt; ++j) {
+            sx += tgt_in[2 * j];
+            sy += tgt_in[2 * j + 1];
+        }
+        mean[0] = (float)(sx / nt);
+        mean[1] = (float)(sy / nt);
+    }
+    for (int j = 0; j < nt; ++j) {
+        tgt[2 * j] = tgt_in[2 * j] - mean[0];
+        tgt[2 * j + 1] = tgt_in[2 * j + 1] - mean[1];
+    }
+    if (P->minimizer == 1) {
+        nrm = (float *)malloc(sizeof(float) * 2 * (size_t)(nt > 0 ? nt : 1));
+        orc_normals2d(tgt, nt, P->normals_knn, nrm);
+    }
+    /* T_refMean_dataIn = T_refIn_refMean^-1 * guess ; inverse of a pure translation */
+    float Tinv[9] = {1, 0, -mean[0], 0, 1, -mean[1], 0, 0, 1};
+    float Tfwd[9] = {1, 0, mean[0], 0, 1, mean[1], 0, 0, 1};
+    float T0[9];
+    mat3_mul_f(Tinv, guess, T0);
+    for (int i = 0; i < ns; ++i) { /* transformations.apply(reading, T_refMean_dataIn) */
+        float x = src[2 * i], y = src[2 * i + 1];
+        rd[2 * i] = (T0[0] * x + T0[1] * y) + T0[2];
+        rd[2 * i + 1] = (T0[3] * x + T0[4] * y) + T0[5];
+    }
+    float Ti[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    /* DifferentialTransformationChecker::init pushes the initial (identity) T_iter */
+    hist[0] = 1.0f;
+    hist[1] = 0.0f; /* (cos, sin) of rotation */
+    nhist = 1;
+    float *htx = (float *)malloc(sizeof(float) * 2 * (size_t)(P->max_iter + 2));
+    htx[0] = 0;
+    htx[1] = 0;
+
+    const float r2_match = P->matcher_max_dist * P->matcher_max_dist;
+    const float r2_filter = P->max_dist_filter * P->max_dist_filter;
+    int counter = 0;
+    int iterate = 1;
+    while (iterate) {
+        /* stepReading = T_iter * reading */
+        for (int i = 0; i < ns; ++i) {
+            float x = rd[2 * i], y = rd[2 * i + 1];
+            cur[2 * i] = (Ti[0] * x + Ti[1] * y) + Ti[2];
+            cur[2 * i + 1] = (Ti[3] * x + Ti[4] * y) + Ti[5];
+        }
+        /* matcher->findClosests */
+        int nfin = 0;
+        for (int i = 0; i < ns; ++i) {
+            int id;
+            float d;
+            nn1(tgt, nt, cur[2 * i], cur[2 * i + 1], &id, &d);
+            if (id < 0 || !(d <= r2_match)) {
+                id = -1;
+                d = INFINITY;
+            } else
+                fin[nfin++] = d;
+            ids[i] = id;
+            d2[i] = d;
+        }
+        /* outlierFilters.compute: product of the filters' 0/1 weights */
+        float limit = INFINITY;
+        if (P->use_trimmed_filter) {
+            if (nfin == 0) { /* Matches::getDistsQuantile */
+                status = ORC_ICP_NO_OUTLIER;
+                break;
+            }
+            if (P->trim_ratio >= 1.0f) {
+                limit = fin[0];
+                for (int i = 1; i < nfin; ++i)
+                    if (fin[i] > limit)
+                        limit = fin[i];
+            } else {
+                qsort(fin, (size_t)nfin, sizeof(float), cmp_float);
+                size_t kq = (size_t)((float)nfin * P->trim_ratio); /* values.size()*quantile in T=float */
+                limit = fin[kq];
+            }
+        }
+        int nkept = 0;
+        /* weights: w = [d2 <= maxDist^2] * [d2 <= limit]; inf fails both */
+        /* errorMinimizer: PointToPoint (weighted Kabsch) or 2-D PointToPlane */
+        float Ts[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        if (P->minimizer == 0) {
+            double c, s, tx, ty;
+            if (P->precision == 0) {
+                /* float, two-pass like ErrorMinimizersImpl PointToPoint: means, centre, m */
+                float w = 0, mpx = 0, mpy = 0, mqx = 0, mqy = 0;
+                for (int i = 0; i < ns; ++i) {
+                    int ok = ids[i] >= 0 && (!P->use_max_dist_filter || d2[i] <= r2_filter) &&
+                             (!P->use_trimmed_filter || d2[i] <= limit);
+                    if (!ok)
+                        continue;
+                    ++nkept;
+                    w += 1.0f;
+                    mpx += cur[2 * i];
+                    mpy += cur[2 * i + 1];
+                    mqx += tgt[2 * ids[i]];
+                    mqy += tgt[2 * ids[i] + 1];
+                }
+                if (nkept == 0) {
+                    status = ORC_ICP_NO_POINT;
+                    break;
+                }
+                float winv = 1.0f / w;
+                mpx *= winv;
+                mpy *= winv;
+                mqx *= winv;
+                mqy *= winv;
+                float m00 = 0, m01 = 0, m10 = 0, m11 = 0;
+                for (int i = 0; i < ns; ++i) {
+                    int ok = ids[i] >= 0 && (!P->use_max_dist_filter || d2[i] <= r2_filter) &&
+                             (!P->use_trimmed_filter || d2[i] <= limit);
+                    if (!ok)
+                        continue;
+                    float px = cur[2 * i] - mpx, py = cur[2 * i + 1] - mpy;
+                    float qx = tgt[2 * ids[i]] - mqx, qy = tgt[2 * ids[i] + 1] - mqy;
+                    m00 += qx * px;
+                    m01 += qx * py;
+                    m10 += qy * px;
+                    m11 += qy * py;
+                }
+                /* R = U V^T of the 2x2 SVD with the det fix == polar rotation */
+                float S = m00 + m11, K = m10 - m01;
+                float h = sqrtf(S * S + K * K);
+                float cf = (h == 0) ? 1.0f : S / h, sf = (h == 0) ? 0.0f : K / h;
+                c = cf;
+                s = sf;
+                tx = mqx - (cf * mpx - sf * mpy);
+                ty = mqy - (sf * mpx + cf * mpy);
+                tx = (float)tx;
+                ty = (float)ty;
+            } else {
+                /* double raw sums: W, Sp, Sq, Sqp (the 9 accumulators of SURVEY a12) */
+                double W = 0, spx = 0, spy = 0, sqx = 0, sqy = 0, a00 = 0, a01 = 0, a10 = 0,
+                       a11 = 0;
+                for (int i = 0; i < ns; ++i) {
+                    int ok = ids[i] >= 0 && (!P->use_max_dist_filter || d2[i] <= r2_filter) &&
+                             (!P->use_trimmed_filter || d2[i] <= limit);
+                    if (!ok)
+                        continue;
+                    ++nkept;
+                    double px = cur[2 * i], py = cur[2 * i + 1];
+                    double qx = tgt[2 * ids[i]], qy = tgt[2 * ids[i] + 1];
+                    W += 1.0;
+                    spx += px;
+                    spy += py;
+                    sqx += qx;
+                    sqy += qy;
+                    a00 += qx * px;
+                    a01 += qx * py;
+                    a10 += qy * px;
+                    a11 += qy * py;
+                }
+                if (nkept == 0) {
+                    status = ORC_ICP_NO_POINT;
+                    break;
+                }
+                double mpx = spx / W, mpy = spy / W, mqx = sqx / W, mqy = sqy / W;
+                double m00 = a00 - sqx * mpx, m01 = a01 - sqx * mpy;
+                double m10 = a10 - sqy * mpx, m11 = a11 - sqy * mpy;
+                double S = m00 + m11, K = m10 - m01;
+                double h = sqrt(S * S + K * K);
+                c = (h == 0) ? 1.0 : S / h;
+                s = (h == 0) ? 0.0 : K / h;
+                tx = mqx - (c * mpx - s * mpy);
+                ty = mqy - (s * mpx + c * mpy);
+            }
+            Ts[0] = (float)c;
+            Ts[1] = (float)-s;
+            Ts[2] = (float)tx;
+            Ts[3] = (float)s;
+            Ts[4] = (float)c;
+            Ts[5] = (float)ty;
+        } else {
+            /* 2-D point-to-plane: rows a=[p x n, nx, ny], e = n.(p-q); A x = -sum a e */
+            double A[6] = {0, 0, 0, 0, 0, 0}, B[3] = {0, 0, 0};
+            for (int i = 0; i < ns; ++i) {
+                int ok = ids[i] >= 0 && (!P->use_max_dist_filter || d2[i] <= r2_filter) &&
+                         (!P->use_trimmed_filter || d2[i] <= limit);
+                if (!ok)
+                    continue;
+                ++nkept;
+                double px = cur[2 * i], py = cur[2 * i + 1];
+                double qx = tgt[2 * ids[i]], qy = tgt[2 * ids[i] + 1];
+                double nx = nrm[2 * ids[i]], ny = nrm[2 * ids[i] + 1];
+                double a0 = px * ny - py * nx;
+                double e = nx * (px - qx) + ny * (py - qy);
+                A[0] += a0 * a0;
+                A[1] += a0 * nx;
+                A[2] += a0 * ny;
+                A[3] += nx * nx;
+                A[4] += nx * ny;
+                A[5] += ny * ny;
+                B[0] -= a0 * e;
+                B[1] -= nx * e;
+                B[2] -= ny * e;
+            }
+            if (nkept == 0) {
+                status = ORC_ICP_NO_POINT;
+                break;
+            }
+            /* Cholesky A = L L^T, A = [[A0,A1,A2],[A1,A3,A4],[A2,A4,A5]] */
+            double l00 = sqrt(A[0]);
+            double l10 = A[1] / l00, l20 = A[2] / l00;
+            double l11 = sqrt(A[3] - l10 * l10);
+            double l21 = (A[4] - l20 * l10) / l11;
+            double l22 = sqrt(A[5] - l20 * l20 - l21 * l21);
+            if (!(l00 > 0) || !(l11 > 0) || !(l22 > 0)) {
+                status = ORC_ICP_SINGULAR;
+                break;
+            }
+            double y0 = B[0] / l00;
+            double y1 = (B[1] - l10 * y0) / l11;
+            double y2 = (B[2] - l20 * y0 - l21 * y1) / l22;
+            double x2 = y2 / l22;
+            double x1 = (y1 - l21 * x2) / l11;
+            double x0 = (y0 - l10 * x1 - l20 * x2) / l00;
+            double c = cos(x0), s = sin(x0);
+            Ts[0] = (float)c;
+            Ts[1] = (float)-s;
+            Ts[2] = (float)x1;
+            Ts[3] = (float)s;
+            Ts[4] = (float)c;
+            Ts[5] = (float)x2;
+        }
+        mat3_mul_f(Ts, Ti, Ti); /* T_iter = T_step * T_iter */
+        ++iters;
+        /* transformationCheckers.check: Counter first (icp.yaml:23), then Differential */
+        ++counter;
+        if (counter >= P->max_iter) {
+            iterate = 0; /* MaxNumIterationsReached -> loop ends, result kept */
+            break;
+        }
+        if (P->use_diff_checker) {
+            hist[2 * nhist] = Ti[0];
+            hist[2 * nhist + 1] = Ti[3];
+            htx[2 * nhist] = Ti[2];
+            htx[2 * nhist + 1] = Ti[5];
+            ++nhist;
+            if (nhist > P->smooth_len) {
+                double rsum = 0, tsum = 0;
+                for (int i = nhist - 1; i >= nhist - P->smooth_len; --i) {
+                    double c1 = hist[2 * i], s1 = hist[2 * i + 1];
+                    double c0 = hist[2 * i - 2], s0 = hist[2 * i - 1];
+                    double dth = atan2(s1 * c0 - c1 * s0, c1 * c0 + s1 * s0);
+                    rsum += fabs(dth);
+                    double dx = (double)htx[2 * i] - htx[2 * i - 2];
+                    double dy = (double)htx[2 * i + 1] - htx[2 * i - 1];
+                    tsum += sqrt(dx * dx + dy * dy);
+                }
+                rsum /= P->smooth_len;
+                tsum /= P->smooth_len;
+                if (rsum < P->min_diff_rot && tsum < P->min_diff_trans)
+                    iterate = 0;
+                if (isnan(rsum)) {
+                    status = ORC_ICP_NAN_ROT;
+                    break;
+                }
+                if (isnan(tsum)) {
+                    status = ORC_ICP_NAN_TRANS;
+                    break;
+                }
+            }
+        }
+    }
+    if (status == ORC_ICP_OK) {
+        float tmp[9];
+        mat3_mul_f(Ti, T0, tmp);   /* T_iter * T_refMean_dataIn */
+        mat3_mul_f(Tfwd, tmp, T_out); /* T_refIn_refMean * ... */
+    } else {
+        memcpy(T_out, guess, sizeof(float) * 9); /* pcl.cpp:203,207-210: T stays = guess */
+    }
+    if (iters_out)
+        *iters_out = iters;
+    free(tgt);
+    free(rd);
+    free(cur);
+    free(d2);
+    free(fin);
+    free(ids);
+    free(nrm);
+    free(hist);
+    free(htx);
+    return status;
+}
+
+/* ------------------------------------------------------------------------- */
+/* pcl.remove_outlier (pcl.cpp:54-74): PCL RadiusOutlierRemoval.  A point is   */
+/* kept iff the radius search around it (which returns the point itself)      */
+/* finds k > min_points entries, i.e. at least min_points OTHER points with    */
+/* squared distance <= radius^2.  Order preserved.  PARITY UNPINNED (PCL).     */
+/* ------------------------------------------------------------------------- */
+int orc_remove_outlier(const float *pts, int n, double radius, int min_points, float *out)
+{
+    int m = 0;
+    const float r2 = (float)(radius * radius);
+    for (int i = 0; i < n; ++i) {
+        int cnt = 0;
+        for (int j = 0; j < n; ++j) {
+            float dx = pts[2 * i] - pts[2 * j], dy = pts[2 * i + 1] - pts[2 * j + 1];
+            float a = dx * dx, b = dy * dy;
+            if (a + b <= r2)
+                ++cnt;
+        }
+        if (cnt > min_points) {
+            out[2 * m] = pts[2 * i];
+            out[2 * m + 1] = pts[2 * i + 1];
+            ++m;
+        }
+    }
+    return m;
+}

@@ -1,0 +1,199 @@
+// Context, device memory, stream timing: the plumbing of libsonarfe (no torch, no CPU fallback).
+#include "sfe_internal.h"
+
+#include <cstring>
+
+static std::string g_create_err;
+
+int sfe_set_err(sfe_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx)
+        ctx->err = buf;
+    else
+        g_create_err = buf;
+    return code;
+}
+
+void *sfe_scratch(sfe_ctx *ctx, int slot, size_t bytes)
+{
+    auto &b = ctx->scratch[slot];
+    if (bytes <= b.cap && b.p)
+        return b.p;
+    if (b.p) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(b.p);
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = bytes + bytes / 4 + 4096;
+    if (hipMalloc(&b.p, want) != hipSuccess) {
+        b.p = nullptr;
+        sfe_set_err(ctx, SFE_ERR_HIP, "hipMalloc(%zu) for scratch slot %d failed", want, slot);
+        return nullptr;
+    }
+    b.cap = want;
+    return b.p;
+}
+
+extern "C" {
+
+const char *sfe_version(void) { return "sonarfe 0.1 (gfx950)"; }
+
+int sfe_device_count(int *count)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        if (count)
+            *count = 0;
+        return sfe_set_err(nullptr, SFE_ERR_NODEV, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    if (count)
+        *count = n;
+    return 0;
+}
+
+int sfe_ctx_create(int device, sfe_ctx **out)
+{
+    if (!out)
+        return sfe_set_err(nullptr, SFE_ERR_ARG, "sfe_ctx_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return sfe_set_err(nullptr, SFE_ERR_NODEV,
+                           "no HIP device available (%s); libsonarfe has no CPU fallback",
+                           e != hipSuccess ? hipGetErrorString(e) : "count = 0");
+    if (device < 0 || device >= n)
+        return sfe_set_err(nullptr, SFE_ERR_ARG, "device %d out of range [0,%d)", device, n);
+    e = hipSetDevice(device);
+    if (e != hipSuccess)
+        return sfe_set_err(nullptr, SFE_ERR_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess)
+        return sfe_set_err(nullptr, SFE_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return sfe_set_err(nullptr, SFE_ERR_NODEV, "device %d is %s; libsonarfe is built for gfx950 only",
+                           device, prop.gcnArchName);
+    sfe_ctx *c = new sfe_ctx();
+    c->device = device;
+    c->n_cu = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        delete c;
+        return sfe_set_err(nullptr, SFE_ERR_HIP, "stream/event creation failed on device %d", device);
+    }
+    *out = c;
+    return 0;
+}
+
+void sfe_ctx_destroy(sfe_ctx *ctx)
+{
+    if (!ctx)
+        return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &b : ctx->scratch)
+        if (b.p)
+            (void)hipFree(b.p);
+    (void)hipEventDestroy(ctx->ev0);
+    (void)hipEventDestroy(ctx->ev1);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *sfe_last_error(sfe_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int sfe_sync(sfe_ctx *ctx)
+{
+    if (int rc = sfe_use(ctx))
+        return rc;
+    SFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int sfe_device_name(sfe_ctx *ctx, char *buf, int cap)
+{
+    if (int rc = sfe_use(ctx))
+        return rc;
+    SFE_ARG(ctx, buf && cap > 0);
+    hipDeviceProp_t prop;
+    SFE_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    snprintf(buf, (size_t)cap, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return 0;
+}
+
+int sfe_malloc(sfe_ctx *ctx, size_t bytes, void **dptr)
+{
+    if (int rc = sfe_use(ctx))
+        return rc;
+    SFE_ARG(ctx, dptr);
+    *dptr = nullptr;
+    SFE_HIP(ctx, hipMalloc(dptr, bytes ? bytes : 1));
+    return 0;
+}
+
+int sfe_free(sfe_ctx *ctx, void *dptr)
+{
+    if (int rc = sfe_use(ctx))
+        return rc;
+    SFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (dptr)
+        SFE_HIP(ctx, hipFree(dptr));
+    return 0;
+}
+
+int sfe_memcpy_h2d(sfe_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes)
+{
+    if (int rc = sfe_use(ctx))
+        return rc;
+    SFE_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int sfe_memcpy_d2h(sfe_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes)
+{
+    if (int rc = sfe_use(ctx))
+        return rc;
+    SFE_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int sfe_memset(sfe_ctx *ctx, void *dst_dev, int value, size_t bytes)
+{
+    if (int rc = sfe_use(ctx))
+        return rc;
+    SFE_HIP(ctx, hipMemsetAsync(dst_dev, value, bytes, ctx->stream));
+    return 0;
+}
+
+int sfe_timer_start(sfe_ctx *ctx)
+{
+    if (int rc = sfe_use(ctx))
+        return rc;
+    SFE_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    return 0;
+}
+
+int sfe_timer_stop(sfe_ctx *ctx, float *elapsed_ms)
+{
+    if (int rc = sfe_use(ctx))
+        return rc;
+    SFE_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    SFE_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0;
+    SFE_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    if (elapsed_ms)
+        *elapsed_ms = ms;
+    return 0;
+}
+
+} // extern "C"

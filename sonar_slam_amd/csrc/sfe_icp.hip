@@ -1,0 +1,885 @@
+// ICP scan matching, nearest-neighbour match and radius outlier filter on gfx950.
+// Replaces bruce_slam/src/bruce_slam/cpp/pcl.cpp:54-74 (remove_outlier), :161-174 (match) and
+// :198-212 (ICP.compute -> libpointmatcher chain of bruce_slam/config/icp.yaml:1-31).
+//
+// The libpointmatcher chain (restated in oracle/sonar_oracle.c):
+//   centre the target on its mean, T0 = T_mean^-1 * guess, reading = T0 * source   (once)
+//   loop: cur = T_iter * reading
+//         exact 1-NN of every cur point in the target (squared distance, lowest index on ties,
+//           none beyond KDTreeMatcher.maxDist)
+//         weights = [d2 <= MaxDist^2] * [d2 <= quantile_ratio(finite d2)]          (0/1)
+//         T_step  = weighted Kabsch (point-to-point) or 2-D point-to-plane normal equations
+//         T_iter  = T_step * T_iter ; Counter / Differential checkers
+//   result = T_mean * T_iter * T0
+//
+// Mapping: ONE workgroup (1024 threads, 16 waves) runs the whole ICP of one job in one launch;
+// the mean-centred target sits in LDS for all iterations (<= 8192 points; larger targets are
+// streamed through the same LDS tile), every lane owns a few source points, the trimmed
+// quantile is an exact radix select on the float bit patterns (LDS histogram), and the 9 (or
+// 9+1) Gauss-Newton / Kabsch accumulators are reduced in fp64 with wave shuffles + LDS.
+// Independent jobs (keyframes, or many initial guesses of one loop-closure pair) are the grid.
+// There is no dense contraction here: fp32 VALU + LDS, no MFMA.
+#include "sfe_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#define ICP_THREADS 1024
+#define ICP_WAVES (ICP_THREADS / 64)
+#define ICP_TCAP 8192 // target points resident in LDS (64 KiB as float2)
+#define ICP_PB 4      // source points per lane per pass over the target
+#define ICP_KMAX 16   // max neighbours for the PCA normals
+#define ICP_MAX_HIST 64 // transformation history kept for the differential checker
+
+struct IcpJob {
+    int src_start, n_src, tgt_start, n_tgt;
+    long long scratch_off; // offset (in points) of this job's slice of the NN scratch
+    long long nrm_off;     // offset (in points) of this job's slice of the normals scratch
+};
+
+__device__ __forceinline__ float f_mul(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float f_add(float a, float b) { return __fadd_rn(a, b); }
+
+// x' = (a*x + b*y) + c with every product/sum rounded to float (Eigen's coefficient product)
+__device__ __forceinline__ float affine1(float a, float b, float c, float x, float y)
+{
+    return f_add(f_add(f_mul(a, x), f_mul(b, y)), c);
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+        v += __shfl_down(v, d);
+    return v;
+}
+
+// block-wide sum of NV doubles per thread; result valid in every thread
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double *s_red /* ICP_WAVES*NV + NV */)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const double s = wave_sum(v[i]);
+        if (lane == 0)
+            s_red[wave * NV + i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        double s = 0;
+        for (int w = 0; w < ICP_WAVES; ++w) // fixed order: deterministic
+            s += s_red[w * NV + threadIdx.x];
+        s_red[ICP_WAVES * NV + threadIdx.x] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        v[i] = s_red[ICP_WAVES * NV + i];
+    __syncthreads();
+}
+
+__device__ __forceinline__ void mat3_mul(const float *a, const float *b, float *c)
+{
+    float r[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float s = f_mul(a[i * 3], b[j]);
+            s = f_add(s, f_mul(a[i * 3 + 1], b[3 + j]));
+            s = f_add(s, f_mul(a[i * 3 + 2], b[6 + j]));
+            r[i * 3 + j] = s;
+        }
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+        c[i] = r[i];
+}
+
+// Scan one LDS tile of centred target points for PB query points; strict '<' keeps the lowest
+// index on ties.  d2 = fl(fl(dx*dx) + fl(dy*dy)) exactly as the oracle / libnabo accumulate it.
+__device__ __forceinline__ void nn_scan_tile(const float2 *__restrict__ s_tgt, int tile_n, int tile_base,
+                                             const float (&px)[ICP_PB], const float (&py)[ICP_PB],
+                                             float (&best)[ICP_PB], int (&bidx)[ICP_PB])
+{
+    int j = 0;
+    for (; j + 2 <= tile_n; j += 2) {
+        const float4 t = *reinterpret_cast<const float4 *>(&s_tgt[j]); // two points, LDS broadcast
+#pragma unroll
+        for (int k = 0; k < ICP_PB; ++k) {
+            float dx = f_add(px[k], -t.x), dy = f_add(py[k], -t.y);
+            float d = f_add(f_mul(dx, dx), f_mul(dy, dy));
+            if (d < best[k]) {
+                best[k] = d;
+                bidx[k] = tile_base + j;
+            }
+            dx = f_add(px[k], -t.z);
+            dy = f_add(py[k], -t.w);
+            d = f_add(f_mul(dx, dx), f_mul(dy, dy));
+            if (d < best[k]) {
+                best[k] = d;
+                bidx[k] = tile_base + j + 1;
+            }
+        }
+    }
+    if (j < tile_n) {
+        const float2 t = s_tgt[j];
+#pragma unroll
+        for (int k = 0; k < ICP_PB; ++k) {
+            const float dx = f_add(px[k], -t.x), dy = f_add(py[k], -t.y);
+            const float d = f_add(f_mul(dx, dx), f_mul(dy, dy));
+            if (d < best[k]) {
+                best[k] = d;
+                bidx[k] = tile_base + j;
+            }
+        }
+    }
+}
+
+// load target points [base, base+n) of the job, centred on `mean`, into the LDS tile
+__device__ __forceinline__ void load_tile(float2 *__restrict__ s_tgt, const float2 *__restrict__ tgt, int base,
+                                          int n, float mx, float my)
+{
+    for (int i = threadIdx.x; i < n; i += ICP_THREADS) {
+        const float2 t = tgt[base + i];
+        s_tgt[i] = make_float2(f_add(t.x, -mx), f_add(t.y, -my));
+    }
+}
+
+struct IcpShared {
+    float2 tgt[ICP_TCAP];
+    double red[ICP_WAVES * 10 + 10];
+    unsigned hist[256];
+    unsigned sel_prefix, sel_k;
+    int flag_iterate, flag_status;
+    float Ti[9];
+    float mean[2];
+    float hist_c[ICP_MAX_HIST], hist_s[ICP_MAX_HIST], hist_x[ICP_MAX_HIST], hist_y[ICP_MAX_HIST];
+};
+
+__global__ __launch_bounds__(ICP_THREADS) void icp_job_kernel(sfe_icp_params P, const IcpJob *__restrict__ jobs,
+                                                              const float2 *__restrict__ src_all,
+                                                              const float2 *__restrict__ tgt_all,
+                                                              const float *__restrict__ guess_all,
+                                                              float *__restrict__ nn_d2_all,
+                                                              int *__restrict__ nn_idx_all,
+                                                              float2 *__restrict__ nrm_all,
+                                                              float *__restrict__ T_out, int *__restrict__ status_out,
+                                                              int *__restrict__ iters_out)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    IcpShared &S = *reinterpret_cast<IcpShared *>(smem_raw);
+
+    const IcpJob J = jobs[blockIdx.x];
+    const int ns = J.n_src, nt = J.n_tgt;
+    const float2 *__restrict__ src = src_all + J.src_start;
+    const float2 *__restrict__ tgt = tgt_all + J.tgt_start;
+    float *__restrict__ nn_d2 = nn_d2_all + J.scratch_off;
+    int *__restrict__ nn_idx = nn_idx_all + J.scratch_off;
+    float2 *__restrict__ nrm = nrm_all ? nrm_all + J.nrm_off : nullptr;
+    const float *guess = guess_all + 9 * (size_t)blockIdx.x;
+    const int tid = threadIdx.x;
+    const bool resident = nt <= ICP_TCAP;
+
+    // ---- reference mean (fp64 accumulation, rounded to float): frame refMean ----
+    {
+        double m[2] = {0, 0};
+        for (int i = tid; i < nt; i += ICP_THREADS) {
+            const float2 t = tgt[i];
+            m[0] += t.x;
+            m[1] += t.y;
+        }
+        block_sum<2>(m, S.red);
+        if (tid == 0) {
+            S.mean[0] = (float)(m[0] / nt);
+            S.mean[1] = (float)(m[1] / nt);
+        }
+        __syncthreads();
+    }
+    const float mx = S.mean[0], my = S.mean[1];
+    if (resident) {
+        load_tile(S.tgt, tgt, 0, nt, mx, my);
+        __syncthreads();
+    }
+
+    // ---- point-to-plane only: PCA normals of the centred target (k nearest incl. self) ----
+    if (P.minimizer == 1) {
+        const int K = min(min(P.normals_knn, ICP_KMAX), nt);
+        for (int i0 = 0; i0 < nt; i0 += ICP_THREADS) {
+            const int i = i0 + tid;
+            const bool act = i < nt;
+            float qx = 0, qy = 0;
+            if (act) {
+                const float2 t = tgt[i];
+                qx = f_add(t.x, -mx);
+                qy = f_add(t.y, -my);
+            }
+            float bd[ICP_KMAX];
+            int bi[ICP_KMAX];
+#pragma unroll
+            for (int q = 0; q < ICP_KMAX; ++q) {
+                bd[q] = INFINITY;
+                bi[q] = 0;
+            }
+            for (int tb = 0; tb < nt; tb += ICP_TCAP) {
+                const int tn = min(ICP_TCAP, nt - tb);
+                if (!resident) {
+                    __syncthreads();
+                    load_tile(S.tgt, tgt, tb, tn, mx, my);
+                    __syncthreads();
+                }
+                if (act) {
+                    for (int j = 0; j < tn; ++j) {
+                        const float2 t = S.tgt[j];
+                        const float dx = f_add(qx, -t.x), dy = f_add(qy, -t.y);
+                        const float d = f_add(f_mul(dx, dx), f_mul(dy, dy));
+                        if (d < bd[ICP_KMAX - 1] || K < ICP_KMAX) {
+                            // position = number of kept entries <= d (ties keep the earlier index)
+                            int p = 0;
+#pragma unroll
+                            for (int q = 0; q < ICP_KMAX; ++q)
+                                p += (q < K && bd[q] <= d) ? 1 : 0;
+                            if (p < K) {
+#pragma unroll
+                                for (int q = ICP_KMAX - 1; q >= 1; --q) {
+                                    if (q < K && q > p) {
+                                        bd[q] = bd[q - 1];
+                                        bi[q] = bi[q - 1];
+                                    }
+                                }
+#pragma unroll
+                                for (int q = 0; q < ICP_KMAX; ++q)
+                                    if (q == p) {
+                                        bd[q] = d;
+                                        bi[q] = tb + j;
+                                    }
+                            }
+                        }
+                    }
+                }
+            }
+            if (act) {
+                double sx = 0, sy = 0;
+#pragma unroll
+                for (int q = 0; q < ICP_KMAX; ++q)
+                    if (q < K) {
+                        const float2 t = tgt[bi[q]];
+                        sx += (double)f_add(t.x, -mx);
+                        sy += (double)f_add(t.y, -my);
+                    }
+                sx /= K;
+                sy /= K;
+                double a = 0, b = 0, d = 0;
+#pragma unroll
+                for (int q = 0; q < ICP_KMAX; ++q)
+                    if (q < K) {
+                        const float2 t = tgt[bi[q]];
+                        const double ux = (double)f_add(t.x, -mx) - sx, uy = (double)f_add(t.y, -my) - sy;
+                        a += ux * ux;
+                        b += ux * uy;
+                        d += uy * uy;
+                    }
+                const double u = a - d, v = 2 * b, h = sqrt(u * u + v * v);
+                double tx, ty;
+                if (h == 0) {
+                    tx = 1;
+                    ty = 0;
+                } else if (u >= 0) {
+                    tx = u + h;
+                    ty = v;
+                } else {
+                    tx = v;
+                    ty = h - u;
+                }
+                double nn = sqrt(tx * tx + ty * ty);
+                if (nn == 0) {
+                    tx = 1;
+                    ty = 0;
+                    nn = 1;
+                }
+                nrm[i] = make_float2((float)(-ty / nn), (float)(tx / nn));
+            }
+        }
+        __syncthreads(); // normals visible to the whole workgroup (same CU: L1-coherent stores + barrier)
+        __threadfence_block();
+    }
+
+    // ---- T0 = T_refIn_refMean^-1 * guess ; T_iter = I ----
+    float T0[9];
+    {
+        const float Tinv[9] = {1, 0, -mx, 0, 1, -my, 0, 0, 1};
+        float g[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+            g[i] = guess[i];
+        mat3_mul(Tinv, g, T0);
+    }
+    if (tid == 0) {
+        const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        for (int i = 0; i < 9; ++i)
+            S.Ti[i] = I[i];
+        S.flag_iterate = 1;
+        S.flag_status = SFE_ICP_OK;
+    }
+    __syncthreads();
+
+    // checker state: history in LDS (only thread 0 touches it), counters in thread 0's registers
+    float *hist_c = S.hist_c, *hist_s = S.hist_s, *hist_x = S.hist_x, *hist_y = S.hist_y;
+    int nhist = 1;
+    if (tid == 0) {
+        hist_c[0] = 1.0f; // DifferentialTransformationChecker::init pushes the identity
+        hist_s[0] = 0.0f;
+        hist_x[0] = 0.0f;
+        hist_y[0] = 0.0f;
+    }
+    int counter = 0, iters = 0;
+
+    const float r2_match = f_mul(P.matcher_max_dist, P.matcher_max_dist);
+    const float r2_filter = f_mul(P.max_dist_filter, P.max_dist_filter);
+
+    while (true) {
+        float Ti[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+            Ti[i] = S.Ti[i];
+
+        // ---- match: exact 1-NN of cur = Ti * (T0 * src) in the centred target ----
+        double nfin_d[1] = {0};
+        for (int base = 0; base < ns; base += ICP_THREADS * ICP_PB) {
+            float px[ICP_PB], py[ICP_PB], best[ICP_PB];
+            int bidx[ICP_PB];
+#pragma unroll
+            for (int k = 0; k < ICP_PB; ++k) {
+                const int i = base + k * ICP_THREADS + tid;
+                float x = 0, y = 0;
+                if (i < ns) {
+                    const float2 s = src[i];
+                    const float rx = affine1(T0[0], T0[1], T0[2], s.x, s.y);
+                    const float ry = affine1(T0[3], T0[4], T0[5], s.x, s.y);
+                    x = affine1(Ti[0], Ti[1], Ti[2], rx, ry);
+                    y = affine1(Ti[3], Ti[4], Ti[5], rx, ry);
+                }
+                px[k] = x;
+                py[k] = y;
+                best[k] = INFINITY;
+                bidx[k] = -1;
+            }
+            if (resident) {
+                nn_scan_tile(S.tgt, nt, 0, px, py, best, bidx);
+            } else {
+                for (int tb = 0; tb < nt; tb += ICP_TCAP) {
+                    const int tn = min(ICP_TCAP, nt - tb);
+                    __syncthreads();
+                    load_tile(S.tgt, tgt, tb, tn, mx, my);
+                    __syncthreads();
+                    nn_scan_tile(S.tgt, tn, tb, px, py, best, bidx);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < ICP_PB; ++k) {
+                const int i = base + k * ICP_THREADS + tid;
+                if (i < ns) {
+                    float d = best[k];
+                    int id = bidx[k];
+                    if (id < 0 || !(d <= r2_match)) {
+                        id = -1;
+                        d = INFINITY;
+                    } else {
+                        nfin_d[0] += 1.0;
+                    }
+                    nn_d2[i] = d;
+                    nn_idx[i] = id;
+                }
+            }
+        }
+        block_sum<1>(nfin_d, S.red); // also orders the nn_d2 / nn_idx stores before the re-reads below
+        const unsigned nfin = (unsigned)nfin_d[0];
+
+        // ---- TrimmedDistOutlierFilter limit: exact order statistic by radix select ----
+        float limit = INFINITY;
+        bool fail = false;
+        if (P.use_trimmed_filter) {
+            if (nfin == 0) {
+                fail = true; // "no outlier to filter"
+                if (tid == 0)
+                    S.flag_status = SFE_ICP_NO_OUTLIER;
+            } else if (P.trim_ratio >= 1.0f) {
+                // max of the finite distances: select rank nfin-1
+                if (tid == 0)
+                    S.sel_k = nfin - 1;
+            } else if (tid == 0) {
+                S.sel_k = (unsigned)f_mul((float)nfin, P.trim_ratio); // values.size()*quantile in float
+            }
+            if (!fail) {
+                if (tid == 0)
+                    S.sel_prefix = 0;
+                __syncthreads();
+                for (int shift = 24; shift >= 0; shift -= 8) {
+                    if (tid < 256)
+                        S.hist[tid] = 0;
+                    __syncthreads();
+                    const unsigned prefix = S.sel_prefix;
+                    const unsigned himask = (shift == 24) ? 0u : (0xFFFFFFFFu << (shift + 8));
+                    for (int i = tid; i < ns; i += ICP_THREADS) {
+                        const float d = nn_d2[i];
+                        if (d != INFINITY) {
+                            const unsigned u = __float_as_uint(d); // d >= 0: bit pattern order == value order
+                            if ((u & himask) == prefix)
+                                atomicAdd(&S.hist[(u >> shift) & 255u], 1u);
+                        }
+                    }
+                    __syncthreads();
+                    if (tid == 0) {
+                        unsigned k = S.sel_k, b = 0;
+                        for (; b < 256; ++b) {
+                            const unsigned h = S.hist[b];
+                            if (k < h)
+                                break;
+                            k -= h;
+                        }
+                        S.sel_k = k;
+                        S.sel_prefix = prefix | (b << shift);
+                    }
+                    __syncthreads();
+                }
+                limit = __uint_as_float(S.sel_prefix);
+            }
+        }
+        __syncthreads();
+        if (fail)
+            break;
+
+        // ---- error minimiser: accumulate over kept pairs ----
+        double acc[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i)
+            acc[i] = 0;
+        for (int i = tid; i < ns; i += ICP_THREADS) {
+            const int id = nn_idx[i];
+            const float d = nn_d2[i];
+            const bool ok = id >= 0 && (!P.use_max_dist_filter || d <= r2_filter) &&
+                            (!P.use_trimmed_filter || d <= limit);
+            if (!ok)
+                continue;
+            const float2 s = src[i];
+            const float rx = affine1(T0[0], T0[1], T0[2], s.x, s.y);
+            const float ry = affine1(T0[3], T0[4], T0[5], s.x, s.y);
+            const double px = affine1(Ti[0], Ti[1], Ti[2], rx, ry);
+            const double py = affine1(Ti[3], Ti[4], Ti[5], rx, ry);
+            float2 q;
+            if (resident)
+                q = S.tgt[id];
+            else {
+                const float2 t = tgt[id];
+                q = make_float2(f_add(t.x, -mx), f_add(t.y, -my));
+            }
+            const double qx = q.x, qy = q.y;
+            acc[0] += 1.0;
+            if (P.minimizer == 0) {
+                acc[1] += px;
+                acc[2] += py;
+                acc[3] += qx;
+                acc[4] += qy;
+                acc[5] += qx * px;
+                acc[6] += qx * py;
+                acc[7] += qy * px;
+                acc[8] += qy * py;
+            } else {
+                const float2 n = nrm[id];
+                const double nx = n.x, ny = n.y;
+                const double a0 = px * ny - py * nx;
+                const double e = nx * (px - qx) + ny * (py - qy);
+                acc[1] += a0 * a0;
+                acc[2] += a0 * nx;
+                acc[3] += a0 * ny;
+                acc[4] += nx * nx;
+                acc[5] += nx * ny;
+                acc[6] += ny * ny;
+                acc[7] -= a0 * e;
+                acc[8] -= nx * e;
+                acc[9] -= ny * e;
+            }
+        }
+        block_sum<10>(acc, S.red);
+
+        // ---- solve, compose, check (thread 0) ----
+        if (tid == 0) {
+            int status = SFE_ICP_OK;
+            int iterate = 1;
+            float Ts[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+            if (acc[0] == 0.0) {
+                status = SFE_ICP_NO_POINT;
+            } else if (P.minimizer == 0) {
+                const double W = acc[0];
+                const double mpx = acc[1] / W, mpy = acc[2] / W, mqx = acc[3] / W, mqy = acc[4] / W;
+                const double m00 = acc[5] - acc[3] * mpx, m01 = acc[6] - acc[3] * mpy;
+                const double m10 = acc[7] - acc[4] * mpx, m11 = acc[8] - acc[4] * mpy;
+                const double Sx = m00 + m11, Kx = m10 - m01;
+                const double h = sqrt(Sx * Sx + Kx * Kx);
+                const double c = (h == 0) ? 1.0 : Sx / h;
+                const double s = (h == 0) ? 0.0 : Kx / h;
+                const double tx = mqx - (c * mpx - s * mpy);
+                const double ty = mqy - (s * mpx + c * mpy);
+                Ts[0] = (float)c;
+                Ts[1] = (float)-s;
+                Ts[2] = (float)tx;
+                Ts[3] = (float)s;
+                Ts[4] = (float)c;
+                Ts[5] = (float)ty;
+            } else {
+                const double l00 = sqrt(acc[1]);
+                const double l10 = acc[2] / l00, l20 = acc[3] / l00;
+                const double l11 = sqrt(acc[4] - l10 * l10);
+                const double l21 = (acc[5] - l20 * l10) / l11;
+                const double l22 = sqrt(acc[6] - l20 * l20 - l21 * l21);
+                if (!(l00 > 0) || !(l11 > 0) || !(l22 > 0)) {
+                    status = SFE_ICP_SINGULAR;
+                } else {
+                    const double y0 = acc[7] / l00;
+                    const double y1 = (acc[8] - l10 * y0) / l11;
+                    const double y2 = (acc[9] - l20 * y0 - l21 * y1) / l22;
+                    const double x2 = y2 / l22;
+                    const double x1 = (y1 - l21 * x2) / l11;
+                    const double x0 = (y0 - l10 * x1 - l20 * x2) / l00;
+                    const double c = cos(x0), s = sin(x0);
+                    Ts[0] = (float)c;
+                    Ts[1] = (float)-s;
+                    Ts[2] = (float)x1;
+                    Ts[3] = (float)s;
+                    Ts[4] = (float)c;
+                    Ts[5] = (float)x2;
+                }
+            }
+            if (status == SFE_ICP_OK) {
+                float Tn[9];
+                mat3_mul(Ts, Ti, Tn);
+                for (int i = 0; i < 9; ++i)
+                    S.Ti[i] = Tn[i];
+                ++iters;
+                ++counter;
+                if (counter >= P.max_iter) {
+                    iterate = 0; // CounterTransformationChecker: MaxNumIterationsReached
+                } else if (P.use_diff_checker) {
+                    if (nhist < ICP_MAX_HIST) {
+                        hist_c[nhist] = Tn[0];
+                        hist_s[nhist] = Tn[3];
+                        hist_x[nhist] = Tn[2];
+                        hist_y[nhist] = Tn[5];
+                        ++nhist;
+                    } else { // keep a sliding window (only the last smooth_len+1 entries are read)
+                        for (int i = 1; i < ICP_MAX_HIST; ++i) {
+                            hist_c[i - 1] = hist_c[i];
+                            hist_s[i - 1] = hist_s[i];
+                            hist_x[i - 1] = hist_x[i];
+                            hist_y[i - 1] = hist_y[i];
+                        }
+                        hist_c[ICP_MAX_HIST - 1] = Tn[0];
+                        hist_s[ICP_MAX_HIST - 1] = Tn[3];
+                        hist_x[ICP_MAX_HIST - 1] = Tn[2];
+                        hist_y[ICP_MAX_HIST - 1] = Tn[5];
+                    }
+                    // rotations.size() > smoothLength; size counts the init entry (= iters + 1)
+                    if (iters + 1 > P.smooth_len) {
+                        double rsum = 0, tsum = 0;
+                        for (int i = nhist - 1; i >= nhist - P.smooth_len; --i) {
+                            const double c1 = hist_c[i], s1 = hist_s[i], c0 = hist_c[i - 1], s0 = hist_s[i - 1];
+                            rsum += fabs(atan2(s1 * c0 - c1 * s0, c1 * c0 + s1 * s0));
+                            const double dx = (double)hist_x[i] - hist_x[i - 1];
+                            const double dy = (double)hist_y[i] - hist_y[i - 1];
+                            tsum += sqrt(dx * dx + dy * dy);
+                        }
+                        rsum /= P.smooth_len;
+                        tsum /= P.smooth_len;
+                        if (rsum < P.min_diff_rot && tsum < P.min_diff_trans)
+                            iterate = 0;
+                        if (isnan(rsum))
+                            status = SFE_ICP_NAN_ROT;
+                        else if (isnan(tsum))
+                            status = SFE_ICP_NAN_TRANS;
+                    }
+                }
+            }
+            S.flag_status = status;
+            S.flag_iterate = (status == SFE_ICP_OK) ? iterate : 0;
+        }
+        __syncthreads();
+        if (!S.flag_iterate)
+            break;
+    }
+
+    if (tid == 0) {
+        const int status = S.flag_status;
+        float *To = T_out + 9 * (size_t)blockIdx.x;
+        if (status == SFE_ICP_OK) {
+            const float Tfwd[9] = {1, 0, mx, 0, 1, my, 0, 0, 1};
+            float Ti[9], tmp[9], res[9];
+            for (int i = 0; i < 9; ++i)
+                Ti[i] = S.Ti[i];
+            mat3_mul(Ti, T0, tmp);
+            mat3_mul(Tfwd, tmp, res);
+            for (int i = 0; i < 9; ++i)
+                To[i] = res[i];
+        } else {
+            for (int i = 0; i < 9; ++i) // pcl.cpp:203,207-210: T stays the guess
+                To[i] = guess[i];
+        }
+        status_out[blockIdx.x] = status;
+        iters_out[blockIdx.x] = iters;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pcl.match: exact 1-NN with a radius; one lane per query point, reference tiled through LDS
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void match_kernel(const float2 *__restrict__ ref, int nref,
+                                                    const float2 *__restrict__ in, int nin, float r2,
+                                                    int *__restrict__ ids, float *__restrict__ d2)
+{
+    __shared__ float2 s_ref[2048];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float px = 0, py = 0;
+    if (i < nin) {
+        const float2 p = in[i];
+        px = p.x;
+        py = p.y;
+    }
+    float best = INFINITY;
+    int bi = -1;
+    for (int tb = 0; tb < nref; tb += 2048) {
+        const int tn = min(2048, nref - tb);
+        __syncthreads();
+        for (int j = threadIdx.x; j < tn; j += 256)
+            s_ref[j] = ref[tb + j];
+        __syncthreads();
+        for (int j = 0; j < tn; ++j) {
+            const float2 t = s_ref[j];
+            const float dx = f_add(px, -t.x), dy = f_add(py, -t.y);
+            const float d = f_add(f_mul(dx, dx), f_mul(dy, dy));
+            if (d < best) {
+                best = d;
+                bi = tb + j;
+            }
+        }
+    }
+    if (i < nin) {
+        if (bi < 0 || !(best <= r2)) {
+            bi = -1;
+            best = INFINITY;
+        }
+        ids[i] = bi;
+        d2[i] = best;
+    }
+}
+
+// pcl.remove_outlier: count points within radius (incl. self); keep iff count > min_points
+__global__ __launch_bounds__(256) void radius_count_kernel(const float2 *__restrict__ pts, int n, float r2,
+                                                           int min_points, int *__restrict__ keep)
+{
+    __shared__ float2 s_p[2048];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float px = 0, py = 0;
+    if (i < n) {
+        const float2 p = pts[i];
+        px = p.x;
+        py = p.y;
+    }
+    int cnt = 0;
+    for (int tb = 0; tb < n; tb += 2048) {
+        const int tn = min(2048, n - tb);
+        __syncthreads();
+        for (int j = threadIdx.x; j < tn; j += 256)
+            s_p[j] = pts[tb + j];
+        __syncthreads();
+        for (int j = 0; j < tn; ++j) {
+            const float2 t = s_p[j];
+            const float dx = f_add(px, -t.x), dy = f_add(py, -t.y);
+            cnt += f_add(f_mul(dx, dx), f_mul(dy, dy)) <= r2;
+        }
+    }
+    if (i < n)
+        keep[i] = cnt > min_points;
+}
+
+// ---------------------------------------------------------------------------------------------
+static int check_params(sfe_ctx *ctx, const sfe_icp_params *p)
+{
+    SFE_ARG(ctx, p != nullptr);
+    SFE_ARG(ctx, p->minimizer == 0 || p->minimizer == 1);
+    SFE_ARG(ctx, p->max_iter >= 1);
+    SFE_ARG(ctx, !p->use_diff_checker || (p->smooth_len >= 1 && p->smooth_len < ICP_MAX_HIST));
+    SFE_ARG(ctx, !p->use_trimmed_filter || (p->trim_ratio >= 0.0f && p->trim_ratio <= 1.0f));
+    SFE_ARG(ctx, p->minimizer == 0 || (p->normals_knn >= 2 && p->normals_knn <= ICP_KMAX));
+    SFE_ARG(ctx, p->matcher_max_dist > 0.0f);
+    return 0;
+}
+
+// jobs4: host array n_jobs x 4 = (src_start, n_src, tgt_start, n_tgt) in points
+static int icp_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_src, const float *d_tgt,
+                      const int32_t *jobs4, const float *d_guess9, int n_jobs, float *d_T9, int32_t *d_status,
+                      int32_t *d_iters)
+{
+    if (int rc = check_params(ctx, p))
+        return rc;
+    std::vector<IcpJob> jobs((size_t)n_jobs);
+    long long soff = 0, noff = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const int32_t *q = jobs4 + 4 * (size_t)j;
+        SFE_ARG(ctx, q[0] >= 0 && q[1] >= 0 && q[2] >= 0 && q[3] >= 0);
+        if (q[1] == 0 || q[3] == 0)
+            return sfe_set_err(ctx, SFE_ERR_ARG, "ICP job %d has an empty cloud (n_src=%d, n_tgt=%d)", j, q[1], q[3]);
+        jobs[j] = {q[0], q[1], q[2], q[3], soff, noff};
+        soff += q[1];
+        noff += q[3];
+    }
+    IcpJob *d_jobs = (IcpJob *)sfe_scratch(ctx, 4, sizeof(IcpJob) * (size_t)n_jobs);
+    float *d_nn_d2 = (float *)sfe_scratch(ctx, 5, sizeof(float) * (size_t)soff);
+    int *d_nn_idx = (int *)sfe_scratch(ctx, 6, sizeof(int) * (size_t)soff);
+    float2 *d_nrm = p->minimizer == 1 ? (float2 *)sfe_scratch(ctx, 7, sizeof(float2) * (size_t)noff) : nullptr;
+    if (!d_jobs || !d_nn_d2 || !d_nn_idx || (p->minimizer == 1 && !d_nrm))
+        return SFE_ERR_HIP;
+    SFE_HIP(ctx, hipMemcpyAsync(d_jobs, jobs.data(), sizeof(IcpJob) * (size_t)n_jobs, hipMemcpyHostToDevice,
+                                ctx->stream));
+    // the pageable host vector must stay alive until the copy has been consumed
+    SFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SFE_HIP(ctx, hipFuncSetAttribute((const void *)icp_job_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)sizeof(IcpShared)));
+    hipLaunchKernelGGL(icp_job_kernel, dim3(n_jobs), dim3(ICP_THREADS), sizeof(IcpShared), ctx->stream, *p, d_jobs,
+                       (const float2 *)d_src, (const float2 *)d_tgt, d_guess9, d_nn_d2, d_nn_idx, d_nrm, d_T9,
+                       d_status, d_iters);
+    SFE_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+extern "C" {
+
+int sfe_icp_batch_dev(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_src, const int32_t *src_off,
+                      const float *d_tgt, const int32_t *tgt_off, const float *d_guess9, int n_jobs, float *d_T9,
+                      int32_t *d_status, int32_t *d_iters)
+{
+    if (int rc = sfe_use(ctx))
+        return rc;
+    SFE_ARG(ctx, d_src && d_tgt && src_off && tgt_off && d_guess9 && d_T9 && d_status && d_iters && n_jobs >= 0);
+    if (n_jobs == 0)
+        return 0;
+    std::vector<int32_t> jobs4(4 * (size_t)n_jobs);
+    for (int j = 0; j < n_jobs; ++j) {
+        jobs4[4 * j] = src_off[j];
+        jobs4[4 * j + 1] = src_off[j + 1] - src_off[j];
+        jobs4[4 * j + 2] = tgt_off[j];
+        jobs4[4 * j + 3] = tgt_off[j + 1] - tgt_off[j];
+    }
+    return icp_launch(ctx, p, d_src, d_tgt, jobs4.data(), d_guess9, n_jobs, d_T9, d_status, d_iters);
+}
+
+int sfe_icp_compute_guesses(sfe_ctx *ctx, const sfe_icp_params *p, const float *src, int n_src, const float *tgt,
+                            int n_tgt, const float *guesses9, int n_guesses, float *T_out9, int32_t *status,
+                            int32_t *iters)
+{
+    if (int rc = sfe_use(ctx))
+        return rc;
+    SFE_ARG(ctx, src && tgt && guesses9 && T_out9 && status && n_src >= 0 && n_tgt >= 0 && n_guesses >= 0);
+    if (n_guesses == 0)
+        return 0;
+    if (n_src == 0 || n_tgt == 0)
+        return sfe_set_err(ctx, SFE_ERR_ARG, "ICP needs non-empty clouds (n_src=%d, n_tgt=%d)", n_src, n_tgt);
+    float *d_src = (float *)sfe_scratch(ctx, 0, sizeof(float) * 2 * (size_t)n_src);
+    float *d_tgt = (float *)sfe_scratch(ctx, 1, sizeof(float) * 2 * (size_t)n_tgt);
+    float *d_g = (float *)sfe_scratch(ctx, 2, sizeof(float) * 9 * (size_t)n_guesses);
+    float *d_T = (float *)sfe_scratch(ctx, 3, sizeof(float) * 9 * (size_t)n_guesses);
+    int32_t *d_st = (int32_t *)sfe_scratch(ctx, 8, sizeof(int32_t) * 2 * (size_t)n_guesses);
+    if (!d_src || !d_tgt || !d_g || !d_T || !d_st)
+        return SFE_ERR_HIP;
+    SFE_HIP(ctx, hipMemcpyAsync(d_src, src, sizeof(float) * 2 * (size_t)n_src, hipMemcpyHostToDevice, ctx->stream));
+    SFE_HIP(ctx, hipMemcpyAsync(d_tgt, tgt, sizeof(float) * 2 * (size_t)n_tgt, hipMemcpyHostToDevice, ctx->stream));
+    SFE_HIP(ctx, hipMemcpyAsync(d_g, guesses9, sizeof(float) * 9 * (size_t)n_guesses, hipMemcpyHostToDevice,
+                                ctx->stream));
+    std::vector<int32_t> jobs4(4 * (size_t)n_guesses);
+    for (int j = 0; j < n_guesses; ++j) {
+        jobs4[4 * j] = 0;
+        jobs4[4 * j + 1] = n_src;
+        jobs4[4 * j + 2] = 0;
+        jobs4[4 * j + 3] = n_tgt;
+    }
+    if (int rc = icp_launch(ctx, p, d_src, d_tgt, jobs4.data(), d_g, n_guesses, d_T, d_st, d_st + n_guesses))
+        return rc;
+    SFE_HIP(ctx, hipMemcpyAsync(T_out9, d_T, sizeof(float) * 9 * (size_t)n_guesses, hipMemcpyDeviceToHost,
+                                ctx->stream));
+    SFE_HIP(ctx, hipMemcpyAsync(status, d_st, sizeof(int32_t) * (size_t)n_guesses, hipMemcpyDeviceToHost,
+                                ctx->stream));
+    if (iters)
+        SFE_HIP(ctx, hipMemcpyAsync(iters, d_st + n_guesses, sizeof(int32_t) * (size_t)n_guesses,
+                                    hipMemcpyDeviceToHost, ctx->stream));
+    SFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int sfe_icp_compute(sfe_ctx *ctx, const sfe_icp_params *p, const float *src, int n_src, const float *tgt, int n_tgt,
+                    const float *guess9, float *T_out9, int *iters)
+{
+    int32_t st = 0, it = 0;
+    const int rc = sfe_icp_compute_guesses(ctx, p, src, n_src, tgt, n_tgt, guess9, 1, T_out9, &st, &it);
+    if (rc)
+        return rc;
+    if (iters)
+        *iters = it;
+    return st;
+}
+
+int sfe_match(sfe_ctx *ctx, const float *ref, int n_ref, const float *in, int n_in, float max_dist, int32_t *ids,
+              float *d2)
+{
+    if (int rc = sfe_use(ctx))
+        return rc;
+    SFE_ARG(ctx, n_ref >= 0 && n_in >= 0 && (n_in == 0 || (in && ids && d2)) && (n_ref == 0 || ref));
+    if (n_in == 0)
+        return 0;
+    float *d_ref = (float *)sfe_scratch(ctx, 0, sizeof(float) * 2 * (size_t)std::max(n_ref, 1));
+    float *d_in = (float *)sfe_scratch(ctx, 1, sizeof(float) * 2 * (size_t)n_in);
+    int *d_ids = (int *)sfe_scratch(ctx, 2, sizeof(int) * (size_t)n_in);
+    float *d_d2 = (float *)sfe_scratch(ctx, 3, sizeof(float) * (size_t)n_in);
+    if (!d_ref || !d_in || !d_ids || !d_d2)
+        return SFE_ERR_HIP;
+    if (n_ref)
+        SFE_HIP(ctx, hipMemcpyAsync(d_ref, ref, sizeof(float) * 2 * (size_t)n_ref, hipMemcpyHostToDevice, ctx->stream));
+    SFE_HIP(ctx, hipMemcpyAsync(d_in, in, sizeof(float) * 2 * (size_t)n_in, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(match_kernel, dim3((n_in + 255) / 256), dim3(256), 0, ctx->stream, (const float2 *)d_ref, n_ref,
+                       (const float2 *)d_in, n_in, max_dist * max_dist, d_ids, d_d2);
+    SFE_LAUNCH_CHECK(ctx);
+    SFE_HIP(ctx, hipMemcpyAsync(ids, d_ids, sizeof(int) * (size_t)n_in, hipMemcpyDeviceToHost, ctx->stream));
+    SFE_HIP(ctx, hipMemcpyAsync(d2, d_d2, sizeof(float) * (size_t)n_in, hipMemcpyDeviceToHost, ctx->stream));
+    SFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int sfe_remove_outlier(sfe_ctx *ctx, const float *pts, int n, double radius, int min_points, float *out, int *n_out)
+{
+    if (int rc = sfe_use(ctx))
+        return rc;
+    SFE_ARG(ctx, n >= 0 && n_out && (n == 0 || (pts && out)));
+    *n_out = 0;
+    if (n == 0)
+        return 0;
+    float *d_pts = (float *)sfe_scratch(ctx, 0, sizeof(float) * 2 * (size_t)n);
+    int *d_keep = (int *)sfe_scratch(ctx, 2, sizeof(int) * (size_t)n);
+    if (!d_pts || !d_keep)
+        return SFE_ERR_HIP;
+    SFE_HIP(ctx, hipMemcpyAsync(d_pts, pts, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(radius_count_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const float2 *)d_pts, n,
+                       (float)(radius * radius), min_points, d_keep);
+    SFE_LAUNCH_CHECK(ctx);
+    std::vector<int> keep((size_t)n);
+    SFE_HIP(ctx, hipMemcpyAsync(keep.data(), d_keep, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    SFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int m = 0;
+    for (int i = 0; i < n; ++i) // order-preserving gather of the kept rows (the decision is the GPU's)
+        if (keep[i]) {
+            out[2 * m] = pts[2 * i];
+            out[2 * m + 1] = pts[2 * i + 1];
+            ++m;
+        }
+    *n_out = m;
+    return 0;
+}
+
+} // extern "C"

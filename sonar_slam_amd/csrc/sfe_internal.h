@@ -1,0 +1,65 @@
+// Internal definitions shared by the libsonarfe translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/sonarfe.h"
+
+#define SFE_NSCRATCH 12
+
+struct sfe_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+    struct Buf {
+        void *p = nullptr;
+        size_t cap = 0;
+    } scratch[SFE_NSCRATCH];
+    int cfar_tile_rows = 0;
+    int cfar_variant = 0;
+    int n_cu = 256;
+};
+
+struct sfe_geom {
+    sfe_ctx *ctx = nullptr;
+    int cart_rows = 0, cart_cols = 0, polar_rows = 0, polar_cols = 0;
+    double width = 0, height = 0;
+    int32_t *d_code = nullptr;   // per Cartesian pixel: packed (iy, ix, table index) or -1
+    int32_t *d_span = nullptr;   // per Cartesian row: [first, last+1) columns with code != -1
+    int words_per_row = 0;       // 64-bit bitmap words per Cartesian row
+};
+
+int sfe_set_err(sfe_ctx *ctx, int code, const char *fmt, ...);
+void *sfe_scratch(sfe_ctx *ctx, int slot, size_t bytes);  // grow-only device scratch; nullptr on failure
+
+#define SFE_HIP(ctx, call)                                                                       \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return sfe_set_err((ctx), SFE_ERR_HIP, "%s failed: %s (%s:%d)", #call,               \
+                               hipGetErrorString(e_), __FILE__, __LINE__);                       \
+    } while (0)
+
+#define SFE_LAUNCH_CHECK(ctx) SFE_HIP(ctx, hipGetLastError())
+
+#define SFE_ARG(ctx, cond)                                                                       \
+    do {                                                                                         \
+        if (!(cond))                                                                             \
+            return sfe_set_err((ctx), SFE_ERR_ARG, "bad argument: %s (%s:%d)", #cond, __FILE__,  \
+                               __LINE__);                                                        \
+    } while (0)
+
+static inline int sfe_use(sfe_ctx *ctx)
+{
+    if (!ctx)
+        return SFE_ERR_ARG;
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess)
+        return sfe_set_err(ctx, SFE_ERR_HIP, "hipSetDevice(%d): %s", ctx->device, hipGetErrorString(e));
+    return 0;
+}

@@ -1,0 +1,354 @@
+// Polar -> Cartesian feature extraction on gfx950.
+// Replaces feature_extraction.py:226,231-238: cv2.remap(INTER_LINEAR) of the detection mask,
+// np.nonzero (row-major order) and the pixel -> metre conversion.
+//
+// cv2.remap semantics restated from OpenCV imgproc (see oracle/sonar_oracle.c, PARITY UNPINNED:
+// OpenCV is not in the reference tree nor in this image): coordinates are quantised to 1/32 px
+// with cvRound (half-to-even), the 2x2 taps use 15-bit fixed-point weights (table entry (0,0)
+// is {32767,0,0,1} after OpenCV's sum fix-up), out = (sum w*v + 16384) >> 15, outside = 0.
+//
+// Layout in HBM: the float maps are decoded ONCE per geometry into one uint32 per Cartesian
+// pixel: [31:10] linear index of the top-left tap in a (polar_rows+1) x (polar_cols+1) grid that
+// is shifted by one so that -1 is representable, [9:0] = fy*32+fx; 0xFFFFFFFF = no tap inside the
+// image.  That halves the per-frame map traffic (4 B instead of 8 B per Cartesian pixel), and a
+// per-row [first,last) span skips the pixels outside the sonar fan.
+#include "sfe_internal.h"
+
+#include <cmath>
+#include <cstring>
+
+#define SFE_CODE_NONE 0xFFFFFFFFu
+
+__device__ __forceinline__ int remap_value(const uint8_t *__restrict__ src, int prows, int pcols, uint32_t code)
+{
+    const int lin = (int)(code >> 10);
+    const int fy = (int)((code >> 5) & 31u), fx = (int)(code & 31u);
+    const int iy = lin / (pcols + 1) - 1, ix = lin % (pcols + 1) - 1;
+    int w00 = (32 - fy) * (32 - fx) * 32, w01 = (32 - fy) * fx * 32;
+    int w10 = fy * (32 - fx) * 32, w11 = fy * fx * 32;
+    if ((fx | fy) == 0) {
+        w00 = 32767;
+        w11 = 1;
+    }
+    const bool y0 = iy >= 0, y1 = iy + 1 < prows, x0 = ix >= 0, x1 = ix + 1 < pcols;
+    const uint8_t *p = src + (long long)iy * pcols + ix;
+    const int v00 = (y0 && x0) ? p[0] : 0;
+    const int v01 = (y0 && x1) ? p[1] : 0;
+    const int v10 = (y1 && x0) ? p[pcols] : 0;
+    const int v11 = (y1 && x1) ? p[pcols + 1] : 0;
+    const int acc = w00 * v00 + w01 * v01 + w10 * v10 + w11 * v11;
+    return (acc + 16384) >> 15; // <= 255 because the weights sum to 32768
+}
+
+// full uint8 remap (visualisation image / drop-in cv2.remap)
+__global__ __launch_bounds__(256) void remap_u8_kernel(const uint8_t *__restrict__ src,
+                                                       const uint32_t *__restrict__ code,
+                                                       uint8_t *__restrict__ dst, int prows, int pcols,
+                                                       long long n_cart, int n_frames)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_cart * n_frames)
+        return;
+    const long long f = i / n_cart, o = i % n_cart;
+    const uint32_t c = code[o];
+    dst[i] = (c == SFE_CODE_NONE) ? 0 : (uint8_t)remap_value(src + f * (long long)prows * pcols, prows, pcols, c);
+}
+
+// pass 1: one workgroup per (Cartesian row, frame): nonzero bits -> 64-bit bitmap words + row count
+__global__ __launch_bounds__(256) void extract_bits_kernel(const uint8_t *__restrict__ mask,
+                                                           const uint32_t *__restrict__ code,
+                                                           const int32_t *__restrict__ span,
+                                                           unsigned long long *__restrict__ bitmap,
+                                                           int32_t *__restrict__ row_count, int prows,
+                                                           int pcols, int crows, int ccols, int wpr)
+{
+    const int row = blockIdx.x, f = blockIdx.y;
+    const uint8_t *__restrict__ src = mask + (long long)f * prows * pcols;
+    const uint32_t *__restrict__ crow = code + (long long)row * ccols;
+    unsigned long long *__restrict__ brow = bitmap + ((long long)f * crows + row) * wpr;
+    const int first = span[2 * row], last = span[2 * row + 1];
+    __shared__ int s_cnt[4];
+    int cnt = 0;
+    // words outside the span are zero; words inside are produced by ballots of 64 columns
+    for (int w = threadIdx.x >> 6; w < wpr; w += 4) {
+        const int c = w * 64 + (threadIdx.x & 63);
+        bool bit = false;
+        if (w * 64 < last && w * 64 + 64 > first) { // wave-uniform
+            if (c >= first && c < last) {
+                const uint32_t cd = crow[c];
+                if (cd != SFE_CODE_NONE)
+                    bit = remap_value(src, prows, pcols, cd) != 0;
+            }
+        }
+        const unsigned long long word = __ballot(bit);
+        if ((threadIdx.x & 63) == 0) {
+            brow[w] = word;
+            cnt += __popcll(word);
+        }
+    }
+    if ((threadIdx.x & 63) == 0)
+        s_cnt[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        row_count[(long long)f * crows + row] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+// pass 2: one workgroup per frame: exclusive scan of the row counts -> row offsets + frame total
+__global__ __launch_bounds__(256) void extract_scan_kernel(const int32_t *__restrict__ row_count,
+                                                           int32_t *__restrict__ row_off,
+                                                           int32_t *__restrict__ frame_count, int crows)
+{
+    const int f = blockIdx.x;
+    const int32_t *__restrict__ cnt = row_count + (long long)f * crows;
+    int32_t *__restrict__ off = row_off + (long long)f * crows;
+    __shared__ int s_part[256];
+    const int per = (crows + 255) / 256;
+    const int b = threadIdx.x * per, e = min(b + per, crows);
+    int s = 0;
+    for (int i = b; i < e; ++i)
+        s += cnt[i];
+    s_part[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) { // Hillis-Steele inclusive scan
+        const int v = (threadIdx.x >= d) ? s_part[threadIdx.x - d] : 0;
+        __syncthreads();
+        s_part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = (threadIdx.x == 0) ? 0 : s_part[threadIdx.x - 1];
+    for (int i = b; i < e; ++i) {
+        off[i] = run;
+        run += cnt[i];
+    }
+    if (threadIdx.x == 255)
+        frame_count[f] = s_part[255];
+}
+
+// pass 3: one wave per (row, frame): expand bitmap words in column order -> (row, col) and metres
+__global__ __launch_bounds__(64) void extract_expand_kernel(const unsigned long long *__restrict__ bitmap,
+                                                            const int32_t *__restrict__ row_count,
+                                                            const int32_t *__restrict__ row_off,
+                                                            long long *__restrict__ rc_out,
+                                                            double *__restrict__ pts_out, long long cap,
+                                                            int crows, int ccols, int wpr, double width,
+                                                            double height)
+{
+    const int row = blockIdx.x, f = blockIdx.y;
+    const long long fr = (long long)f * crows + row;
+    if (row_count[fr] == 0)
+        return;
+    const unsigned long long *__restrict__ brow = bitmap + fr * wpr;
+    long long base = row_off[fr];
+    const int lane = threadIdx.x;
+    // feature_extraction.py:236-237 in float64, operation by operation
+    const double half_cols = ccols / 2.;
+    const double y = (-1 * ((double)row / (double)crows) * height) + height;
+    for (int w0 = 0; w0 < wpr; w0 += 64) {
+        const int w = w0 + lane;
+        unsigned long long word = (w < wpr) ? brow[w] : 0ull;
+        const int n = __popcll(word);
+        int incl = n; // inclusive wave scan of the per-word counts
+        for (int d = 1; d < 64; d <<= 1) {
+            const int v = __shfl_up(incl, d);
+            if (lane >= d)
+                incl += v;
+        }
+        long long o = base + incl - n;
+        while (word) {
+            const int b = __ffsll((long long)word) - 1;
+            word &= word - 1;
+            if (o < cap) {
+                const int col = w * 64 + b;
+                const long long dsto = ((long long)f * cap + o) * 2;
+                if (rc_out) {
+                    rc_out[dsto] = row;
+                    rc_out[dsto + 1] = col;
+                }
+                if (pts_out) {
+                    double x = (double)col - half_cols;
+                    x = (-1 * ((x / half_cols) * (width / 2.)));
+                    pts_out[dsto] = y;
+                    pts_out[dsto + 1] = x;
+                }
+            }
+            ++o;
+        }
+        base += __shfl(incl, 63);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_frames, long long cap,
+                       long long *d_rc, double *d_pts, int32_t *d_counts)
+{
+    const int crows = g->cart_rows, wpr = g->words_per_row;
+    const int chunk = 256; // frames per pass: bounds the bitmap scratch
+    const size_t bm_bytes = (size_t)chunk * crows * wpr * sizeof(unsigned long long);
+    unsigned long long *d_bm = (unsigned long long *)sfe_scratch(ctx, 4, bm_bytes);
+    int32_t *d_rcnt = (int32_t *)sfe_scratch(ctx, 5, (size_t)chunk * crows * 4);
+    int32_t *d_roff = (int32_t *)sfe_scratch(ctx, 6, (size_t)chunk * crows * 4);
+    if (!d_bm || !d_rcnt || !d_roff)
+        return SFE_ERR_HIP;
+    for (int f0 = 0; f0 < n_frames; f0 += chunk) {
+        const int nf = std::min(chunk, n_frames - f0);
+        const uint8_t *m = d_mask + (size_t)f0 * g->polar_rows * g->polar_cols;
+        hipLaunchKernelGGL(extract_bits_kernel, dim3(crows, nf), dim3(256), 0, ctx->stream, m,
+                           (const uint32_t *)g->d_code, g->d_span, d_bm, d_rcnt, g->polar_rows, g->polar_cols,
+                           crows, g->cart_cols, wpr);
+        hipLaunchKernelGGL(extract_scan_kernel, dim3(nf), dim3(256), 0, ctx->stream, d_rcnt, d_roff,
+                           d_counts + f0, crows);
+        hipLaunchKernelGGL(extract_expand_kernel, dim3(crows, nf), dim3(64), 0, ctx->stream, d_bm, d_rcnt, d_roff,
+                           d_rc ? d_rc + (size_t)f0 * cap * 2 : nullptr,
+                           d_pts ? d_pts + (size_t)f0 * cap * 2 : nullptr, cap, crows, g->cart_cols, wpr,
+                           g->width, g->height);
+    }
+    SFE_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+static inline int cv_round_f(float v)
+{
+    return (int)lrintf(v); // nearest-even in the default rounding mode == cvRound
+}
+
+extern "C" {
+
+int sfe_geom_create(sfe_ctx *ctx, const float *map_x, const float *map_y, int cart_rows, int cart_cols,
+                    int polar_rows, int polar_cols, double width, double height, sfe_geom **out)
+{
+    if (int rc = sfe_use(ctx))
+        return rc;
+    SFE_ARG(ctx, out && map_x && map_y);
+    *out = nullptr;
+    SFE_ARG(ctx, cart_rows > 0 && cart_cols > 0 && polar_rows > 0 && polar_cols > 0);
+    if ((long long)(polar_rows + 1) * (polar_cols + 1) > (1ll << 22))
+        return sfe_set_err(ctx, SFE_ERR_ARG, "polar image %dx%d too large for the packed remap code (max 2^22 px)",
+                           polar_rows, polar_cols);
+    const size_t n = (size_t)cart_rows * cart_cols;
+    std::vector<uint32_t> code(n);
+    std::vector<int32_t> span(2 * (size_t)cart_rows);
+    for (int r = 0; r < cart_rows; ++r) {
+        int first = cart_cols, last = 0;
+        for (int c = 0; c < cart_cols; ++c) {
+            const size_t o = (size_t)r * cart_cols + c;
+            const float mx = map_x[o] * 32.0f, my = map_y[o] * 32.0f;
+            uint32_t cd = SFE_CODE_NONE;
+            // |coordinate| < 2^20 px keeps cvRound and the >>5 well defined; anything larger is far outside
+            if (std::fabs(mx) < 3.3e7f && std::fabs(my) < 3.3e7f) {
+                const int sx = cv_round_f(mx), sy = cv_round_f(my);
+                const int ix = sx >> 5, iy = sy >> 5;
+                if (ix >= -1 && ix < polar_cols && iy >= -1 && iy < polar_rows) {
+                    const uint32_t lin = (uint32_t)(iy + 1) * (uint32_t)(polar_cols + 1) + (uint32_t)(ix + 1);
+                    cd = (lin << 10) | (uint32_t)((sy & 31) << 5) | (uint32_t)(sx & 31);
+                    if (c < first)
+                        first = c;
+                    last = c + 1;
+                }
+            }
+            code[o] = cd;
+        }
+        if (first > last)
+            first = last = 0;
+        span[2 * r] = first;
+        span[2 * r + 1] = last;
+    }
+    sfe_geom *g = new sfe_geom();
+    g->ctx = ctx;
+    g->cart_rows = cart_rows;
+    g->cart_cols = cart_cols;
+    g->polar_rows = polar_rows;
+    g->polar_cols = polar_cols;
+    g->width = width;
+    g->height = height;
+    g->words_per_row = (cart_cols + 63) / 64;
+    if (hipMalloc((void **)&g->d_code, n * 4) != hipSuccess ||
+        hipMalloc((void **)&g->d_span, span.size() * 4) != hipSuccess) {
+        sfe_geom_destroy(g);
+        return sfe_set_err(ctx, SFE_ERR_HIP, "hipMalloc for geometry failed");
+    }
+    if (hipMemcpy(g->d_code, code.data(), n * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(g->d_span, span.data(), span.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        sfe_geom_destroy(g);
+        return sfe_set_err(ctx, SFE_ERR_HIP, "hipMemcpy for geometry failed");
+    }
+    *out = g;
+    return 0;
+}
+
+void sfe_geom_destroy(sfe_geom *g)
+{
+    if (!g)
+        return;
+    if (g->ctx) {
+        (void)hipSetDevice(g->ctx->device);
+        (void)hipStreamSynchronize(g->ctx->stream);
+    }
+    if (g->d_code)
+        (void)hipFree(g->d_code);
+    if (g->d_span)
+        (void)hipFree(g->d_span);
+    delete g;
+}
+
+int sfe_remap_u8(sfe_ctx *ctx, sfe_geom *g, const uint8_t *src, uint8_t *dst)
+{
+    if (int rc = sfe_use(ctx))
+        return rc;
+    SFE_ARG(ctx, g && src && dst && g->ctx == ctx);
+    const size_t np = (size_t)g->polar_rows * g->polar_cols, nc = (size_t)g->cart_rows * g->cart_cols;
+    uint8_t *d_src = (uint8_t *)sfe_scratch(ctx, 0, np);
+    uint8_t *d_dst = (uint8_t *)sfe_scratch(ctx, 3, nc);
+    if (!d_src || !d_dst)
+        return SFE_ERR_HIP;
+    SFE_HIP(ctx, hipMemcpyAsync(d_src, src, np, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(remap_u8_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, ctx->stream, d_src,
+                       (const uint32_t *)g->d_code, d_dst, g->polar_rows, g->polar_cols, (long long)nc, 1);
+    SFE_LAUNCH_CHECK(ctx);
+    SFE_HIP(ctx, hipMemcpyAsync(dst, d_dst, nc, hipMemcpyDeviceToHost, ctx->stream));
+    SFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int sfe_extract_points_batch_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_frames, int64_t cap,
+                                 double *d_pts, int32_t *d_counts)
+{
+    if (int rc = sfe_use(ctx))
+        return rc;
+    SFE_ARG(ctx, g && d_mask && d_counts && g->ctx == ctx && n_frames >= 0 && cap >= 0);
+    if (n_frames == 0)
+        return 0;
+    return extract_dev(ctx, g, d_mask, n_frames, cap, nullptr, d_pts, d_counts);
+}
+
+int sfe_extract_points(sfe_ctx *ctx, sfe_geom *g, const uint8_t *mask, int64_t cap, int64_t *rc_out,
+                       double *pts_out, int64_t *n_out)
+{
+    if (int rc = sfe_use(ctx))
+        return rc;
+    SFE_ARG(ctx, g && mask && n_out && g->ctx == ctx && cap >= 0);
+    const size_t np = (size_t)g->polar_rows * g->polar_cols;
+    uint8_t *d_mask = (uint8_t *)sfe_scratch(ctx, 1, np);
+    int32_t *d_count = (int32_t *)sfe_scratch(ctx, 7, 64);
+    long long *d_rc = rc_out ? (long long *)sfe_scratch(ctx, 8, (size_t)std::max<int64_t>(cap, 1) * 16) : nullptr;
+    double *d_pts = pts_out ? (double *)sfe_scratch(ctx, 9, (size_t)std::max<int64_t>(cap, 1) * 16) : nullptr;
+    if (!d_mask || !d_count || (rc_out && !d_rc) || (pts_out && !d_pts))
+        return SFE_ERR_HIP;
+    SFE_HIP(ctx, hipMemcpyAsync(d_mask, mask, np, hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = extract_dev(ctx, g, d_mask, 1, cap, d_rc, d_pts, d_count))
+        return rc;
+    int32_t n = 0;
+    SFE_HIP(ctx, hipMemcpyAsync(&n, d_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+    SFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *n_out = n;
+    const size_t m = (size_t)std::min<int64_t>(n, cap);
+    if (m && rc_out)
+        SFE_HIP(ctx, hipMemcpyAsync(rc_out, d_rc, m * 16, hipMemcpyDeviceToHost, ctx->stream));
+    if (m && pts_out)
+        SFE_HIP(ctx, hipMemcpyAsync(pts_out, d_pts, m * 16, hipMemcpyDeviceToHost, ctx->stream));
+    SFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (n > cap)
+        return sfe_set_err(ctx, SFE_ERR_CAP, "extract_points: %d points exceed capacity %lld", n, (long long)cap);
+    return 0;
+}
+
+} // extern "C"

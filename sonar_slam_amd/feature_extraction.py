@@ -1,0 +1,225 @@
+"""ROS-free core of the reference's feature-extraction node.
+
+Mirror of ``bruce_slam.feature_extraction.FeatureExtraction``
+(bruce_slam/src/bruce_slam/feature_extraction.py:27-252): same attribute names, same
+``configure()`` / ``generate_map_xy(ping)`` / ``callback(ping)`` flow, same YAML keys
+(bruce_slam/config/feature.yaml), but every per-pixel stage runs on the GPU:
+
+    CFAR.detect + intensity gate      feature_extraction.py:223-224  -> sfe_cfar_u8 (fused)
+    cv2.remap(peaks) + np.nonzero     feature_extraction.py:231-232  -> sfe_extract_points
+    pixel -> metres                   feature_extraction.py:235-238  ->   "      (same launch)
+    cv2.remap(img) for the vis image  feature_extraction.py:226      -> sfe_remap_u8
+    pcl.downsample / remove_outlier   feature_extraction.py:241-249  -> sonar_slam_amd.pcl
+
+The rospy plumbing (subscriber, PointCloud2 publisher, cv_bridge) is NOT reproduced here: a
+rospy node wraps this class by forwarding ``sonar_msg`` to ``callback`` and publishing the
+returned points (INTEGRATION.md shows the 10-line wrapper).  ``ping`` is any object with the
+OculusPing fields the reference reads: ``ping_id``, ``bearings`` (1/100 deg), ``range_resolution``,
+``num_ranges`` and the decoded uint8 image as ``image`` (rows = range bins, cols = beams).
+"""
+import ctypes as _C
+
+import numpy as np
+import yaml
+from scipy.interpolate import interp1d
+
+from . import _lib as _L
+from . import pcl
+from .CFAR import CFAR
+
+
+class SonarPing(object):
+    """Minimal stand-in for sonar_oculus/OculusPing(Uncompressed) (last row)."""
+
+    def __init__(self, image, bearings, range_resolution, ping_id=0, stamp=None):
+        self.image = np.ascontiguousarray(image, np.uint8)
+        self.bearings = np.asarray(bearings)
+        self.range_resolution = float(range_resolution)
+        self.num_ranges = int(self.image.shape[0])
+        self.ping_id = int(ping_id)
+        self.stamp = stamp
+
+
+def oculus_bearings(n_beams, aperture_deg=130.0):
+    """Evenly spaced beam bearings in 1/100 degree, int16 like OculusPing.bearings."""
+    half = aperture_deg * 50.0
+    return np.round(np.linspace(-half, half, n_beams)).astype(np.int16)
+
+
+class Geometry(object):
+    """Device-side polar->Cartesian geometry (``sfe_geom``) built from the float maps."""
+
+    def __init__(self, ctx, map_x, map_y, polar_shape, width, height):
+        self.ctx = ctx
+        self.map_x = np.ascontiguousarray(map_x, np.float32)
+        self.map_y = np.ascontiguousarray(map_y, np.float32)
+        self.cart_rows, self.cart_cols = self.map_x.shape
+        self.polar_rows, self.polar_cols = polar_shape
+        self.width, self.height = float(width), float(height)
+        h = _C.c_void_p()
+        with ctx.lock:
+            ctx._check(ctx.lib.sfe_geom_create(
+                ctx.handle, _L.ptr(self.map_x, _C.c_float), _L.ptr(self.map_y, _C.c_float),
+                self.cart_rows, self.cart_cols, self.polar_rows, self.polar_cols, self.width,
+                self.height, _C.byref(h)))
+        self.handle = h
+
+    def remap(self, img):
+        """cv2.remap(img, map_x, map_y, cv2.INTER_LINEAR) for a uint8 polar image."""
+        img = np.ascontiguousarray(img, np.uint8)
+        if img.shape != (self.polar_rows, self.polar_cols):
+            raise ValueError("remap: image shape %r does not match the geometry" % (img.shape,))
+        dst = np.zeros((self.cart_rows, self.cart_cols), np.uint8)
+        with self.ctx.lock:
+            self.ctx._check(self.ctx.lib.sfe_remap_u8(self.ctx.handle, self.handle,
+                                                      _L.ptr(img, _C.c_uint8), _L.ptr(dst, _C.c_uint8)))
+        return dst
+
+    def extract(self, mask, cap=None):
+        """remap(mask) -> nonzero -> px->m.  Returns (locs int64 [N x 2] = (row, col) row-major,
+        points float64 [N x 2] = (y_forward, x_lateral) metres)."""
+        mask = np.ascontiguousarray(mask, np.uint8)
+        if mask.shape != (self.polar_rows, self.polar_cols):
+            raise ValueError("extract: mask shape %r does not match the geometry" % (mask.shape,))
+        cap = int(cap) if cap is not None else 1 << 16
+        while True:
+            rc = np.zeros((cap, 2), np.int64)
+            pts = np.zeros((cap, 2), np.float64)
+            n = _C.c_int64(0)
+            with self.ctx.lock:
+                ret = self.ctx.lib.sfe_extract_points(self.ctx.handle, self.handle,
+                                                      _L.ptr(mask, _C.c_uint8), cap,
+                                                      _L.ptr(rc, _C.c_int64), _L.ptr(pts, _C.c_double),
+                                                      _C.byref(n))
+            if ret == _L.SFE_ERR_CAP:
+                cap = int(n.value)
+                continue
+            self.ctx._check(ret)
+            return rc[:n.value].copy(), pts[:n.value].copy()
+
+    def close(self):
+        if self.handle is not None:
+            self.ctx.lib.sfe_geom_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def build_maps(bearings, range_resolution, num_ranges):
+    """The body of FeatureExtraction.generate_map_xy (feature_extraction.py:141-173), host side
+    like the reference (numpy float64 math -> float32 maps, scipy interp1d for bearing->column).
+    Returns (res, height, rows, width, cols, map_x, map_y)."""
+    to_rad = lambda bearing: bearing * np.pi / 18000
+    res = range_resolution
+    height = num_ranges * res
+    rows = num_ranges
+    width = np.sin(to_rad(bearings[-1] - bearings[0]) / 2) * height * 2
+    cols = int(np.ceil(width / res))
+
+    rad = to_rad(np.asarray(bearings, dtype=np.float32))
+    col_of_bearing = interp1d(rad, range(len(rad)), kind="linear", bounds_error=False,
+                              fill_value=-1, assume_sorted=True)
+    yy = np.arange(rows).reshape(-1, 1)
+    xx = np.arange(cols).reshape(1, -1)
+    x = res * (rows - yy) + np.zeros_like(xx)           # forward distance of the pixel row
+    y = res * (-cols / 2.0 + xx + 0.5) + np.zeros_like(yy)  # lateral offset of the pixel column
+    b = np.arctan2(y, x) * 1
+    r = np.sqrt(np.square(x) + np.square(y))
+    map_y = np.asarray(r / res, dtype=np.float32)
+    map_x = np.asarray(col_of_bearing(b), dtype=np.float32)
+    return res, height, rows, width, cols, map_x, map_y
+
+
+class FeatureExtraction(object):
+    """Sonar image -> in-plane feature cloud, on the GPU."""
+
+    def __init__(self, ctx=None):
+        self.ctx = ctx
+        # CFAR defaults (feature_extraction.py:37-45)
+        self.Ntc, self.Ngc, self.Pfa, self.rank = 40, 10, 1e-2, None
+        self.alg = "SOCA"
+        self.detector = None
+        self.threshold = 0
+        # point-cloud defaults (feature_extraction.py:47-53)
+        self.resolution = 0.5
+        self.outlier_filter_radius = 1.0
+        self.outlier_filter_min_points = 5
+        self.skip = 5
+        # polar -> Cartesian state (feature_extraction.py:58-70)
+        self.res = self.height = self.rows = self.width = self.cols = None
+        self.map_x = self.map_y = None
+        self.geometry = None
+        self.feature_img = None
+        self.make_vis_image = False
+
+    # ---- configuration: the rosparam keys of init_node (feature_extraction.py:83-110) ----
+    def load_yaml(self, path):
+        with open(path, "r") as fh:
+            cfg = yaml.safe_load(fh)
+        self.Ntc = cfg["CFAR"]["Ntc"]
+        self.Ngc = cfg["CFAR"]["Ngc"]
+        self.Pfa = cfg["CFAR"]["Pfa"]
+        self.rank = cfg["CFAR"]["rank"]
+        self.alg = cfg["CFAR"].get("alg", "SOCA")
+        self.threshold = cfg["filter"]["threshold"]
+        self.resolution = cfg["filter"]["resolution"]
+        self.outlier_filter_radius = cfg["filter"]["radius"]
+        self.outlier_filter_min_points = cfg["filter"]["min_points"]
+        self.skip = cfg["filter"]["skip"]
+        self.configure()
+
+    def configure(self):
+        self.detector = CFAR(self.Ntc, self.Ngc, self.Pfa, self.rank)
+
+    def _context(self):
+        if self.ctx is None:
+            self.ctx = _L.default_context()
+        return self.ctx
+
+    def generate_map_xy(self, ping):
+        """feature_extraction.py:134-173; cached until the ping geometry changes (:150-151)."""
+        res = ping.range_resolution
+        height = ping.num_ranges * res
+        rows = ping.num_ranges
+        width = np.sin((ping.bearings[-1] - ping.bearings[0]) * np.pi / 18000 / 2) * height * 2
+        cols = int(np.ceil(width / res))
+        if (self.res, self.height, self.rows, self.width, self.cols) == (res, height, rows, width, cols):
+            return
+        (self.res, self.height, self.rows, self.width, self.cols,
+         self.map_x, self.map_y) = build_maps(ping.bearings, res, rows)
+        if self.geometry is not None:
+            self.geometry.close()
+        self.geometry = Geometry(self._context(), self.map_x, self.map_y,
+                                 (rows, len(ping.bearings)), self.width, self.height)
+
+    # ---- stages, exposed separately for tests and for resident pipelines ----
+    def detect(self, img):
+        """peaks = detector.detect(img, alg); peaks &= img > threshold  (:223-224)."""
+        return self.detector.detect_gated(img, self.alg, self.threshold)
+
+    def extract(self, peaks):
+        """peaks -> (locs, points) (:231-238)."""
+        return self.geometry.extract(peaks)
+
+    def callback(self, ping):
+        """feature_extraction.py:196-252 without the ROS publishers.  Returns the N x 2 float
+        feature cloud (y_forward, x_lateral); skipped frames return [[nan, nan]] (:201-207)."""
+        if ping.ping_id % self.skip != 0:
+            self.feature_img = None
+            return np.array([[np.nan, np.nan]])
+        img = ping.image
+        self.generate_map_xy(ping)
+        peaks = self.detect(img)
+        if self.make_vis_image:
+            self.feature_img = self.geometry.remap(img)  # :226 (colour map is applied by the node)
+        _, points = self.extract(peaks)
+        if len(points) and self.resolution > 0:
+            points = pcl.downsample(points, self.resolution)  # :241-242
+        if self.outlier_filter_min_points > 1 and len(points) > 0:
+            points = pcl.remove_outlier(points, self.outlier_filter_radius,
+                                        self.outlier_filter_min_points)  # :245-249
+        return points

@@ -1,0 +1,143 @@
+"""Drop-in for the reference's pybind11 module ``bruce_slam.pcl``.
+
+Same names and call signatures as ``PYBIND11_MODULE(pcl, m)``
+(bruce_slam/src/bruce_slam/cpp/pcl.cpp:176-214), backed by the HIP kernels of libsonarfe.so:
+
+    match(ref, in, knn, max_dist) -> (ids int32 [knn x N], dists float32 [knn x N])  pcl.cpp:161
+    remove_outlier(points, radius, min_points) -> points'                           pcl.cpp:54
+    class ICP: loadFromYaml(path), compute(source, target, guess) -> (message, T),
+               getCovariance()                                                      pcl.cpp:184-213
+    downsample / density_filter: see NotImplementedError text
+
+Extension (not in the reference): ``ICP.compute_batch(source, target, guesses)`` runs the
+many-guesses-one-pair loop of SLAM.compute_icp_with_cov (slam.py:346-358) in one launch.
+"""
+import ctypes as _C
+
+import numpy as _np
+
+from . import _lib as _L
+from . import icp_config as _cfg
+
+
+def _cloud(a, name):
+    a = _np.ascontiguousarray(a, _np.float32)
+    if a.ndim != 2 or a.shape[1] not in (2, 3):
+        raise TypeError("%s: expected an N x 2 array, got shape %r" % (name, a.shape))
+    if a.shape[1] == 3:
+        raise NotImplementedError(
+            "%s: N x 3 clouds (3-D ICP) are outside the sonar front-end path; the SLAM node only "
+            "passes N x 2 in-plane points (slam.py:309-310)" % name)
+    return a
+
+
+def match(ref, pts, knn, max_dist, ctx=None):
+    """KDTreeMatcher replacement (pcl.cpp:161-174): exact NN, squared distances, -1 / inf beyond
+    max_dist, ties resolved to the lowest reference index."""
+    if int(knn) != 1:
+        raise NotImplementedError("pcl.match: only knn=1 is used by the SLAM path (slam.py:418)")
+    ctx = ctx or _L.default_context()
+    ref = _cloud(ref, "match(ref)")
+    pts = _cloud(pts, "match(in)")
+    ids = _np.full(len(pts), -1, _np.int32)
+    d2 = _np.full(len(pts), _np.inf, _np.float32)
+    if len(pts):
+        with ctx.lock:
+            ctx._check(ctx.lib.sfe_match(ctx.handle, _L.ptr(ref, _C.c_float), len(ref),
+                                         _L.ptr(pts, _C.c_float), len(pts), float(max_dist),
+                                         _L.ptr(ids, _C.c_int32), _L.ptr(d2, _C.c_float)))
+    return ids[None, :], d2[None, :]
+
+
+def remove_outlier(points, radius, min_points, ctx=None):
+    """PCL RadiusOutlierRemoval replacement (pcl.cpp:54-74)."""
+    ctx = ctx or _L.default_context()
+    pts = _cloud(points, "remove_outlier(points)")
+    out = _np.zeros_like(pts)
+    n = _C.c_int(0)
+    if len(pts):
+        with ctx.lock:
+            ctx._check(ctx.lib.sfe_remove_outlier(ctx.handle, _L.ptr(pts, _C.c_float), len(pts),
+                                                  float(radius), int(min_points),
+                                                  _L.ptr(out, _C.c_float), _C.byref(n)))
+    return out[:n.value].copy()
+
+
+def downsample(*args):
+    raise NotImplementedError(
+        "pcl.downsample (libpointmatcher OctreeGridDataPointsFilter, pcl.cpp:128-159) is the next "
+        "row of the scope table (SURVEY 8 f1) and is not built yet; no CPU stand-in is shipped")
+
+
+def density_filter(*args):
+    raise NotImplementedError(
+        "pcl.density_filter (pcl.cpp:76-126) has no caller in the reference and is not built")
+
+
+class ICP(object):
+    """``pcl.ICP`` (PM::ICP bound at pcl.cpp:184-213)."""
+
+    def __init__(self, ctx=None):
+        self._ctx = ctx
+        # PM::ICP() starts without a chain; the SLAM node always calls loadFromYaml next
+        self.params = _cfg.shipped_params()
+        self._configured = False
+
+    def loadFromYaml(self, filename):
+        try:
+            with open(filename, "r") as fh:
+                text = fh.read()
+        except (IOError, OSError):
+            # pcl.cpp:190-194
+            print("Failed to load %s. Use default configuration." % filename)
+            self.params = _cfg.default_params()
+            self._configured = True
+            return
+        self.params = _cfg.parse_icp_yaml(text)
+        self._configured = True
+
+    def setParams(self, params):
+        """Extension: install an ``IcpParams`` directly."""
+        self.params = params
+        self._configured = True
+
+    @staticmethod
+    def _guess(guess):
+        g = _np.asarray(guess, _np.float32)
+        if g.shape == (4, 4):
+            raise NotImplementedError("4 x 4 guesses (3-D ICP) are outside the sonar front-end path")
+        if g.shape != (3, 3):
+            raise TypeError("ICP.compute: guess must be 3 x 3, got %r" % (g.shape,))
+        return _np.ascontiguousarray(g)
+
+    def compute(self, source, target, guess):
+        """-> (message, T): ("success", T 3x3 float32) or (ConvergenceError text, guess)."""
+        msgs, Ts, _ = self.compute_batch(source, target, [guess])
+        return msgs[0], Ts[0]
+
+    def compute_batch(self, source, target, guesses):
+        """Many initial guesses on one cloud pair in one launch.
+        -> (messages [n], T [n x 3 x 3] float32, iterations [n])"""
+        ctx = self._ctx or _L.default_context()
+        src = _cloud(source, "ICP.compute(source)")
+        tgt = _cloud(target, "ICP.compute(target)")
+        g = _np.ascontiguousarray(_np.stack([self._guess(x) for x in guesses]), _np.float32)
+        n = len(g)
+        if len(src) == 0 or len(tgt) == 0:
+            raise RuntimeError("ICP.compute: empty point cloud (libpointmatcher would throw)")
+        T = _np.zeros((n, 3, 3), _np.float32)
+        st = _np.zeros(n, _np.int32)
+        it = _np.zeros(n, _np.int32)
+        with ctx.lock:
+            ctx._check(ctx.lib.sfe_icp_compute_guesses(
+                ctx.handle, _C.byref(self.params), _L.ptr(src, _C.c_float), len(src),
+                _L.ptr(tgt, _C.c_float), len(tgt), _L.ptr(g, _C.c_float), n, _L.ptr(T, _C.c_float),
+                _L.ptr(st, _C.c_int32), _L.ptr(it, _C.c_int32)))
+        msgs = [_L.ICP_STATUS_MESSAGES.get(int(s), "ICP failure %d" % s) for s in st]
+        return msgs, T, it
+
+    def getCovariance(self):
+        """errorMinimizer->getCovariance() (pcl.cpp:213).  libpointmatcher's base ErrorMinimizer
+        returns a zero dim x dim matrix unless the point-to-plane minimiser estimated one; no
+        caller in the reference reads it (grep).  Returned: 3 x 3 zeros."""
+        return _np.zeros((3, 3), _np.float32)

@@ -1,0 +1,112 @@
+"""Device-resident batched front end: B keyframes per step, everything stays in HBM.
+
+One keyframe job = one sonar ping through CFAR+gate -> polar->Cartesian extraction -> feature
+cloud (feature_extraction.py:223-238), plus one scan-match of a (source, target, guess) cloud
+triple (slam.py:294-323 -> pcl.ICP.compute).  Inputs are uploaded once; ``run()`` only enqueues
+kernels on the context's stream (no host round trip between the stages) and ``results()``
+downloads the small per-job outputs.  This is the unit bench.py times and the farm shards.
+"""
+import ctypes as _C
+
+import numpy as np
+
+from . import _lib as _L
+
+
+class KeyframeBatch(object):
+    def __init__(self, ctx, geometry, cfar_params, alg, intensity_thr, icp_params, n_jobs,
+                 max_points=16384):
+        self.ctx, self.geom = ctx, geometry
+        self.alg = _L.ALG[alg]
+        if alg == "OS":
+            self.train_hs, self.guard_hs, self.k, self.tau = cfar_params
+        else:
+            self.train_hs, self.guard_hs, self.tau = cfar_params
+            self.k = 0
+        self.intensity_thr = int(intensity_thr)
+        self.icp_params = icp_params
+        self.n = int(n_jobs)
+        self.rows, self.cols = geometry.polar_rows, geometry.polar_cols
+        self.cap = int(max_points)
+        fb = self.n * self.rows * self.cols
+        self.d_img = ctx.alloc(fb)
+        self.d_mask = ctx.alloc(fb)
+        self.d_pts = ctx.alloc(self.n * self.cap * 16)
+        self.d_cnt = ctx.alloc(self.n * 4)
+        self.d_src = self.d_tgt = self.d_guess = None
+        self.d_T = ctx.alloc(self.n * 36)
+        self.d_status = ctx.alloc(self.n * 4)
+        self.d_iters = ctx.alloc(self.n * 4)
+        self.src_off = self.tgt_off = None
+
+    def upload_frames(self, frames):
+        frames = np.ascontiguousarray(frames, np.uint8)
+        assert frames.shape == (self.n, self.rows, self.cols)
+        self.d_img.upload(frames)
+
+    def upload_scan_pairs(self, sources, targets, guesses):
+        """sources/targets: lists of N_i x 2 float32 clouds; guesses: n x 3 x 3."""
+        assert len(sources) == len(targets) == len(guesses) == self.n
+        so = np.zeros(self.n + 1, np.int32)
+        to = np.zeros(self.n + 1, np.int32)
+        so[1:] = np.cumsum([len(s) for s in sources])
+        to[1:] = np.cumsum([len(t) for t in targets])
+        src = np.ascontiguousarray(np.concatenate(sources), np.float32)
+        tgt = np.ascontiguousarray(np.concatenate(targets), np.float32)
+        g = np.ascontiguousarray(np.asarray(guesses, np.float32).reshape(self.n, 9))
+        self.d_src, self.d_tgt, self.d_guess = (self.ctx.alloc(src.nbytes), self.ctx.alloc(tgt.nbytes),
+                                                self.ctx.alloc(g.nbytes))
+        self.d_src.upload(src)
+        self.d_tgt.upload(tgt)
+        self.d_guess.upload(g)
+        self.src_off, self.tgt_off = so, to
+        self.pair_evals_per_iter = int(sum(len(s) * len(t) for s, t in zip(sources, targets)))
+
+    # ---- stages (enqueue only) ----
+    def run_cfar(self):
+        c = self.ctx
+        c._check(c.lib.sfe_cfar_u8_batch_dev(c.handle, self.d_img.ptr, self.n, self.rows, self.cols, self.alg,
+                                             self.train_hs, self.guard_hs, self.k, float(self.tau),
+                                             self.intensity_thr, self.d_mask.ptr, None))
+
+    def run_extract(self):
+        c = self.ctx
+        c._check(c.lib.sfe_extract_points_batch_dev(c.handle, self.geom.handle, self.d_mask.ptr, self.n,
+                                                    self.cap, self.d_pts.ptr, self.d_cnt.ptr))
+
+    def run_icp(self):
+        c = self.ctx
+        c._check(c.lib.sfe_icp_batch_dev(c.handle, _C.byref(self.icp_params), self.d_src.ptr,
+                                         _L.ptr(self.src_off, _C.c_int32), self.d_tgt.ptr,
+                                         _L.ptr(self.tgt_off, _C.c_int32), self.d_guess.ptr, self.n,
+                                         self.d_T.ptr, self.d_status.ptr, self.d_iters.ptr))
+
+    def run(self):
+        """One step: all stages of all n keyframes, enqueued back to back on the stream."""
+        self.run_cfar()
+        self.run_extract()
+        self.run_icp()
+
+    def results(self):
+        self.ctx.sync()
+        return {
+            "counts": self.d_cnt.download(np.int32, self.n),
+            "T": self.d_T.download(np.float32, self.n * 9).reshape(self.n, 3, 3),
+            "status": self.d_status.download(np.int32, self.n),
+            "iters": self.d_iters.download(np.int32, self.n),
+        }
+
+    def points(self, j):
+        n = int(self.d_cnt.download(np.int32, 1, offset=4 * j)[0])
+        m = min(n, self.cap)
+        return self.d_pts.download(np.float64, 2 * m, offset=j * self.cap * 16).reshape(m, 2)
+
+    def mask(self, j):
+        sz = self.rows * self.cols
+        return self.d_mask.download(np.uint8, sz, offset=j * sz).reshape(self.rows, self.cols)
+
+    def free(self):
+        for b in (self.d_img, self.d_mask, self.d_pts, self.d_cnt, self.d_src, self.d_tgt, self.d_guess,
+                  self.d_T, self.d_status, self.d_iters):
+            if b is not None:
+                b.free()

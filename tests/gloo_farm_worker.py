@@ -1,0 +1,32 @@
+"""Helper of test_host.test_two_rank_gloo_farm: one rank of a 2-process gloo job farm."""
+import os
+import sys
+
+import numpy as np
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import oracle  # noqa: E402  (tests may use the oracle as the compute stand-in)
+from sonar_slam_amd import farm, synth  # noqa: E402
+
+
+def job(j):
+    src, tgt, guess, _ = synth.scan_pair(seed=j, n_src=200, n_tgt=200)
+    st, T, it = oracle.icp(src, tgt, guess)
+    return (st, T.tobytes(), it)
+
+
+def main():
+    dist.init_process_group("gloo")
+    n_jobs = 7
+    res = farm.run_sharded(job, n_jobs)
+    serial = [job(j) for j in range(n_jobs)]
+    assert res == serial, "sharded results differ from serial ones"
+    assert len(farm.shard(n_jobs, dist.get_rank(), dist.get_world_size())) in (3, 4)
+    dist.barrier()
+    dist.destroy_process_group()
+    print("FARM_OK rank", os.environ["RANK"])
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,127 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures in this directory FROM THE REFERENCE's own Python code.
+
+Run in the build container (needs /root/reference; the GPU box does not have it):
+
+    python tests/golden/make_golden.py
+
+The reference modules cannot be imported as a package here (rospy, cv2, gtsam and the compiled
+``cfar`` module are absent), so the two pieces of pure-Python reference logic on the hot path
+are executed straight from the reference sources:
+
+  * ``bruce_slam/src/bruce_slam/CFAR.py`` is exec'd with its three package-relative imports
+    removed and a stub ``cfar`` module -> the threshold factors tau of CFAR.__init__
+    (CFAR.py:17-52,71-121) for several (Ntc, Ngc, Pfa, rank) -> ``cfar_tau.json``
+  * ``FeatureExtraction.generate_map_xy`` (feature_extraction.py:134-173) is cut out of the
+    class by AST and run on synthetic pings -> ``maps_small.npz`` (full float32 maps of a small
+    geometry) and ``maps_digest.json`` (sha256 + samples of the 512x1024 and 1024x2048 ones)
+
+Nothing of the reference is copied into the repository: only the numbers it produces.
+"""
+import ast
+import hashlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = "/root/reference/bruce_slam/src/bruce_slam"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def reference_cfar_class():
+    src = open(os.path.join(REF, "CFAR.py")).read()
+    keep = [ln for ln in src.splitlines()
+            if not ln.startswith(("from .utils", "from .sonar", "from . import cfar"))]
+    stub = types.SimpleNamespace(**{n: None for n in
+                                    ("ca", "soca", "goca", "os", "ca2", "soca2", "goca2", "os2")})
+    ns = {"cfar": stub}
+    exec(compile("\n".join(keep), "reference:CFAR.py", "exec"), ns)
+    return ns["CFAR"]
+
+
+def reference_generate_map_xy():
+    src = open(os.path.join(REF, "feature_extraction.py")).read()
+    tree = ast.parse(src)
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef) and node.name == "generate_map_xy":
+            fn_src = ast.get_source_segment(src, node)
+            break
+    else:
+        raise RuntimeError("generate_map_xy not found")
+    import textwrap
+    from scipy.interpolate import interp1d
+    ns = {"np": np, "interp1d": interp1d}
+    exec(compile(textwrap.dedent(fn_src), "reference:feature_extraction.py", "exec"), ns)
+    return ns["generate_map_xy"]
+
+
+class _Self(object):
+    """The attributes generate_map_xy reads (feature_extraction.py:58-70)."""
+
+    def __init__(self):
+        self.res = self.height = self.rows = self.width = self.cols = None
+        self.map_x = self.map_y = None
+        self.to_rad = lambda bearing: bearing * np.pi / 18000
+        self.REVERSE_Z = 1
+
+
+class _Ping(object):
+    def __init__(self, bearings, res, num_ranges):
+        self.bearings = [int(b) for b in bearings]  # ROS delivers a tuple of ints
+        self.range_resolution = res
+        self.num_ranges = num_ranges
+
+
+def bearings_for(n, aperture_deg=130.0):
+    half = aperture_deg * 50.0
+    return np.round(np.linspace(-half, half, n)).astype(np.int16)
+
+
+def main():
+    if not os.path.isdir(REF):
+        sys.exit("reference tree not present; fixtures are committed, nothing to do")
+
+    # ---- tau ----
+    CFAR = reference_cfar_class()
+    taus = []
+    for Ntc, Ngc, Pfa, rank in [(40, 10, 0.1, 10), (40, 10, 1e-2, 20), (20, 4, 0.05, 5),
+                                (32, 8, 1e-3, 16), (16, 2, 0.2, 3)]:
+        c = CFAR(Ntc, Ngc, Pfa, rank)
+        taus.append({"Ntc": Ntc, "Ngc": Ngc, "Pfa": Pfa, "rank": rank,
+                     "CA": float(c.threshold_factor_CA), "SOCA": float(c.threshold_factor_SOCA),
+                     "GOCA": float(c.threshold_factor_GOCA), "OS": float(c.threshold_factor_OS),
+                     "params_SOCA": [int(c.params["SOCA"][0]), int(c.params["SOCA"][1])],
+                     "params_OS_rank": c.params["OS"][2]})
+    json.dump(taus, open(os.path.join(HERE, "cfar_tau.json"), "w"), indent=1)
+
+    # ---- maps ----
+    gen = reference_generate_map_xy()
+    s = _Self()
+    small = _Ping(bearings_for(64), 0.25, 96)
+    gen(s, small)
+    np.savez_compressed(os.path.join(HERE, "maps_small.npz"), map_x=s.map_x, map_y=s.map_y,
+                        bearings=np.asarray(small.bearings, np.int16), res=small.range_resolution,
+                        num_ranges=small.num_ranges, width=s.width, height=s.height, cols=s.cols)
+    digests = []
+    for nb, nr, res in [(512, 1024, 30.0 / 1024), (1024, 2048, 30.0 / 2048)]:
+        s = _Self()
+        p = _Ping(bearings_for(nb), res, nr)
+        gen(s, p)
+        rng = np.random.default_rng(7)
+        idx = rng.integers(0, s.map_x.size, 64)
+        digests.append({"beams": nb, "ranges": nr, "res": res, "cols": int(s.cols),
+                        "width": float(s.width), "height": float(s.height),
+                        "sha256_map_x": hashlib.sha256(s.map_x.tobytes()).hexdigest(),
+                        "sha256_map_y": hashlib.sha256(s.map_y.tobytes()).hexdigest(),
+                        "sample_idx": idx.tolist(),
+                        "sample_map_x": [float(v) for v in s.map_x.ravel()[idx]],
+                        "sample_map_y": [float(v) for v in s.map_y.ravel()[idx]]})
+    json.dump(digests, open(os.path.join(HERE, "maps_digest.json"), "w"), indent=1)
+    print("wrote cfar_tau.json, maps_small.npz, maps_digest.json")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,56 @@
+"""CPU: host-side mirrors against fixtures generated FROM THE REFERENCE's Python code
+(tests/golden/make_golden.py): CFAR threshold factors and the polar->Cartesian maps."""
+import hashlib
+import json
+import os
+
+import numpy as np
+
+from sonar_slam_amd.CFAR import CFAR
+from sonar_slam_amd.feature_extraction import build_maps, oculus_bearings
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_tau_matches_reference_cfar_py():
+    for t in json.load(open(os.path.join(G, "cfar_tau.json"))):
+        c = CFAR(t["Ntc"], t["Ngc"], t["Pfa"], t["rank"])
+        assert c.threshold_factor_CA == t["CA"]
+        assert c.threshold_factor_SOCA == t["SOCA"]
+        assert c.threshold_factor_GOCA == t["GOCA"]
+        assert c.threshold_factor_OS == t["OS"]
+        assert list(c.params["SOCA"][:2]) == t["params_SOCA"]
+        assert c.params["OS"][2] == t["params_OS_rank"]
+
+
+def test_shipped_tau_values():
+    # SURVEY section 8 header: tau for feature.yaml (Ntc 40, Ngc 10, Pfa 0.1, rank 10)
+    c = CFAR(40, 10, 0.1, 10)
+    assert c.threshold_factor_CA == 2.3701490070915554
+    assert c.threshold_factor_SOCA == 2.749063720096473
+    assert c.threshold_factor_GOCA == 2.121926842646487
+    assert c.threshold_factor_OS == 9.137608674642355
+
+
+def test_maps_small_bit_exact():
+    g = np.load(os.path.join(G, "maps_small.npz"))
+    res, height, rows, width, cols, mx, my = build_maps(g["bearings"], float(g["res"]), int(g["num_ranges"]))
+    assert cols == int(g["cols"]) and width == float(g["width"]) and height == float(g["height"])
+    assert mx.dtype == np.float32 and np.array_equal(mx, g["map_x"])
+    assert my.dtype == np.float32 and np.array_equal(my, g["map_y"])
+
+
+def test_maps_full_size_digest():
+    for d in json.load(open(os.path.join(G, "maps_digest.json"))):
+        res, height, rows, width, cols, mx, my = build_maps(oculus_bearings(d["beams"]), d["res"], d["ranges"])
+        assert cols == d["cols"] and width == d["width"] and height == d["height"]
+        assert hashlib.sha256(mx.tobytes()).hexdigest() == d["sha256_map_x"]
+        assert hashlib.sha256(my.tobytes()).hexdigest() == d["sha256_map_y"]
+        idx = np.asarray(d["sample_idx"])
+        assert np.array_equal(mx.ravel()[idx], np.asarray(d["sample_map_x"], np.float32))
+
+
+def test_canvas_sizes_of_the_survey():
+    # 130 deg fan -> 1857 (A) / 3713 (B) Cartesian columns
+    for d in json.load(open(os.path.join(G, "maps_digest.json"))):
+        assert d["cols"] == {1024: 1857, 2048: 3713}[d["ranges"]]

@@ -1,0 +1,128 @@
+"""GPU parity: CFAR through the C ABI (sonar_slam_amd.cfar shim) vs the CPU oracle, bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle
+from sonar_slam_amd import _lib, cfar, synth
+
+pytestmark = pytest.mark.gpu
+
+ALGS = ["CA", "SOCA", "GOCA", "OS"]
+FN = {"CA": cfar.ca, "SOCA": cfar.soca, "GOCA": cfar.goca, "OS": cfar.os}
+FN2 = {"CA": cfar.ca2, "SOCA": cfar.soca2, "GOCA": cfar.goca2, "OS": cfar.os2}
+
+
+def _args(shipped_cfar, alg):
+    return shipped_cfar.params[alg]
+
+
+def _oracle(img, alg, p, thr=False):
+    k = p[2] if alg == "OS" else 0
+    return oracle.cfar(img, alg, p[0], p[1], p[-1], k=k, want_threshold=thr)
+
+
+@pytest.mark.parametrize("alg", ALGS)
+@pytest.mark.parametrize("shape", [(1024, 512), (300, 256), (130, 260), (120, 37), (60, 512), (51, 8),
+                                   (50, 8), (7, 5), (1, 1)])
+def test_mask_bit_exact_random(alg, shape, shipped_cfar):
+    rng = np.random.default_rng(abs(hash((alg, shape))) % 2**32)
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    p = _args(shipped_cfar, alg)
+    got = FN[alg](img, *p)
+    assert got.dtype == np.uint8 and got.shape == img.shape
+    assert np.array_equal(got, _oracle(img, alg, p))
+
+
+@pytest.mark.parametrize("alg", ["CA", "SOCA", "GOCA"])
+def test_ring_and_generic_kernels_agree_with_oracle(alg, shipped_cfar, ctx):
+    img = synth.sonar_frame(seed=11)
+    p = _args(shipped_cfar, alg)
+    want = _oracle(img, alg, p)
+    try:
+        for variant, tile in [(1, 0), (2, 0), (2, 52), (2, 208), (2, 1024), (3, 0), (3, 156)]:
+            ctx._check(ctx.lib.sfe_cfar_set_tuning(ctx.handle, tile, variant))
+            assert np.array_equal(FN[alg](img, *p), want), (variant, tile)
+    finally:
+        ctx._check(ctx.lib.sfe_cfar_set_tuning(ctx.handle, 0, 0))
+
+
+def test_structured_frames_and_extremes(shipped_cfar):
+    p = _args(shipped_cfar, "SOCA")
+    frames = [synth.sonar_frame(seed=s) for s in range(3)]
+    frames += [np.zeros((1024, 512), np.uint8), np.full((1024, 512), 255, np.uint8)]
+    step = np.full((1024, 512), 12, np.uint8)
+    step[500:] = 240                      # step exactly across guard/train boundaries
+    step[300:306] = 255
+    frames.append(step)
+    for img in frames:
+        assert np.array_equal(cfar.soca(img, *p), _oracle(img, "SOCA", p))
+
+
+@pytest.mark.parametrize("alg", ALGS)
+def test_threshold_maps(alg, shipped_cfar):
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (200, 64), dtype=np.uint8)
+    p = _args(shipped_cfar, alg)
+    m, t = FN2[alg](img, *p)
+    mo, to = _oracle(img, alg, p, thr=True)
+    assert np.array_equal(m, mo)
+    assert t.dtype == np.float32 and np.array_equal(t, to)
+
+
+@pytest.mark.parametrize("alg", ALGS)
+def test_other_windows_and_taus(alg):
+    rng = np.random.default_rng(17)
+    img = rng.integers(0, 256, (150, 96), dtype=np.uint8)
+    for th, gh, tau, k in [(3, 0, 1.3, 2), (8, 2, 0.9, 5), (20, 5, 2.7490637, 39), (30, 1, 4.0, 0)]:
+        p = (th, gh, k, tau) if alg == "OS" else (th, gh, tau)
+        assert np.array_equal(FN[alg](img, *p), oracle.cfar(img, alg, th, gh, tau, k=k)), (th, gh)
+
+
+@pytest.mark.parametrize("alg", ALGS)
+def test_float_images_take_the_float_path(alg):
+    rng = np.random.default_rng(23)
+    img = rng.gamma(2.0, 11.3, (140, 50)).astype(np.float32)
+    p = (6, 2, 4, 1.7) if alg == "OS" else (6, 2, 1.7)
+    m, t = FN2[alg](img, *p)
+    mo, to = oracle.cfar(img, alg, 6, 2, 1.7, k=4, want_threshold=True)
+    assert np.array_equal(m, mo) and np.array_equal(t, to)
+    # float64 input is cast to float32 like the pybind Eigen caster does
+    assert np.array_equal(FN[alg](img.astype(np.float64), *p), mo)
+
+
+def test_fused_intensity_gate(shipped_cfar):
+    img = synth.sonar_frame(seed=2)
+    for alg in ALGS:
+        p = _args(shipped_cfar, alg)
+        want = oracle.gate(img, _oracle(img, alg, p), 65)
+        assert np.array_equal(cfar.detect_gated(img, alg, p, 65), want)
+    assert want.sum() > 0
+
+
+def test_os_requires_integer_rank():
+    with pytest.raises(TypeError):
+        cfar.os(np.zeros((60, 4), np.uint8), 20, 5, 20.0, 1.0)
+
+
+def test_batched_device_path_full_size(shipped_cfar, ctx):
+    """BASELINE config sizes, device-resident batch: every frame equals the oracle, and the
+    batch is translation invariant (frame f of a batch == the same frame processed alone)."""
+    n, rows, cols = 6, 1024, 512
+    frames = np.stack([synth.sonar_frame(seed=100 + s) for s in range(n)])
+    th, gh, tau = shipped_cfar.params["SOCA"]
+    d_img, d_mask = ctx.alloc(frames.nbytes), ctx.alloc(frames.nbytes)
+    d_img.upload(frames)
+    ctx._check(ctx.lib.sfe_cfar_u8_batch_dev(ctx.handle, d_img.ptr, n, rows, cols, 1, th, gh, 0, tau, 65,
+                                             d_mask.ptr, None))
+    ctx.sync()
+    got = d_mask.download(np.uint8, frames.size).reshape(frames.shape)
+    for f in range(n):
+        want = oracle.gate(frames[f], oracle.cfar(frames[f], "SOCA", th, gh, tau), 65)
+        assert np.array_equal(got[f], want), f
+    # high-res Oculus config (2048 x 1024)
+    big = synth.sonar_frame(seed=7, rows=2048, cols=1024, n_blobs=120)
+    assert np.array_equal(cfar.soca(big, th, gh, tau), oracle.cfar(big, "SOCA", th, gh, tau))
+    d_img.free()
+    d_mask.free()

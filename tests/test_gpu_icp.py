@@ -1,0 +1,152 @@
+"""GPU parity: pcl.match / pcl.remove_outlier / pcl.ICP through the C ABI vs the CPU oracle.
+
+Tolerances.  Index work (match ids, outlier decisions) is bit-exact.  ICP poses: the HIP path
+accumulates in fp64 and rounds each iteration's transform to float; against the oracle's
+fp64-accumulation mode it must agree to 1e-6 (same discrete decisions, same float transforms up
+to one ulp of a sum); against the oracle's float mode (libpointmatcher's own precision) the bar
+is BASELINE.json's 1e-4 m / 1e-4 rad."""
+import numpy as np
+import pytest
+
+import oracle
+from sonar_slam_amd import icp_config, pcl, synth
+
+pytestmark = pytest.mark.gpu
+
+TOL_TIGHT = 1e-6
+TOL_REF = 1e-4
+
+
+def _pose_diff(Ta, Tb):
+    a, b = synth.pose_of(Ta), synth.pose_of(Tb)
+    return max(abs(a[0] - b[0]), abs(a[1] - b[1]), abs(np.arctan2(np.sin(a[2] - b[2]), np.cos(a[2] - b[2]))))
+
+
+def _icp(params, ctx=None):
+    icp = pcl.ICP(ctx)
+    icp.setParams(params)
+    return icp
+
+
+def test_match_bit_exact():
+    rng = np.random.default_rng(1)
+    ref = rng.uniform(-15, 15, (3000, 2)).astype(np.float32)
+    q = rng.uniform(-16, 16, (2500, 2)).astype(np.float32)
+    for md in (0.5, 3.0, 100.0):
+        ids, d2 = pcl.match(ref, q, 1, md)
+        oi, od = oracle.match(ref, q, md)
+        assert ids.shape == (1, 2500) and ids.dtype == np.int32 and d2.dtype == np.float32
+        assert np.array_equal(ids, oi) and np.array_equal(d2, od)
+    # ties and duplicates -> lowest index; empty query
+    dup = np.array([[1, 0], [-1, 0], [1, 0]], np.float32)
+    assert pcl.match(dup, np.zeros((1, 2), np.float32), 1, 5.0)[0][0, 0] == 0
+    ids, d2 = pcl.match(ref, np.zeros((0, 2), np.float32), 1, 1.0)
+    assert ids.shape == (1, 0)
+
+
+def test_remove_outlier_bit_exact():
+    rng = np.random.default_rng(2)
+    pts = np.r_[rng.normal(0, 0.6, (400, 2)), rng.uniform(-20, 20, (300, 2))].astype(np.float32)
+    for radius, mp in ((1.0, 5), (0.5, 2), (2.0, 40)):
+        assert np.array_equal(pcl.remove_outlier(pts, radius, mp), oracle.remove_outlier(pts, radius, mp))
+    assert pcl.remove_outlier(np.zeros((0, 2), np.float32), 1.0, 5).shape == (0, 2)
+
+
+@pytest.mark.parametrize("seed,n", [(0, 300), (1, 1000), (2, 2500), (3, 5000)])
+def test_icp_reference_chain_point_to_point(seed, n):
+    src, tgt, guess, _ = synth.scan_pair(seed=seed, n_src=n, n_tgt=n - 37)
+    icp = _icp(icp_config.shipped_params())
+    msg, T = icp.compute(src, tgt, guess)
+    assert msg == "success" and T.shape == (3, 3) and T.dtype == np.float32
+    st, Td, itd = oracle.icp(src, tgt, guess, oracle.shipped_icp_params(precision=1))
+    st, Tf, itf = oracle.icp(src, tgt, guess, oracle.shipped_icp_params(precision=0))
+    _, _, it = icp.compute_batch(src, tgt, [guess])
+    assert it[0] == itd
+    assert _pose_diff(T, Td) < TOL_TIGHT
+    assert _pose_diff(T, Tf) < TOL_REF
+
+
+@pytest.mark.parametrize("seed", [4, 5])
+def test_icp_point_to_plane_30_iterations(seed):
+    """BASELINE config 2: fixed 30-iteration 2-D point-to-plane."""
+    src, tgt, guess, truth = synth.scan_pair(seed=seed, n_src=5000, n_tgt=5000)
+    p = icp_config.shipped_params(minimizer=1, use_diff_checker=0, max_iter=30)
+    msgs, T, it = _icp(p).compute_batch(src, tgt, [guess])
+    assert msgs[0] == "success" and it[0] == 30
+    st, To, ito = oracle.icp(src, tgt, guess, oracle.shipped_icp_params(minimizer=1, use_diff_checker=0, max_iter=30))
+    assert st == 0 and ito == 30
+    assert _pose_diff(T[0], To) < TOL_REF
+    assert _pose_diff(T[0], truth) < 0.02
+
+
+def test_normals_and_large_target_streaming():
+    """target larger than the LDS-resident tile (8192 points): streamed tiles must give the
+    same matches; also the 20k-point high-res config shape."""
+    src, tgt, guess, _ = synth.scan_pair(seed=8, n_src=3000, n_tgt=9000)
+    for mz in (0, 1):
+        p = icp_config.shipped_params(minimizer=mz, max_iter=6, use_diff_checker=0)
+        msgs, T, it = _icp(p).compute_batch(src, tgt, [guess])
+        st, To, _ = oracle.icp(src, tgt, guess, oracle.shipped_icp_params(minimizer=mz, max_iter=6, use_diff_checker=0))
+        assert msgs[0] == "success" and st == 0
+        assert _pose_diff(T[0], To) < (TOL_TIGHT if mz == 0 else TOL_REF)
+
+
+def test_many_guesses_one_pair():
+    """the NSSM loop of compute_icp_with_cov (slam.py:346-358) as one launch"""
+    src, tgt, guess, _ = synth.scan_pair(seed=6, n_src=1200, n_tgt=1200)
+    rng = np.random.default_rng(0)
+    base = synth.pose_of(guess)
+    guesses = [synth.pose_matrix(base[0] + dx, base[1] + dy, base[2] + dt).astype(np.float32)
+               for dx, dy, dt in rng.normal(0, [0.3, 0.3, 0.05], (30, 3))]
+    icp = _icp(icp_config.shipped_params())
+    msgs, T, it = icp.compute_batch(src, tgt, guesses)
+    assert len(msgs) == 30
+    for g, m, Tg, i in zip(guesses, msgs, T, it):
+        st, To, ito = oracle.icp(src, tgt, g, oracle.shipped_icp_params(precision=1))
+        assert (m == "success") == (st == 0)
+        assert i == ito
+        assert _pose_diff(Tg, To) < TOL_TIGHT
+    # and the single-call API returns the same thing
+    m0, T0 = icp.compute(src, tgt, guesses[0])
+    assert m0 == msgs[0] and np.array_equal(T0, T[0])
+
+
+def test_failures_return_the_guess():
+    src, tgt, guess, _ = synth.scan_pair(seed=7, n_src=400, n_tgt=400)
+    far = tgt + np.float32(1000.0)
+    msg, T = _icp(icp_config.shipped_params()).compute(src, far, guess)
+    assert msg == "no outlier to filter" and np.array_equal(T, guess)
+    msg, T = _icp(icp_config.shipped_params(use_trimmed_filter=0)).compute(src, far, guess)
+    assert msg == "ErrorMnimizer: no point to minimize" and np.array_equal(T, guess)
+
+
+def test_stop_rules():
+    src, tgt, guess, _ = synth.scan_pair(seed=3, n_src=700, n_tgt=700)
+    _, _, it = _icp(icp_config.shipped_params(use_diff_checker=0, max_iter=7)).compute_batch(src, tgt, [guess])
+    assert it[0] == 7
+    _, _, it = _icp(icp_config.shipped_params()).compute_batch(src, tgt, [guess])
+    _, _, ito = oracle.icp(src, tgt, guess, oracle.shipped_icp_params())
+    assert it[0] == ito and it[0] >= 4
+
+
+def test_loads_shipped_yaml_text(tmp_path):
+    from test_host import SHIPPED_ICP_YAML
+    f = tmp_path / "icp.yaml"
+    f.write_text(SHIPPED_ICP_YAML)
+    icp = pcl.ICP()
+    icp.loadFromYaml(str(f))
+    assert icp.params.as_dict() == icp_config.shipped_params().as_dict()
+    src, tgt, guess, _ = synth.scan_pair(seed=12, n_src=500, n_tgt=500)
+    msg, T = icp.compute(src, tgt, guess)
+    st, To, _ = oracle.icp(src, tgt, guess, oracle.shipped_icp_params(precision=1))
+    assert msg == "success" and _pose_diff(T, To) < TOL_TIGHT
+
+
+def test_tiny_and_degenerate_clouds():
+    one = np.array([[1.0, 2.0]], np.float32)
+    msg, T = _icp(icp_config.shipped_params()).compute(one, one, np.eye(3, dtype=np.float32))
+    st, To, _ = oracle.icp(one, one, np.eye(3, dtype=np.float32), oracle.shipped_icp_params(precision=1))
+    assert (msg == "success") == (st == 0)
+    assert np.allclose(T, To, atol=1e-6)
+    with pytest.raises(RuntimeError):
+        _icp(icp_config.shipped_params()).compute(np.zeros((0, 2), np.float32), one, np.eye(3))

@@ -1,0 +1,137 @@
+"""CPU: host logic -- ICP YAML parsing, the C-ABI surface, loud failure without a GPU,
+the job-farm sharding (incl. a 2-process gloo run)."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from sonar_slam_amd import _lib, farm, icp_config
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SHIPPED_ICP_YAML = """readingDataPointsFilters:
+
+referenceDataPointsFilters:
+
+matcher:
+  KDTreeMatcher:
+    knn: 1
+    epsilon: 0 
+    maxDist: 10.0
+
+outlierFilters:
+  - MaxDistOutlierFilter:
+      maxDist: 3.0
+  - TrimmedDistOutlierFilter:
+      ratio: 0.8
+
+errorMinimizer:
+  # PointToPlaneErrorMinimizer:
+  #   force2D: 1
+  PointToPointErrorMinimizer
+
+transformationCheckers:
+  - CounterTransformationChecker:
+      maxIterationCount: 40
+  - DifferentialTransformationChecker:
+      minDiffRotErr: 0.01
+      minDiffTransErr: 0.1
+      smoothLength: 4   
+
+inspector:
+  NullInspector
+"""
+
+
+def test_parse_shipped_icp_yaml():
+    p = icp_config.parse_icp_yaml(SHIPPED_ICP_YAML)
+    assert p.as_dict() == icp_config.shipped_params().as_dict()
+    assert (p.minimizer, p.max_iter, p.smooth_len) == (0, 40, 4)
+    assert p.trim_ratio == np.float32(0.8) and p.max_dist_filter == 3.0 and p.matcher_max_dist == 10.0
+
+
+def test_parse_point_to_plane_variant():
+    y = SHIPPED_ICP_YAML.replace("  PointToPointErrorMinimizer", "").replace(
+        "  # PointToPlaneErrorMinimizer:\n  #   force2D: 1", "  PointToPlaneErrorMinimizer:\n    force2D: 1")
+    assert icp_config.parse_icp_yaml(y).minimizer == 1
+
+
+@pytest.mark.parametrize("bad", [
+    "matcher:\n  KDTreeMatcher:\n    knn: 3\n",
+    "matcher:\n  NullMatcher\n",
+    "outlierFilters:\n  - VarTrimmedDistOutlierFilter:\n      minRatio: 0.1\n",
+    "errorMinimizer:\n  PointToPlaneErrorMinimizer\n",
+    "referenceDataPointsFilters:\n  - SurfaceNormalDataPointsFilter:\n      knn: 5\n",
+    "transformationCheckers:\n  - BoundTransformationChecker:\n      maxRotationNorm: 1\n",
+    "somethingElse: 1\n",
+])
+def test_unknown_modules_are_rejected(bad):
+    with pytest.raises(icp_config.IcpConfigError):
+        icp_config.parse_icp_yaml(bad)
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "sonarfe.h")).read()
+    declared = set(re.findall(r"\b(sfe_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no prototypes found in include/sonarfe.h"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    lib = _lib.load_library()          # dlopen works without a GPU
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.sfe_version()
+
+
+def test_params_struct_matches_header():
+    hdr = open(os.path.join(ROOT, "include", "sonarfe.h")).read()
+    body = hdr[hdr.index("typedef struct sfe_icp_params {"):hdr.index("} sfe_icp_params;")]
+    fields = re.findall(r"^\s*(?:float|int)\s+([a-z_]+);", body, re.M)
+    assert fields == [n for n, _ in _lib.IcpParams._fields_]
+
+
+def test_no_device_fails_loudly_not_silently():
+    """On a box without a GPU the product must raise, never fall back to a CPU path."""
+    import ctypes as C
+    lib = _lib.load_library()
+    n = C.c_int(-1)
+    rc = lib.sfe_device_count(C.byref(n))
+    if rc == 0 and n.value > 0:
+        pytest.skip("a HIP device is visible")
+    with pytest.raises(_lib.SonarFEError):
+        _lib.Context(0)
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "sonar_slam_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", txt, re.M), f
+                assert "libsonar_oracle" not in txt, f          # never dlopen'ed
+                assert not re.search(r'#include\s+"[^"]*oracle', txt), f  # never compiled in
+
+
+def test_shard_and_scatter_back():
+    for n, w in [(10, 3), (7, 8), (0, 2), (16, 4)]:
+        shards = [farm.shard(n, r, w) for r in range(w)]
+        assert sorted(sum(shards, [])) == list(range(n))
+        res = [[j * j for j in s] for s in shards]
+        assert farm.scatter_back(n, w, res) == [j * j for j in range(n)]
+    with pytest.raises(ValueError):
+        farm.shard(4, 2, 2)
+
+
+def test_two_rank_gloo_farm():
+    """world_size 2 over gloo on CPU: each rank matches its shard of ICP jobs (with the oracle as
+    the stand-in compute, tests may use it) and every rank ends up with all poses in job order."""
+    script = os.path.join(ROOT, "tests", "gloo_farm_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2",
+               PYTHONPATH=ROOT)
+    procs = [subprocess.Popen([sys.executable, script], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+        assert "FARM_OK" in o, o
