@@ -371,23 +371,11 @@ static void launch_ring(sfe_ctx *ctx, int alg, const uint8_t *d_img, uint8_t *d_
                            d_mask, rows, cols, n_frames, groups, tiles, chunks, lut);
 }
 
-// R-row groups per tile: enough waves to fill the chip several times over, but tiles tall enough
-// that the 2*halo warm-up rows stay a small fraction of the rows a lane streams
-static int default_groups(const sfe_ctx *ctx, int rows, int cols, int n_frames, int R)
-{
-    const int max_groups = rows / R;
-    const long long chunks = ((cols >> 2) + 63) / 64;
-    const long long want_waves = (long long)ctx->n_cu * 16;
-    long long tiles = (want_waves + n_frames * chunks - 1) / (n_frames * chunks);
-    if (tiles < 1)
-        tiles = 1;
-    int g = (int)((rows + tiles * R - 1) / (tiles * R));
-    if (g < 4)
-        g = 4;
-    if (g > max_groups)
-        g = max_groups;
-    return g;
-}
+// R-row groups per tile.  Measured on MI355X (tools/cfar_sweep.py, 1024 frames of 1024x512):
+// 1 group/tile 5.2 TB/s, 2 -> 5.1, 4 -> 4.8, 10 -> 4.5, whole column -> 3.1.  Short tiles win: the
+// kernel is bound by each wave's serial row march, more independent waves hide it, and the
+// 2*(T+G) warm-up rows a tile re-reads are served by L2 (FETCH_SIZE stays ~1.07x algorithmic).
+static int default_groups(const sfe_ctx *, int, int, int, int) { return 1; }
 
 static int cfar_u8_dev(sfe_ctx *ctx, const uint8_t *d_img, int n_frames, int rows, int cols, int alg,
                        int T, int G, int k, double tau, int intensity_thr, uint8_t *d_mask, float *d_thr)

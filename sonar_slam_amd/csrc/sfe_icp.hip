@@ -28,7 +28,8 @@
 #define ICP_THREADS 1024
 #define ICP_WAVES (ICP_THREADS / 64)
 #define ICP_TCAP 8192 // target points resident in LDS (64 KiB as float2)
-#define ICP_PB 4      // source points per lane per pass over the target
+#define ICP_PB 8      // max source points per lane per pass over the target
+#define ICP_CH 16     // target points per chunk of the two-level arg-min
 #define ICP_KMAX 16   // max neighbours for the PCA normals
 #define ICP_MAX_HIST 64 // transformation history kept for the differential checker
 
@@ -97,53 +98,61 @@ __device__ __forceinline__ void mat3_mul(const float *a, const float *b, float *
         c[i] = r[i];
 }
 
-// Scan one LDS tile of centred target points for PB query points; strict '<' keeps the lowest
-// index on ties.  d2 = fl(fl(dx*dx) + fl(dy*dy)) exactly as the oracle / libnabo accumulate it.
-__device__ __forceinline__ void nn_scan_tile(const float2 *__restrict__ s_tgt, int tile_n, int tile_base,
-                                             const float (&px)[ICP_PB], const float (&py)[ICP_PB],
-                                             float (&best)[ICP_PB], int (&bidx)[ICP_PB])
+__device__ __forceinline__ float dist2(float px, float py, float tx, float ty)
 {
-    int j = 0;
-    for (; j + 2 <= tile_n; j += 2) {
-        const float4 t = *reinterpret_cast<const float4 *>(&s_tgt[j]); // two points, LDS broadcast
+    // fl(fl(dx*dx) + fl(dy*dy)): how the oracle / libnabo accumulate the squared distance
+    const float dx = f_add(px, -tx), dy = f_add(py, -ty);
+    return f_add(f_mul(dx, dx), f_mul(dy, dy));
+}
+
+// Two-level exact arg-min over one LDS tile of centred target points for NP query points per
+// lane.  Level 1 keeps only the running minimum of each 16-point chunk (v_min3, no index
+// bookkeeping: 5.5 VALU ops per pair instead of 8) and remembers the first chunk that lowered
+// the minimum; level 2 (nn_resolve) rescans that one chunk for the first point that attains it.
+// Strict '<' between chunks + first hit inside the chunk == lowest index on ties.
+// The tile is padded to a multiple of ICP_CH with +inf points (distance inf, never selected).
+template <int NP>
+__device__ __forceinline__ void nn_scan_tile(const float2 *__restrict__ s_tgt, int tile_n, int chunk_base,
+                                             const float (&px)[ICP_PB], const float (&py)[ICP_PB],
+                                             float (&best)[ICP_PB], int (&bchunk)[ICP_PB])
+{
+    const int nchunks = (tile_n + ICP_CH - 1) / ICP_CH;
+    for (int c = 0; c < nchunks; ++c) {
+        float cmin[NP];
 #pragma unroll
-        for (int k = 0; k < ICP_PB; ++k) {
-            float dx = f_add(px[k], -t.x), dy = f_add(py[k], -t.y);
-            float d = f_add(f_mul(dx, dx), f_mul(dy, dy));
-            if (d < best[k]) {
-                best[k] = d;
-                bidx[k] = tile_base + j;
-            }
-            dx = f_add(px[k], -t.z);
-            dy = f_add(py[k], -t.w);
-            d = f_add(f_mul(dx, dx), f_mul(dy, dy));
-            if (d < best[k]) {
-                best[k] = d;
-                bidx[k] = tile_base + j + 1;
+        for (int k = 0; k < NP; ++k)
+            cmin[k] = INFINITY;
+#pragma unroll
+        for (int jj = 0; jj < ICP_CH; jj += 2) {
+            const float4 t = *reinterpret_cast<const float4 *>(&s_tgt[c * ICP_CH + jj]); // LDS broadcast
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const float d0 = dist2(px[k], py[k], t.x, t.y);
+                const float d1 = dist2(px[k], py[k], t.z, t.w);
+                cmin[k] = fminf(fminf(cmin[k], d0), d1);
             }
         }
-    }
-    if (j < tile_n) {
-        const float2 t = s_tgt[j];
 #pragma unroll
-        for (int k = 0; k < ICP_PB; ++k) {
-            const float dx = f_add(px[k], -t.x), dy = f_add(py[k], -t.y);
-            const float d = f_add(f_mul(dx, dx), f_mul(dy, dy));
-            if (d < best[k]) {
-                best[k] = d;
-                bidx[k] = tile_base + j;
+        for (int k = 0; k < NP; ++k)
+            if (cmin[k] < best[k]) {
+                best[k] = cmin[k];
+                bchunk[k] = chunk_base + c;
             }
-        }
     }
 }
 
-// load target points [base, base+n) of the job, centred on `mean`, into the LDS tile
+// load target points [base, base+n) of the job, centred on `mean`, into the LDS tile (+inf pad)
 __device__ __forceinline__ void load_tile(float2 *__restrict__ s_tgt, const float2 *__restrict__ tgt, int base,
                                           int n, float mx, float my)
 {
-    for (int i = threadIdx.x; i < n; i += ICP_THREADS) {
-        const float2 t = tgt[base + i];
-        s_tgt[i] = make_float2(f_add(t.x, -mx), f_add(t.y, -my));
+    const int npad = (n + ICP_CH - 1) / ICP_CH * ICP_CH;
+    for (int i = threadIdx.x; i < npad; i += ICP_THREADS) {
+        float2 v = make_float2(INFINITY, INFINITY);
+        if (i < n) {
+            const float2 t = tgt[base + i];
+            v = make_float2(f_add(t.x, -mx), f_add(t.y, -my));
+        }
+        s_tgt[i] = v;
     }
 }
 
@@ -347,13 +356,14 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_job_kernel(sfe_icp_params P, 
         // ---- match: exact 1-NN of cur = Ti * (T0 * src) in the centred target ----
         double nfin_d[1] = {0};
         for (int base = 0; base < ns; base += ICP_THREADS * ICP_PB) {
+            const int np = min(ICP_PB, (ns - base + ICP_THREADS - 1) / ICP_THREADS); // uniform
             float px[ICP_PB], py[ICP_PB], best[ICP_PB];
-            int bidx[ICP_PB];
+            int bchunk[ICP_PB];
 #pragma unroll
             for (int k = 0; k < ICP_PB; ++k) {
                 const int i = base + k * ICP_THREADS + tid;
                 float x = 0, y = 0;
-                if (i < ns) {
+                if (k < np && i < ns) {
                     const float2 s = src[i];
                     const float rx = affine1(T0[0], T0[1], T0[2], s.x, s.y);
                     const float ry = affine1(T0[3], T0[4], T0[5], s.x, s.y);
@@ -363,25 +373,49 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_job_kernel(sfe_icp_params P, 
                 px[k] = x;
                 py[k] = y;
                 best[k] = INFINITY;
-                bidx[k] = -1;
+                bchunk[k] = -1;
             }
-            if (resident) {
-                nn_scan_tile(S.tgt, nt, 0, px, py, best, bidx);
-            } else {
-                for (int tb = 0; tb < nt; tb += ICP_TCAP) {
-                    const int tn = min(ICP_TCAP, nt - tb);
+            for (int tb = 0; tb < nt; tb += ICP_TCAP) {
+                const int tn = min(ICP_TCAP, nt - tb);
+                if (!resident) {
                     __syncthreads();
                     load_tile(S.tgt, tgt, tb, tn, mx, my);
                     __syncthreads();
-                    nn_scan_tile(S.tgt, tn, tb, px, py, best, bidx);
+                }
+                switch (np) { // one instantiation per points-per-lane count keeps everything in registers
+                case 1: nn_scan_tile<1>(S.tgt, tn, tb / ICP_CH, px, py, best, bchunk); break;
+                case 2: nn_scan_tile<2>(S.tgt, tn, tb / ICP_CH, px, py, best, bchunk); break;
+                case 3: nn_scan_tile<3>(S.tgt, tn, tb / ICP_CH, px, py, best, bchunk); break;
+                case 4: nn_scan_tile<4>(S.tgt, tn, tb / ICP_CH, px, py, best, bchunk); break;
+                case 5: nn_scan_tile<5>(S.tgt, tn, tb / ICP_CH, px, py, best, bchunk); break;
+                case 6: nn_scan_tile<6>(S.tgt, tn, tb / ICP_CH, px, py, best, bchunk); break;
+                case 7: nn_scan_tile<7>(S.tgt, tn, tb / ICP_CH, px, py, best, bchunk); break;
+                default: nn_scan_tile<8>(S.tgt, tn, tb / ICP_CH, px, py, best, bchunk); break;
                 }
             }
 #pragma unroll
             for (int k = 0; k < ICP_PB; ++k) {
                 const int i = base + k * ICP_THREADS + tid;
-                if (i < ns) {
+                if (k < np && i < ns) {
                     float d = best[k];
-                    int id = bidx[k];
+                    int id = -1;
+                    if (bchunk[k] >= 0) { // level 2: first point of the winning chunk that attains the minimum
+                        const int j0 = bchunk[k] * ICP_CH;
+                        for (int jj = ICP_CH - 1; jj >= 0; --jj) {
+                            const int j = j0 + jj;
+                            if (j < nt) {
+                                float2 t;
+                                if (resident)
+                                    t = S.tgt[j];
+                                else {
+                                    const float2 g = tgt[j];
+                                    t = make_float2(f_add(g.x, -mx), f_add(g.y, -my));
+                                }
+                                if (dist2(px[k], py[k], t.x, t.y) == d)
+                                    id = j;
+                            }
+                        }
+                    }
                     if (id < 0 || !(d <= r2_match)) {
                         id = -1;
                         d = INFINITY;
