@@ -162,6 +162,8 @@ int sfe_icp_compute(sfe_ctx *ctx, const sfe_icp_params *p, const float *src, int
 int sfe_icp_compute_guesses(sfe_ctx *ctx, const sfe_icp_params *p, const float *src, int n_src,
                             const float *tgt, int n_tgt, const float *guesses9, int n_guesses,
                             float *T_out9, int32_t *status, int32_t *iters);
+/* A-B knob for the ICP nearest-neighbour inner loop: 0 = packed fp32 (v_pk_*_f32, default), 1 = scalar fp32 */
+int sfe_icp_set_tuning(sfe_ctx *ctx, int variant);
 /* independent jobs, device-resident: clouds concatenated, job j uses
  * src[src_off[j]..src_off[j+1]) and tgt[tgt_off[j]..tgt_off[j+1]) (offsets in points, host
  * arrays of n_jobs+1), guess d_guess9 + 9*j; outputs d_T9 (9 floats), d_status, d_iters per job */

@@ -22,6 +22,7 @@ struct sfe_ctx {
     } scratch[SFE_NSCRATCH];
     int cfar_tile_rows = 0;
     int cfar_variant = 0;
+    int icp_variant = 0;
     int n_cu = 256;
 };
 

@@ -150,3 +150,24 @@ def test_tiny_and_degenerate_clouds():
     assert np.allclose(T, To, atol=1e-6)
     with pytest.raises(RuntimeError):
         _icp(icp_config.shipped_params()).compute(np.zeros((0, 2), np.float32), one, np.eye(3))
+
+
+def test_duplicated_targets_exercise_the_exact_fallbacks():
+    """many coincident target points: the approximate NN filter cannot separate their chunks, so
+    the per-query cooperative scan (moderate duplication) and the whole-pass exact scan (queue
+    overflow, heavy duplication) must take over and still match the oracle bit for bit"""
+    src, tgt, guess, _ = synth.scan_pair(seed=21, n_src=1500, n_tgt=1600)
+    rng = np.random.default_rng(0)
+    for n_unique in (1200, 40):
+        t = tgt[rng.integers(0, n_unique, len(tgt))]          # heavy repetition, random order
+        for nn_variant in (0, 1):
+            from sonar_slam_amd import _lib
+            c = _lib.default_context()
+            c._check(c.lib.sfe_icp_set_tuning(c.handle, nn_variant))
+            try:
+                msgs, T, it = _icp(icp_config.shipped_params(max_iter=8, use_diff_checker=0)).compute_batch(src, t, [guess])
+            finally:
+                c._check(c.lib.sfe_icp_set_tuning(c.handle, 0))
+            st, To, ito = oracle.icp(src, t, guess, oracle.shipped_icp_params(max_iter=8, use_diff_checker=0))
+            assert msgs[0] == "success" and st == 0 and it[0] == ito
+            assert _pose_diff(T[0], To) < TOL_TIGHT, (n_unique, nn_variant)
