@@ -10,6 +10,7 @@
  *   bruce_slam.pcl   (bruce_slam/src/bruce_slam/cpp/pcl.cpp:176-214)
  *       match                                       -> sfe_match
  *       remove_outlier                              -> sfe_remove_outlier
+ *       downsample (both overloads)                 -> sfe_downsample
  *       ICP.loadFromYaml / compute / getCovariance  -> sfe_icp_* (params parsed host-side)
  *   feature_extraction.py:223-238 (CFAR gate, cv2.remap, nonzero, px->m)
  *                                                   -> sfe_geom_*, sfe_remap_u8, sfe_extract_points
@@ -154,6 +155,11 @@ int sfe_match(sfe_ctx *ctx, const float *ref, int n_ref, const float *in, int n_
 /* pcl.remove_outlier(points, radius, min_points) (pcl.cpp:54-74): order preserved */
 int sfe_remove_outlier(sfe_ctx *ctx, const float *pts, int n, double radius, int min_points,
                        float *out, int *n_out);
+/* pcl.downsample(points, resolution) (pcl.cpp:128-159): libpointmatcher OctreeGridDataPointsFilter
+ * (maxSizeByNode = resolution, medoid per leaf, leaves in depth-first order).  out: up to n points,
+ * out_idx (nullable): their indices in the input (the descriptor overload gathers with them). */
+int sfe_downsample(sfe_ctx *ctx, const float *pts, int n, float resolution, float *out,
+                   int32_t *out_idx, int *n_out);
 /* pcl.ICP.compute(source, target, guess) (pcl.cpp:198-212).  Returns SFE_ICP_* (>= 0) or a
  * hard error (< 0).  On a nonzero status T_out = guess (pcl.cpp:203,207-210). */
 int sfe_icp_compute(sfe_ctx *ctx, const sfe_icp_params *p, const float *src, int n_src,
@@ -162,7 +168,7 @@ int sfe_icp_compute(sfe_ctx *ctx, const sfe_icp_params *p, const float *src, int
 int sfe_icp_compute_guesses(sfe_ctx *ctx, const sfe_icp_params *p, const float *src, int n_src,
                             const float *tgt, int n_tgt, const float *guesses9, int n_guesses,
                             float *T_out9, int32_t *status, int32_t *iters);
-/* A-B knob for the ICP nearest-neighbour inner loop: 0 = packed fp32 (v_pk_*_f32, default), 1 = scalar fp32 */
+/* A-B knob for the ICP kernel: bit 0: 0 = packed fp32 NN loop (default), 1 = scalar fp32; bit 1: 0 = 64-VGPR build, 2 workgroups/CU (default), 1 = 128-VGPR build */
 int sfe_icp_set_tuning(sfe_ctx *ctx, int variant);
 /* independent jobs, device-resident: clouds concatenated, job j uses
  * src[src_off[j]..src_off[j+1]) and tgt[tgt_off[j]..tgt_off[j+1]) (offsets in points, host

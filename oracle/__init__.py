@@ -89,6 +89,7 @@ def lib():
                               C.POINTER(C.c_int)]
         L.orc_remove_outlier.argtypes = [f32p, C.c_int, C.c_double, C.c_int, f32p]
         L.orc_bilinear_tab.argtypes = [C.POINTER(C.c_int16)]
+        L.orc_downsample.argtypes = [f32p, C.c_int, C.c_float, f32p, i32p]
         _lib = L
     return _lib
 
@@ -197,3 +198,14 @@ def bilinear_tab():
     t = np.zeros((1024, 4), np.int16)
     lib().orc_bilinear_tab(_p(t, C.c_int16))
     return t
+
+
+def downsample(pts, resolution, return_index=False):
+    """pcl.downsample(points, resolution) (pcl.cpp:128-141): octree-grid medoid sampling."""
+    pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+    out = np.zeros_like(pts)
+    idx = np.zeros(len(pts), np.int32)
+    # pcl.cpp passes std::to_string(resolution): six decimals survive
+    res = np.float32(float("%f" % np.float32(resolution)))
+    m = lib().orc_downsample(_p(pts, C.c_float), len(pts), float(res), _p(out, C.c_float), _p(idx, C.c_int32))
+    return (out[:m].copy(), idx[:m].copy()) if return_index else out[:m].copy()

@@ -701,3 +701,103 @@ int orc_remove_outlier(const float *pts, int n, double radius, int min_points, f
     }
     return m;
 }
+
+/* ------------------------------------------------------------------------- */
+/* pcl.downsample (pcl.cpp:128-141): libpointmatcher OctreeGridDataPointsFilter */
+/* {maxSizeByNode = resolution, samplingMethod = 3 (MEDOID), maxPointByNode = 1 */
+/* (default)} on 2-D points.  Restated from the library's Octree.hpp /          */
+/* OctreeGrid.cpp (not in the reference tree, PARITY UNPINNED):                  */
+/*  - root box: centre = min + (max-min)*0.5, radius = max extent * 0.5          */
+/*  - a node is a leaf when radius*2.0 <= maxSizeByNode or it holds <= 1 point    */
+/*  - child index bit0 = x > centre.x, bit1 = y > centre.y; child centre =        */
+/*    centre +- radius/2; children are visited in index order 0..3 (depth first)  */
+/*  - every non-empty leaf contributes the point closest to the float centroid    */
+/*    of its points (first one on ties, points kept in original order)           */
+/* Output: the selected points in visit order (+ their original indices).        */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    const float *pts;
+    float max_size;
+    float *out;
+    int32_t *out_idx;
+    int n_out;
+} orc_ds_ctx;
+
+static void orc_ds_node(orc_ds_ctx *C, int *ids, int n, float cx, float cy, float radius)
+{
+    if (n == 0)
+        return;
+    if (((double)radius * 2.0 <= (double)C->max_size) || n <= 1) {
+        /* leaf: medoid = point closest to the centroid */
+        float sx = 0.0f, sy = 0.0f;
+        for (int i = 0; i < n; ++i) {
+            sx += C->pts[2 * ids[i]];
+            sy += C->pts[2 * ids[i] + 1];
+        }
+        sx /= (float)n;
+        sy /= (float)n;
+        float best = 3.402823466e+38f; /* numeric_limits<float>::max() */
+        int bi = ids[0];
+        for (int i = 0; i < n; ++i) {
+            float dx = C->pts[2 * ids[i]] - sx, dy = C->pts[2 * ids[i] + 1] - sy;
+            float a = dx * dx, b = dy * dy;
+            float d = sqrtf(a + b);
+            if (d < best) {
+                best = d;
+                bi = ids[i];
+            }
+        }
+        C->out[2 * C->n_out] = C->pts[2 * bi];
+        C->out[2 * C->n_out + 1] = C->pts[2 * bi + 1];
+        if (C->out_idx)
+            C->out_idx[C->n_out] = bi;
+        C->n_out++;
+        return;
+    }
+    int *buf = (int *)malloc(sizeof(int) * (size_t)n);
+    int cnt[4] = {0, 0, 0, 0}, off[4];
+    for (int i = 0; i < n; ++i) {
+        int c = (C->pts[2 * ids[i]] > cx ? 1 : 0) | (C->pts[2 * ids[i] + 1] > cy ? 2 : 0);
+        cnt[c]++;
+    }
+    off[0] = 0;
+    for (int c = 1; c < 4; ++c)
+        off[c] = off[c - 1] + cnt[c - 1];
+    int pos[4] = {off[0], off[1], off[2], off[3]};
+    for (int i = 0; i < n; ++i) { /* stable split: original order kept inside each child */
+        int c = (C->pts[2 * ids[i]] > cx ? 1 : 0) | (C->pts[2 * ids[i] + 1] > cy ? 2 : 0);
+        buf[pos[c]++] = ids[i];
+    }
+    const float hr = radius * 0.5f;
+    for (int c = 0; c < 4; ++c) {
+        float ccx = cx + ((c & 1) ? hr : -hr), ccy = cy + ((c & 2) ? hr : -hr);
+        orc_ds_node(C, buf + off[c], cnt[c], ccx, ccy, hr);
+    }
+    free(buf);
+}
+
+int orc_downsample(const float *pts, int n, float resolution, float *out, int32_t *out_idx)
+{
+    if (n == 0)
+        return 0;
+    float mnx = pts[0], mxx = pts[0], mny = pts[1], mxy = pts[1];
+    for (int i = 1; i < n; ++i) {
+        if (pts[2 * i] < mnx) mnx = pts[2 * i];
+        if (pts[2 * i] > mxx) mxx = pts[2 * i];
+        if (pts[2 * i + 1] < mny) mny = pts[2 * i + 1];
+        if (pts[2 * i + 1] > mxy) mxy = pts[2 * i + 1];
+    }
+    float rx = mxx - mnx, ry = mxy - mny;
+    float cx = mnx + rx * 0.5f, cy = mny + ry * 0.5f;
+    float radius = rx;
+    if (radius < ry)
+        radius = ry;
+    radius *= 0.5f;
+    int *ids = (int *)malloc(sizeof(int) * (size_t)n);
+    for (int i = 0; i < n; ++i)
+        ids[i] = i;
+    orc_ds_ctx C = {pts, resolution, out, out_idx, 0};
+    orc_ds_node(&C, ids, n, cx, cy, radius);
+    free(ids);
+    return C.n_out;
+}

@@ -92,6 +92,7 @@ SIGNATURES = {
     "sfe_match": (C.c_int, [_vp, _f32p, C.c_int, _f32p, C.c_int, C.c_float, _i32p, _f32p]),
     "sfe_remove_outlier": (C.c_int, [_vp, _f32p, C.c_int, C.c_double, C.c_int, _f32p,
                                      C.POINTER(C.c_int)]),
+    "sfe_downsample": (C.c_int, [_vp, _f32p, C.c_int, C.c_float, _f32p, _i32p, C.POINTER(C.c_int)]),
     "sfe_icp_compute": (C.c_int, [_vp, C.POINTER(IcpParams), _f32p, C.c_int, _f32p, C.c_int, _f32p,
                                   _f32p, C.POINTER(C.c_int)]),
     "sfe_icp_compute_guesses": (C.c_int, [_vp, C.POINTER(IcpParams), _f32p, C.c_int, _f32p, C.c_int,

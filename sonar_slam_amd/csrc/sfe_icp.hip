@@ -216,7 +216,8 @@ struct IcpShared {
     float hist_c[ICP_MAX_HIST], hist_s[ICP_MAX_HIST], hist_x[ICP_MAX_HIST], hist_y[ICP_MAX_HIST];
 };
 
-__global__ __launch_bounds__(ICP_THREADS) void icp_job_kernel(sfe_icp_params P, int nn_variant,
+template <int MINW>
+__global__ __launch_bounds__(ICP_THREADS, MINW) void icp_job_kernel(sfe_icp_params P, int nn_variant,
                                                               const IcpJob *__restrict__ jobs,
                                                               const float2 *__restrict__ src_all,
                                                               const float2 *__restrict__ tgt_all,
@@ -841,12 +842,21 @@ static int icp_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_src,
                                 ctx->stream));
     // the pageable host vector must stay alive until the copy has been consumed
     SFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    SFE_HIP(ctx, hipFuncSetAttribute((const void *)icp_job_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)sizeof(IcpShared)));
-    hipLaunchKernelGGL(icp_job_kernel, dim3(n_jobs), dim3(ICP_THREADS), sizeof(IcpShared), ctx->stream, *p,
-                       ctx->icp_variant, d_jobs,
-                       (const float2 *)d_src, (const float2 *)d_tgt, d_guess9, d_nn_d2, d_nn_idx, d_nrm, d_T9,
-                       d_status, d_iters);
+    // occupancy A/B: bit 1 of the tuning variant selects the 128-VGPR build (1 workgroup per CU)
+    const int nnv = ctx->icp_variant & 1;
+    if (!(ctx->icp_variant & 2)) { // default: 64-VGPR build, two workgroups per CU (measured 7 % faster)
+        SFE_HIP(ctx, hipFuncSetAttribute((const void *)icp_job_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)sizeof(IcpShared)));
+        hipLaunchKernelGGL(icp_job_kernel<8>, dim3(n_jobs), dim3(ICP_THREADS), sizeof(IcpShared), ctx->stream, *p, nnv,
+                           d_jobs, (const float2 *)d_src, (const float2 *)d_tgt, d_guess9, d_nn_d2, d_nn_idx, d_nrm,
+                           d_T9, d_status, d_iters);
+    } else {
+        SFE_HIP(ctx, hipFuncSetAttribute((const void *)icp_job_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)sizeof(IcpShared)));
+        hipLaunchKernelGGL(icp_job_kernel<4>, dim3(n_jobs), dim3(ICP_THREADS), sizeof(IcpShared), ctx->stream, *p, nnv,
+                           d_jobs, (const float2 *)d_src, (const float2 *)d_tgt, d_guess9, d_nn_d2, d_nn_idx, d_nrm,
+                           d_T9, d_status, d_iters);
+    }
     SFE_LAUNCH_CHECK(ctx);
     return 0;
 }
@@ -857,7 +867,7 @@ int sfe_icp_set_tuning(sfe_ctx *ctx, int variant)
 {
     if (!ctx)
         return SFE_ERR_ARG;
-    SFE_ARG(ctx, variant >= 0 && variant <= 1);
+    SFE_ARG(ctx, variant >= 0 && variant <= 3);
     ctx->icp_variant = variant;
     return 0;
 }

@@ -33,6 +33,7 @@ struct sfe_geom {
     int32_t *d_code = nullptr;   // per Cartesian pixel: packed (iy, ix, table index) or -1
     int32_t *d_span = nullptr;   // per Cartesian row: [first, last+1) columns with code != -1
     int words_per_row = 0;       // 64-bit bitmap words per Cartesian row
+    unsigned rcp = 0;            // ceil(2^32 / (polar_cols+1))
 };
 
 int sfe_set_err(sfe_ctx *ctx, int code, const char *fmt, ...);

@@ -19,23 +19,33 @@
 
 #define SFE_CODE_NONE 0xFFFFFFFFu
 
-__device__ __forceinline__ int remap_value(const uint8_t *__restrict__ src, int prows, int pcols, uint32_t code)
+// Decode one Cartesian pixel.  `rcp` = ceil(2^32 / (pcols+1)) turns the divide of the packed
+// linear index into one v_mul_hi (exact for lin < 2^22, checked at geometry creation).
+__device__ __forceinline__ int remap_value(const uint8_t *__restrict__ src, int prows, int pcols, unsigned rcp,
+                                           uint32_t code)
 {
-    const int lin = (int)(code >> 10);
+    const unsigned lin = code >> 10;
     const int fy = (int)((code >> 5) & 31u), fx = (int)(code & 31u);
-    const int iy = lin / (pcols + 1) - 1, ix = lin % (pcols + 1) - 1;
+    const unsigned q = __umulhi(lin, rcp);
+    const int iy = (int)q - 1, ix = (int)(lin - q * (unsigned)(pcols + 1)) - 1;
+    // branch-free taps: clamp the coordinates (always a valid address, all four loads in flight
+    // together) and zero the out-of-image ones afterwards (BORDER_CONSTANT 0)
+    const int ya = max(iy, 0), yb = min(iy + 1, prows - 1), xa = max(ix, 0), xb = min(ix + 1, pcols - 1);
+    const uint8_t *ra = src + (size_t)ya * pcols, *rb = src + (size_t)yb * pcols;
+    const int my0 = (iy >= 0) ? 0xff : 0, my1 = (iy + 1 < prows) ? 0xff : 0;
+    const int mx0 = (ix >= 0) ? 0xff : 0, mx1 = (ix + 1 < pcols) ? 0xff : 0;
+    const int v00 = ra[xa] & my0 & mx0;
+    const int v01 = ra[xb] & my0 & mx1;
+    const int v10 = rb[xa] & my1 & mx0;
+    const int v11 = rb[xb] & my1 & mx1;
+    if ((v00 | v01 | v10 | v11) == 0)
+        return 0; // sparse detection masks: most taps are empty
     int w00 = (32 - fy) * (32 - fx) * 32, w01 = (32 - fy) * fx * 32;
     int w10 = fy * (32 - fx) * 32, w11 = fy * fx * 32;
     if ((fx | fy) == 0) {
         w00 = 32767;
         w11 = 1;
     }
-    const bool y0 = iy >= 0, y1 = iy + 1 < prows, x0 = ix >= 0, x1 = ix + 1 < pcols;
-    const uint8_t *p = src + (long long)iy * pcols + ix;
-    const int v00 = (y0 && x0) ? p[0] : 0;
-    const int v01 = (y0 && x1) ? p[1] : 0;
-    const int v10 = (y1 && x0) ? p[pcols] : 0;
-    const int v11 = (y1 && x1) ? p[pcols + 1] : 0;
     const int acc = w00 * v00 + w01 * v01 + w10 * v10 + w11 * v11;
     return (acc + 16384) >> 15; // <= 255 because the weights sum to 32768
 }
@@ -44,69 +54,109 @@ __device__ __forceinline__ int remap_value(const uint8_t *__restrict__ src, int 
 __global__ __launch_bounds__(256) void remap_u8_kernel(const uint8_t *__restrict__ src,
                                                        const uint32_t *__restrict__ code,
                                                        uint8_t *__restrict__ dst, int prows, int pcols,
-                                                       long long n_cart, int n_frames)
+                                                       unsigned rcp, long long n_cart, int n_frames)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n_cart * n_frames)
         return;
     const long long f = i / n_cart, o = i % n_cart;
     const uint32_t c = code[o];
-    dst[i] = (c == SFE_CODE_NONE) ? 0 : (uint8_t)remap_value(src + f * (long long)prows * pcols, prows, pcols, c);
+    dst[i] = (c == SFE_CODE_NONE) ? 0 : (uint8_t)remap_value(src + f * (long long)prows * pcols, prows, pcols, rcp, c);
 }
 
-// pass 1: one workgroup per (Cartesian row, frame): nonzero bits -> 64-bit bitmap words + row count
+// pass 1: detection bits of the Cartesian canvas as 64-bit ballot words.
+// A wave owns one 64-column word position and EXTRACT_RG consecutive Cartesian rows.  The kernel
+// is latency-bound, not bandwidth-bound (a dependent chain code -> 4 taps -> ballot per word; the
+// first version ran one chain at a time per wave and took 2.1 ms per 256 frames at 32 waves/CU),
+// so EXTRACT_U rows are processed together: all code loads first, then all 4*U tap loads, with
+// clamped addresses instead of branches so that everything is in flight at once.
+// Workgroup -> (frame, row group, word group) with the word group fastest: XCD k keeps word
+// groups k (mod 8), i.e. one vertical strip of the canvas = 1/8 of the code table (L2-resident)
+// and roughly one bearing sector of every mask.
+#define EXTRACT_RG 16
+#define EXTRACT_U 8
 __global__ __launch_bounds__(256) void extract_bits_kernel(const uint8_t *__restrict__ mask,
                                                            const uint32_t *__restrict__ code,
                                                            const int32_t *__restrict__ span,
-                                                           unsigned long long *__restrict__ bitmap,
-                                                           int32_t *__restrict__ row_count, int prows,
-                                                           int pcols, int crows, int ccols, int wpr)
+                                                           unsigned long long *__restrict__ bitmap, int prows,
+                                                           int pcols, unsigned rcp, int crows, int ccols, int wpr,
+                                                           int word_groups, int tiles_per_frame)
 {
-    const int row = blockIdx.x, f = blockIdx.y;
+    const int f = blockIdx.x / tiles_per_frame, tile = blockIdx.x % tiles_per_frame;
+    const int w = (tile % word_groups) * 4 + (threadIdx.x >> 6); // wave-uniform
+    if (w >= wpr)
+        return;
+    const int r0 = (tile / word_groups) * EXTRACT_RG, r1 = min(r0 + EXTRACT_RG, crows);
+    const int c = w * 64 + (threadIdx.x & 63);
+    const int cc = min(c, ccols - 1);
     const uint8_t *__restrict__ src = mask + (long long)f * prows * pcols;
-    const uint32_t *__restrict__ crow = code + (long long)row * ccols;
-    unsigned long long *__restrict__ brow = bitmap + ((long long)f * crows + row) * wpr;
-    const int first = span[2 * row], last = span[2 * row + 1];
-    __shared__ int s_cnt[4];
-    int cnt = 0;
-    // words outside the span are zero; words inside are produced by ballots of 64 columns
-    for (int w = threadIdx.x >> 6; w < wpr; w += 4) {
-        const int c = w * 64 + (threadIdx.x & 63);
-        bool bit = false;
-        if (w * 64 < last && w * 64 + 64 > first) { // wave-uniform
-            if (c >= first && c < last) {
-                const uint32_t cd = crow[c];
-                if (cd != SFE_CODE_NONE)
-                    bit = remap_value(src, prows, pcols, cd) != 0;
-            }
+    for (int rb = r0; rb < r1; rb += EXTRACT_U) {
+        uint32_t cd[EXTRACT_U];
+#pragma unroll
+        for (int i = 0; i < EXTRACT_U; ++i) {
+            const int row = min(rb + i, crows - 1);
+            cd[i] = code[(long long)row * ccols + cc];
         }
-        const unsigned long long word = __ballot(bit);
-        if ((threadIdx.x & 63) == 0) {
-            brow[w] = word;
-            cnt += __popcll(word);
+        int v[EXTRACT_U][4], fxy[EXTRACT_U];
+#pragma unroll
+        for (int i = 0; i < EXTRACT_U; ++i) {
+            const unsigned lin = cd[i] >> 10;
+            fxy[i] = (int)(cd[i] & 1023u);
+            const unsigned q = __umulhi(lin, rcp);
+            const int iy = (int)q - 1, ix = (int)(lin - q * (unsigned)(pcols + 1)) - 1;
+            const int ya = min(max(iy, 0), prows - 1), yb = min(max(iy + 1, 0), prows - 1);
+            const int xa = min(max(ix, 0), pcols - 1), xb = min(max(ix + 1, 0), pcols - 1);
+            const uint8_t *ra = src + (size_t)ya * pcols, *rbp = src + (size_t)yb * pcols;
+            const int my0 = (iy >= 0 && iy < prows) ? 0xff : 0, my1 = (iy + 1 >= 0 && iy + 1 < prows) ? 0xff : 0;
+            const int mx0 = (ix >= 0 && ix < pcols) ? 0xff : 0, mx1 = (ix + 1 >= 0 && ix + 1 < pcols) ? 0xff : 0;
+            v[i][0] = ra[xa] & my0 & mx0;
+            v[i][1] = ra[xb] & my0 & mx1;
+            v[i][2] = rbp[xa] & my1 & mx0;
+            v[i][3] = rbp[xb] & my1 & mx1;
+        }
+#pragma unroll
+        for (int i = 0; i < EXTRACT_U; ++i) {
+            const int row = rb + i;
+            const int rowc = min(row, crows - 1);
+            const int first = span[2 * rowc], last = span[2 * rowc + 1];
+            const int fy = fxy[i] >> 5, fx = fxy[i] & 31;
+            int w00 = (32 - fy) * (32 - fx) * 32, w01 = (32 - fy) * fx * 32;
+            int w10 = fy * (32 - fx) * 32, w11 = fy * fx * 32;
+            if ((fx | fy) == 0) {
+                w00 = 32767;
+                w11 = 1;
+            }
+            const int acc = w00 * v[i][0] + w01 * v[i][1] + w10 * v[i][2] + w11 * v[i][3];
+            const bool ok = row < r1 && c >= first && c < last && cd[i] != SFE_CODE_NONE;
+            const bool bit = ok && ((acc + 16384) >> 15) != 0;
+            const unsigned long long word = __ballot(bit);
+            if ((threadIdx.x & 63) == 0 && row < r1)
+                bitmap[((long long)f * crows + row) * wpr + w] = word;
         }
     }
-    if ((threadIdx.x & 63) == 0)
-        s_cnt[threadIdx.x >> 6] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0)
-        row_count[(long long)f * crows + row] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 }
 
-// pass 2: one workgroup per frame: exclusive scan of the row counts -> row offsets + frame total
-__global__ __launch_bounds__(256) void extract_scan_kernel(const int32_t *__restrict__ row_count,
+// pass 2: one workgroup per frame: row counts from the bitmap, exclusive scan -> row offsets + total
+__global__ __launch_bounds__(256) void extract_scan_kernel(const unsigned long long *__restrict__ bitmap,
+                                                           int32_t *__restrict__ row_count,
                                                            int32_t *__restrict__ row_off,
-                                                           int32_t *__restrict__ frame_count, int crows)
+                                                           int32_t *__restrict__ frame_count, int crows, int wpr)
 {
     const int f = blockIdx.x;
-    const int32_t *__restrict__ cnt = row_count + (long long)f * crows;
+    int32_t *__restrict__ cnt = row_count + (long long)f * crows;
     int32_t *__restrict__ off = row_off + (long long)f * crows;
     __shared__ int s_part[256];
     const int per = (crows + 255) / 256;
     const int b = threadIdx.x * per, e = min(b + per, crows);
     int s = 0;
-    for (int i = b; i < e; ++i)
-        s += cnt[i];
+    for (int i = b; i < e; ++i) {
+        const unsigned long long *__restrict__ brow = bitmap + ((long long)f * crows + i) * wpr;
+        int c = 0;
+        for (int w = 0; w < wpr; ++w)
+            c += __popcll(brow[w]);
+        cnt[i] = c;
+        s += c;
+    }
     s_part[threadIdx.x] = s;
     __syncthreads();
     for (int d = 1; d < 256; d <<= 1) { // Hillis-Steele inclusive scan
@@ -192,11 +242,13 @@ static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_f
     for (int f0 = 0; f0 < n_frames; f0 += chunk) {
         const int nf = std::min(chunk, n_frames - f0);
         const uint8_t *m = d_mask + (size_t)f0 * g->polar_rows * g->polar_cols;
-        hipLaunchKernelGGL(extract_bits_kernel, dim3(crows, nf), dim3(256), 0, ctx->stream, m,
-                           (const uint32_t *)g->d_code, g->d_span, d_bm, d_rcnt, g->polar_rows, g->polar_cols,
-                           crows, g->cart_cols, wpr);
-        hipLaunchKernelGGL(extract_scan_kernel, dim3(nf), dim3(256), 0, ctx->stream, d_rcnt, d_roff,
-                           d_counts + f0, crows);
+        const int word_groups = (wpr + 3) / 4;
+        const int tiles = word_groups * ((crows + EXTRACT_RG - 1) / EXTRACT_RG);
+        hipLaunchKernelGGL(extract_bits_kernel, dim3((unsigned)(nf * tiles)), dim3(256), 0, ctx->stream, m,
+                           (const uint32_t *)g->d_code, g->d_span, d_bm, g->polar_rows, g->polar_cols, g->rcp, crows,
+                           g->cart_cols, wpr, word_groups, tiles);
+        hipLaunchKernelGGL(extract_scan_kernel, dim3(nf), dim3(256), 0, ctx->stream, d_bm, d_rcnt, d_roff,
+                           d_counts + f0, crows, wpr);
         hipLaunchKernelGGL(extract_expand_kernel, dim3(crows, nf), dim3(64), 0, ctx->stream, d_bm, d_rcnt, d_roff,
                            d_rc ? d_rc + (size_t)f0 * cap * 2 : nullptr,
                            d_pts ? d_pts + (size_t)f0 * cap * 2 : nullptr, cap, crows, g->cart_cols, wpr,
@@ -261,6 +313,16 @@ int sfe_geom_create(sfe_ctx *ctx, const float *map_x, const float *map_y, int ca
     g->width = width;
     g->height = height;
     g->words_per_row = (cart_cols + 63) / 64;
+    {   // reciprocal of (polar_cols+1) for the in-kernel divide; verify exactness over the whole range
+        const unsigned d = (unsigned)(polar_cols + 1);
+        g->rcp = (unsigned)((0x100000000ull + d - 1) / d);
+        const unsigned lin_max = (unsigned)(polar_rows + 1) * d;
+        for (unsigned lin = 0; lin < lin_max; ++lin)
+            if ((unsigned)(((unsigned long long)lin * g->rcp) >> 32) != lin / d) {
+                sfe_geom_destroy(g);
+                return sfe_set_err(ctx, SFE_ERR_ARG, "reciprocal divide not exact for polar_cols=%d", polar_cols);
+            }
+    }
     if (hipMalloc((void **)&g->d_code, n * 4) != hipSuccess ||
         hipMalloc((void **)&g->d_span, span.size() * 4) != hipSuccess) {
         sfe_geom_destroy(g);
@@ -302,7 +364,7 @@ int sfe_remap_u8(sfe_ctx *ctx, sfe_geom *g, const uint8_t *src, uint8_t *dst)
         return SFE_ERR_HIP;
     SFE_HIP(ctx, hipMemcpyAsync(d_src, src, np, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(remap_u8_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, ctx->stream, d_src,
-                       (const uint32_t *)g->d_code, d_dst, g->polar_rows, g->polar_cols, (long long)nc, 1);
+                       (const uint32_t *)g->d_code, d_dst, g->polar_rows, g->polar_cols, g->rcp, (long long)nc, 1);
     SFE_LAUNCH_CHECK(ctx);
     SFE_HIP(ctx, hipMemcpyAsync(dst, d_dst, nc, hipMemcpyDeviceToHost, ctx->stream));
     SFE_HIP(ctx, hipStreamSynchronize(ctx->stream));

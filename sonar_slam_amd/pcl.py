@@ -7,7 +7,8 @@ Same names and call signatures as ``PYBIND11_MODULE(pcl, m)``
     remove_outlier(points, radius, min_points) -> points'                           pcl.cpp:54
     class ICP: loadFromYaml(path), compute(source, target, guess) -> (message, T),
                getCovariance()                                                      pcl.cpp:184-213
-    downsample / density_filter: see NotImplementedError text
+    downsample(points[, descriptors], resolution) -> points'[, descriptors']       pcl.cpp:128-159
+    density_filter: not built (no caller in the reference)
 
 Extension (not in the reference): ``ICP.compute_batch(source, target, guesses)`` runs the
 many-guesses-one-pair loop of SLAM.compute_icp_with_cov (slam.py:346-358) in one launch.
@@ -63,10 +64,30 @@ def remove_outlier(points, radius, min_points, ctx=None):
     return out[:n.value].copy()
 
 
-def downsample(*args):
-    raise NotImplementedError(
-        "pcl.downsample (libpointmatcher OctreeGridDataPointsFilter, pcl.cpp:128-159) is the next "
-        "row of the scope table (SURVEY 8 f1) and is not built yet; no CPU stand-in is shipped")
+def downsample(points, *args, **kw):
+    """libpointmatcher OctreeGridDataPointsFilter replacement (pcl.cpp:128-159), both overloads:
+    ``downsample(points, resolution)`` -> points' and
+    ``downsample(points, descriptors, resolution)`` -> (points', descriptors')."""
+    ctx = kw.pop("ctx", None) or _L.default_context()
+    if len(args) == 1:
+        desc, resolution = None, args[0]
+    elif len(args) == 2:
+        desc, resolution = _np.ascontiguousarray(args[0], _np.float32), args[1]
+    else:
+        raise TypeError("downsample(points, resolution) or downsample(points, descriptors, resolution)")
+    pts = _cloud(points, "downsample(points)")
+    if desc is not None and len(desc) != len(pts):
+        raise TypeError("downsample: %d descriptors for %d points" % (len(desc), len(pts)))
+    if len(pts) == 0:  # pcl.cpp:130-131,145-146
+        return pts if desc is None else (pts, desc)
+    out = _np.zeros_like(pts)
+    idx = _np.zeros(len(pts), _np.int32)
+    n = _C.c_int(0)
+    with ctx.lock:
+        ctx._check(ctx.lib.sfe_downsample(ctx.handle, _L.ptr(pts, _C.c_float), len(pts), float(resolution),
+                                          _L.ptr(out, _C.c_float), _L.ptr(idx, _C.c_int32), _C.byref(n)))
+    out = out[:n.value].copy()
+    return out if desc is None else (out, desc[idx[:n.value]].copy())
 
 
 def density_filter(*args):

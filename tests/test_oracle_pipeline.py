@@ -138,3 +138,21 @@ def test_remove_outlier_semantics():
     out = oracle.remove_outlier(pts, 1.0, 3)   # needs > 3 points in radius counting itself
     assert np.array_equal(out, pts[[0, 1, 2, 4]])
     assert len(oracle.remove_outlier(pts, 1.0, 4)) == 0
+
+
+def test_downsample_oracle_properties():
+    rng = np.random.default_rng(11)
+    pts = rng.uniform(-10, 10, (2500, 2)).astype(np.float32)
+    out, idx = oracle.downsample(pts, 0.5, return_index=True)
+    assert np.array_equal(out, pts[idx]) and len(set(idx.tolist())) == len(idx)
+    # every input point lies in the same <= 0.5 m cell as some output point
+    assert 0.2 * len(pts) < len(out) < len(pts)
+    d = np.sqrt(((pts[:, None, :] - out[None, :, :]) ** 2).sum(-1)).min(1)
+    assert d.max() <= 0.5 * np.sqrt(2) + 1e-5
+    # a single point / identical points collapse to one
+    assert len(oracle.downsample(pts[:1], 0.5)) == 1
+    assert len(oracle.downsample(np.repeat(pts[:1], 9, axis=0), 0.5)) == 1
+    # coarse resolution >= bounding box: one medoid for the whole cloud
+    one = oracle.downsample(pts, 100.0)
+    c = pts.mean(0)
+    assert len(one) == 1 and np.allclose(one[0], pts[np.argmin(((pts - c) ** 2).sum(1))])

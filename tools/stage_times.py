@@ -1,0 +1,53 @@
+#!/usr/bin/env python
+"""Per-stage HIP-event timing of the keyframe pipeline (CFAR / extract / ICP) for quick A/B."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from sonar_slam_amd import _lib, icp_config  # noqa: E402
+from sonar_slam_amd.CFAR import CFAR  # noqa: E402
+from sonar_slam_amd.feature_extraction import FeatureExtraction, SonarPing, oculus_bearings  # noqa: E402
+from sonar_slam_amd.pipeline import KeyframeBatch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--icp-variants", default="0,2")
+    a = ap.parse_args()
+    ctx = _lib.default_context()
+    det = CFAR(40, 10, 0.1, 10)
+    fe = FeatureExtraction(ctx)
+    fe.Ntc, fe.Ngc, fe.Pfa, fe.rank, fe.alg, fe.threshold = 40, 10, 0.1, 10, "SOCA", 65
+    fe.configure()
+    frames, srcs, tgts, guesses = bench.make_inputs(0, a.batch)
+    fe.generate_map_xy(SonarPing(frames[0], oculus_bearings(bench.COLS), 30.0 / bench.ROWS))
+
+    def timed(fn, reps):
+        fn()
+        ctx.sync()
+        ctx.timer_start()
+        for _ in range(reps):
+            fn()
+        return ctx.timer_stop() / reps
+    for mode, p in (("p2plane30", icp_config.shipped_params(minimizer=1, use_diff_checker=0, max_iter=30)),
+                    ("reference", icp_config.shipped_params())):
+        kb = KeyframeBatch(ctx, fe.geometry, det.params["SOCA"], "SOCA", 65, p, a.batch)
+        kb.upload_frames(frames)
+        kb.upload_scan_pairs(srcs, tgts, guesses)
+        if mode == "p2plane30":
+            print("cfar    %8.3f ms / %d frames" % (timed(kb.run_cfar, 10), a.batch))
+            print("extract %8.3f ms / %d frames" % (timed(kb.run_extract, 10), a.batch))
+        for v in [int(x) for x in a.icp_variants.split(",")]:
+            ctx._check(ctx.lib.sfe_icp_set_tuning(ctx.handle, v))
+            print("icp %-9s variant %d %8.3f ms / %d jobs" % (mode, v, timed(kb.run_icp, 3), a.batch))
+        ctx._check(ctx.lib.sfe_icp_set_tuning(ctx.handle, 0))
+        kb.free()
+
+
+if __name__ == "__main__":
+    main()
