@@ -9,7 +9,7 @@
 
 #include "../../include/sonarfe.h"
 
-#define SFE_NSCRATCH 12
+#define SFE_NSCRATCH 14
 
 struct sfe_ctx {
     int device = -1;
@@ -34,6 +34,8 @@ struct sfe_geom {
     int32_t *d_span = nullptr;   // per Cartesian row: [first, last+1) columns with code != -1
     int words_per_row = 0;       // 64-bit bitmap words per Cartesian row
     unsigned rcp = 0;            // ceil(2^32 / (polar_cols+1))
+    int32_t *d_tile_rows = nullptr; // per canvas tile: [ylo, yhi] polar rows tapped by its valid pixels
+    int word_groups = 0, tiles_per_frame = 0, lds_bytes = 0;
 };
 
 int sfe_set_err(sfe_ctx *ctx, int code, const char *fmt, ...);

@@ -64,32 +64,100 @@ __global__ __launch_bounds__(256) void remap_u8_kernel(const uint8_t *__restrict
     dst[i] = (c == SFE_CODE_NONE) ? 0 : (uint8_t)remap_value(src + f * (long long)prows * pcols, prows, pcols, rcp, c);
 }
 
+// pass 0: pack the uint8 detection mask into bits (bit iy*pcols+ix of the frame's bit stream,
+// LSB first) and note whether any byte is > 1 (then the binary shortcut of pass 1 is not valid).
+__global__ __launch_bounds__(256) void mask_pack_kernel(const uint8_t *__restrict__ mask,
+                                                        uint32_t *__restrict__ bits, int32_t *__restrict__ nonbinary,
+                                                        long long px_per_frame, long long words_per_frame)
+{
+    const long long wi = (long long)blockIdx.x * 256 + threadIdx.x; // word index inside the frame
+    const int f = blockIdx.y;
+    if (wi >= words_per_frame)
+        return;
+    const uint8_t *__restrict__ src = mask + (long long)f * px_per_frame + wi * 32;
+    const long long left = px_per_frame - wi * 32;
+    uint32_t out = 0, big = 0;
+    if (left >= 32 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        const uint4 a = reinterpret_cast<const uint4 *>(src)[0], b = reinterpret_cast<const uint4 *>(src)[1];
+        const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t nz = ((w[i] | ((w[i] & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u) >> 7;
+            out |= (((nz * 0x00204081u) >> 21) & 0xfu) << (4 * i);
+            big |= w[i] & 0xfefefefeu;
+        }
+    } else {
+        for (int i = 0; i < 32 && i < left; ++i) {
+            out |= (uint32_t)(src[i] != 0) << i;
+            big |= src[i] & 0xfeu;
+        }
+    }
+    bits[(long long)f * words_per_frame + wi] = out;
+    if (big)
+        nonbinary[f] = 1;
+}
+
 // pass 1: detection bits of the Cartesian canvas as 64-bit ballot words.
-// A wave owns one 64-column word position and EXTRACT_RG consecutive Cartesian rows.  The kernel
-// is latency-bound, not bandwidth-bound (a dependent chain code -> 4 taps -> ballot per word; the
-// first version ran one chain at a time per wave and took 2.1 ms per 256 frames at 32 waves/CU),
-// so EXTRACT_U rows are processed together: all code loads first, then all 4*U tap loads, with
-// clamped addresses instead of branches so that everything is in flight at once.
-// Workgroup -> (frame, row group, word group) with the word group fastest: XCD k keeps word
-// groups k (mod 8), i.e. one vertical strip of the canvas = 1/8 of the code table (L2-resident)
-// and roughly one bearing sector of every mask.
-#define EXTRACT_RG 16
-#define EXTRACT_U 8
+// Gathering the four taps of every Cartesian pixel straight from the byte mask is bound by the
+// L1 tag pipeline (adjacent Cartesian pixels fall into different 128-byte lines of the polar
+// image: ~1 lane per clock, 2.1 ms per 256 frames whatever the loop structure).  So the mask is
+// bit-packed (64 KiB per 1024x512 frame) and each workgroup stages the polar rows its tile
+// of the canvas needs -- a precomputed [ylo, yhi] range -- into LDS, where random bit reads cost
+// a ds_read each.  Tile = 4 ballot words (256 columns) x EXTRACT_RG rows; a wave owns one word
+// position and walks the rows, EXTRACT_U rows per batch so the code loads overlap.
+// Workgroup -> (frame, row group, word group) with the word group fastest: XCD k keeps the word
+// groups k (mod 8), i.e. a vertical strip of the canvas = 1/8 of the code table (L2-resident).
+// Non-binary masks (values > 1, where cv2.remap's result depends on the values) take the
+// general byte-gather path.
+#define EXTRACT_RG 32
+#define EXTRACT_U 4
 __global__ __launch_bounds__(256) void extract_bits_kernel(const uint8_t *__restrict__ mask,
+                                                           const uint32_t *__restrict__ bits,
+                                                           const int32_t *__restrict__ nonbinary,
                                                            const uint32_t *__restrict__ code,
                                                            const int32_t *__restrict__ span,
+                                                           const int32_t *__restrict__ tile_rows,
                                                            unsigned long long *__restrict__ bitmap, int prows,
                                                            int pcols, unsigned rcp, int crows, int ccols, int wpr,
-                                                           int word_groups, int tiles_per_frame)
+                                                           int word_groups, int tiles_per_frame,
+                                                           long long words_per_frame)
 {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_bits[];
     const int f = blockIdx.x / tiles_per_frame, tile = blockIdx.x % tiles_per_frame;
     const int w = (tile % word_groups) * 4 + (threadIdx.x >> 6); // wave-uniform
-    if (w >= wpr)
-        return;
     const int r0 = (tile / word_groups) * EXTRACT_RG, r1 = min(r0 + EXTRACT_RG, crows);
     const int c = w * 64 + (threadIdx.x & 63);
     const int cc = min(c, ccols - 1);
-    const uint8_t *__restrict__ src = mask + (long long)f * prows * pcols;
+    const int ylo = tile_rows[2 * tile], yhi = tile_rows[2 * tile + 1];
+    // general path: non-binary mask, or rows that are not a whole number of 32-bit words
+    const bool general = nonbinary[f] != 0 || (pcols & 31) != 0; // block-uniform
+    const int pw = pcols >> 5;  // words per polar row
+    const int S = pw | 1;       // LDS row stride: odd, so rows 2 apart do not share a bank
+    if (!general && ylo <= yhi) {
+        const uint32_t *__restrict__ src = bits + (long long)f * words_per_frame + (long long)ylo * pw;
+        const int nw = (yhi - ylo + 1) * pw;
+        // 8 independent loads in flight per lane (the staging is otherwise a chain of L2 latencies)
+        for (int i0 = threadIdx.x; i0 < nw; i0 += 256 * 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 256;
+                v[u] = (i < nw) ? src[i] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 256;
+                if (i < nw) {
+                    const int r = i / pw, cw = i - r * pw;
+                    s_bits[r * S + cw] = v[u];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (w >= wpr)
+        return;
+    const uint8_t *__restrict__ msrc = mask + (long long)f * prows * pcols;
     for (int rb = r0; rb < r1; rb += EXTRACT_U) {
         uint32_t cd[EXTRACT_U];
 #pragma unroll
@@ -97,38 +165,43 @@ __global__ __launch_bounds__(256) void extract_bits_kernel(const uint8_t *__rest
             const int row = min(rb + i, crows - 1);
             cd[i] = code[(long long)row * ccols + cc];
         }
-        int v[EXTRACT_U][4], fxy[EXTRACT_U];
-#pragma unroll
-        for (int i = 0; i < EXTRACT_U; ++i) {
-            const unsigned lin = cd[i] >> 10;
-            fxy[i] = (int)(cd[i] & 1023u);
-            const unsigned q = __umulhi(lin, rcp);
-            const int iy = (int)q - 1, ix = (int)(lin - q * (unsigned)(pcols + 1)) - 1;
-            const int ya = min(max(iy, 0), prows - 1), yb = min(max(iy + 1, 0), prows - 1);
-            const int xa = min(max(ix, 0), pcols - 1), xb = min(max(ix + 1, 0), pcols - 1);
-            const uint8_t *ra = src + (size_t)ya * pcols, *rbp = src + (size_t)yb * pcols;
-            const int my0 = (iy >= 0 && iy < prows) ? 0xff : 0, my1 = (iy + 1 >= 0 && iy + 1 < prows) ? 0xff : 0;
-            const int mx0 = (ix >= 0 && ix < pcols) ? 0xff : 0, mx1 = (ix + 1 >= 0 && ix + 1 < pcols) ? 0xff : 0;
-            v[i][0] = ra[xa] & my0 & mx0;
-            v[i][1] = ra[xb] & my0 & mx1;
-            v[i][2] = rbp[xa] & my1 & mx0;
-            v[i][3] = rbp[xb] & my1 & mx1;
-        }
 #pragma unroll
         for (int i = 0; i < EXTRACT_U; ++i) {
             const int row = rb + i;
             const int rowc = min(row, crows - 1);
             const int first = span[2 * rowc], last = span[2 * rowc + 1];
-            const int fy = fxy[i] >> 5, fx = fxy[i] & 31;
-            int w00 = (32 - fy) * (32 - fx) * 32, w01 = (32 - fy) * fx * 32;
-            int w10 = fy * (32 - fx) * 32, w11 = fy * fx * 32;
-            if ((fx | fy) == 0) {
-                w00 = 32767;
-                w11 = 1;
-            }
-            const int acc = w00 * v[i][0] + w01 * v[i][1] + w10 * v[i][2] + w11 * v[i][3];
             const bool ok = row < r1 && c >= first && c < last && cd[i] != SFE_CODE_NONE;
-            const bool bit = ok && ((acc + 16384) >> 15) != 0;
+            bool bit = false;
+            if (w * 64 >= last || w * 64 + 64 <= first) {
+                // wave-uniform: the whole word lies outside the sonar fan
+            } else if (general) {
+                if (ok)
+                    bit = remap_value(msrc, prows, pcols, rcp, cd[i]) != 0;
+            } else if (ylo <= yhi) { // (a tile without any valid pixel has nothing staged)
+                const unsigned lin = cd[i] >> 10;
+                const int fy = (int)((cd[i] >> 5) & 31u), fx = (int)(cd[i] & 31u);
+                const unsigned q = __umulhi(lin, rcp);
+                const int iy = (int)q - 1, ix = (int)(lin - q * (unsigned)(pcols + 1)) - 1;
+                // clamp into the staged rows (valid pixels are inside by construction), zero the
+                // out-of-image taps afterwards
+                const int ya = min(max(iy, ylo), yhi), yb = min(max(iy + 1, ylo), yhi);
+                const int xa = min(max(ix, 0), pcols - 1), xb = min(max(ix + 1, 0), pcols - 1);
+                const int my0 = (iy >= 0 && iy < prows), my1 = (iy + 1 >= 0 && iy + 1 < prows);
+                const int mx0 = (ix >= 0 && ix < pcols), mx1 = (ix + 1 >= 0 && ix + 1 < pcols);
+                const int ra = (ya - ylo) * S, rb2 = (yb - ylo) * S;
+                const int v00 = (s_bits[ra + (xa >> 5)] >> (xa & 31)) & my0 & mx0;
+                const int v01 = (s_bits[ra + (xb >> 5)] >> (xb & 31)) & my0 & mx1;
+                const int v10 = (s_bits[rb2 + (xa >> 5)] >> (xa & 31)) & my1 & mx0;
+                const int v11 = (s_bits[rb2 + (xb >> 5)] >> (xb & 31)) & my1 & mx1;
+                int w00 = (32 - fy) * (32 - fx) * 32, w01 = (32 - fy) * fx * 32;
+                int w10 = fy * (32 - fx) * 32, w11 = fy * fx * 32;
+                if ((fx | fy) == 0) {
+                    w00 = 32767;
+                    w11 = 1;
+                }
+                const int acc = w00 * v00 + w01 * v01 + w10 * v10 + w11 * v11;
+                bit = ok && ((acc + 16384) >> 15) != 0;
+            }
             const unsigned long long word = __ballot(bit);
             if ((threadIdx.x & 63) == 0 && row < r1)
                 bitmap[((long long)f * crows + row) * wpr + w] = word;
@@ -239,14 +312,25 @@ static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_f
     int32_t *d_roff = (int32_t *)sfe_scratch(ctx, 6, (size_t)chunk * crows * 4);
     if (!d_bm || !d_rcnt || !d_roff)
         return SFE_ERR_HIP;
+    const long long px = (long long)g->polar_rows * g->polar_cols;
+    const long long wpf = (px + 31) / 32 + 1; // +1 pad word: a tap's word index may be one past the last row
+    uint32_t *d_bits = (uint32_t *)sfe_scratch(ctx, 10, (size_t)chunk * wpf * 4);
+    int32_t *d_nonbin = (int32_t *)sfe_scratch(ctx, 11, (size_t)chunk * 4);
+    if (!d_bits || !d_nonbin)
+        return SFE_ERR_HIP;
+    SFE_HIP(ctx, hipFuncSetAttribute((const void *)extract_bits_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     g->lds_bytes));
     for (int f0 = 0; f0 < n_frames; f0 += chunk) {
         const int nf = std::min(chunk, n_frames - f0);
         const uint8_t *m = d_mask + (size_t)f0 * g->polar_rows * g->polar_cols;
-        const int word_groups = (wpr + 3) / 4;
-        const int tiles = word_groups * ((crows + EXTRACT_RG - 1) / EXTRACT_RG);
-        hipLaunchKernelGGL(extract_bits_kernel, dim3((unsigned)(nf * tiles)), dim3(256), 0, ctx->stream, m,
-                           (const uint32_t *)g->d_code, g->d_span, d_bm, g->polar_rows, g->polar_cols, g->rcp, crows,
-                           g->cart_cols, wpr, word_groups, tiles);
+        const int word_groups = g->word_groups;
+        const int tiles = g->tiles_per_frame;
+        SFE_HIP(ctx, hipMemsetAsync(d_nonbin, 0, (size_t)nf * 4, ctx->stream));
+        hipLaunchKernelGGL(mask_pack_kernel, dim3((unsigned)((wpf + 255) / 256), nf), dim3(256), 0, ctx->stream, m,
+                           d_bits, d_nonbin, px, wpf);
+        hipLaunchKernelGGL(extract_bits_kernel, dim3((unsigned)(nf * tiles)), dim3(256), g->lds_bytes, ctx->stream, m,
+                           d_bits, d_nonbin, (const uint32_t *)g->d_code, g->d_span, g->d_tile_rows, d_bm,
+                           g->polar_rows, g->polar_cols, g->rcp, crows, g->cart_cols, wpr, word_groups, tiles, wpf);
         hipLaunchKernelGGL(extract_scan_kernel, dim3(nf), dim3(256), 0, ctx->stream, d_bm, d_rcnt, d_roff,
                            d_counts + f0, crows, wpr);
         hipLaunchKernelGGL(extract_expand_kernel, dim3(crows, nf), dim3(64), 0, ctx->stream, d_bm, d_rcnt, d_roff,
@@ -323,13 +407,43 @@ int sfe_geom_create(sfe_ctx *ctx, const float *map_x, const float *map_y, int ca
                 return sfe_set_err(ctx, SFE_ERR_ARG, "reciprocal divide not exact for polar_cols=%d", polar_cols);
             }
     }
+    // per tile of the canvas (4 ballot words x EXTRACT_RG rows): the polar rows its valid pixels tap
+    g->word_groups = (g->words_per_row + 3) / 4;
+    const int row_groups = (cart_rows + EXTRACT_RG - 1) / EXTRACT_RG;
+    g->tiles_per_frame = g->word_groups * row_groups;
+    std::vector<int32_t> tile_rows(2 * (size_t)g->tiles_per_frame);
+    long long max_words = 2;
+    for (int t = 0; t < g->tiles_per_frame; ++t) {
+        const int wg = t % g->word_groups, rg = t / g->word_groups;
+        int ylo = polar_rows, yhi = -1;
+        for (int r = rg * EXTRACT_RG; r < std::min((rg + 1) * EXTRACT_RG, cart_rows); ++r)
+            for (int c = wg * 256; c < std::min((wg + 1) * 256, cart_cols); ++c) {
+                const uint32_t cd = code[(size_t)r * cart_cols + c];
+                if (cd == SFE_CODE_NONE)
+                    continue;
+                const int iy = (int)((cd >> 10) / (uint32_t)(polar_cols + 1)) - 1;
+                ylo = std::min(ylo, std::max(iy, 0));
+                yhi = std::max(yhi, std::min(iy + 1, polar_rows - 1));
+            }
+        tile_rows[2 * t] = ylo;
+        tile_rows[2 * t + 1] = yhi;
+        if (ylo <= yhi)
+            max_words = std::max(max_words, (long long)(yhi - ylo + 1) * ((polar_cols >> 5) | 1));
+    }
+    g->lds_bytes = (int)(max_words * 4);
+    if (g->lds_bytes > 150 * 1024) {
+        sfe_geom_destroy(g);
+        return sfe_set_err(ctx, SFE_ERR_ARG, "geometry needs %d bytes of LDS per canvas tile (max 153600)", g->lds_bytes);
+    }
     if (hipMalloc((void **)&g->d_code, n * 4) != hipSuccess ||
-        hipMalloc((void **)&g->d_span, span.size() * 4) != hipSuccess) {
+        hipMalloc((void **)&g->d_span, span.size() * 4) != hipSuccess ||
+        hipMalloc((void **)&g->d_tile_rows, tile_rows.size() * 4) != hipSuccess) {
         sfe_geom_destroy(g);
         return sfe_set_err(ctx, SFE_ERR_HIP, "hipMalloc for geometry failed");
     }
     if (hipMemcpy(g->d_code, code.data(), n * 4, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(g->d_span, span.data(), span.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        hipMemcpy(g->d_span, span.data(), span.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(g->d_tile_rows, tile_rows.data(), tile_rows.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
         sfe_geom_destroy(g);
         return sfe_set_err(ctx, SFE_ERR_HIP, "hipMemcpy for geometry failed");
     }
@@ -349,6 +463,8 @@ void sfe_geom_destroy(sfe_geom *g)
         (void)hipFree(g->d_code);
     if (g->d_span)
         (void)hipFree(g->d_span);
+    if (g->d_tile_rows)
+        (void)hipFree(g->d_tile_rows);
     delete g;
 }
 
