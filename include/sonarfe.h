@@ -168,8 +168,15 @@ int sfe_icp_compute(sfe_ctx *ctx, const sfe_icp_params *p, const float *src, int
 int sfe_icp_compute_guesses(sfe_ctx *ctx, const sfe_icp_params *p, const float *src, int n_src,
                             const float *tgt, int n_tgt, const float *guesses9, int n_guesses,
                             float *T_out9, int32_t *status, int32_t *iters);
-/* A-B knob for the ICP kernel: bit 0: 0 = packed fp32 NN loop (default), 1 = scalar fp32; bit 1: 0 = 64-VGPR build, 2 workgroups/CU (default), 1 = 128-VGPR build */
+/* A-B knob for the ICP kernels.  bit 2: 0 = sorted-sweep exact NN search (default; targets of up to
+ * 8192 points, larger ones take the brute-force kernel), 1 = brute-force tile scan for everything.
+ * Brute-force only: bit 0: 0 = packed fp32 NN loop, 1 = scalar fp32; bit 1: 0 = 64-VGPR build,
+ * 2 workgroups/CU, 1 = 128-VGPR build.  All variants return identical results. */
 int sfe_icp_set_tuning(sfe_ctx *ctx, int variant);
+/* debug: enable/disable per-phase cycle counters of the sweep kernel (workgroup 0) and read the
+ * counts of the last launch: [0] setup, [1] transform+binary search, [2] sweep, [3] trimmed
+ * quantile, [4] reduction, [5] solve; summed over iterations */
+int sfe_icp_get_profile(sfe_ctx *ctx, int enable, long long *cycles8);
 /* independent jobs, device-resident: clouds concatenated, job j uses
  * src[src_off[j]..src_off[j+1]) and tgt[tgt_off[j]..tgt_off[j+1]) (offsets in points, host
  * arrays of n_jobs+1), guess d_guess9 + 9*j; outputs d_T9 (9 floats), d_status, d_iters per job */

@@ -25,85 +25,7 @@
 #include <cmath>
 #include <cstring>
 
-#define ICP_THREADS 1024
-#define ICP_WAVES (ICP_THREADS / 64)
-#define ICP_TCAP 8192 // target points resident in LDS (64 KiB as float2)
-#define ICP_PB 8      // max source points per lane per pass over the target
-#define ICP_CH 16     // target points per chunk of the two-level arg-min
-#define ICP_KMAX 16   // max neighbours for the PCA normals
-#define ICP_MAX_HIST 64 // transformation history kept for the differential checker
-
-struct IcpJob {
-    int src_start, n_src, tgt_start, n_tgt;
-    long long scratch_off; // offset (in points) of this job's slice of the NN scratch
-    long long nrm_off;     // offset (in points) of this job's slice of the normals scratch
-};
-
-__device__ __forceinline__ float f_mul(float a, float b) { return __fmul_rn(a, b); }
-__device__ __forceinline__ float f_add(float a, float b) { return __fadd_rn(a, b); }
-
-// x' = (a*x + b*y) + c with every product/sum rounded to float (Eigen's coefficient product)
-__device__ __forceinline__ float affine1(float a, float b, float c, float x, float y)
-{
-    return f_add(f_add(f_mul(a, x), f_mul(b, y)), c);
-}
-
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1)
-        v += __shfl_down(v, d);
-    return v;
-}
-
-// block-wide sum of NV doubles per thread; result valid in every thread
-template <int NV>
-__device__ __forceinline__ void block_sum(double (&v)[NV], double *s_red /* ICP_WAVES*NV + NV */)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const double s = wave_sum(v[i]);
-        if (lane == 0)
-            s_red[wave * NV + i] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x < NV) {
-        double s = 0;
-        for (int w = 0; w < ICP_WAVES; ++w) // fixed order: deterministic
-            s += s_red[w * NV + threadIdx.x];
-        s_red[ICP_WAVES * NV + threadIdx.x] = s;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NV; ++i)
-        v[i] = s_red[ICP_WAVES * NV + i];
-    __syncthreads();
-}
-
-__device__ __forceinline__ void mat3_mul(const float *a, const float *b, float *c)
-{
-    float r[9];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            float s = f_mul(a[i * 3], b[j]);
-            s = f_add(s, f_mul(a[i * 3 + 1], b[3 + j]));
-            s = f_add(s, f_mul(a[i * 3 + 2], b[6 + j]));
-            r[i * 3 + j] = s;
-        }
-#pragma unroll
-    for (int i = 0; i < 9; ++i)
-        c[i] = r[i];
-}
-
-__device__ __forceinline__ float dist2(float px, float py, float tx, float ty)
-{
-    // fl(fl(dx*dx) + fl(dy*dy)): how the oracle / libnabo accumulate the squared distance
-    const float dx = f_add(px, -tx), dy = f_add(py, -ty);
-    return f_add(f_mul(dx, dx), f_mul(dy, dy));
-}
+#include "sfe_icp_common.h"
 
 // Two-level exact arg-min over one LDS tile of centred target points for NP query points per
 // lane.  Level 1 keeps only the running minimum of each 16-point chunk (v_min3, no index
@@ -387,15 +309,13 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_job_kernel(sfe_icp_para
     __syncthreads();
 
     // checker state: history in LDS (only thread 0 touches it), counters in thread 0's registers
-    float *hist_c = S.hist_c, *hist_s = S.hist_s, *hist_x = S.hist_x, *hist_y = S.hist_y;
-    int nhist = 1;
+    IcpCheck chk = {S.hist_c, S.hist_s, S.hist_x, S.hist_y, 1, 0, 0};
     if (tid == 0) {
-        hist_c[0] = 1.0f; // DifferentialTransformationChecker::init pushes the identity
-        hist_s[0] = 0.0f;
-        hist_x[0] = 0.0f;
-        hist_y[0] = 0.0f;
+        S.hist_c[0] = 1.0f; // DifferentialTransformationChecker::init pushes the identity
+        S.hist_s[0] = 0.0f;
+        S.hist_x[0] = 0.0f;
+        S.hist_y[0] = 0.0f;
     }
-    int counter = 0, iters = 0;
 
     const float r2_match = f_mul(P.matcher_max_dist, P.matcher_max_dist);
     const float r2_filter = f_mul(P.max_dist_filter, P.max_dist_filter);
@@ -605,101 +525,8 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_job_kernel(sfe_icp_para
 
         // ---- solve, compose, check (thread 0) ----
         if (tid == 0) {
-            int status = SFE_ICP_OK;
-            int iterate = 1;
-            float Ts[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-            if (acc[0] == 0.0) {
-                status = SFE_ICP_NO_POINT;
-            } else if (P.minimizer == 0) {
-                const double W = acc[0];
-                const double mpx = acc[1] / W, mpy = acc[2] / W, mqx = acc[3] / W, mqy = acc[4] / W;
-                const double m00 = acc[5] - acc[3] * mpx, m01 = acc[6] - acc[3] * mpy;
-                const double m10 = acc[7] - acc[4] * mpx, m11 = acc[8] - acc[4] * mpy;
-                const double Sx = m00 + m11, Kx = m10 - m01;
-                const double h = sqrt(Sx * Sx + Kx * Kx);
-                const double c = (h == 0) ? 1.0 : Sx / h;
-                const double s = (h == 0) ? 0.0 : Kx / h;
-                const double tx = mqx - (c * mpx - s * mpy);
-                const double ty = mqy - (s * mpx + c * mpy);
-                Ts[0] = (float)c;
-                Ts[1] = (float)-s;
-                Ts[2] = (float)tx;
-                Ts[3] = (float)s;
-                Ts[4] = (float)c;
-                Ts[5] = (float)ty;
-            } else {
-                const double l00 = sqrt(acc[1]);
-                const double l10 = acc[2] / l00, l20 = acc[3] / l00;
-                const double l11 = sqrt(acc[4] - l10 * l10);
-                const double l21 = (acc[5] - l20 * l10) / l11;
-                const double l22 = sqrt(acc[6] - l20 * l20 - l21 * l21);
-                if (!(l00 > 0) || !(l11 > 0) || !(l22 > 0)) {
-                    status = SFE_ICP_SINGULAR;
-                } else {
-                    const double y0 = acc[7] / l00;
-                    const double y1 = (acc[8] - l10 * y0) / l11;
-                    const double y2 = (acc[9] - l20 * y0 - l21 * y1) / l22;
-                    const double x2 = y2 / l22;
-                    const double x1 = (y1 - l21 * x2) / l11;
-                    const double x0 = (y0 - l10 * x1 - l20 * x2) / l00;
-                    const double c = cos(x0), s = sin(x0);
-                    Ts[0] = (float)c;
-                    Ts[1] = (float)-s;
-                    Ts[2] = (float)x1;
-                    Ts[3] = (float)s;
-                    Ts[4] = (float)c;
-                    Ts[5] = (float)x2;
-                }
-            }
-            if (status == SFE_ICP_OK) {
-                float Tn[9];
-                mat3_mul(Ts, Ti, Tn);
-                for (int i = 0; i < 9; ++i)
-                    S.Ti[i] = Tn[i];
-                ++iters;
-                ++counter;
-                if (counter >= P.max_iter) {
-                    iterate = 0; // CounterTransformationChecker: MaxNumIterationsReached
-                } else if (P.use_diff_checker) {
-                    if (nhist < ICP_MAX_HIST) {
-                        hist_c[nhist] = Tn[0];
-                        hist_s[nhist] = Tn[3];
-                        hist_x[nhist] = Tn[2];
-                        hist_y[nhist] = Tn[5];
-                        ++nhist;
-                    } else { // keep a sliding window (only the last smooth_len+1 entries are read)
-                        for (int i = 1; i < ICP_MAX_HIST; ++i) {
-                            hist_c[i - 1] = hist_c[i];
-                            hist_s[i - 1] = hist_s[i];
-                            hist_x[i - 1] = hist_x[i];
-                            hist_y[i - 1] = hist_y[i];
-                        }
-                        hist_c[ICP_MAX_HIST - 1] = Tn[0];
-                        hist_s[ICP_MAX_HIST - 1] = Tn[3];
-                        hist_x[ICP_MAX_HIST - 1] = Tn[2];
-                        hist_y[ICP_MAX_HIST - 1] = Tn[5];
-                    }
-                    // rotations.size() > smoothLength; size counts the init entry (= iters + 1)
-                    if (iters + 1 > P.smooth_len) {
-                        double rsum = 0, tsum = 0;
-                        for (int i = nhist - 1; i >= nhist - P.smooth_len; --i) {
-                            const double c1 = hist_c[i], s1 = hist_s[i], c0 = hist_c[i - 1], s0 = hist_s[i - 1];
-                            rsum += fabs(atan2(s1 * c0 - c1 * s0, c1 * c0 + s1 * s0));
-                            const double dx = (double)hist_x[i] - hist_x[i - 1];
-                            const double dy = (double)hist_y[i] - hist_y[i - 1];
-                            tsum += sqrt(dx * dx + dy * dy);
-                        }
-                        rsum /= P.smooth_len;
-                        tsum /= P.smooth_len;
-                        if (rsum < P.min_diff_rot && tsum < P.min_diff_trans)
-                            iterate = 0;
-                        if (isnan(rsum))
-                            status = SFE_ICP_NAN_ROT;
-                        else if (isnan(tsum))
-                            status = SFE_ICP_NAN_TRANS;
-                    }
-                }
-            }
+            int status, iterate;
+            icp_solve_and_check(P, acc, Ti, S.Ti, chk, status, iterate);
             S.flag_status = status;
             S.flag_iterate = (status == SFE_ICP_OK) ? iterate : 0;
         }
@@ -725,7 +552,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_job_kernel(sfe_icp_para
                 To[i] = guess[i];
         }
         status_out[blockIdx.x] = status;
-        iters_out[blockIdx.x] = iters;
+        iters_out[blockIdx.x] = chk.iters;
     }
 }
 
@@ -832,6 +659,11 @@ static int icp_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_src,
         soff += q[1];
         noff += q[3];
     }
+    if (!(ctx->icp_variant & 4)) { // default: sorted-sweep search (sfe_icp_sweep.hip), same results
+        const int rc = sfe_icp_sweep_launch(ctx, p, d_src, d_tgt, jobs4, d_guess9, n_jobs, d_T9, d_status, d_iters);
+        if (rc != 1)
+            return rc;
+    }
     IcpJob *d_jobs = (IcpJob *)sfe_scratch(ctx, 4, sizeof(IcpJob) * (size_t)n_jobs);
     float *d_nn_d2 = (float *)sfe_scratch(ctx, 5, sizeof(float) * (size_t)soff);
     int *d_nn_idx = (int *)sfe_scratch(ctx, 6, sizeof(int) * (size_t)soff);
@@ -867,7 +699,7 @@ int sfe_icp_set_tuning(sfe_ctx *ctx, int variant)
 {
     if (!ctx)
         return SFE_ERR_ARG;
-    SFE_ARG(ctx, variant >= 0 && variant <= 3);
+    SFE_ARG(ctx, variant >= 0 && variant <= 7);
     ctx->icp_variant = variant;
     return 0;
 }

@@ -9,7 +9,7 @@
 
 #include "../../include/sonarfe.h"
 
-#define SFE_NSCRATCH 14
+#define SFE_NSCRATCH 24
 
 struct sfe_ctx {
     int device = -1;
@@ -23,6 +23,8 @@ struct sfe_ctx {
     int cfar_tile_rows = 0;
     int cfar_variant = 0;
     int icp_variant = 0;
+    int icp_prof = 0;            // debug: per-phase cycle counts of workgroup 0 of the sweep kernel
+    long long icp_prof_host[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int n_cu = 256;
 };
 
@@ -57,6 +59,11 @@ void *sfe_scratch(sfe_ctx *ctx, int slot, size_t bytes);  // grow-only device sc
             return sfe_set_err((ctx), SFE_ERR_ARG, "bad argument: %s (%s:%d)", #cond, __FILE__,  \
                                __LINE__);                                                        \
     } while (0)
+
+// sfe_icp_sweep.hip: 0 = launched, 1 = a target exceeds the LDS capacity (use the brute-force kernel), < 0 = error
+int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_src, const float *d_tgt,
+                         const int32_t *jobs4, const float *d_guess9, int n_jobs, float *d_T9, int32_t *d_status,
+                         int32_t *d_iters);
 
 static inline int sfe_use(sfe_ctx *ctx)
 {

@@ -17,7 +17,7 @@ from sonar_slam_amd.pipeline import KeyframeBatch  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--icp-variants", default="0,2")
+    ap.add_argument("--icp-variants", default="0,4")  # 0 = sweep, 4 = brute force
     a = ap.parse_args()
     ctx = _lib.default_context()
     det = CFAR(40, 10, 0.1, 10)
@@ -45,6 +45,17 @@ def main():
         for v in [int(x) for x in a.icp_variants.split(",")]:
             ctx._check(ctx.lib.sfe_icp_set_tuning(ctx.handle, v))
             print("icp %-9s variant %d %8.3f ms / %d jobs" % (mode, v, timed(kb.run_icp, 3), a.batch))
+            if not (v & 4):
+                import ctypes
+                cyc = (ctypes.c_longlong * 8)()
+                ctx._check(ctx.lib.sfe_icp_get_profile(ctx.handle, 1, cyc))
+                kb.run_icp()
+                ctx.sync()
+                ctx._check(ctx.lib.sfe_icp_get_profile(ctx.handle, 0, cyc))
+                names = ["setup", "xform+bsearch", "sweep", "quantile", "reduce", "solve"]
+                it = int(kb.results()["iters"][0])
+                print("   workgroup 0, %d iterations, cycles: " % it +
+                      ", ".join("%s %d" % (n, c) for n, c in zip(names, list(cyc)[:6])))
         ctx._check(ctx.lib.sfe_icp_set_tuning(ctx.handle, 0))
         kb.free()
 
