@@ -174,9 +174,11 @@ int sfe_icp_compute_guesses(sfe_ctx *ctx, const sfe_icp_params *p, const float *
  * 2 workgroups/CU, 1 = 128-VGPR build.  All variants return identical results. */
 int sfe_icp_set_tuning(sfe_ctx *ctx, int variant);
 /* debug: enable/disable per-phase cycle counters of the sweep kernel (workgroup 0) and read the
- * counts of the last launch: [0] setup, [1] transform+binary search, [2] sweep, [3] trimmed
- * quantile, [4] reduction, [5] solve; summed over iterations */
-int sfe_icp_get_profile(sfe_ctx *ctx, int enable, long long *cycles8);
+ * 80 values of the last launch (buffer of 80 long long), summed over iterations.  Cycles: [0] setup, [1] transform + binary
+ * search, [3] trimmed quantile, [4] reduction, [5] solve, [6] lane-per-query walks, [7] cooperative
+ * walks, [8] finite/exact census.  Counts: [9] search rounds, [10] walks handed to the cooperative
+ * tier, [11] walks started or resumed. */
+int sfe_icp_get_profile(sfe_ctx *ctx, int enable, long long *cycles16);
 /* independent jobs, device-resident: clouds concatenated, job j uses
  * src[src_off[j]..src_off[j+1]) and tgt[tgt_off[j]..tgt_off[j+1]) (offsets in points, host
  * arrays of n_jobs+1), guess d_guess9 + 9*j; outputs d_T9 (9 floats), d_status, d_iters per job */

@@ -28,6 +28,7 @@
 #include "sfe_icp_common.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <map>
 #include <utility>
 
@@ -283,16 +284,28 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_sweep_prep_kernel(sfe_icp_
 // ---------------------------------------------------------------------------------------------
 // loop: one workgroup per job
 // ---------------------------------------------------------------------------------------------
+// Only pairs that end up with weight 1 need their exact neighbour: d2 <= the trimmed-quantile
+// limit (and <= MaxDist^2).  A search is therefore exhaustive only out to a cap C (squared
+// radius), and merely keeps going until it has seen SOME target within KDTreeMatcher.maxDist so
+// that the count of finite matches is exact.  A query ends as
+//   none    : no target within maxDist (exact: its whole maxDist window was walked)
+//   exact   : best <= C, every candidate with fl(dx*dx) <= best was evaluated
+//   inexact : finite, C < d2_NN <= best            (its walk is suspended, state kept)
+// If the exact set holds more than k = floor(n_finite * ratio) values, the k-th smallest of them
+// IS the k-th smallest of all (everything else is > C), the limit is exact and so are all
+// weight-1 pairs.  Otherwise C grows 4x and the suspended walks resume where they stopped.  C
+// starts from the previous iteration's limit, so far outliers cost a handful of steps instead of
+// a walk across the whole cloud.  Decisions and results are identical to the exhaustive search.
 struct SweepShared {
     float2 tgt[SW_TCAP + 2];
     double red[ICP_WAVES * 10 + 10];
     unsigned hist[256];
     unsigned sel_prefix, sel_k;
-    int qnext;
+    int qnext, long_next, long_n, wl_n[2];
     int flag_iterate, flag_status;
     float Ti[9];
     float hist_c[ICP_MAX_HIST], hist_s[ICP_MAX_HIST], hist_x[ICP_MAX_HIST], hist_y[ICP_MAX_HIST];
-    long long prof_t, prof[8];
+    long long prof_t, prof[16], prof_it[64], prof_b0;
 };
 
 #define SW_PROF(k)                                                                               \
@@ -304,13 +317,105 @@ struct SweepShared {
         }                                                                                        \
     } while (0)
 
+// debug watchdog: a loop that exceeds its bound records a code instead of hanging the device
+#define SW_WATCH(cnt, bound, code)                                                               \
+    if (++(cnt) > (bound)) {                                                                     \
+        if (dbg)                                                                                 \
+            atomicMax(dbg + (code), (int)blockIdx.x + 1);                                        \
+        break;                                                                                   \
+    }
+#define SW_BUDGET 24 // tier-1 loop trips (4 candidates each) before a query goes to the cooperative tier
+#define SW_NONE (-1)
+#define SW_INEXACT (-2)
+
+struct SweepQ { // per-job views of the per-query scratch
+    float2 *xy;   // transformed query
+    int4 *st;     // suspended walk: x = iL, y = iR, z = bpos | tied << 31
+    float *d2;    // best so far / final d2
+    int *pos;     // >= 0 sorted position of the NN, SW_NONE, SW_INEXACT
+    int *wl[2];   // work lists of suspended queries (ping-pong between rounds)
+    int *longl;   // queries handed to the cooperative tier this round
+    const int *perm;
+    int nt;
+};
+
+// ties at the final best: lowest original index among the points at distance `best`, found by
+// walking the final window once more (rare)
+__device__ __forceinline__ int sweep_resolve_tie(const float2 *__restrict__ s_tgt, const SweepQ &Q, float px,
+                                                 float py, float best, int iL, int iR)
+{
+    // the walk window is bounded by the suspended cursors: everything with e <= best lies inside
+    int bo = 0x7FFFFFFF, bp = 0;
+    int lo = 1, hi = Q.nt + 1; // first position with x >= px
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (s_tgt[mid].x < px)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    (void)iL;
+    (void)iR;
+    for (int j = lo - 1; j >= 1; --j) {
+        const float2 t = s_tgt[j];
+        const float dx = f_add(px, -t.x), e = f_mul(dx, dx);
+        if (!(e <= best))
+            break;
+        const float dy = f_add(py, -t.y);
+        if (f_add(e, f_mul(dy, dy)) == best) {
+            const int o = Q.perm[j - 1];
+            if (o < bo) {
+                bo = o;
+                bp = j;
+            }
+        }
+    }
+    for (int j = lo; j <= Q.nt; ++j) {
+        const float2 t = s_tgt[j];
+        const float dx = f_add(px, -t.x), e = f_mul(dx, dx);
+        if (!(e <= best))
+            break;
+        const float dy = f_add(py, -t.y);
+        if (f_add(e, f_mul(dy, dy)) == best) {
+            const int o = Q.perm[j - 1];
+            if (o < bo) {
+                bo = o;
+                bp = j;
+            }
+        }
+    }
+    return bp;
+}
+
+// a walk has stopped (both frontiers beyond the stop bound): classify and store
+__device__ __forceinline__ void sweep_finish(const float2 *__restrict__ s_tgt, const SweepQ &Q, int q, float px,
+                                             float py, float best, int bpos, bool tied, int iL, int iR, float C,
+                                             int *wl_next, int *wl_next_n)
+{
+    if (bpos == 0) {
+        Q.d2[q] = INFINITY;
+        Q.pos[q] = SW_NONE;
+    } else if (best <= C) {
+        if (tied)
+            bpos = sweep_resolve_tie(s_tgt, Q, px, py, best, iL, iR);
+        Q.d2[q] = best;
+        Q.pos[q] = bpos - 1;
+    } else {
+        Q.d2[q] = best;
+        Q.pos[q] = SW_INEXACT;
+        Q.st[q] = make_int4(iL, iR, bpos | (tied ? (int)0x80000000 : 0), 0);
+        wl_next[atomicAdd(wl_next_n, 1)] = q;
+    }
+}
+
 template <int MINW>
 __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
     sfe_icp_params P, const SweepJob *__restrict__ jobs, const float2 *__restrict__ src_all,
     const float *__restrict__ guess_all, const float2 *__restrict__ stgt_all, const int *__restrict__ perm_all,
     const float2 *__restrict__ snrm_all, const float *__restrict__ mean_all, float2 *__restrict__ q_xy_all,
-    int *__restrict__ q_start_all, float *__restrict__ nn_d2_all, int *__restrict__ nn_pos_all,
-    float *__restrict__ T_out, int *__restrict__ status_out, int *__restrict__ iters_out, long long *prof)
+    int4 *__restrict__ q_st_all, int *__restrict__ q_wl_all, float *__restrict__ nn_d2_all,
+    int *__restrict__ nn_pos_all, float *__restrict__ T_out, int *__restrict__ status_out,
+    int *__restrict__ iters_out, long long *prof, int *dbg, int sw_refill, int sw_budget)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     SweepShared &S = *reinterpret_cast<SweepShared *>(smem_raw);
@@ -319,22 +424,27 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
     const int ns = J.n_src, nt = J.n_tgt;
     const float2 *__restrict__ src = src_all + J.src_start;
     const float2 *__restrict__ stgt = stgt_all + J.tgt_off;
-    const int *__restrict__ perm = perm_all + J.tgt_off;
     const float2 *__restrict__ snrm = snrm_all ? snrm_all + J.tgt_off : nullptr;
-    float2 *__restrict__ q_xy = q_xy_all + J.q_off;
-    int *__restrict__ q_start = q_start_all + J.q_off;
-    float *__restrict__ nn_d2 = nn_d2_all + J.q_off;
-    int *__restrict__ nn_pos = nn_pos_all + J.q_off;
+    SweepQ Q;
+    Q.xy = q_xy_all + J.q_off;
+    Q.st = q_st_all + J.q_off;
+    Q.d2 = nn_d2_all + J.q_off;
+    Q.pos = nn_pos_all + J.q_off;
+    Q.wl[0] = q_wl_all + 3 * J.q_off;
+    Q.wl[1] = Q.wl[0] + ns;
+    Q.longl = Q.wl[1] + ns;
+    Q.perm = perm_all + J.tgt_off;
+    Q.nt = nt;
     const float *guess = guess_all + 9 * (size_t)blockIdx.x;
     const int tid = threadIdx.x, lane = threadIdx.x & 63;
     const float mx = mean_all[2 * J.prep], my = mean_all[2 * J.prep + 1];
 
     if (prof != nullptr && tid == 0) {
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 16; ++i)
             S.prof[i] = 0;
         S.prof_t = clock64();
     }
-    // sorted centred target -> LDS, NaN sentinels at both ends (a NaN stops a sweep direction)
+    // sorted centred target -> LDS, NaN sentinels at both ends (a NaN stops a walk direction)
     {
         const float qnan = __uint_as_float(0x7FC00000u);
         for (int i = tid; i < nt; i += ICP_THREADS)
@@ -371,15 +481,30 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
 
     const float r2_match = f_mul(P.matcher_max_dist, P.matcher_max_dist);
     const float r2_filter = f_mul(P.max_dist_filter, P.max_dist_filter);
+    // best starts just above maxDist^2 so that `d < best` accepts d == maxDist^2
+    const float r2m_up = __uint_as_float(__float_as_uint(r2_match) + 1u);
+    // no pair beyond Cmax can get weight 1
+    const float Cmax = P.use_max_dist_filter ? fminf(r2_filter, r2_match) : r2_match;
+    float Cinit;
+    {
+        const float ext = f_add(S.tgt[nt].x, -S.tgt[1].x); // x extent of the sorted target
+        const float h = 8.0f * ext / (float)nt;
+        Cinit = h * h;
+        if (!(Cinit > 1e-30f) || !(Cinit < Cmax))
+            Cinit = Cmax;
+    }
+    float Cnext = P.use_trimmed_filter ? Cinit : Cmax; // cap the next iteration starts with
     SW_PROF(0);
 
+    int wd_outer = 0;
     while (true) {
+        SW_WATCH(wd_outer, P.max_iter + 2, 0)
         float Ti[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i)
             Ti[i] = S.Ti[i];
 
-        // ---- A: cur = Ti * (T0 * src), start position = lower bound of cur.x in the sorted x ----
+        // ---- A: cur = Ti * (T0 * src); walk start = lower bound of cur.x in the sorted x ----
         for (int i = tid; i < ns; i += ICP_THREADS) {
             const float2 s = src[i];
             const float rx = affine1(T0[0], T0[1], T0[2], s.x, s.y);
@@ -394,128 +519,225 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                 else
                     hi = mid;
             }
-            q_xy[i] = make_float2(px, py);
-            q_start[i] = lo;
+            Q.xy[i] = make_float2(px, py);
+            Q.st[i] = make_int4(lo - 1, lo, 0, 0);
+            Q.d2[i] = r2m_up;
         }
-        if (tid == 0)
-            S.qnext = 0;
-        __syncthreads();
         SW_PROF(1);
 
-        // ---- B: exact 1-NN by the two-sided sweep; lanes pull queries from the workgroup queue ----
-        double nfin_d[1] = {0};
+        // ---- B: exact NN for every pair that can matter (capped two-sided walks, rounds) ----
+        if (prof != nullptr && tid == 0)
+            S.prof_b0 = clock64();
+        float C = Cnext;
+        unsigned nfin = 0, nexact = 0, ksel = 0;
+        bool limit_inf = false;
         {
-            bool active = false, more = true, tied = false;
-            float px = 0, py = 0, best = INFINITY;
-            int bpos = 0, iL = 0, iR = 0, myq = 0;
-            while (true) {
-                const unsigned long long im = __ballot(!active);
-                if (im) {
-                    if (more && (__popcll(im) >= SW_REFILL || im == ~0ull)) {
-                        const int cnt = __popcll(im);
-                        int base = 0;
-                        if (lane == 0)
-                            base = atomicAdd(&S.qnext, cnt);
-                        base = __builtin_amdgcn_readfirstlane(base);
-                        more = base + cnt < ns;
-                        if (!active) {
-                            const int q = base + __popcll(im & ((1ull << lane) - 1ull));
-                            if (q < ns) {
-                                const float2 p = q_xy[q];
-                                const int st = q_start[q];
-                                px = p.x;
-                                py = p.y;
-                                iR = st;
-                                iL = st - 1;
-                                best = INFINITY;
-                                bpos = 0;
-                                tied = false;
-                                myq = q;
-                                active = true;
+            int nwork = ns, cur = 0;
+            bool identity = true;
+            for (int round = 0;; ++round) {
+                if (round > 20) {
+                    if (dbg)
+                        atomicMax(dbg + 3, (int)blockIdx.x + 1);
+                    break;
+                }
+                if (tid == 0) {
+                    S.qnext = 0;
+                    S.long_next = 0;
+                    S.long_n = 0;
+                    S.wl_n[cur ^ 1] = 0;
+                }
+                __syncthreads();
+                const int *wl = Q.wl[cur];
+                int *wl_next = Q.wl[cur ^ 1];
+                // -- tier 1: one lane per query, lanes pull queries from the workgroup queue --
+                {
+                    bool active = false, more = true, tied = false;
+                    float px = 0, py = 0, best = 0;
+                    int bpos = 0, iL = 0, iR = 0, myq = 0, trips = 0, wd1 = 0;
+                    while (true) {
+                        SW_WATCH(wd1, 4 * (ns + 64) * (sw_budget + 1), 1)
+                        const unsigned long long im = __ballot(!active);
+                        if (im) {
+                            if (more && (__popcll(im) >= sw_refill || im == ~0ull)) {
+                                const int cnt = __popcll(im);
+                                int base = 0;
+                                if (lane == 0)
+                                    base = atomicAdd(&S.qnext, cnt);
+                                base = __builtin_amdgcn_readfirstlane(base);
+                                more = base + cnt < nwork;
+                                if (!active) {
+                                    const int slot = base + __popcll(im & ((1ull << lane) - 1ull));
+                                    if (slot < nwork) {
+                                        myq = identity ? slot : wl[slot];
+                                        const float2 p = Q.xy[myq];
+                                        const int4 st = Q.st[myq];
+                                        px = p.x;
+                                        py = p.y;
+                                        iL = st.x;
+                                        iR = st.y;
+                                        bpos = st.z & 0x7FFFFFFF;
+                                        tied = st.z < 0;
+                                        best = Q.d2[myq];
+                                        trips = 0;
+                                        active = true;
+                                    }
+                                }
+                            } else if (im == ~0ull) {
+                                break;
                             }
                         }
-                    } else if (im == ~0ull) {
-                        break;
-                    }
-                }
-                if (active) {
-                    bool fin = false;
+                        if (active) {
+                            bool fin = false;
 #pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        const float2 tl = S.tgt[iL], tr = S.tgt[iR];
-                        const float dxl = f_add(px, -tl.x), el = f_mul(dxl, dxl);
-                        const float dyl = f_add(py, -tl.y), dl = f_add(el, f_mul(dyl, dyl));
-                        const float dxr = f_add(px, -tr.x), er = f_mul(dxr, dxr);
-                        const float dyr = f_add(py, -tr.y), dr = f_add(er, f_mul(dyr, dyr));
-                        const bool okl = el <= best, okr = er <= best; // NaN sentinel -> false
-                        tied |= (dl == best);
-                        if (dl < best) {
-                            best = dl;
-                            bpos = iL;
-                        }
-                        tied |= (dr == best);
-                        if (dr < best) {
-                            best = dr;
-                            bpos = iR;
-                        }
-                        iL -= okl ? 1 : 0;
-                        iR += okr ? 1 : 0;
-                        fin = !(okl || okr);
-                    }
-                    if (fin) {
-                        if (tied && best < INFINITY) {
-                            // some candidate tied with a running best: walk the final window again and
-                            // take the lowest original index among the points at distance `best`
-                            const int st = q_start[myq];
-                            int bo = 0x7FFFFFFF, bp = 0;
-                            for (int j = st - 1; j >= 1; --j) {
-                                const float2 t = S.tgt[j];
-                                const float dx = f_add(px, -t.x), e = f_mul(dx, dx);
-                                if (!(e <= best))
-                                    break;
-                                const float dy = f_add(py, -t.y);
-                                if (f_add(e, f_mul(dy, dy)) == best) {
-                                    const int o = perm[j - 1];
-                                    if (o < bo) {
-                                        bo = o;
-                                        bp = j;
-                                    }
+                            for (int s = 0; s < 2; ++s) {
+                                const float2 tl = S.tgt[iL], tr = S.tgt[iR];
+                                const float dxl = f_add(px, -tl.x), el = f_mul(dxl, dxl);
+                                const float dyl = f_add(py, -tl.y), dl = f_add(el, f_mul(dyl, dyl));
+                                const float dxr = f_add(px, -tr.x), er = f_mul(dxr, dxr);
+                                const float dyr = f_add(py, -tr.y), dr = f_add(er, f_mul(dyr, dyr));
+                                const float sb = bpos ? fminf(best, C) : best; // stop bound
+                                const bool okl = el <= sb, okr = er <= sb;    // NaN sentinel -> false
+                                tied |= (dl == best);
+                                if (dl < best) {
+                                    best = dl;
+                                    bpos = iL;
                                 }
-                            }
-                            for (int j = st; j <= nt; ++j) {
-                                const float2 t = S.tgt[j];
-                                const float dx = f_add(px, -t.x), e = f_mul(dx, dx);
-                                if (!(e <= best))
-                                    break;
-                                const float dy = f_add(py, -t.y);
-                                if (f_add(e, f_mul(dy, dy)) == best) {
-                                    const int o = perm[j - 1];
-                                    if (o < bo) {
-                                        bo = o;
-                                        bp = j;
-                                    }
+                                tied |= (dr == best);
+                                if (dr < best) {
+                                    best = dr;
+                                    bpos = iR;
                                 }
+                                iL -= okl ? 1 : 0;
+                                iR += okr ? 1 : 0;
+                                fin = !(okl || okr);
                             }
-                            bpos = bp;
+                            if (fin) {
+                                sweep_finish(S.tgt, Q, myq, px, py, best, bpos, tied, iL, iR, C, wl_next,
+                                             &S.wl_n[cur ^ 1]);
+                                active = false;
+                            } else if (++trips >= sw_budget) { // long walk: suspend, the cooperative tier continues it
+                                Q.d2[myq] = best;
+                                Q.st[myq] = make_int4(iL, iR, bpos | (tied ? (int)0x80000000 : 0), 0);
+                                Q.longl[atomicAdd(&S.long_n, 1)] = myq;
+                                active = false;
+                            }
                         }
-                        float d = best;
-                        int id = bpos - 1;
-                        if (bpos <= 0 || !(d <= r2_match)) {
-                            id = -1;
-                            d = INFINITY;
-                        } else {
-                            nfin_d[0] += 1.0;
-                        }
-                        nn_d2[myq] = d;
-                        nn_pos[myq] = id;
-                        active = false;
                     }
                 }
+                __syncthreads();
+                SW_PROF(6);
+                if (prof != nullptr && tid == 0) {
+                    S.prof[9] += 1;
+                    S.prof[10] += S.long_n;
+                    S.prof[11] += nwork;
+                }
+                // -- tier 2: one wave per long walk, 32 candidates per side and step --
+                {
+                    const int nlong = S.long_n;
+                    int wd2 = 0;
+                    while (true) {
+                        SW_WATCH(wd2, ns + 2, 2)
+                        int slot = 0;
+                        if (lane == 0)
+                            slot = atomicAdd(&S.long_next, 1);
+                        slot = __builtin_amdgcn_readfirstlane(slot);
+                        if (slot >= nlong)
+                            break;
+                        const int q = Q.longl[slot];
+                        const float2 p = Q.xy[q];
+                        const int4 st = Q.st[q];
+                        const float px = p.x, py = p.y;
+                        int iL = st.x, iR = st.y, bpos = st.z & 0x7FFFFFFF;
+                        bool tied = st.z < 0;
+                        float best = Q.d2[q];
+                        const bool left = lane < 32;
+                        bool doneL = false, doneR = false;
+                        for (int guard = 0; guard <= nt / 32 + 2; ++guard) { // at most nt/32 + 2 trips by construction
+
+                            const int j = left ? max(iL - lane, 0) : min(iR + lane - 32, nt + 1);
+                            const bool on = left ? !doneL : !doneR;
+                            const float2 t = S.tgt[j];
+                            const float dx = f_add(px, -t.x), e = f_mul(dx, dx);
+                            const float dy = f_add(py, -t.y);
+                            float d = f_add(e, f_mul(dy, dy));
+                            if (!on || d != d)
+                                d = INFINITY;
+                            float wmin = INFINITY;
+                            if (__ballot(d <= best)) { // rare for far queries: only then pay for the wave reduction
+                                wmin = d;
+#pragma unroll
+                                for (int o = 32; o >= 1; o >>= 1)
+                                    wmin = fminf(wmin, __shfl_xor(wmin, o));
+                            }
+                            if (wmin < best) {
+                                const unsigned long long who = __ballot(d == wmin);
+                                tied = __popcll(who) > 1;
+                                const int first = __builtin_amdgcn_readfirstlane(__ffsll((long long)who) - 1);
+                                bpos = __builtin_amdgcn_readlane(j, first);
+                                best = wmin;
+                            } else if (wmin == best && wmin < INFINITY) {
+                                tied = true;
+                            }
+                            const float sb = bpos ? fminf(best, C) : best;
+                            const float eLf = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(e), 31));
+                            const float eRf = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(e), 63));
+                            if (!doneL) {
+                                if (eLf <= sb)
+                                    iL -= 32;
+                                else
+                                    doneL = true;
+                            }
+                            if (!doneR) {
+                                if (eRf <= sb)
+                                    iR += 32;
+                                else
+                                    doneR = true;
+                            }
+                            if (doneL && doneR)
+                                break;
+                        }
+                        if (lane == 0)
+                            sweep_finish(S.tgt, Q, q, px, py, best, bpos, tied, iL, iR, C, wl_next, &S.wl_n[cur ^ 1]);
+                    }
+                }
+                __syncthreads();
+                SW_PROF(7);
+                // -- how many matches are finite / exact so far --
+                double cnt[2] = {0, 0};
+                for (int i = tid; i < ns; i += ICP_THREADS) {
+                    const int pz = Q.pos[i];
+                    cnt[0] += (pz != SW_NONE) ? 1.0 : 0.0;
+                    cnt[1] += (pz >= 0) ? 1.0 : 0.0;
+                }
+                block_sum<2>(cnt, S.red);
+                nfin = (unsigned)cnt[0];
+                nexact = (unsigned)cnt[1];
+                SW_PROF(8);
+                bool done;
+                if (P.use_trimmed_filter && nfin > 0) {
+                    ksel = (P.trim_ratio >= 1.0f) ? nfin - 1 : (unsigned)f_mul((float)nfin, P.trim_ratio);
+                    done = nexact > ksel;
+                } else {
+                    done = nexact == nfin;
+                }
+                if (!done && C >= Cmax) {
+                    // the k-th finite distance exceeds MaxDist^2: every pair within MaxDist^2 is kept
+                    limit_inf = true;
+                    done = true;
+                }
+                if (done)
+                    break;
+                C = (round >= 12) ? Cmax : fminf(fmaxf(4.0f * C, Cinit), Cmax);
+                cur ^= 1;
+                identity = false;
+                nwork = S.wl_n[cur];
             }
         }
-        block_sum<1>(nfin_d, S.red); // also orders the nn_d2 / nn_pos stores before the re-reads below
-        const unsigned nfin = (unsigned)nfin_d[0];
         SW_PROF(2);
+        if (prof != nullptr && tid == 0 && chk.iters < 32) {
+            S.prof_it[2 * chk.iters] = clock64() - S.prof_b0;
+            S.prof_it[2 * chk.iters + 1] = ((long long)__float_as_uint(C) << 32) | nexact;
+        }
 
         // ---- C: TrimmedDistOutlierFilter limit: exact order statistic by radix select ----
         float limit = INFINITY;
@@ -525,15 +747,11 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                 fail = true; // "no outlier to filter"
                 if (tid == 0)
                     S.flag_status = SFE_ICP_NO_OUTLIER;
-            } else if (P.trim_ratio >= 1.0f) {
-                if (tid == 0)
-                    S.sel_k = nfin - 1; // max of the finite distances
-            } else if (tid == 0) {
-                S.sel_k = (unsigned)f_mul((float)nfin, P.trim_ratio); // values.size()*quantile in float
-            }
-            if (!fail) {
-                if (tid == 0)
+            } else if (!limit_inf) {
+                if (tid == 0) {
+                    S.sel_k = ksel;
                     S.sel_prefix = 0;
+                }
                 __syncthreads();
                 for (int shift = 24; shift >= 0; shift -= 8) {
                     if (tid < 256)
@@ -544,18 +762,19 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                     for (int i0 = 0; i0 < ns; i0 += ICP_THREADS) {
                         const int i = i0 + tid;
                         unsigned bin = 0xFFFFFFFFu; // no contribution
-                        if (i < ns) {
-                            const float d = nn_d2[i];
-                            const unsigned u = __float_as_uint(d); // d >= 0: bit pattern order == value order
-                            if (d != INFINITY && (u & himask) == prefix)
+                        if (i < ns && Q.pos[i] >= 0) {
+                            const unsigned u = __float_as_uint(Q.d2[i]); // d >= 0: bit pattern order == value order
+                            if ((u & himask) == prefix)
                                 bin = (u >> shift) & 255u;
                         }
                         if (shift == 24) {
                             // the exponent byte is the same for nearly every point: aggregate per wave
                             // instead of serialising 64 LDS atomics on one address
                             unsigned long long todo = __ballot(bin != 0xFFFFFFFFu);
+                            int wd4 = 0;
                             while (todo) {
-                                const int leader = __ffsll((long long)todo) - 1;
+                                SW_WATCH(wd4, 64, 4)
+                                const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
                                 const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)bin, leader);
                                 const unsigned long long same = __ballot(bin == b);
                                 if (lane == leader)
@@ -569,8 +788,8 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                     __syncthreads();
                     if (tid < 64) { // one wave: rank-in-histogram by shuffles instead of a 256-step serial walk
                         const unsigned k = S.sel_k;
-                        unsigned h0 = S.hist[4 * lane], h1 = S.hist[4 * lane + 1], h2 = S.hist[4 * lane + 2],
-                                 h3 = S.hist[4 * lane + 3];
+                        const unsigned h0 = S.hist[4 * lane], h1 = S.hist[4 * lane + 1], h2 = S.hist[4 * lane + 2],
+                                       h3 = S.hist[4 * lane + 3];
                         const unsigned tot = h0 + h1 + h2 + h3;
                         unsigned incl = tot;
 #pragma unroll
@@ -606,6 +825,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
         __syncthreads();
         if (fail)
             break;
+        Cnext = P.use_trimmed_filter ? ((limit < Cmax) ? fmaxf(limit, Cinit * 0.0625f) : Cmax) : Cmax;
         SW_PROF(3);
 
         // ---- D: error minimiser sums over the kept pairs ----
@@ -614,13 +834,13 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
         for (int i = 0; i < 10; ++i)
             acc[i] = 0;
         for (int i = tid; i < ns; i += ICP_THREADS) {
-            const int id = nn_pos[i];
-            const float d = nn_d2[i];
+            const int id = Q.pos[i];
+            const float d = Q.d2[i];
             const bool ok = id >= 0 && (!P.use_max_dist_filter || d <= r2_filter) &&
                             (!P.use_trimmed_filter || d <= limit);
             if (!ok)
                 continue;
-            const float2 p = q_xy[i];
+            const float2 p = Q.xy[i];
             const double px = p.x, py = p.y;
             const float2 q = S.tgt[id + 1];
             const double qx = q.x, qy = q.y;
@@ -684,9 +904,12 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
         }
         status_out[blockIdx.x] = status;
         iters_out[blockIdx.x] = chk.iters;
-        if (prof != nullptr && blockIdx.x == 0)
-            for (int i = 0; i < 8; ++i)
+        if (prof != nullptr && blockIdx.x == 0) {
+            for (int i = 0; i < 16; ++i)
                 prof[i] = S.prof[i];
+            for (int i = 0; i < 64; ++i)
+                prof[16 + i] = S.prof_it[i];
+        }
     }
 }
 
@@ -726,10 +949,11 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
     float2 *d_snrm = p->minimizer == 1 ? (float2 *)sfe_scratch(ctx, 16, sizeof(float2) * (size_t)toff) : nullptr;
     float *d_mean = (float *)sfe_scratch(ctx, 17, sizeof(float) * 2 * (size_t)n_prep);
     float2 *d_qxy = (float2 *)sfe_scratch(ctx, 18, sizeof(float2) * (size_t)qoff);
-    int *d_qstart = (int *)sfe_scratch(ctx, 19, sizeof(int) * (size_t)qoff);
+    int4 *d_qst = (int4 *)sfe_scratch(ctx, 19, sizeof(int4) * (size_t)qoff);
+    int *d_qwl = (int *)sfe_scratch(ctx, 21, sizeof(int) * 3 * (size_t)qoff);
     float *d_nn_d2 = (float *)sfe_scratch(ctx, 5, sizeof(float) * (size_t)qoff);
     int *d_nn_pos = (int *)sfe_scratch(ctx, 6, sizeof(int) * (size_t)qoff);
-    if (!d_preps || !d_jobs || !d_stgt || !d_perm || (p->minimizer == 1 && !d_snrm) || !d_mean || !d_qxy || !d_qstart ||
+    if (!d_preps || !d_jobs || !d_stgt || !d_perm || (p->minimizer == 1 && !d_snrm) || !d_mean || !d_qxy || !d_qst || !d_qwl ||
         !d_nn_d2 || !d_nn_pos)
         return SFE_ERR_HIP;
     SFE_HIP(ctx, hipMemcpyAsync(d_preps, preps.data(), sizeof(SweepPrep) * (size_t)n_prep, hipMemcpyHostToDevice,
@@ -744,28 +968,46 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
     hipLaunchKernelGGL(icp_sweep_prep_kernel, dim3(n_prep), dim3(ICP_THREADS), sizeof(PrepShared), ctx->stream, *p,
                        d_preps, (const float2 *)d_tgt, d_stgt, d_perm, d_snrm, d_mean);
     SFE_LAUNCH_CHECK(ctx);
-    long long *d_prof = ctx->icp_prof ? (long long *)sfe_scratch(ctx, 20, sizeof(long long) * 8) : nullptr;
+    static const bool debug = getenv("SFE_ICP_DEBUG") != nullptr;
+    const int sw_refill = getenv("SFE_SW_REFILL") ? atoi(getenv("SFE_SW_REFILL")) : SW_REFILL;
+    const int sw_budget = getenv("SFE_SW_BUDGET") ? atoi(getenv("SFE_SW_BUDGET")) : SW_BUDGET;
+    int *d_dbg = nullptr;
+    if (debug) {
+        d_dbg = (int *)sfe_scratch(ctx, 22, sizeof(int) * 8);
+        if (!d_dbg)
+            return SFE_ERR_HIP;
+        SFE_HIP(ctx, hipMemsetAsync(d_dbg, 0, sizeof(int) * 8, ctx->stream));
+    }
+    long long *d_prof = ctx->icp_prof ? (long long *)sfe_scratch(ctx, 20, sizeof(long long) * 80) : nullptr;
     SFE_HIP(ctx, hipFuncSetAttribute((const void *)icp_sweep_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)sizeof(SweepShared)));
     hipLaunchKernelGGL(icp_sweep_kernel<8>, dim3(n_jobs), dim3(ICP_THREADS), sizeof(SweepShared), ctx->stream, *p,
-                       d_jobs, (const float2 *)d_src, d_guess9, d_stgt, d_perm, d_snrm, d_mean, d_qxy, d_qstart,
-                       d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof);
+                       d_jobs, (const float2 *)d_src, d_guess9, d_stgt, d_perm, d_snrm, d_mean, d_qxy, d_qst, d_qwl,
+                       d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof, d_dbg, sw_refill, sw_budget);
     SFE_LAUNCH_CHECK(ctx);
+    if (debug) {
+        int h[8];
+        SFE_HIP(ctx, hipMemcpyAsync(h, d_dbg, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+        SFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < 8; ++i)
+            if (h[i])
+                fprintf(stderr, "sfe_icp_sweep: watchdog %d tripped (workgroup %d)\n", i, h[i] - 1);
+    }
     if (d_prof) {
-        SFE_HIP(ctx, hipMemcpyAsync(ctx->icp_prof_host, d_prof, sizeof(long long) * 8, hipMemcpyDeviceToHost,
+        SFE_HIP(ctx, hipMemcpyAsync(ctx->icp_prof_host, d_prof, sizeof(long long) * 80, hipMemcpyDeviceToHost,
                                     ctx->stream));
         SFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     return 0;
 }
 
-extern "C" int sfe_icp_get_profile(sfe_ctx *ctx, int enable, long long *cycles8)
+extern "C" int sfe_icp_get_profile(sfe_ctx *ctx, int enable, long long *cycles16)
 {
     if (!ctx)
         return SFE_ERR_ARG;
-    if (cycles8)
-        for (int i = 0; i < 8; ++i)
-            cycles8[i] = ctx->icp_prof_host[i];
+    if (cycles16)
+        for (int i = 0; i < 80; ++i)
+            cycles16[i] = ctx->icp_prof_host[i];
     ctx->icp_prof = enable;
     return 0;
 }

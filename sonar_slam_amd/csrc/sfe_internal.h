@@ -24,7 +24,7 @@ struct sfe_ctx {
     int cfar_variant = 0;
     int icp_variant = 0;
     int icp_prof = 0;            // debug: per-phase cycle counts of workgroup 0 of the sweep kernel
-    long long icp_prof_host[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long icp_prof_host[80] = {0};
     int n_cu = 256;
 };
 

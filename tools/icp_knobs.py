@@ -1,0 +1,51 @@
+#!/usr/bin/env python
+"""Sweep the walk kernel's debug knobs (env SFE_SW_REFILL / SFE_SW_BUDGET) on the bench scan pairs."""
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from sonar_slam_amd import _lib, icp_config  # noqa: E402
+from sonar_slam_amd.CFAR import CFAR  # noqa: E402
+from sonar_slam_amd.feature_extraction import FeatureExtraction, SonarPing, oculus_bearings  # noqa: E402
+from sonar_slam_amd.pipeline import KeyframeBatch  # noqa: E402
+
+B = 256
+ctx = _lib.default_context()
+det = CFAR(40, 10, 0.1, 10)
+fe = FeatureExtraction(ctx)
+fe.Ntc, fe.Ngc, fe.Pfa, fe.rank, fe.alg, fe.threshold = 40, 10, 0.1, 10, "SOCA", 65
+fe.configure()
+frames, srcs, tgts, guesses = bench.make_inputs(0, B)
+fe.generate_map_xy(SonarPing(frames[0], oculus_bearings(bench.COLS), 30.0 / bench.ROWS))
+
+
+def timed(fn, reps):
+    fn()
+    ctx.sync()
+    ctx.timer_start()
+    for _ in range(reps):
+        fn()
+    return ctx.timer_stop() / reps
+
+
+kbs = {}
+for mode, p in (("p2plane30", icp_config.shipped_params(minimizer=1, use_diff_checker=0, max_iter=30)),
+                ("reference", icp_config.shipped_params())):
+    kb = KeyframeBatch(ctx, fe.geometry, det.params["SOCA"], "SOCA", 65, p, B)
+    kb.upload_scan_pairs(srcs, tgts, guesses)
+    kbs[mode] = kb
+for refill, budget in [(16, 24), (32, 24), (48, 24), (16, 8), (32, 8), (16, 4), (32, 4), (16, 64), (1, 24)]:
+    os.environ["SFE_SW_REFILL"] = str(refill)
+    os.environ["SFE_SW_BUDGET"] = str(budget)
+    line = "refill %2d budget %2d:" % (refill, budget)
+    for mode, kb in kbs.items():
+        ms = timed(kb.run_icp, 3)
+        cyc = (ctypes.c_longlong * 80)()
+        ctx._check(ctx.lib.sfe_icp_get_profile(ctx.handle, 1, cyc))
+        kb.run_icp()
+        ctx.sync()
+        ctx._check(ctx.lib.sfe_icp_get_profile(ctx.handle, 0, cyc))
+        line += "  %s %.2f ms (tier1 %dk tier2 %dk long %d)" % (mode, ms, cyc[6] // 1000, cyc[7] // 1000, cyc[10])
+    print(line, flush=True)

@@ -47,15 +47,20 @@ def main():
             print("icp %-9s variant %d %8.3f ms / %d jobs" % (mode, v, timed(kb.run_icp, 3), a.batch))
             if not (v & 4):
                 import ctypes
-                cyc = (ctypes.c_longlong * 8)()
+                cyc = (ctypes.c_longlong * 80)()
                 ctx._check(ctx.lib.sfe_icp_get_profile(ctx.handle, 1, cyc))
                 kb.run_icp()
                 ctx.sync()
                 ctx._check(ctx.lib.sfe_icp_get_profile(ctx.handle, 0, cyc))
-                names = ["setup", "xform+bsearch", "sweep", "quantile", "reduce", "solve"]
+                names = ["setup", "xform+bsearch", "-", "quantile", "reduce", "solve", "tier1", "tier2", "census",
+                         "#rounds", "#long", "#walks"]
                 it = int(kb.results()["iters"][0])
-                print("   workgroup 0, %d iterations, cycles: " % it +
-                      ", ".join("%s %d" % (n, c) for n, c in zip(names, list(cyc)[:6])))
+                print("   workgroup 0, %d iterations: " % it +
+                      ", ".join("%s %d" % (n, c) for n, c in zip(names, list(cyc)[:12]) if n != "-"))
+                import struct
+                print("   per iteration (kcycles search, cap C, n_exact): " + " ".join(
+                    "%d/%.3g/%d" % (cyc[16 + 2 * i] // 1000, struct.unpack("f", struct.pack("I", (cyc[17 + 2 * i] >> 32) & 0xFFFFFFFF))[0],
+                                    cyc[17 + 2 * i] & 0xFFFFFFFF) for i in range(min(it, 32))))
         ctx._check(ctx.lib.sfe_icp_set_tuning(ctx.handle, 0))
         kb.free()
 
