@@ -33,7 +33,6 @@
 #include <utility>
 
 #define SW_TCAP 8192   // target points resident in LDS
-#define SW_REFILL 16   // idle lanes per wave that trigger a queue refill
 
 struct SweepPrep {
     int tgt_start, n_tgt;
@@ -297,11 +296,11 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_sweep_prep_kernel(sfe_icp_
 // starts from the previous iteration's limit, so far outliers cost a handful of steps instead of
 // a walk across the whole cloud.  Decisions and results are identical to the exhaustive search.
 struct SweepShared {
-    float2 tgt[SW_TCAP + 2];
+    float2 tgt[SW_TCAP + 4];
     double red[ICP_WAVES * 10 + 10];
     unsigned hist[256];
     unsigned sel_prefix, sel_k;
-    int qnext, long_next, long_n, wl_n[2];
+    int long_n, wl_n[2];
     int flag_iterate, flag_status;
     float Ti[9];
     float hist_c[ICP_MAX_HIST], hist_s[ICP_MAX_HIST], hist_x[ICP_MAX_HIST], hist_y[ICP_MAX_HIST];
@@ -324,7 +323,7 @@ struct SweepShared {
             atomicMax(dbg + (code), (int)blockIdx.x + 1);                                        \
         break;                                                                                   \
     }
-#define SW_BUDGET 24 // tier-1 loop trips (4 candidates each) before a query goes to the cooperative tier
+#define SW_BUDGET 24    // tier-1 trips (4 candidates each) before a walk is handed to the cooperative tier
 #define SW_NONE (-1)
 #define SW_INEXACT (-2)
 
@@ -334,7 +333,7 @@ struct SweepQ { // per-job views of the per-query scratch
     float *d2;    // best so far / final d2
     int *pos;     // >= 0 sorted position of the NN, SW_NONE, SW_INEXACT
     int *wl[2];   // work lists of suspended queries (ping-pong between rounds)
-    int *longl;   // queries handed to the cooperative tier this round
+    int4 *longe;  // walks handed to the cooperative tier this round: (q, iL, iR, bpos|tied), (px, py, best, -)
     const int *perm;
     int nt;
 };
@@ -387,35 +386,14 @@ __device__ __forceinline__ int sweep_resolve_tie(const float2 *__restrict__ s_tg
     return bp;
 }
 
-// a walk has stopped (both frontiers beyond the stop bound): classify and store
-__device__ __forceinline__ void sweep_finish(const float2 *__restrict__ s_tgt, const SweepQ &Q, int q, float px,
-                                             float py, float best, int bpos, bool tied, int iL, int iR, float C,
-                                             int *wl_next, int *wl_next_n)
-{
-    if (bpos == 0) {
-        Q.d2[q] = INFINITY;
-        Q.pos[q] = SW_NONE;
-    } else if (best <= C) {
-        if (tied)
-            bpos = sweep_resolve_tie(s_tgt, Q, px, py, best, iL, iR);
-        Q.d2[q] = best;
-        Q.pos[q] = bpos - 1;
-    } else {
-        Q.d2[q] = best;
-        Q.pos[q] = SW_INEXACT;
-        Q.st[q] = make_int4(iL, iR, bpos | (tied ? (int)0x80000000 : 0), 0);
-        wl_next[atomicAdd(wl_next_n, 1)] = q;
-    }
-}
-
 template <int MINW>
 __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
     sfe_icp_params P, const SweepJob *__restrict__ jobs, const float2 *__restrict__ src_all,
     const float *__restrict__ guess_all, const float2 *__restrict__ stgt_all, const int *__restrict__ perm_all,
     const float2 *__restrict__ snrm_all, const float *__restrict__ mean_all, float2 *__restrict__ q_xy_all,
-    int4 *__restrict__ q_st_all, int *__restrict__ q_wl_all, float *__restrict__ nn_d2_all,
+    int4 *__restrict__ q_st_all, int *__restrict__ q_wl_all, int4 *__restrict__ q_long_all, float *__restrict__ nn_d2_all,
     int *__restrict__ nn_pos_all, float *__restrict__ T_out, int *__restrict__ status_out,
-    int *__restrict__ iters_out, long long *prof, int *dbg, int sw_refill, int sw_budget)
+    int *__restrict__ iters_out, long long *prof, int *dbg, int sw_budget)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     SweepShared &S = *reinterpret_cast<SweepShared *>(smem_raw);
@@ -430,9 +408,9 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
     Q.st = q_st_all + J.q_off;
     Q.d2 = nn_d2_all + J.q_off;
     Q.pos = nn_pos_all + J.q_off;
-    Q.wl[0] = q_wl_all + 3 * J.q_off;
+    Q.wl[0] = q_wl_all + 2 * J.q_off;
     Q.wl[1] = Q.wl[0] + ns;
-    Q.longl = Q.wl[1] + ns;
+    Q.longe = q_long_all + 2 * J.q_off;
     Q.perm = perm_all + J.tgt_off;
     Q.nt = nt;
     const float *guess = guess_all + 9 * (size_t)blockIdx.x;
@@ -452,6 +430,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
         if (tid == 0) {
             S.tgt[0] = make_float2(qnan, qnan);
             S.tgt[nt + 1] = make_float2(qnan, qnan);
+            S.tgt[nt + 2] = make_float2(qnan, qnan); // the exhaustive scan reads pairs of points
         }
     }
 
@@ -504,28 +483,11 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
         for (int i = 0; i < 9; ++i)
             Ti[i] = S.Ti[i];
 
-        // ---- A: cur = Ti * (T0 * src); walk start = lower bound of cur.x in the sorted x ----
-        for (int i = tid; i < ns; i += ICP_THREADS) {
-            const float2 s = src[i];
-            const float rx = affine1(T0[0], T0[1], T0[2], s.x, s.y);
-            const float ry = affine1(T0[3], T0[4], T0[5], s.x, s.y);
-            const float px = affine1(Ti[0], Ti[1], Ti[2], rx, ry);
-            const float py = affine1(Ti[3], Ti[4], Ti[5], rx, ry);
-            int lo = 1, hi = nt + 1; // first 1-based position whose x is not < px
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (S.tgt[mid].x < px)
-                    lo = mid + 1;
-                else
-                    hi = mid;
-            }
-            Q.xy[i] = make_float2(px, py);
-            Q.st[i] = make_int4(lo - 1, lo, 0, 0);
-            Q.d2[i] = r2m_up;
-        }
-        SW_PROF(1);
-
-        // ---- B: exact NN for every pair that can matter (capped two-sided walks, rounds) ----
+        // ---- A+B: cur = Ti * (T0 * src); exact NN for every pair that can matter.  Round 0 walks
+        // every query (lane i handles queries i, i + 1024, ...: transform, lower bound of cur.x in the
+        // sorted x, two-sided walk of at most `sw_budget` trips), later rounds resume the suspended
+        // walks with a 4x larger cap.  Walks that exhaust their budget are finished by an exhaustive
+        // scan (tier 2), which yields their true neighbour. ----
         if (prof != nullptr && tid == 0)
             S.prof_b0 = clock64();
         float C = Cnext;
@@ -533,7 +495,6 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
         bool limit_inf = false;
         {
             int nwork = ns, cur = 0;
-            bool identity = true;
             for (int round = 0;; ++round) {
                 if (round > 20) {
                     if (dbg)
@@ -541,55 +502,61 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                     break;
                 }
                 if (tid == 0) {
-                    S.qnext = 0;
-                    S.long_next = 0;
                     S.long_n = 0;
                     S.wl_n[cur ^ 1] = 0;
                 }
                 __syncthreads();
                 const int *wl = Q.wl[cur];
                 int *wl_next = Q.wl[cur ^ 1];
-                // -- tier 1: one lane per query, lanes pull queries from the workgroup queue --
-                {
-                    bool active = false, more = true, tied = false;
-                    float px = 0, py = 0, best = 0;
-                    int bpos = 0, iL = 0, iR = 0, myq = 0, trips = 0, wd1 = 0;
-                    while (true) {
-                        SW_WATCH(wd1, 4 * (ns + 64) * (sw_budget + 1), 1)
-                        const unsigned long long im = __ballot(!active);
-                        if (im) {
-                            if (more && (__popcll(im) >= sw_refill || im == ~0ull)) {
-                                const int cnt = __popcll(im);
-                                int base = 0;
-                                if (lane == 0)
-                                    base = atomicAdd(&S.qnext, cnt);
-                                base = __builtin_amdgcn_readfirstlane(base);
-                                more = base + cnt < nwork;
-                                if (!active) {
-                                    const int slot = base + __popcll(im & ((1ull << lane) - 1ull));
-                                    if (slot < nwork) {
-                                        myq = identity ? slot : wl[slot];
-                                        const float2 p = Q.xy[myq];
-                                        const int4 st = Q.st[myq];
-                                        px = p.x;
-                                        py = p.y;
-                                        iL = st.x;
-                                        iR = st.y;
-                                        bpos = st.z & 0x7FFFFFFF;
-                                        tied = st.z < 0;
-                                        best = Q.d2[myq];
-                                        trips = 0;
-                                        active = true;
-                                    }
-                                }
-                            } else if (im == ~0ull) {
-                                break;
+                // -- tier 1: one lane per query --
+                for (int k0 = 0; k0 < nwork; k0 += ICP_THREADS) {
+                    const int slot = k0 + tid;
+                    const bool valid = slot < nwork;
+                    int q = 0, iL = 0, iR = 0, bpos = 0;
+                    float px = 0, py = 0, best = r2m_up;
+                    bool tied = false;
+                    if (valid) {
+                        if (round == 0) {
+                            q = slot;
+                            const float2 sp = src[q];
+                            const float rx = affine1(T0[0], T0[1], T0[2], sp.x, sp.y);
+                            const float ry = affine1(T0[3], T0[4], T0[5], sp.x, sp.y);
+                            px = affine1(Ti[0], Ti[1], Ti[2], rx, ry);
+                            py = affine1(Ti[3], Ti[4], Ti[5], rx, ry);
+                            Q.xy[q] = make_float2(px, py);
+                        } else {
+                            q = wl[slot];
+                            const float2 p = Q.xy[q];
+                            const int4 st = Q.st[q];
+                            px = p.x;
+                            py = p.y;
+                            iL = st.x;
+                            iR = st.y;
+                            bpos = st.z & 0x7FFFFFFF;
+                            tied = st.z < 0;
+                            best = Q.d2[q];
+                        }
+                    }
+                    if (round == 0) { // first 1-based position whose x is not < px (convergent: 14 trips)
+                        int lo = 1, hi = nt + 1;
+                        while (__ballot(lo < hi)) {
+                            const int mid = (lo + hi) >> 1;
+                            const bool lt = S.tgt[min(mid, nt + 1)].x < px;
+                            if (lo < hi) {
+                                if (lt)
+                                    lo = mid + 1;
+                                else
+                                    hi = mid;
                             }
                         }
-                        if (active) {
-                            bool fin = false;
+                        iR = lo;
+                        iL = lo - 1;
+                    }
+                    bool fin = !valid;
+                    for (int trip = 0; trip < sw_budget; ++trip) {
+                        if (!fin) {
 #pragma unroll
-                            for (int s = 0; s < 2; ++s) {
+                            for (int s2 = 0; s2 < 2; ++s2) {
                                 const float2 tl = S.tgt[iL], tr = S.tgt[iR];
                                 const float dxl = f_add(px, -tl.x), el = f_mul(dxl, dxl);
                                 const float dyl = f_add(py, -tl.y), dl = f_add(el, f_mul(dyl, dyl));
@@ -597,13 +564,15 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                                 const float dyr = f_add(py, -tr.y), dr = f_add(er, f_mul(dyr, dyr));
                                 const float sb = bpos ? fminf(best, C) : best; // stop bound
                                 const bool okl = el <= sb, okr = er <= sb;    // NaN sentinel -> false
-                                tied |= (dl == best);
-                                if (dl < best) {
+                                // only consumed candidates (cursor moves past them) may update the state:
+                                // nothing is ever evaluated twice, so `tied` flags real ties only
+                                tied |= okl && (dl == best);
+                                if (okl && dl < best) {
                                     best = dl;
                                     bpos = iL;
                                 }
-                                tied |= (dr == best);
-                                if (dr < best) {
+                                tied |= okr && (dr == best);
+                                if (okr && dr < best) {
                                     best = dr;
                                     bpos = iR;
                                 }
@@ -611,56 +580,99 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                                 iR += okr ? 1 : 0;
                                 fin = !(okl || okr);
                             }
-                            if (fin) {
-                                sweep_finish(S.tgt, Q, myq, px, py, best, bpos, tied, iL, iR, C, wl_next,
-                                             &S.wl_n[cur ^ 1]);
-                                active = false;
-                            } else if (++trips >= sw_budget) { // long walk: suspend, the cooperative tier continues it
-                                Q.d2[myq] = best;
-                                Q.st[myq] = make_int4(iL, iR, bpos | (tied ? (int)0x80000000 : 0), 0);
-                                Q.longl[atomicAdd(&S.long_n, 1)] = myq;
-                                active = false;
+                        }
+                        if (!__ballot(!fin))
+                            break;
+                    }
+                    // classify: none / exact / suspended (inexact) / long (budget exhausted)
+                    const bool is_long = valid && !fin;
+                    const bool is_none = valid && fin && bpos == 0;
+                    const bool is_exact = valid && fin && bpos != 0 && best <= C;
+                    const bool is_susp = valid && fin && bpos != 0 && !(best <= C);
+                    if (is_none) {
+                        Q.d2[q] = INFINITY;
+                        Q.pos[q] = SW_NONE;
+                    }
+                    if (is_exact) {
+                        if (tied)
+                            bpos = sweep_resolve_tie(S.tgt, Q, px, py, best, iL, iR);
+                        Q.d2[q] = best;
+                        Q.pos[q] = bpos - 1;
+                    }
+                    if (is_susp) {
+                        Q.d2[q] = best;
+                        Q.pos[q] = SW_INEXACT;
+                        Q.st[q] = make_int4(iL, iR, bpos | (tied ? (int)0x80000000 : 0), 0);
+                    }
+                    { // wave-aggregated appends
+                        const unsigned long long ms = __ballot(is_susp), ml = __ballot(is_long);
+                        const unsigned long long below = (1ull << lane) - 1ull;
+                        if (ms) {
+                            int base = 0;
+                            if (lane == 0)
+                                base = atomicAdd(&S.wl_n[cur ^ 1], __popcll(ms));
+                            base = __builtin_amdgcn_readfirstlane(base);
+                            if (is_susp)
+                                wl_next[base + __popcll(ms & below)] = q;
+                        }
+                        if (ml) {
+                            int base = 0;
+                            if (lane == 0)
+                                base = atomicAdd(&S.long_n, __popcll(ml));
+                            base = __builtin_amdgcn_readfirstlane(base);
+                            if (is_long) {
+                                const int e = base + __popcll(ml & below);
+                                Q.longe[2 * e] = make_int4(q, iL, iR, bpos | (tied ? (int)0x80000000 : 0));
+                                Q.longe[2 * e + 1] = make_int4(__float_as_int(px), __float_as_int(py),
+                                                               __float_as_int(best), 0);
                             }
                         }
                     }
                 }
                 __syncthreads();
                 SW_PROF(6);
+                const int nlong = S.long_n;
                 if (prof != nullptr && tid == 0) {
                     S.prof[9] += 1;
-                    S.prof[10] += S.long_n;
+                    S.prof[10] += nlong;
                     S.prof[11] += nwork;
                 }
-                // -- tier 2: one wave per long walk, 32 candidates per side and step --
-                {
-                    const int nlong = S.long_n;
-                    int wd2 = 0;
-                    while (true) {
-                        SW_WATCH(wd2, ns + 2, 2)
-                        int slot = 0;
-                        if (lane == 0)
-                            slot = atomicAdd(&S.long_next, 1);
-                        slot = __builtin_amdgcn_readfirstlane(slot);
-                        if (slot >= nlong)
-                            break;
-                        const int q = Q.longl[slot];
-                        const float2 p = Q.xy[q];
-                        const int4 st = Q.st[q];
-                        const float px = p.x, py = p.y;
-                        int iL = st.x, iR = st.y, bpos = st.z & 0x7FFFFFFF;
-                        bool tied = st.z < 0;
-                        float best = Q.d2[q];
-                        const bool left = lane < 32;
+                // -- tier 2: one wave per long walk, 32 candidates per side and trip; the walk's state
+                // travels in the list entry and the next entry is fetched while this one is walked --
+                if (nlong > 0) {
+                    const int wave = tid >> 6;
+                    const bool left = lane < 32;
+                    int slot = wave;
+                    int4 e0 = make_int4(0, 0, 0, 0), e1 = make_int4(0, 0, 0, 0);
+                    if (slot < nlong) {
+                        e0 = Q.longe[2 * slot];
+                        e1 = Q.longe[2 * slot + 1];
+                    }
+                    while (slot < nlong) {
+                        const int q = e0.x;
+                        int iL = e0.y, iR = e0.z, bpos = e0.w & 0x7FFFFFFF;
+                        bool tied = e0.w < 0;
+                        const float px = __int_as_float(e1.x), py = __int_as_float(e1.y);
+                        float best = __int_as_float(e1.z);
+                        slot += ICP_WAVES;
+                        if (slot < nlong) { // prefetch the next walk
+                            e0 = Q.longe[2 * slot];
+                            e1 = Q.longe[2 * slot + 1];
+                        }
                         bool doneL = false, doneR = false;
                         for (int guard = 0; guard <= nt / 32 + 2; ++guard) { // at most nt/32 + 2 trips by construction
-
+                            const float sb = bpos ? fminf(best, C) : best; // stop bound at the start of the trip
                             const int j = left ? max(iL - lane, 0) : min(iR + lane - 32, nt + 1);
                             const bool on = left ? !doneL : !doneR;
                             const float2 t = S.tgt[j];
                             const float dx = f_add(px, -t.x), e = f_mul(dx, dx);
                             const float dy = f_add(py, -t.y);
                             float d = f_add(e, f_mul(dy, dy));
-                            if (!on || d != d)
+                            // consumed = within the stop bound (a prefix of each side, e is monotone outwards);
+                            // only consumed candidates count and the cursors move past exactly those
+                            const bool cons = on && (e <= sb);
+                            const unsigned long long mc = __ballot(cons);
+                            if (!cons || d != d)
                                 d = INFINITY;
                             float wmin = INFINITY;
                             if (__ballot(d <= best)) { // rare for far queries: only then pay for the wave reduction
@@ -678,59 +690,67 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                             } else if (wmin == best && wmin < INFINITY) {
                                 tied = true;
                             }
-                            const float sb = bpos ? fminf(best, C) : best;
-                            const float eLf = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(e), 31));
-                            const float eRf = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(e), 63));
-                            if (!doneL) {
-                                if (eLf <= sb)
-                                    iL -= 32;
-                                else
-                                    doneL = true;
-                            }
-                            if (!doneR) {
-                                if (eRf <= sb)
-                                    iR += 32;
-                                else
-                                    doneR = true;
-                            }
+                            const int nL = __popcll(mc & 0xFFFFFFFFull), nR = __popcll(mc >> 32);
+                            iL -= nL;
+                            iR += nR;
+                            doneL |= nL < 32;
+                            doneR |= nR < 32;
+                            if (prof != nullptr && lane == 0)
+                                atomicAdd((unsigned long long *)&S.prof[12], 1ull);
                             if (doneL && doneR)
                                 break;
                         }
-                        if (lane == 0)
-                            sweep_finish(S.tgt, Q, q, px, py, best, bpos, tied, iL, iR, C, wl_next, &S.wl_n[cur ^ 1]);
+                        if (prof != nullptr && lane == 0 && tied && bpos != 0 && best <= C)
+                            atomicAdd((unsigned long long *)&S.prof[13], 1ull);
+                        if (lane == 0) {
+                            if (bpos == 0) {
+                                Q.d2[q] = INFINITY;
+                                Q.pos[q] = SW_NONE;
+                            } else if (best <= C) {
+                                if (tied)
+                                    bpos = sweep_resolve_tie(S.tgt, Q, px, py, best, iL, iR);
+                                Q.d2[q] = best;
+                                Q.pos[q] = bpos - 1;
+                            } else {
+                                Q.d2[q] = best;
+                                Q.pos[q] = SW_INEXACT;
+                                Q.st[q] = make_int4(iL, iR, bpos | (tied ? (int)0x80000000 : 0), 0);
+                                wl_next[atomicAdd(&S.wl_n[cur ^ 1], 1)] = q;
+                            }
+                        }
                     }
                 }
                 __syncthreads();
                 SW_PROF(7);
-                // -- how many matches are finite / exact so far --
+                // -- census: finite matches, and true neighbours within the cap --
                 double cnt[2] = {0, 0};
                 for (int i = tid; i < ns; i += ICP_THREADS) {
                     const int pz = Q.pos[i];
                     cnt[0] += (pz != SW_NONE) ? 1.0 : 0.0;
-                    cnt[1] += (pz >= 0) ? 1.0 : 0.0;
+                    cnt[1] += (pz >= 0 && Q.d2[i] <= C) ? 1.0 : 0.0;
                 }
                 block_sum<2>(cnt, S.red);
                 nfin = (unsigned)cnt[0];
                 nexact = (unsigned)cnt[1];
                 SW_PROF(8);
+                const int nsusp = S.wl_n[cur ^ 1];
                 bool done;
                 if (P.use_trimmed_filter && nfin > 0) {
                     ksel = (P.trim_ratio >= 1.0f) ? nfin - 1 : (unsigned)f_mul((float)nfin, P.trim_ratio);
                     done = nexact > ksel;
                 } else {
-                    done = nexact == nfin;
+                    done = nsusp == 0;
                 }
-                if (!done && C >= Cmax) {
-                    // the k-th finite distance exceeds MaxDist^2: every pair within MaxDist^2 is kept
-                    limit_inf = true;
+                if (!done && (C >= Cmax || nsusp == 0)) {
+                    // the k-th finite distance exceeds MaxDist^2 (or every neighbour is already known)
+                    limit_inf = C >= Cmax && nsusp != 0;
                     done = true;
                 }
                 if (done)
                     break;
                 C = (round >= 12) ? Cmax : fminf(fmaxf(4.0f * C, Cinit), Cmax);
                 cur ^= 1;
-                identity = false;
-                nwork = S.wl_n[cur];
+                nwork = nsusp;
             }
         }
         SW_PROF(2);
@@ -950,10 +970,11 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
     float *d_mean = (float *)sfe_scratch(ctx, 17, sizeof(float) * 2 * (size_t)n_prep);
     float2 *d_qxy = (float2 *)sfe_scratch(ctx, 18, sizeof(float2) * (size_t)qoff);
     int4 *d_qst = (int4 *)sfe_scratch(ctx, 19, sizeof(int4) * (size_t)qoff);
-    int *d_qwl = (int *)sfe_scratch(ctx, 21, sizeof(int) * 3 * (size_t)qoff);
+    int *d_qwl = (int *)sfe_scratch(ctx, 21, sizeof(int) * 2 * (size_t)qoff);
+    int4 *d_qlong = (int4 *)sfe_scratch(ctx, 23, sizeof(int4) * 2 * (size_t)qoff);
     float *d_nn_d2 = (float *)sfe_scratch(ctx, 5, sizeof(float) * (size_t)qoff);
     int *d_nn_pos = (int *)sfe_scratch(ctx, 6, sizeof(int) * (size_t)qoff);
-    if (!d_preps || !d_jobs || !d_stgt || !d_perm || (p->minimizer == 1 && !d_snrm) || !d_mean || !d_qxy || !d_qst || !d_qwl ||
+    if (!d_preps || !d_jobs || !d_stgt || !d_perm || (p->minimizer == 1 && !d_snrm) || !d_mean || !d_qxy || !d_qst || !d_qwl || !d_qlong ||
         !d_nn_d2 || !d_nn_pos)
         return SFE_ERR_HIP;
     SFE_HIP(ctx, hipMemcpyAsync(d_preps, preps.data(), sizeof(SweepPrep) * (size_t)n_prep, hipMemcpyHostToDevice,
@@ -969,7 +990,6 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
                        d_preps, (const float2 *)d_tgt, d_stgt, d_perm, d_snrm, d_mean);
     SFE_LAUNCH_CHECK(ctx);
     static const bool debug = getenv("SFE_ICP_DEBUG") != nullptr;
-    const int sw_refill = getenv("SFE_SW_REFILL") ? atoi(getenv("SFE_SW_REFILL")) : SW_REFILL;
     const int sw_budget = getenv("SFE_SW_BUDGET") ? atoi(getenv("SFE_SW_BUDGET")) : SW_BUDGET;
     int *d_dbg = nullptr;
     if (debug) {
@@ -982,8 +1002,8 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
     SFE_HIP(ctx, hipFuncSetAttribute((const void *)icp_sweep_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)sizeof(SweepShared)));
     hipLaunchKernelGGL(icp_sweep_kernel<8>, dim3(n_jobs), dim3(ICP_THREADS), sizeof(SweepShared), ctx->stream, *p,
-                       d_jobs, (const float2 *)d_src, d_guess9, d_stgt, d_perm, d_snrm, d_mean, d_qxy, d_qst, d_qwl,
-                       d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof, d_dbg, sw_refill, sw_budget);
+                       d_jobs, (const float2 *)d_src, d_guess9, d_stgt, d_perm, d_snrm, d_mean, d_qxy, d_qst, d_qwl, d_qlong,
+                       d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof, d_dbg, sw_budget);
     SFE_LAUNCH_CHECK(ctx);
     if (debug) {
         int h[8];

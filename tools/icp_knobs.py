@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Sweep the walk kernel's debug knobs (env SFE_SW_REFILL / SFE_SW_BUDGET) on the bench scan pairs."""
+"""Sweep the walk kernel's debug knobs (env SFE_SW_PART / SFE_SW_BUDGET) on the bench scan pairs."""
 import ctypes
 import os
 import sys
@@ -36,10 +36,10 @@ for mode, p in (("p2plane30", icp_config.shipped_params(minimizer=1, use_diff_ch
     kb = KeyframeBatch(ctx, fe.geometry, det.params["SOCA"], "SOCA", 65, p, B)
     kb.upload_scan_pairs(srcs, tgts, guesses)
     kbs[mode] = kb
-for refill, budget in [(16, 24), (32, 24), (48, 24), (16, 8), (32, 8), (16, 4), (32, 4), (16, 64), (1, 24)]:
-    os.environ["SFE_SW_REFILL"] = str(refill)
+for refill, budget in [(0, 12), (0, 24)]:
+    os.environ["SFE_SW_PART"] = str(refill)
     os.environ["SFE_SW_BUDGET"] = str(budget)
-    line = "refill %2d budget %2d:" % (refill, budget)
+    line = "part %6d budget %2d:" % (refill, budget)
     for mode, kb in kbs.items():
         ms = timed(kb.run_icp, 3)
         cyc = (ctypes.c_longlong * 80)()
@@ -47,5 +47,5 @@ for refill, budget in [(16, 24), (32, 24), (48, 24), (16, 8), (32, 8), (16, 4), 
         kb.run_icp()
         ctx.sync()
         ctx._check(ctx.lib.sfe_icp_get_profile(ctx.handle, 0, cyc))
-        line += "  %s %.2f ms (tier1 %dk tier2 %dk long %d)" % (mode, ms, cyc[6] // 1000, cyc[7] // 1000, cyc[10])
+        line += "  %s %.2f ms (tier1 %dk tier2 %dk long %d trips %d resolves %d)" % (mode, ms, cyc[6] // 1000, cyc[7] // 1000, cyc[10], cyc[12], cyc[13])
     print(line, flush=True)
