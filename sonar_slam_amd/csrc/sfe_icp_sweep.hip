@@ -36,7 +36,8 @@
 
 struct SweepPrep {
     int tgt_start, n_tgt;
-    long long off; // offset (points) of this target's slice of the sorted-cloud scratch
+    long long off;     // offset (points) of this target's slice of the sorted-cloud scratch (stride n_tgt + 4)
+    long long key_off; // targets beyond the LDS capacity: offset of their sort keys in HBM scratch
 };
 
 struct SweepJob {
@@ -88,93 +89,13 @@ struct PrepShared {
 // ---------------------------------------------------------------------------------------------
 // prep: one workgroup per distinct target cloud
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(ICP_THREADS, 4) void icp_sweep_prep_kernel(sfe_icp_params P,
-                                                                        const SweepPrep *__restrict__ preps,
-                                                                        const float2 *__restrict__ tgt_all,
-                                                                        float2 *__restrict__ stgt_all,
-                                                                        int *__restrict__ perm_all,
-                                                                        float2 *__restrict__ snrm_all,
-                                                                        float *__restrict__ mean_all)
+// PCA normals of the centred target: K nearest incl. the point itself, ordered by (d2, original
+// index) exactly like the brute-force scan (sfe_icp.hip).  s_tgt = sorted cloud with sentinels
+// (1-based positions), in LDS or in HBM scratch.
+__device__ __forceinline__ void sweep_knn_normals(const sfe_icp_params &P, const float2 *__restrict__ s_tgt,
+                                                  const int *__restrict__ perm, float2 *__restrict__ snrm, int nt)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    PrepShared &S = *reinterpret_cast<PrepShared *>(smem_raw);
-    const SweepPrep J = preps[blockIdx.x];
-    const int nt = J.n_tgt, tid = threadIdx.x;
-    const float2 *__restrict__ tgt = tgt_all + J.tgt_start;
-    float2 *__restrict__ stgt = stgt_all + J.off;
-    int *__restrict__ perm = perm_all + J.off;
-
-    // reference mean (fp64 accumulation, rounded to float), as the brute-force kernel
-    {
-        double m[2] = {0, 0};
-        for (int i = tid; i < nt; i += ICP_THREADS) {
-            const float2 t = tgt[i];
-            m[0] += t.x;
-            m[1] += t.y;
-        }
-        block_sum<2>(m, S.red);
-        if (tid == 0) {
-            S.mean[0] = (float)(m[0] / nt);
-            S.mean[1] = (float)(m[1] / nt);
-            mean_all[2 * blockIdx.x] = S.mean[0];
-            mean_all[2 * blockIdx.x + 1] = S.mean[1];
-        }
-        __syncthreads();
-    }
-    const float mx = S.mean[0], my = S.mean[1];
-
-    // sort (key(x - mean_x), index)
-    unsigned n2 = 2;
-    while (n2 < (unsigned)nt)
-        n2 <<= 1;
-    unsigned long long *keys = S.buf;
-    for (unsigned i = tid; i < n2; i += ICP_THREADS) {
-        unsigned long long k = ~0ull;
-        if (i < (unsigned)nt)
-            k = ((unsigned long long)mono_key(f_add(tgt[i].x, -mx)) << 32) | i;
-        keys[i] = k;
-    }
-    __syncthreads();
-    bitonic_sort_lds(keys, n2);
-
-    // keys -> sorted centred cloud (registers -> same LDS bytes, shifted by the left sentinel)
-    constexpr int PER = SW_TCAP / ICP_THREADS;
-    float2 v[PER];
-    int id[PER];
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const int pos = k * ICP_THREADS + tid;
-        v[k] = make_float2(0, 0);
-        id[k] = 0;
-        if (pos < nt) {
-            const unsigned long long key = keys[pos];
-            id[k] = (int)(unsigned)(key & 0xFFFFFFFFu);
-            v[k] = make_float2(mono_inv((unsigned)(key >> 32)), f_add(tgt[id[k]].y, -my));
-        }
-    }
-    __syncthreads();
-    float2 *s_tgt = reinterpret_cast<float2 *>(S.buf);
-    const float qnan = __uint_as_float(0x7FC00000u);
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const int pos = k * ICP_THREADS + tid;
-        if (pos < nt) {
-            s_tgt[pos + 1] = v[k];
-            stgt[pos] = v[k];
-            perm[pos] = id[k];
-        }
-    }
-    if (tid == 0) {
-        s_tgt[0] = make_float2(qnan, qnan);
-        s_tgt[nt + 1] = make_float2(qnan, qnan);
-    }
-    __syncthreads();
-    if (P.minimizer != 1)
-        return;
-
-    // ---- PCA normals of the centred target: K nearest incl. the point itself, ordered by
-    // (d2, original index) exactly like the brute-force scan (sfe_icp.hip) ----
-    float2 *__restrict__ snrm = snrm_all + J.off;
+    const int tid = threadIdx.x;
     const int K = min(min(P.normals_knn, ICP_KMAX), nt);
     for (int c = tid; c < nt; c += ICP_THREADS) {
         const float2 q = s_tgt[c + 1];
@@ -280,6 +201,134 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_sweep_prep_kernel(sfe_icp_
     }
 }
 
+// bitonic sort of n2 (power of two) 64-bit keys in HBM scratch by one workgroup (targets that do
+// not fit LDS; once per target, the keys stay in L2)
+__device__ __forceinline__ void bitonic_sort_global(unsigned long long *keys, unsigned n2)
+{
+    for (unsigned k = 2; k <= n2; k <<= 1) {
+        for (unsigned j = k >> 1; j > 0; j >>= 1) {
+            for (unsigned t = threadIdx.x; t < n2 / 2; t += ICP_THREADS) {
+                const unsigned i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const unsigned l = i | j;
+                const unsigned long long a = keys[i], b = keys[l];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) {
+                    keys[i] = b;
+                    keys[l] = a;
+                }
+            }
+            __syncthreads(); // same workgroup, same CU: its L1 sees its own write-through stores
+        }
+    }
+}
+
+// Sorted-cloud scratch layout per target (stride n_tgt + 4 points): [0] NaN sentinel,
+// [1 .. n_tgt] centred points ascending in x, [n_tgt+1], [n_tgt+2] NaN sentinels.  perm / snrm
+// use the same stride, entry p-1 belongs to sorted position p.
+__global__ __launch_bounds__(ICP_THREADS, 4) void icp_sweep_prep_kernel(sfe_icp_params P,
+                                                                        const SweepPrep *__restrict__ preps,
+                                                                        const float2 *__restrict__ tgt_all,
+                                                                        float2 *__restrict__ stgt_all,
+                                                                        int *__restrict__ perm_all,
+                                                                        float2 *__restrict__ snrm_all,
+                                                                        float *__restrict__ mean_all,
+                                                                        unsigned long long *__restrict__ gkeys_all)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    PrepShared &S = *reinterpret_cast<PrepShared *>(smem_raw);
+    const SweepPrep J = preps[blockIdx.x];
+    const int nt = J.n_tgt, tid = threadIdx.x;
+    const float2 *__restrict__ tgt = tgt_all + J.tgt_start;
+    float2 *__restrict__ stgt = stgt_all + J.off;
+    int *__restrict__ perm = perm_all + J.off;
+    const float qnan = __uint_as_float(0x7FC00000u);
+
+    // reference mean (fp64 accumulation, rounded to float), as the brute-force kernel
+    {
+        double m[2] = {0, 0};
+        for (int i = tid; i < nt; i += ICP_THREADS) {
+            const float2 t = tgt[i];
+            m[0] += t.x;
+            m[1] += t.y;
+        }
+        block_sum<2>(m, S.red);
+        if (tid == 0) {
+            S.mean[0] = (float)(m[0] / nt);
+            S.mean[1] = (float)(m[1] / nt);
+            mean_all[2 * blockIdx.x] = S.mean[0];
+            mean_all[2 * blockIdx.x + 1] = S.mean[1];
+        }
+        __syncthreads();
+    }
+    const float mx = S.mean[0], my = S.mean[1];
+
+    // sort (key(x - mean_x), index)
+    unsigned n2 = 2;
+    while (n2 < (unsigned)nt)
+        n2 <<= 1;
+    const bool in_lds = nt <= SW_TCAP;
+    unsigned long long *keys = in_lds ? S.buf : gkeys_all + J.key_off;
+    for (unsigned i = tid; i < n2; i += ICP_THREADS) {
+        unsigned long long k = ~0ull;
+        if (i < (unsigned)nt)
+            k = ((unsigned long long)mono_key(f_add(tgt[i].x, -mx)) << 32) | i;
+        keys[i] = k;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        stgt[0] = make_float2(qnan, qnan);
+        stgt[nt + 1] = make_float2(qnan, qnan);
+        stgt[nt + 2] = make_float2(qnan, qnan);
+    }
+    if (in_lds) {
+        bitonic_sort_lds(S.buf, n2);
+        // keys -> sorted centred cloud (registers -> same LDS bytes, shifted by the left sentinel)
+        constexpr int PER = SW_TCAP / ICP_THREADS;
+        float2 v[PER];
+        int id[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int pos = k * ICP_THREADS + tid;
+            v[k] = make_float2(0, 0);
+            id[k] = 0;
+            if (pos < nt) {
+                const unsigned long long key = S.buf[pos];
+                id[k] = (int)(unsigned)(key & 0xFFFFFFFFu);
+                v[k] = make_float2(mono_inv((unsigned)(key >> 32)), f_add(tgt[id[k]].y, -my));
+            }
+        }
+        __syncthreads();
+        float2 *s_tgt = reinterpret_cast<float2 *>(S.buf);
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int pos = k * ICP_THREADS + tid;
+            if (pos < nt) {
+                s_tgt[pos + 1] = v[k];
+                stgt[pos + 1] = v[k];
+                perm[pos] = id[k];
+            }
+        }
+        if (tid == 0) {
+            s_tgt[0] = make_float2(qnan, qnan);
+            s_tgt[nt + 1] = make_float2(qnan, qnan);
+        }
+        __syncthreads();
+        if (P.minimizer == 1)
+            sweep_knn_normals(P, s_tgt, perm, snrm_all + J.off, nt);
+    } else {
+        bitonic_sort_global(keys, n2);
+        for (int pos = tid; pos < nt; pos += ICP_THREADS) {
+            const unsigned long long key = keys[pos];
+            const int id = (int)(unsigned)(key & 0xFFFFFFFFu);
+            stgt[pos + 1] = make_float2(mono_inv((unsigned)(key >> 32)), f_add(tgt[id].y, -my));
+            perm[pos] = id;
+        }
+        __syncthreads();
+        if (P.minimizer == 1)
+            sweep_knn_normals(P, stgt, perm, snrm_all + J.off, nt);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // loop: one workgroup per job
 // ---------------------------------------------------------------------------------------------
@@ -295,8 +344,8 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_sweep_prep_kernel(sfe_icp_
 // weight-1 pairs.  Otherwise C grows 4x and the suspended walks resume where they stopped.  C
 // starts from the previous iteration's limit, so far outliers cost a handful of steps instead of
 // a walk across the whole cloud.  Decisions and results are identical to the exhaustive search.
+// control block of a job; the LDS-resident variant places the sorted target right behind it
 struct SweepShared {
-    float2 tgt[SW_TCAP + 4];
     double red[ICP_WAVES * 10 + 10];
     unsigned hist[256];
     unsigned sel_prefix, sel_k;
@@ -386,9 +435,11 @@ __device__ __forceinline__ int sweep_resolve_tie(const float2 *__restrict__ s_tg
     return bp;
 }
 
-template <int MINW>
+// LDS_TGT: sorted target resident in LDS (n_tgt <= SW_TCAP) or read from its HBM scratch slice (it
+// stays in L2: <= 160 KB for a 20k-point cloud, shared by all guesses of a many-to-one batch)
+template <int MINW, bool LDS_TGT>
 __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
-    sfe_icp_params P, const SweepJob *__restrict__ jobs, const float2 *__restrict__ src_all,
+    sfe_icp_params P, const SweepJob *__restrict__ jobs, const int *__restrict__ job_ids, const float2 *__restrict__ src_all,
     const float *__restrict__ guess_all, const float2 *__restrict__ stgt_all, const int *__restrict__ perm_all,
     const float2 *__restrict__ snrm_all, const float *__restrict__ mean_all, float2 *__restrict__ q_xy_all,
     int4 *__restrict__ q_st_all, int *__restrict__ q_wl_all, int4 *__restrict__ q_long_all, float *__restrict__ nn_d2_all,
@@ -398,10 +449,13 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     SweepShared &S = *reinterpret_cast<SweepShared *>(smem_raw);
 
-    const SweepJob J = jobs[blockIdx.x];
+    const int jb = job_ids[blockIdx.x];
+    const SweepJob J = jobs[jb];
     const int ns = J.n_src, nt = J.n_tgt;
     const float2 *__restrict__ src = src_all + J.src_start;
     const float2 *__restrict__ stgt = stgt_all + J.tgt_off;
+    float2 *lds_tgt = reinterpret_cast<float2 *>(smem_raw + ((sizeof(SweepShared) + 15) & ~(size_t)15));
+    const float2 *__restrict__ T = LDS_TGT ? (const float2 *)lds_tgt : stgt; // sorted target incl. sentinels
     const float2 *__restrict__ snrm = snrm_all ? snrm_all + J.tgt_off : nullptr;
     SweepQ Q;
     Q.xy = q_xy_all + J.q_off;
@@ -413,7 +467,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
     Q.longe = q_long_all + 2 * J.q_off;
     Q.perm = perm_all + J.tgt_off;
     Q.nt = nt;
-    const float *guess = guess_all + 9 * (size_t)blockIdx.x;
+    const float *guess = guess_all + 9 * (size_t)jb;
     const int tid = threadIdx.x, lane = threadIdx.x & 63;
     const float mx = mean_all[2 * J.prep], my = mean_all[2 * J.prep + 1];
 
@@ -422,16 +476,10 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
             S.prof[i] = 0;
         S.prof_t = clock64();
     }
-    // sorted centred target -> LDS, NaN sentinels at both ends (a NaN stops a walk direction)
-    {
-        const float qnan = __uint_as_float(0x7FC00000u);
-        for (int i = tid; i < nt; i += ICP_THREADS)
-            S.tgt[i + 1] = stgt[i];
-        if (tid == 0) {
-            S.tgt[0] = make_float2(qnan, qnan);
-            S.tgt[nt + 1] = make_float2(qnan, qnan);
-            S.tgt[nt + 2] = make_float2(qnan, qnan); // the exhaustive scan reads pairs of points
-        }
+    // sorted centred target (with its NaN sentinels: a NaN stops a walk direction) -> LDS
+    if (LDS_TGT) {
+        for (int i = tid; i < nt + 3; i += ICP_THREADS)
+            lds_tgt[i] = stgt[i];
     }
 
     // ---- T0 = T_refIn_refMean^-1 * guess ; T_iter = I ----
@@ -466,7 +514,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
     const float Cmax = P.use_max_dist_filter ? fminf(r2_filter, r2_match) : r2_match;
     float Cinit;
     {
-        const float ext = f_add(S.tgt[nt].x, -S.tgt[1].x); // x extent of the sorted target
+        const float ext = f_add(T[nt].x, -T[1].x); // x extent of the sorted target
         const float h = 8.0f * ext / (float)nt;
         Cinit = h * h;
         if (!(Cinit > 1e-30f) || !(Cinit < Cmax))
@@ -541,7 +589,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                         int lo = 1, hi = nt + 1;
                         while (__ballot(lo < hi)) {
                             const int mid = (lo + hi) >> 1;
-                            const bool lt = S.tgt[min(mid, nt + 1)].x < px;
+                            const bool lt = T[min(mid, nt + 1)].x < px;
                             if (lo < hi) {
                                 if (lt)
                                     lo = mid + 1;
@@ -557,7 +605,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                         if (!fin) {
 #pragma unroll
                             for (int s2 = 0; s2 < 2; ++s2) {
-                                const float2 tl = S.tgt[iL], tr = S.tgt[iR];
+                                const float2 tl = T[iL], tr = T[iR];
                                 const float dxl = f_add(px, -tl.x), el = f_mul(dxl, dxl);
                                 const float dyl = f_add(py, -tl.y), dl = f_add(el, f_mul(dyl, dyl));
                                 const float dxr = f_add(px, -tr.x), er = f_mul(dxr, dxr);
@@ -595,7 +643,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                     }
                     if (is_exact) {
                         if (tied)
-                            bpos = sweep_resolve_tie(S.tgt, Q, px, py, best, iL, iR);
+                            bpos = sweep_resolve_tie(T, Q, px, py, best, iL, iR);
                         Q.d2[q] = best;
                         Q.pos[q] = bpos - 1;
                     }
@@ -664,7 +712,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                             const float sb = bpos ? fminf(best, C) : best; // stop bound at the start of the trip
                             const int j = left ? max(iL - lane, 0) : min(iR + lane - 32, nt + 1);
                             const bool on = left ? !doneL : !doneR;
-                            const float2 t = S.tgt[j];
+                            const float2 t = T[j];
                             const float dx = f_add(px, -t.x), e = f_mul(dx, dx);
                             const float dy = f_add(py, -t.y);
                             float d = f_add(e, f_mul(dy, dy));
@@ -708,7 +756,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                                 Q.pos[q] = SW_NONE;
                             } else if (best <= C) {
                                 if (tied)
-                                    bpos = sweep_resolve_tie(S.tgt, Q, px, py, best, iL, iR);
+                                    bpos = sweep_resolve_tie(T, Q, px, py, best, iL, iR);
                                 Q.d2[q] = best;
                                 Q.pos[q] = bpos - 1;
                             } else {
@@ -862,7 +910,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                 continue;
             const float2 p = Q.xy[i];
             const double px = p.x, py = p.y;
-            const float2 q = S.tgt[id + 1];
+            const float2 q = T[id + 1];
             const double qx = q.x, qy = q.y;
             acc[0] += 1.0;
             if (P.minimizer == 0) {
@@ -908,7 +956,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
 
     if (tid == 0) {
         const int status = S.flag_status;
-        float *To = T_out + 9 * (size_t)blockIdx.x;
+        float *To = T_out + 9 * (size_t)jb;
         if (status == SFE_ICP_OK) {
             const float Tfwd[9] = {1, 0, mx, 0, 1, my, 0, 0, 1};
             float Ti[9], tmp[9], res[9];
@@ -922,9 +970,9 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
             for (int i = 0; i < 9; ++i) // pcl.cpp:203,207-210: T stays the guess
                 To[i] = guess[i];
         }
-        status_out[blockIdx.x] = status;
-        iters_out[blockIdx.x] = chk.iters;
-        if (prof != nullptr && blockIdx.x == 0) {
+        status_out[jb] = status;
+        iters_out[jb] = chk.iters;
+        if (prof != nullptr && jb == 0) {
             for (int i = 0; i < 16; ++i)
                 prof[i] = S.prof[i];
             for (int i = 0; i < 64; ++i)
@@ -935,31 +983,37 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
 
 // ---------------------------------------------------------------------------------------------
 // host side: job tables, scratch, two launches.  jobs4 = n_jobs x (src_start, n_src, tgt_start,
-// n_tgt) in points.  Returns 1 if some target is too large for the sweep (caller falls back).
+// n_tgt) in points.
 // ---------------------------------------------------------------------------------------------
 int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_src, const float *d_tgt,
                          const int32_t *jobs4, const float *d_guess9, int n_jobs, float *d_T9, int32_t *d_status,
                          int32_t *d_iters)
 {
-    for (int j = 0; j < n_jobs; ++j)
-        if (jobs4[4 * (size_t)j + 3] > SW_TCAP)
-            return 1;
     std::vector<SweepPrep> preps;
     std::vector<SweepJob> jobs((size_t)n_jobs);
+    std::vector<int> ids_lds, ids_glb; // jobs whose target fits LDS / is read from HBM scratch
     std::map<std::pair<int, int>, int> seen; // many guesses on one pair share one prep
-    long long toff = 0, qoff = 0;
+    long long toff = 0, qoff = 0, koff = 0;
     for (int j = 0; j < n_jobs; ++j) {
         const int32_t *q = jobs4 + 4 * (size_t)j;
         const auto key = std::make_pair((int)q[2], (int)q[3]);
         auto it = seen.find(key);
         if (it == seen.end()) {
             it = seen.emplace(key, (int)preps.size()).first;
-            preps.push_back({q[2], q[3], toff});
-            toff += q[3];
+            long long n2 = 0;
+            if (q[3] > SW_TCAP) {
+                n2 = 2;
+                while (n2 < q[3])
+                    n2 <<= 1;
+            }
+            preps.push_back({q[2], q[3], toff, koff});
+            toff += q[3] + 4;
+            koff += n2;
         }
         const SweepPrep &pr = preps[(size_t)it->second];
         jobs[(size_t)j] = {q[0], q[1], q[3], it->second, pr.off, qoff};
         qoff += q[1];
+        (q[3] <= SW_TCAP ? ids_lds : ids_glb).push_back(j);
     }
     const int n_prep = (int)preps.size();
     SweepPrep *d_preps = (SweepPrep *)sfe_scratch(ctx, 12, sizeof(SweepPrep) * (size_t)n_prep);
@@ -967,19 +1021,25 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
     float2 *d_stgt = (float2 *)sfe_scratch(ctx, 14, sizeof(float2) * (size_t)toff);
     int *d_perm = (int *)sfe_scratch(ctx, 15, sizeof(int) * (size_t)toff);
     float2 *d_snrm = p->minimizer == 1 ? (float2 *)sfe_scratch(ctx, 16, sizeof(float2) * (size_t)toff) : nullptr;
-    float *d_mean = (float *)sfe_scratch(ctx, 17, sizeof(float) * 2 * (size_t)n_prep);
+    float *d_mean = (float *)sfe_scratch(ctx, 17, sizeof(float) * 2 * (size_t)n_prep + sizeof(int) * (size_t)n_jobs);
+    int *d_ids = d_mean ? (int *)(d_mean + 2 * (size_t)n_prep) : nullptr;
+    unsigned long long *d_gkeys = (unsigned long long *)sfe_scratch(ctx, 24, sizeof(unsigned long long) * (size_t)std::max(koff, 1LL));
     float2 *d_qxy = (float2 *)sfe_scratch(ctx, 18, sizeof(float2) * (size_t)qoff);
     int4 *d_qst = (int4 *)sfe_scratch(ctx, 19, sizeof(int4) * (size_t)qoff);
     int *d_qwl = (int *)sfe_scratch(ctx, 21, sizeof(int) * 2 * (size_t)qoff);
     int4 *d_qlong = (int4 *)sfe_scratch(ctx, 23, sizeof(int4) * 2 * (size_t)qoff);
     float *d_nn_d2 = (float *)sfe_scratch(ctx, 5, sizeof(float) * (size_t)qoff);
     int *d_nn_pos = (int *)sfe_scratch(ctx, 6, sizeof(int) * (size_t)qoff);
-    if (!d_preps || !d_jobs || !d_stgt || !d_perm || (p->minimizer == 1 && !d_snrm) || !d_mean || !d_qxy || !d_qst || !d_qwl || !d_qlong ||
+    if (!d_preps || !d_jobs || !d_stgt || !d_perm || (p->minimizer == 1 && !d_snrm) || !d_mean || !d_gkeys || !d_qxy || !d_qst || !d_qwl || !d_qlong ||
         !d_nn_d2 || !d_nn_pos)
         return SFE_ERR_HIP;
     SFE_HIP(ctx, hipMemcpyAsync(d_preps, preps.data(), sizeof(SweepPrep) * (size_t)n_prep, hipMemcpyHostToDevice,
                                 ctx->stream));
     SFE_HIP(ctx, hipMemcpyAsync(d_jobs, jobs.data(), sizeof(SweepJob) * (size_t)n_jobs, hipMemcpyHostToDevice,
+                                ctx->stream));
+    const int n_lds = (int)ids_lds.size(), n_glb = (int)ids_glb.size();
+    ids_lds.insert(ids_lds.end(), ids_glb.begin(), ids_glb.end()); // [LDS-resident jobs | HBM-resident jobs]
+    SFE_HIP(ctx, hipMemcpyAsync(d_ids, ids_lds.data(), sizeof(int) * (size_t)n_jobs, hipMemcpyHostToDevice,
                                 ctx->stream));
     // the pageable host vectors must stay alive until the copies have been consumed
     SFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -987,7 +1047,7 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
     SFE_HIP(ctx, hipFuncSetAttribute((const void *)icp_sweep_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)sizeof(PrepShared)));
     hipLaunchKernelGGL(icp_sweep_prep_kernel, dim3(n_prep), dim3(ICP_THREADS), sizeof(PrepShared), ctx->stream, *p,
-                       d_preps, (const float2 *)d_tgt, d_stgt, d_perm, d_snrm, d_mean);
+                       d_preps, (const float2 *)d_tgt, d_stgt, d_perm, d_snrm, d_mean, d_gkeys);
     SFE_LAUNCH_CHECK(ctx);
     static const bool debug = getenv("SFE_ICP_DEBUG") != nullptr;
     const int sw_budget = getenv("SFE_SW_BUDGET") ? atoi(getenv("SFE_SW_BUDGET")) : SW_BUDGET;
@@ -999,12 +1059,22 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
         SFE_HIP(ctx, hipMemsetAsync(d_dbg, 0, sizeof(int) * 8, ctx->stream));
     }
     long long *d_prof = ctx->icp_prof ? (long long *)sfe_scratch(ctx, 20, sizeof(long long) * 80) : nullptr;
-    SFE_HIP(ctx, hipFuncSetAttribute((const void *)icp_sweep_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)sizeof(SweepShared)));
-    hipLaunchKernelGGL(icp_sweep_kernel<8>, dim3(n_jobs), dim3(ICP_THREADS), sizeof(SweepShared), ctx->stream, *p,
-                       d_jobs, (const float2 *)d_src, d_guess9, d_stgt, d_perm, d_snrm, d_mean, d_qxy, d_qst, d_qwl, d_qlong,
-                       d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof, d_dbg, sw_budget);
-    SFE_LAUNCH_CHECK(ctx);
+    const size_t ctl_bytes = (sizeof(SweepShared) + 15) & ~(size_t)15;
+    if (n_lds) {
+        const size_t smem = ctl_bytes + sizeof(float2) * (SW_TCAP + 4);
+        SFE_HIP(ctx, hipFuncSetAttribute((const void *)icp_sweep_kernel<8, true>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL((icp_sweep_kernel<8, true>), dim3(n_lds), dim3(ICP_THREADS), smem, ctx->stream, *p, d_jobs,
+                           d_ids, (const float2 *)d_src, d_guess9, d_stgt, d_perm, d_snrm, d_mean, d_qxy, d_qst, d_qwl,
+                           d_qlong, d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof, d_dbg, sw_budget);
+        SFE_LAUNCH_CHECK(ctx);
+    }
+    if (n_glb) {
+        hipLaunchKernelGGL((icp_sweep_kernel<8, false>), dim3(n_glb), dim3(ICP_THREADS), ctl_bytes, ctx->stream, *p,
+                           d_jobs, d_ids + n_lds, (const float2 *)d_src, d_guess9, d_stgt, d_perm, d_snrm, d_mean, d_qxy,
+                           d_qst, d_qwl, d_qlong, d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof, d_dbg, sw_budget);
+        SFE_LAUNCH_CHECK(ctx);
+    }
     if (debug) {
         int h[8];
         SFE_HIP(ctx, hipMemcpyAsync(h, d_dbg, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
