@@ -187,6 +187,32 @@ int sfe_icp_batch_dev(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_src,
                       const float *d_guess9, int n_jobs, float *d_T9, int32_t *d_status,
                       int32_t *d_iters);
 
+/* ---- global-initialisation matching cost: slam.py:461-570 ---------------- */
+/*
+ * get_matching_cost_subroutine1 builds a dilated occupancy grid of the target cloud and hands
+ * scipy.optimize.shgo a function that counts the source points falling on set cells under a
+ * candidate transform (slam.py:692-701, 952-961 call it 50-500+ times per keyframe, one pose per
+ * call).  Here the grid lives on the device and MANY candidate transforms are scored per launch.
+ *
+ * sfe_costgrid_create: tgt_r / tgt_c = the target cells exactly as slam.py:515-518 computes them
+ * (rounded, clipped; host int32), rows x cols = target_grids.shape, dilate_hs = slam.py:522.  The
+ * grid is target_grids after cv2.dilate with getStructuringElement(MORPH_ELLIPSE, (2h+1, 2h+1), (h, h)).
+ */
+typedef struct sfe_costgrid sfe_costgrid;
+int sfe_costgrid_create(sfe_ctx *ctx, const int32_t *tgt_r, const int32_t *tgt_c, int n_tgt, int rows,
+                        int cols, int dilate_hs, sfe_costgrid **out);
+void sfe_costgrid_destroy(sfe_costgrid *g);
+/* the dilated grid as the reference holds it: rows x cols uint8, 0 / 255 (host buffer) */
+int sfe_costgrid_download(sfe_ctx *ctx, sfe_costgrid *g, uint8_t *grid_out);
+/*
+ * The body of `subroutine` (slam.py:531-564) for n_poses transforms.  src: n_src x 2 float32 source
+ * points (host); T6: per pose the float32 entries T00 T01 T02 T10 T11 T12 of
+ * sample_transform.matrix(); xmin, ymin, resolution as float32 (slam.py:508-510);
+ * cost_out[p] = -(number of source points on a set cell).
+ */
+int sfe_matching_cost_batch(sfe_ctx *ctx, sfe_costgrid *g, const float *src, int n_src, const float *T6,
+                            int n_poses, float xmin, float ymin, float resolution, int32_t *cost_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -90,6 +90,10 @@ def lib():
         L.orc_remove_outlier.argtypes = [f32p, C.c_int, C.c_double, C.c_int, f32p]
         L.orc_bilinear_tab.argtypes = [C.POINTER(C.c_int16)]
         L.orc_downsample.argtypes = [f32p, C.c_int, C.c_float, f32p, i32p]
+        L.orc_ellipse_spans.argtypes = [C.c_int, i32p, i32p]
+        L.orc_cost_grid.argtypes = [i32p, i32p, C.c_int, C.c_int, C.c_int, C.c_int, u8p]
+        L.orc_matching_cost.argtypes = [u8p, C.c_int, C.c_int, f32p, C.c_int, f32p, C.c_int, C.c_float,
+                                        C.c_float, C.c_float, i32p]
         _lib = L
     return _lib
 
@@ -209,3 +213,36 @@ def downsample(pts, resolution, return_index=False):
     res = np.float32(float("%f" % np.float32(resolution)))
     m = lib().orc_downsample(_p(pts, C.c_float), len(pts), float(res), _p(out, C.c_float), _p(idx, C.c_int32))
     return (out[:m].copy(), idx[:m].copy()) if return_index else out[:m].copy()
+
+
+def ellipse_kernel(hs):
+    """cv2.getStructuringElement(cv2.MORPH_ELLIPSE, (2hs+1, 2hs+1), (hs, hs)) as a 0/1 array."""
+    size = 2 * hs + 1
+    j1 = np.zeros(size, np.int32)
+    j2 = np.zeros(size, np.int32)
+    lib().orc_ellipse_spans(int(hs), _p(j1, C.c_int32), _p(j2, C.c_int32))
+    k = np.zeros((size, size), np.uint8)
+    for i in range(size):
+        k[i, j1[i]:j2[i]] = 1
+    return k
+
+
+def cost_grid(tgt_r, tgt_c, rows, cols, dilate_hs):
+    """target_grids after cv2.dilate (slam.py:515-527): rows x cols uint8 0/255."""
+    tr = np.ascontiguousarray(tgt_r, np.int32)
+    tc = np.ascontiguousarray(tgt_c, np.int32)
+    g = np.zeros((rows, cols), np.uint8)
+    lib().orc_cost_grid(_p(tr, C.c_int32), _p(tc, C.c_int32), len(tr), rows, cols, int(dilate_hs), _p(g, C.c_uint8))
+    return g
+
+
+def matching_cost(grid, src, T6, xmin, ymin, resolution):
+    """costs (= -hits, slam.py:549-562) of n_poses float32 transforms [n x 6]."""
+    grid = np.ascontiguousarray(grid, np.uint8)
+    src = np.ascontiguousarray(src, np.float32).reshape(-1, 2)
+    T6 = np.ascontiguousarray(T6, np.float32).reshape(-1, 6)
+    out = np.zeros(len(T6), np.int32)
+    lib().orc_matching_cost(_p(grid, C.c_uint8), grid.shape[0], grid.shape[1], _p(src, C.c_float), len(src),
+                            _p(T6, C.c_float), len(T6), np.float32(xmin), np.float32(ymin), np.float32(resolution),
+                            _p(out, C.c_int32))
+    return out

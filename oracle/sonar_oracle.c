@@ -801,3 +801,85 @@ int orc_downsample(const float *pts, int n, float resolution, float *out, int32_
     free(ids);
     return C.n_out;
 }
+
+/* =============================================================================================
+ * Global-initialisation matching cost: bruce_slam/src/bruce_slam/slam.py:461-570
+ * (get_matching_cost_subroutine1, driven by scipy.optimize.shgo at slam.py:692-701,952-961).
+ *
+ *   target_grids[r, c] = 255 at the (already rounded and clipped) target cells      slam.py:515-519
+ *   kernel = cv2.getStructuringElement(MORPH_ELLIPSE, (2h+1, 2h+1), (h, h))          slam.py:522-526
+ *   target_grids = cv2.dilate(target_grids, kernel)                                  slam.py:527
+ *   per candidate transform T (3x3 -> float32): points = src.dot(T[:2,:2].T) + T[:2,2]
+ *     r = int32(round((points[:,1] - ymin) / resolution)), c likewise, inside test,
+ *     cost = -sum(target_grids[r[inside], c[inside]] > 0)                            slam.py:549-562
+ *
+ * OpenCV is not vendored (parity unpinned).  Restated from its published source:
+ * getStructuringElement(MORPH_ELLIPSE): r = h, c = h, inv_r2 = 1/(r*r); row i: dy = i - r,
+ * dx = cvRound(c * sqrt((r*r - dy*dy) * inv_r2)), columns [max(c-dx,0), min(c+dx+1, width)) set.
+ * dilate with BORDER_CONSTANT / morphologyDefaultBorderValue: outside pixels never contribute, so
+ * dilation = stamping the (symmetric) element at every set pixel, clipped at the image edges.
+ * Float recipe of the per-point part (numpy float32 arithmetic, no contraction):
+ *   x' = fl(fl(fl(px*T00) + fl(py*T01)) + T02), c = (int)rint(fl(fl(x' - xmin) / res32)),
+ *   rint = round-half-even like np.round.
+ * ============================================================================================= */
+void orc_ellipse_spans(int hs, int *j1, int *j2)
+{
+    const int r = hs, c = hs, size = 2 * hs + 1;
+    const double inv_r2 = r ? 1.0 / ((double)r * r) : 0.0;
+    for (int i = 0; i < size; ++i) {
+        const int dy = i - r;
+        const int dx = (int)lrint(c * sqrt(((double)r * r - (double)dy * dy) * inv_r2)); /* cvRound */
+        j1[i] = c - dx > 0 ? c - dx : 0;
+        j2[i] = c + dx + 1 < size ? c + dx + 1 : size;
+    }
+}
+
+/* grid_out: rows x cols uint8 (0 / 255) */
+void orc_cost_grid(const int32_t *tr, const int32_t *tc, int n_tgt, int rows, int cols, int hs, uint8_t *grid_out)
+{
+    const int size = 2 * hs + 1;
+    int *j1 = (int *)malloc(sizeof(int) * (size_t)size), *j2 = (int *)malloc(sizeof(int) * (size_t)size);
+    orc_ellipse_spans(hs, j1, j2);
+    memset(grid_out, 0, (size_t)rows * cols);
+    for (int p = 0; p < n_tgt; ++p) {
+        for (int i = 0; i < size; ++i) {
+            const int rr = tr[p] + i - hs;
+            if (rr < 0 || rr >= rows)
+                continue;
+            for (int j = j1[i]; j < j2[i]; ++j) {
+                const int cc = tc[p] + j - hs;
+                if (cc >= 0 && cc < cols)
+                    grid_out[(size_t)rr * cols + cc] = 255;
+            }
+        }
+    }
+    free(j1);
+    free(j2);
+}
+
+/* T6 per pose: T00 T01 T02 T10 T11 T12 (float32 of pose.matrix()); cost_out[p] = -hits */
+void orc_matching_cost(const uint8_t *grid, int rows, int cols, const float *src, int n_src, const float *T6,
+                       int n_poses, float xmin, float ymin, float res, int32_t *cost_out)
+{
+    for (int p = 0; p < n_poses; ++p) {
+        const float *T = T6 + 6 * (size_t)p;
+        int hits = 0;
+        for (int i = 0; i < n_src; ++i) {
+            const float px = src[2 * i], py = src[2 * i + 1];
+            volatile float a = px * T[0], b = py * T[1];
+            volatile float s = a + b;
+            const float x = s + T[2];
+            a = px * T[3];
+            b = py * T[4];
+            s = a + b;
+            const float y = s + T[5];
+            volatile float ux = x - xmin, uy = y - ymin;
+            const float qx = ux / res, qy = uy / res;
+            const double rc = rint((double)qx), rr = rint((double)qy);
+            if (!(rr >= 0 && rr < rows && rc >= 0 && rc < cols))
+                continue; /* also NaN */
+            hits += grid[(size_t)(int)rr * cols + (int)rc] > 0;
+        }
+        cost_out[p] = -hits;
+    }
+}
