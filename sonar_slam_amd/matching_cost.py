@@ -15,57 +15,15 @@ initialization_params[0]); ``subroutine(x)`` is ``batch([x])[0]``.
 
 Poses: any object with gtsam.Pose2's ``compose / between / matrix / x / y / theta`` is used through
 those methods (so with the real gtsam installed the host-side pose algebra IS gtsam's); plain
-``(x, y, theta)`` triples go through ``Pose2`` below, a restatement of gtsam's Pose2/Rot2 algebra
+``(x, y, theta)`` triples go through ``pose2.Pose2``, a restatement of gtsam's Pose2/Rot2 algebra
 (gtsam is absent from this image: parity unpinned for that fallback only).
 """
 import ctypes as _C
-import math
 
 import numpy as np
 
 from . import _lib as _L
-
-
-class Pose2(object):
-    """Minimal gtsam.Pose2: rotation kept as (c, s) like gtsam::Rot2, products renormalised only
-    when |c^2 + s^2 - 1| > 1e-10 (Rot2::normalize)."""
-
-    __slots__ = ("_x", "_y", "_c", "_s")
-
-    def __init__(self, x=0.0, y=0.0, theta=0.0, _cs=None):
-        self._x, self._y = float(x), float(y)
-        if _cs is None:
-            self._c, self._s = math.cos(theta), math.sin(theta)
-        else:
-            c, s = _cs
-            scale = c * c + s * s
-            if abs(scale - 1.0) > 1e-10:
-                scale = 1.0 / math.sqrt(scale)
-                c, s = c * scale, s * scale
-            self._c, self._s = c, s
-
-    def x(self):
-        return self._x
-
-    def y(self):
-        return self._y
-
-    def theta(self):
-        return math.atan2(self._s, self._c)
-
-    def compose(self, o):
-        return Pose2(self._x + self._c * o._x - self._s * o._y, self._y + self._s * o._x + self._c * o._y,
-                     _cs=(self._c * o._c - self._s * o._s, self._s * o._c + self._c * o._s))
-
-    def inverse(self):
-        return Pose2(-(self._c * self._x + self._s * self._y), -(-self._s * self._x + self._c * self._y),
-                     _cs=(self._c, -self._s))
-
-    def between(self, o):
-        return self.inverse().compose(o)
-
-    def matrix(self):
-        return np.array([[self._c, -self._s, self._x], [self._s, self._c, self._y], [0.0, 0.0, 1.0]])
+from .pose2 import Pose2
 
 
 def _as_pose(p):
