@@ -90,6 +90,7 @@ def lib():
         L.orc_remove_outlier.argtypes = [f32p, C.c_int, C.c_double, C.c_int, f32p]
         L.orc_bilinear_tab.argtypes = [C.POINTER(C.c_int16)]
         L.orc_downsample.argtypes = [f32p, C.c_int, C.c_float, f32p, i32p]
+        L.orc_set_kdtree.argtypes = [C.c_int]
         L.orc_ellipse_spans.argtypes = [C.c_int, i32p, i32p]
         L.orc_cost_grid.argtypes = [i32p, i32p, C.c_int, C.c_int, C.c_int, C.c_int, u8p]
         L.orc_matching_cost.argtypes = [u8p, C.c_int, C.c_int, f32p, C.c_int, f32p, C.c_int, C.c_float,
@@ -246,3 +247,9 @@ def matching_cost(grid, src, T6, xmin, ymin, resolution):
                             _p(T6, C.c_float), len(T6), np.float32(xmin), np.float32(ymin), np.float32(resolution),
                             _p(out, C.c_int32))
     return out
+
+
+def set_kdtree(on):
+    """Route the NN searches of icp / match / normals2d through the oracle's exact kd-tree (same
+    neighbours, O(N log N)); bench.py turns it on for the CPU baseline, the parity tests leave it off."""
+    lib().orc_set_kdtree(1 if on else 0)

@@ -219,6 +219,145 @@ void orc_px_to_m(const int64_t *rc, int64_t n, int rows, int cols, double width,
 }
 
 /* ------------------------------------------------------------------------- */
+/* Optional exact kd-tree behind the same searches (orc_set_kdtree(1)).       */
+/* libpointmatcher's KDTreeMatcher uses libnabo's kd-tree; brute force above   */
+/* is the plain restatement the parity tests run against, the tree exists so   */
+/* that bench.py's CPU baseline is not handicapped by an O(N^2) search.  It    */
+/* returns the SAME neighbours: candidates are compared as (d2, index) pairs   */
+/* with the same float d2, and a subtree is skipped only if the squared gap to */
+/* its splitting coordinate, fl(fl(q - split)^2), exceeds the current bound    */
+/* (rounding is monotone, so every point behind the split is at least that     */
+/* far).  tests/test_oracle_pipeline.py checks tree == brute force.            */
+/* ------------------------------------------------------------------------- */
+static int g_use_kdtree = 0;
+void orc_set_kdtree(int on) { g_use_kdtree = on; }
+
+typedef struct {
+    int lo, hi;     /* range in idx[] */
+    int dim;        /* -1 = leaf */
+    float split;
+    int left, right;
+} kd_node;
+
+typedef struct {
+    const float *pts;
+    int n;
+    int *idx;
+    kd_node *nodes;
+    int n_nodes;
+} kd_tree;
+
+static const float *g_kd_sort_pts;
+static int g_kd_sort_dim;
+static int kd_cmp(const void *a, const void *b)
+{
+    const int ia = *(const int *)a, ib = *(const int *)b;
+    const float va = g_kd_sort_pts[2 * ia + g_kd_sort_dim], vb = g_kd_sort_pts[2 * ib + g_kd_sort_dim];
+    if (va < vb)
+        return -1;
+    if (va > vb)
+        return 1;
+    return (ia > ib) - (ia < ib);
+}
+
+#define KD_LEAF 10
+
+static int kd_build(kd_tree *T, int lo, int hi)
+{
+    const int me = T->n_nodes++;
+    kd_node *N = &T->nodes[me];
+    N->lo = lo;
+    N->hi = hi;
+    N->dim = -1;
+    N->left = N->right = -1;
+    if (hi - lo <= KD_LEAF)
+        return me;
+    float mn[2] = {INFINITY, INFINITY}, mx[2] = {-INFINITY, -INFINITY};
+    for (int i = lo; i < hi; ++i)
+        for (int d = 0; d < 2; ++d) {
+            const float v = T->pts[2 * T->idx[i] + d];
+            if (v < mn[d])
+                mn[d] = v;
+            if (v > mx[d])
+                mx[d] = v;
+        }
+    const int dim = (mx[1] - mn[1] > mx[0] - mn[0]) ? 1 : 0;
+    if (!(mx[dim] > mn[dim]))
+        return me; /* all points identical (or NaN): stay a leaf */
+    g_kd_sort_pts = T->pts;
+    g_kd_sort_dim = dim;
+    qsort(T->idx + lo, (size_t)(hi - lo), sizeof(int), kd_cmp);
+    const int mid = (lo + hi) / 2;
+    const float split = T->pts[2 * T->idx[mid] + dim];
+    const int l = kd_build(T, lo, mid), r = kd_build(T, mid, hi);
+    N = &T->nodes[me]; /* nodes[] is preallocated, the pointer stays valid; re-read for clarity */
+    N->dim = dim;
+    N->split = split;
+    N->left = l;
+    N->right = r;
+    return me;
+}
+
+static kd_tree *kd_create(const float *pts, int n)
+{
+    kd_tree *T = (kd_tree *)malloc(sizeof(kd_tree));
+    T->pts = pts;
+    T->n = n;
+    T->idx = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+    for (int i = 0; i < n; ++i)
+        T->idx[i] = i;
+    T->nodes = (kd_node *)malloc(sizeof(kd_node) * (size_t)(2 * n + 2));
+    T->n_nodes = 0;
+    if (n > 0)
+        kd_build(T, 0, n);
+    return T;
+}
+
+static void kd_free(kd_tree *T)
+{
+    if (!T)
+        return;
+    free(T->idx);
+    free(T->nodes);
+    free(T);
+}
+
+/* k best as (d2, index) pairs in ascending lexicographic order; *m = how many are filled */
+static void kd_search(const kd_tree *T, int node, float px, float py, int k, float *bd, int *bi, int *m)
+{
+    const kd_node *N = &T->nodes[node];
+    if (N->dim < 0) {
+        for (int i = N->lo; i < N->hi; ++i) {
+            const int j = T->idx[i];
+            float dx = px - T->pts[2 * j], dy = py - T->pts[2 * j + 1];
+            float a = dx * dx, b = dy * dy;
+            float d = a + b;
+            if (!(d < INFINITY))
+                continue; /* brute force never accepts inf / NaN either */
+            if (*m == k && !(d < bd[k - 1] || (d == bd[k - 1] && j < bi[k - 1])))
+                continue;
+            int p = (*m < k) ? (*m)++ : k - 1;
+            while (p > 0 && (bd[p - 1] > d || (bd[p - 1] == d && bi[p - 1] > j))) {
+                bd[p] = bd[p - 1];
+                bi[p] = bi[p - 1];
+                --p;
+            }
+            bd[p] = d;
+            bi[p] = j;
+        }
+        return;
+    }
+    const float q = N->dim ? py : px;
+    const int near = (q < N->split) ? N->left : N->right;
+    const int far = (q < N->split) ? N->right : N->left;
+    kd_search(T, near, px, py, k, bd, bi, m);
+    float gap = q - N->split;
+    gap = gap * gap;
+    if (*m < k || gap <= bd[k - 1]) /* <=: an equal-distance point with a lower index may hide there */
+        kd_search(T, far, px, py, k, bd, bi, m);
+}
+
+/* ------------------------------------------------------------------------- */
 /* pcl.match (pcl.cpp:161-174): KDTreeMatcher knn=1 -> exact NN (epsilon 0),   */
 /* squared distance (libnabo convention), id -1 / dist inf beyond maxDist.    */
 /* Brute force; ties -> lowest reference index (documented choice).           */
@@ -245,10 +384,22 @@ void orc_match(const float *ref, int nref, const float *in, int nin, float max_d
                float *d2)
 {
     const float r2 = max_dist * max_dist;
+    kd_tree *tree = g_use_kdtree ? kd_create(ref, nref) : NULL;
     for (int i = 0; i < nin; ++i) {
         int id;
         float d;
-        nn1(ref, nref, in[2 * i], in[2 * i + 1], &id, &d);
+        if (tree) {
+            int m = 0;
+            id = -1;
+            d = INFINITY;
+            if (nref > 0)
+                kd_search(tree, 0, in[2 * i], in[2 * i + 1], 1, &d, &id, &m);
+            if (m == 0) {
+                id = -1;
+                d = INFINITY;
+            }
+        } else
+            nn1(ref, nref, in[2 * i], in[2 * i + 1], &id, &d);
         if (id < 0 || !(d <= r2)) {
             id = -1;
             d = INFINITY;
@@ -256,6 +407,7 @@ void orc_match(const float *ref, int nref, const float *in, int nin, float max_d
         ids[i] = id;
         d2[i] = d;
     }
+    kd_free(tree);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -306,9 +458,12 @@ void orc_normals2d(const float *tgt, int nt, int k, float *nrm)
         k = nt;
     int *bi = (int *)malloc(sizeof(int) * (size_t)(k > 0 ? k : 1));
     float *bd = (float *)malloc(sizeof(float) * (size_t)(k > 0 ? k : 1));
+    kd_tree *tree = g_use_kdtree ? kd_create(tgt, nt) : NULL;
     for (int i = 0; i < nt; ++i) {
         int m = 0;
-        for (int j = 0; j < nt; ++j) {
+        if (tree)
+            kd_search(tree, 0, tgt[2 * i], tgt[2 * i + 1], k, bd, bi, &m);
+        for (int j = 0; j < nt && !tree; ++j) {
             float dx = tgt[2 * i] - tgt[2 * j], dy = tgt[2 * i + 1] - tgt[2 * j + 1];
             float a = dx * dx, b = dy * dy;
             float d = a + b;
@@ -359,6 +514,7 @@ void orc_normals2d(const float *tgt, int nt, int k, float *nrm)
         nrm[2 * i] = (float)(-ty / nn);
         nrm[2 * i + 1] = (float)(tx / nn);
     }
+    kd_free(tree);
     free(bi);
     free(bd);
 }
@@ -426,6 +582,7 @@ int orc_icp(const orc_icp_params *P, const float *src, int ns, const float *tgt_
 
     const float r2_match = P->matcher_max_dist * P->matcher_max_dist;
     const float r2_filter = P->max_dist_filter * P->max_dist_filter;
+    kd_tree *tree = g_use_kdtree ? kd_create(tgt, nt) : NULL; /* KDTreeMatcher::init builds it once per call */
     int counter = 0;
     int iterate = 1;
     while (iterate) {
@@ -440,7 +597,17 @@ int orc_icp(const orc_icp_params *P, const float *src, int ns, const float *tgt_
         for (int i = 0; i < ns; ++i) {
             int id;
             float d;
-            nn1(tgt, nt, cur[2 * i], cur[2 * i + 1], &id, &d);
+            if (tree) {
+                int m = 0;
+                id = -1;
+                d = INFINITY;
+                kd_search(tree, 0, cur[2 * i], cur[2 * i + 1], 1, &d, &id, &m);
+                if (m == 0) {
+                    id = -1;
+                    d = INFINITY;
+                }
+            } else
+                nn1(tgt, nt, cur[2 * i], cur[2 * i + 1], &id, &d);
             if (id < 0 || !(d <= r2_match)) {
                 id = -1;
                 d = INFINITY;
@@ -663,6 +830,7 @@ int orc_icp(const orc_icp_params *P, const float *src, int ns, const float *tgt_
     }
     if (iters_out)
         *iters_out = iters;
+    kd_free(tree);
     free(tgt);
     free(rd);
     free(cur);

@@ -156,3 +156,28 @@ def test_downsample_oracle_properties():
     one = oracle.downsample(pts, 100.0)
     c = pts.mean(0)
     assert len(one) == 1 and np.allclose(one[0], pts[np.argmin(((pts - c) ** 2).sum(1))])
+
+
+def test_kdtree_backend_returns_the_same_neighbours_and_poses():
+    """the CPU-baseline accelerator (exact kd-tree) must not change a single decision"""
+    import time
+    src, tgt, guess, _ = synth.scan_pair(seed=12, n_src=1500, n_tgt=1700)
+    tgt = np.concatenate([tgt, tgt[:200]]).astype(np.float32)      # exact duplicates: ties -> lowest index
+    out = {}
+    for on in (0, 1):
+        oracle.set_kdtree(on)
+        try:
+            t0 = time.perf_counter()
+            ids, d2 = oracle.match(tgt, src, 0.5)
+            nrm = oracle.normals2d(tgt - tgt.mean(0).astype(np.float32), 10)
+            res = [oracle.icp(src, tgt, guess, oracle.shipped_icp_params(minimizer=mz, precision=0,
+                                                                         use_diff_checker=1 - mz, max_iter=12))
+                   for mz in (0, 1)]
+            out[on] = (ids, d2, nrm, res, time.perf_counter() - t0)
+        finally:
+            oracle.set_kdtree(0)
+    a, b = out[0], out[1]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    for (sa, Ta, ia), (sb, Tb, ib) in zip(a[3], b[3]):
+        assert sa == sb and ia == ib and np.array_equal(Ta, Tb)
+    assert b[4] < a[4]
