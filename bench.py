@@ -37,7 +37,8 @@ def parse():
     ap.add_argument("--cfar-frames", type=int, default=1024, help="frames per launch for the CFAR roofline leg")
     ap.add_argument("--cfar-launches", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-keyframes", type=int, default=0, help="0 = 64 per host core, at most the batch (about 10 s)")
+    ap.add_argument("--cpu-keyframes", type=int, default=0,
+                    help="CPU-baseline keyframes per host core (0 = about 10 s of work per core)")
     ap.add_argument("--icp-mode", choices=["p2plane30", "reference"], default="p2plane30")
     return ap.parse_args()
 
@@ -90,14 +91,20 @@ def cpu_baseline(frames, srcs, tgts, guesses, n_kf, det, fe, icp_mode):
     _CPU.update(frames=frames, srcs=srcs, tgts=tgts, guesses=guesses, th=th, gh=gh, tau=tau, map_x=fe.map_x,
                 map_y=fe.map_y, rows=fe.rows, cols=fe.cols, width=fe.width, height=fe.height, prm=prm)
     cores = os.cpu_count() or 1
+    nb = len(frames)
     t0 = time.perf_counter()
-    one = [_cpu_keyframe(j) for j in range(min(4, n_kf))]          # 1 core
+    one = [_cpu_keyframe(j) for j in range(min(4, nb))]            # 1 core
     dt1 = time.perf_counter() - t0
+    # about 10 s of work per core (the batch's keyframes, cycled), so that pool start-up and
+    # dispatch do not dominate on a many-core host
+    per_core = n_kf if n_kf else int(min(max(10.0 / (dt1 / len(one)), 8), 400))
+    jobs = [j % nb for j in range(per_core * cores)]
+    n_kf = len(jobs)
     try:
         with mp.get_context("fork").Pool(cores) as pool:           # fork: the workers inherit the inputs
-            pool.map(_cpu_keyframe, range(min(cores, n_kf)))       # warm the pool
+            pool.map(_cpu_keyframe, jobs[:cores])                   # warm the pool
             t0 = time.perf_counter()
-            pool.map(_cpu_keyframe, range(n_kf), chunksize=1)
+            pool.map(_cpu_keyframe, jobs, chunksize=max(per_core // 4, 1))
             dt = time.perf_counter() - t0
     finally:
         oracle.set_kdtree(0)
@@ -134,7 +141,7 @@ def main():
         res_, height_, rows_, width_, cols_, map_x_, map_y_ = build_maps(oculus_bearings(COLS), 30.0 / ROWS, ROWS)
         host_fe = SimpleNamespace(map_x=map_x_, map_y=map_y_, rows=rows_, cols=cols_, width=width_, height=height_)
         cpu = cpu_baseline(frames, srcs, tgts, guesses,
-                           min(args.cpu_keyframes or 64 * (os.cpu_count() or 1), args.batch), det, host_fe,
+                           args.cpu_keyframes, det, host_fe,
                            args.icp_mode)
     ctx = _lib.Context(local_rank)
     fe = FeatureExtraction(ctx)
