@@ -92,13 +92,20 @@ __global__ __launch_bounds__(256, 3) void cfar_u8_ring(const uint8_t *__restrict
     // wave-uniform work item: (frame f, row tile t, 64-lane column chunk); lane -> 4 beams
     const int lane = threadIdx.x & 63;
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long long wv = (long long)blockIdx.x * 4 + wave_in_block;
-    const int chunk = (int)(wv % chunks_per_row);
-    const long long tt = wv / chunks_per_row;
-    const int t = (int)(tt % tiles_per_frame);
-    const long long f = tt / tiles_per_frame;
-    if (f >= n_frames)
+    // XCD-aware block -> tile map.  Workgroup b runs on XCD b % 8 and every XCD has its own L2: all
+    // tiles of one frame go to ONE XCD (frame f -> XCD f % 8, its workgroups consecutive in that
+    // XCD's dispatch order), so the 2*(T+G) halo rows a tile shares with its neighbours are L2 hits
+    // instead of a second trip over the fabric (FETCH_SIZE 1.92x -> ~1.0x of the image bytes).
+    const int wpf = tiles_per_frame * chunks_per_row; // waves per frame
+    const int bpf = (wpf + 3) >> 2;                    // workgroups per frame
+    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int fg = k / bpf;
+    const long long f = (long long)fg * 8 + xcd;
+    const int wvf = (k - fg * bpf) * 4 + wave_in_block;
+    if (f >= n_frames || wvf >= wpf)
         return;
+    const int chunk = wvf % chunks_per_row;
+    const int t = wvf / chunks_per_row;
     const int lpr = cols >> 2;                       // 4-beam lanes per row (>= 64)
     const int cx0 = min(chunk * 64, lpr - 64);       // last chunk shifted left
     const uint32_t voff = (uint32_t)(cx0 + lane) * 4u;
@@ -114,8 +121,15 @@ __global__ __launch_bounds__(256, 3) void cfar_u8_ring(const uint8_t *__restrict
     // Rows outside the image are clamped instead of zero-filled: a window that touches them
     // belongs to a border row whose output is forced to 0 anyway, and prefix differences of
     // in-image windows do not see them.
+    // Even tiles march UP the range axis, odd tiles DOWN (the CA / SOCA / GOCA window is symmetric, so
+    // the result is the same): vertically adjacent tiles then touch the halo rows they share at the
+    // same time (both at their start, or both at their end) and the second reader hits L2 instead of
+    // re-fetching rows that were evicted long ago.  phys(i) = rbase + rs * i maps the logical row
+    // of the march to the image row.
+    const bool flip = (t & 1) == 0;
+    const int rs = flip ? -1 : 1, rbase = flip ? 2 * r0 + tile_rows - 1 : 0;
     auto ld = [&](int i) -> uint32_t {
-        const int ic = min(max(i, 0), rows - 1);
+        const int ic = min(max(rbase + rs * i, 0), rows - 1);
         return __builtin_amdgcn_raw_buffer_load_b32(src, voff, ic * cols, 0);
     };
 
@@ -166,9 +180,10 @@ __global__ __launch_bounds__(256, 3) void cfar_u8_ring(const uint8_t *__restrict
             const uint32_t dH = pk_sub(sH, l2 | (l3 << 16));
             // sign bits sit in bit 7 of bytes 1 and 3: gather the 4 bytes, shift to bit 0
             uint32_t o = (__builtin_amdgcn_perm(dH, dL, 0x07050301u) >> 7) & 0x01010101u;
-            const uint32_t keep = (r >= H && r < rows - H) ? 0xffffffffu : 0u; // cfar.cpp:16,36
+            const int pr = rbase + rs * r; // image row of this output
+            const uint32_t keep = (pr >= H && pr < rows - H) ? 0xffffffffu : 0u; // cfar.cpp:16,36
             o &= keep;
-            __builtin_amdgcn_raw_buffer_store_b32(o, dst, voff, r * cols, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(o, dst, voff, pr * cols, 0);
 
             const uint32_t x = pre[(j + R - 1) % D]; // row r+H+1
             pre[(j + R - 1) % D] = ld(r + H + 1 + D);
@@ -358,8 +373,8 @@ static void launch_ring(sfe_ctx *ctx, int alg, const uint8_t *d_img, uint8_t *d_
                         int n_frames, int groups, int tiles, const CfarLut &lut)
 {
     const int chunks = ((cols >> 2) + 63) / 64;
-    const long long waves = (long long)n_frames * tiles * chunks;
-    const unsigned blocks = (unsigned)((waves + 3) / 4);
+    const long long bpf = ((long long)tiles * chunks + 3) / 4;             // workgroups per frame
+    const unsigned blocks = (unsigned)((((long long)n_frames + 7) / 8) * 8 * bpf); // frames padded to the 8 XCDs
     if (alg == SFE_CFAR_SOCA)
         hipLaunchKernelGGL((cfar_u8_ring<T, G, SFE_CFAR_SOCA, D>), dim3(blocks), dim3(256), 0, ctx->stream, d_img,
                            d_mask, rows, cols, n_frames, groups, tiles, chunks, lut);
@@ -371,11 +386,12 @@ static void launch_ring(sfe_ctx *ctx, int alg, const uint8_t *d_img, uint8_t *d_
                            d_mask, rows, cols, n_frames, groups, tiles, chunks, lut);
 }
 
-// R-row groups per tile.  Measured on MI355X (tools/cfar_sweep.py, 1024 frames of 1024x512):
-// 1 group/tile 5.2 TB/s, 2 -> 5.1, 4 -> 4.8, 10 -> 4.5, whole column -> 3.1.  Short tiles win: the
-// kernel is bound by each wave's serial row march, more independent waves hide it, and the
-// 2*(T+G) warm-up rows a tile re-reads are served by L2 (FETCH_SIZE stays ~1.07x algorithmic).
-static int default_groups(const sfe_ctx *, int, int, int, int) { return 1; }
+// R-row groups per tile.  Measured on MI355X (tools/cfar_sweep.py, 1024 frames of 1024x512, XCD-aware
+// map + alternating march direction):  1 group/tile 5.1 TB/s with FETCH = 1.30x the image bytes,
+// 2 groups 5.1 TB/s with 1.13x, 4 groups 4.9 TB/s with 1.07x, whole column 3.1 TB/s.  Short tiles win
+// on time (the kernel is bound by each wave's serial row march, more independent waves hide it);
+// 2 groups keep that speed and most of the 2*(T+G) halo rows a tile re-reads are L2 hits.
+static int default_groups(const sfe_ctx *, int rows, int, int, int R) { return rows >= 2 * R ? 2 : 1; }
 
 static int cfar_u8_dev(sfe_ctx *ctx, const uint8_t *d_img, int n_frames, int rows, int cols, int alg,
                        int T, int G, int k, double tau, int intensity_thr, uint8_t *d_mask, float *d_thr)

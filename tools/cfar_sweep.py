@@ -47,6 +47,8 @@ def main():
 
     bytes_ = 2.0 * fb * a.frames
     if a.only:
+        if len(a.tiles.split(",")) == 1:
+            ctx._check(ctx.lib.sfe_cfar_set_tuning(ctx.handle, int(a.tiles), 0))
         for _ in range(3):
             ms = timed()
             print("default: %.4f ms  %.0f GB/s" % (ms, bytes_ / ms / 1e6))
