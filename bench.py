@@ -134,7 +134,7 @@ def main():
     det = CFAR(40, 10, 0.1, 10)                      # feature.yaml:3-7
     frames, srcs, tgts, guesses = make_inputs(rank, args.batch)
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # contract: rank 0 at N=1 only
         # before any HIP call: the worker processes are forked and must not inherit a live GPU context
         from types import SimpleNamespace
         from sonar_slam_amd.feature_extraction import build_maps
