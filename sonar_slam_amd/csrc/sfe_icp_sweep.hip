@@ -697,6 +697,9 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                         e1 = Q.longe[2 * slot + 1];
                     }
                     while (slot < nlong) {
+                        long long tp0 = 0;
+                        if (prof != nullptr && tid == 0)
+                            tp0 = clock64();
                         const int q = e0.x;
                         int iL = e0.y, iR = e0.z, bpos = e0.w & 0x7FFFFFFF;
                         bool tied = e0.w < 0;
@@ -707,21 +710,41 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                             e0 = Q.longe[2 * slot];
                             e1 = Q.longe[2 * slot + 1];
                         }
+                        if (prof != nullptr && tid == 0) {
+                            const long long t_ = clock64();
+                            S.prof[13] += t_ - tp0;
+                            tp0 = t_;
+                        }
                         bool doneL = false, doneR = false;
-                        for (int guard = 0; guard <= nt / 32 + 2; ++guard) { // at most nt/32 + 2 trips by construction
+                        constexpr int U = 4; // candidates per lane and trip: four independent LDS reads in flight
+                        const int lo = left ? lane : lane - 32;
+                        for (int guard = 0; guard <= nt / (32 * U) + 2; ++guard) { // bounded by construction
                             const float sb = bpos ? fminf(best, C) : best; // stop bound at the start of the trip
-                            const int j = left ? max(iL - lane, 0) : min(iR + lane - 32, nt + 1);
                             const bool on = left ? !doneL : !doneR;
-                            const float2 t = T[j];
-                            const float dx = f_add(px, -t.x), e = f_mul(dx, dx);
-                            const float dy = f_add(py, -t.y);
-                            float d = f_add(e, f_mul(dy, dy));
-                            // consumed = within the stop bound (a prefix of each side, e is monotone outwards);
-                            // only consumed candidates count and the cursors move past exactly those
-                            const bool cons = on && (e <= sb);
-                            const unsigned long long mc = __ballot(cons);
-                            if (!cons || d != d)
-                                d = INFINITY;
+                            float d = INFINITY;
+                            int jb = 0, nL = 0, nR = 0;
+                            bool eqf = false;
+#pragma unroll
+                            for (int u = 0; u < U; ++u) {
+                                const int j = left ? max(iL - lo - 32 * u, 0) : min(iR + lo + 32 * u, nt + 1);
+                                const float2 t = T[j];
+                                const float dx = f_add(px, -t.x), e = f_mul(dx, dx);
+                                const float dy = f_add(py, -t.y);
+                                const float du = f_add(e, f_mul(dy, dy));
+                                // consumed = within the stop bound (a prefix of each side: e is monotone
+                                // outwards); only consumed candidates count, the cursors move past exactly those
+                                const bool cons = on && (e <= sb);
+                                const unsigned long long mc = __ballot(cons);
+                                nL += __popcll(mc & 0xFFFFFFFFull);
+                                nR += __popcll(mc >> 32);
+                                if (cons && du < d) { // NaN never passes
+                                    d = du;
+                                    jb = j;
+                                    eqf = false;
+                                } else if (cons && du == d && du < INFINITY) {
+                                    eqf = true; // two of this lane's candidates at the same distance
+                                }
+                            }
                             float wmin = INFINITY;
                             if (__ballot(d <= best)) { // rare for far queries: only then pay for the wave reduction
                                 wmin = d;
@@ -731,25 +754,27 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                             }
                             if (wmin < best) {
                                 const unsigned long long who = __ballot(d == wmin);
-                                tied = __popcll(who) > 1;
+                                tied = __popcll(who) > 1 || __ballot(eqf && d == wmin) != 0;
                                 const int first = __builtin_amdgcn_readfirstlane(__ffsll((long long)who) - 1);
-                                bpos = __builtin_amdgcn_readlane(j, first);
+                                bpos = __builtin_amdgcn_readlane(jb, first);
                                 best = wmin;
                             } else if (wmin == best && wmin < INFINITY) {
                                 tied = true;
                             }
-                            const int nL = __popcll(mc & 0xFFFFFFFFull), nR = __popcll(mc >> 32);
                             iL -= nL;
                             iR += nR;
-                            doneL |= nL < 32;
-                            doneR |= nR < 32;
+                            doneL |= nL < 32 * U;
+                            doneR |= nR < 32 * U;
                             if (prof != nullptr && lane == 0)
                                 atomicAdd((unsigned long long *)&S.prof[12], 1ull);
                             if (doneL && doneR)
                                 break;
                         }
-                        if (prof != nullptr && lane == 0 && tied && bpos != 0 && best <= C)
-                            atomicAdd((unsigned long long *)&S.prof[13], 1ull);
+                        if (prof != nullptr && tid == 0) {
+                            const long long t_ = clock64();
+                            S.prof[14] += t_ - tp0;
+                            tp0 = t_;
+                        }
                         if (lane == 0) {
                             if (bpos == 0) {
                                 Q.d2[q] = INFINITY;
@@ -766,6 +791,8 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                                 wl_next[atomicAdd(&S.wl_n[cur ^ 1], 1)] = q;
                             }
                         }
+                        if (prof != nullptr && tid == 0)
+                            S.prof[15] += clock64() - tp0;
                     }
                 }
                 __syncthreads();

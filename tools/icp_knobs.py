@@ -36,7 +36,7 @@ for mode, p in (("p2plane30", icp_config.shipped_params(minimizer=1, use_diff_ch
     kb = KeyframeBatch(ctx, fe.geometry, det.params["SOCA"], "SOCA", 65, p, B)
     kb.upload_scan_pairs(srcs, tgts, guesses)
     kbs[mode] = kb
-for refill, budget in [(0, 12), (0, 24)]:
+for refill, budget in [(0, 24), (0, 12)]:
     os.environ["SFE_SW_PART"] = str(refill)
     os.environ["SFE_SW_BUDGET"] = str(budget)
     line = "part %6d budget %2d:" % (refill, budget)
@@ -47,5 +47,5 @@ for refill, budget in [(0, 12), (0, 24)]:
         kb.run_icp()
         ctx.sync()
         ctx._check(ctx.lib.sfe_icp_get_profile(ctx.handle, 0, cyc))
-        line += "  %s %.2f ms (tier1 %dk tier2 %dk long %d trips %d resolves %d)" % (mode, ms, cyc[6] // 1000, cyc[7] // 1000, cyc[10], cyc[12], cyc[13])
+        line += "  %s %.2f ms (tier1 %dk tier2 %dk long %d trips %d | wave0: fetch %dk walk %dk finish %dk)" % (mode, ms, cyc[6] // 1000, cyc[7] // 1000, cyc[10], cyc[12], cyc[13] // 1000, cyc[14] // 1000, cyc[15] // 1000)
     print(line, flush=True)
