@@ -282,3 +282,42 @@ def test_mixed_size_device_batch(ctx):
         assert np.array_equal(out[0][k], out[4][k]), k
     st, To, _ = oracle.icp(pairs[0][0], pairs[0][1], pairs[0][2], oracle.shipped_icp_params(precision=1))
     assert st == 0 and _pose_diff(out[0]["T"][0], To) < TOL_TIGHT
+
+
+def test_sweep_vs_brute_force_fuzz(ctx):
+    """Randomised differential test of the two ICP kernels: cloud sizes from 1 point up, every filter
+    on/off, both minimisers, duplicated / collinear / far-away / non-finite points.  Both kernels
+    must return identical transforms, statuses and iteration counts."""
+    rng = np.random.default_rng(2024)
+    from sonar_slam_amd._lib import IcpParams
+    n_fail = 0
+    for case in range(70):
+        ns, nt = int(rng.integers(1, 400)), int(rng.integers(1, 400))
+        if case % 7 == 0:
+            ns, nt = int(rng.integers(1, 6)), int(rng.integers(1, 6))
+        tgt = rng.uniform(-8, 8, (nt, 2)).astype(np.float32)
+        if case % 3 == 0:                                   # points on a few lines (x-degenerate windows)
+            tgt[:, 0] = np.round(tgt[:, 0])
+        if case % 5 == 0 and nt > 4:                        # exact duplicates
+            tgt[nt // 2:] = tgt[:nt - nt // 2]
+        th = rng.uniform(-0.2, 0.2)
+        R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+        src = (tgt[rng.integers(0, nt, ns)] @ R.T + rng.normal(0, 0.05, (ns, 2)) + rng.uniform(-0.5, 0.5, 2)).astype(np.float32)
+        if case % 4 == 0:
+            src[rng.integers(0, ns)] += 100.0               # nothing within maxDist
+        if case % 11 == 0:
+            src[rng.integers(0, ns), 0] = np.nan
+        if case % 13 == 0:
+            tgt[rng.integers(0, nt), 1] = np.inf
+        p = IcpParams(matcher_max_dist=float(rng.choice([0.5, 3.0, 10.0])), use_max_dist_filter=int(rng.integers(0, 2)),
+                      max_dist_filter=float(rng.choice([0.3, 3.0, 20.0])), use_trimmed_filter=int(rng.integers(0, 2)),
+                      trim_ratio=float(rng.choice([0.3, 0.8, 1.0])), minimizer=int(rng.integers(0, 2)),
+                      max_iter=int(rng.integers(1, 15)), use_diff_checker=int(rng.integers(0, 2)), min_diff_rot=0.001,
+                      min_diff_trans=0.01, smooth_len=int(rng.integers(1, 4)), normals_knn=int(rng.integers(2, 12)))
+        guesses = [synth.pose_matrix(*rng.normal(0, [0.3, 0.3, 0.05])).astype(np.float32) for _ in range(3)]
+        a = _with_variant(ctx, 0, lambda: _icp(p, ctx).compute_batch(src, tgt, guesses))
+        b = _with_variant(ctx, 4, lambda: _icp(p, ctx).compute_batch(src, tgt, guesses))
+        same = a[0] == b[0] and np.array_equal(a[1], b[1], equal_nan=True) and np.array_equal(a[2], b[2])
+        assert same, (case, ns, nt, p.as_dict(), a[0], b[0], a[2], b[2])
+        n_fail += sum(m != "success" for m in a[0])
+    assert 0 < n_fail < 200      # the fuzz reaches both the success and the failure paths
