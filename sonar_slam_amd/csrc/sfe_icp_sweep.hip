@@ -349,7 +349,7 @@ struct SweepShared {
     double red[ICP_WAVES * 10 + 10];
     unsigned hist[256];
     unsigned sel_prefix, sel_k;
-    int long_n, wl_n[2];
+    int long_n, mid_n, wl_n[2];
     int flag_iterate, flag_status;
     float Ti[9];
     float hist_c[ICP_MAX_HIST], hist_s[ICP_MAX_HIST], hist_x[ICP_MAX_HIST], hist_y[ICP_MAX_HIST];
@@ -372,6 +372,7 @@ struct SweepShared {
             atomicMax(dbg + (code), (int)blockIdx.x + 1);                                        \
         break;                                                                                   \
     }
+#define SW_BUDGET_A 8   // first-pass trips per walk (4 candidates each)
 #define SW_BUDGET 24    // tier-1 trips (4 candidates each) before a walk is handed to the cooperative tier
 #define SW_NONE (-1)
 #define SW_INEXACT (-2)
@@ -382,6 +383,7 @@ struct SweepQ { // per-job views of the per-query scratch
     float *d2;    // best so far / final d2
     int *pos;     // >= 0 sorted position of the NN, SW_NONE, SW_INEXACT
     int *wl[2];   // work lists of suspended queries (ping-pong between rounds)
+    int *mid;     // walks that outlived the short first pass (compacted for the second)
     int4 *longe;  // walks handed to the cooperative tier this round: (q, iL, iR, bpos|tied), (px, py, best, -)
     const int *perm;
     int nt;
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
     const float2 *__restrict__ snrm_all, const float *__restrict__ mean_all, float2 *__restrict__ q_xy_all,
     int4 *__restrict__ q_st_all, int *__restrict__ q_wl_all, int4 *__restrict__ q_long_all, float *__restrict__ nn_d2_all,
     int *__restrict__ nn_pos_all, float *__restrict__ T_out, int *__restrict__ status_out,
-    int *__restrict__ iters_out, long long *prof, int *dbg, int sw_budget)
+    int *__restrict__ iters_out, long long *prof, int *dbg, int sw_budget, int sw_budget_a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     SweepShared &S = *reinterpret_cast<SweepShared *>(smem_raw);
@@ -462,8 +464,9 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
     Q.st = q_st_all + J.q_off;
     Q.d2 = nn_d2_all + J.q_off;
     Q.pos = nn_pos_all + J.q_off;
-    Q.wl[0] = q_wl_all + 2 * J.q_off;
+    Q.wl[0] = q_wl_all + 3 * J.q_off;
     Q.wl[1] = Q.wl[0] + ns;
+    Q.mid = Q.wl[1] + ns;
     Q.longe = q_long_all + 2 * J.q_off;
     Q.perm = perm_all + J.tgt_off;
     Q.nt = nt;
@@ -551,20 +554,25 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                 }
                 if (tid == 0) {
                     S.long_n = 0;
+                    S.mid_n = 0;
                     S.wl_n[cur ^ 1] = 0;
                 }
                 __syncthreads();
                 const int *wl = Q.wl[cur];
                 int *wl_next = Q.wl[cur ^ 1];
-                // -- tier 1: one lane per query --
-                for (int k0 = 0; k0 < nwork; k0 += ICP_THREADS) {
+                // -- tier 1: one lane per query, two passes.  Pass A gives every walk a short budget (most
+                // finish: the typical window holds ~20 candidates); the rest is COMPACTED into dense
+                // waves for pass B with the long budget, so lanes that finished early do not sit idle
+                // through the long walks of their neighbours.  What still runs on goes to tier 2. --
+                auto walk_pass = [&](const int *list, int n, bool fresh, int budget, bool last) {
+                for (int k0 = 0; k0 < n; k0 += ICP_THREADS) {
                     const int slot = k0 + tid;
-                    const bool valid = slot < nwork;
+                    const bool valid = slot < n;
                     int q = 0, iL = 0, iR = 0, bpos = 0;
                     float px = 0, py = 0, best = r2m_up;
                     bool tied = false;
                     if (valid) {
-                        if (round == 0) {
+                        if (fresh) {
                             q = slot;
                             const float2 sp = src[q];
                             const float rx = affine1(T0[0], T0[1], T0[2], sp.x, sp.y);
@@ -573,7 +581,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                             py = affine1(Ti[3], Ti[4], Ti[5], rx, ry);
                             Q.xy[q] = make_float2(px, py);
                         } else {
-                            q = wl[slot];
+                            q = list[slot];
                             const float2 p = Q.xy[q];
                             const int4 st = Q.st[q];
                             px = p.x;
@@ -585,7 +593,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                             best = Q.d2[q];
                         }
                     }
-                    if (round == 0) { // first 1-based position whose x is not < px (convergent: 14 trips)
+                    if (fresh) { // first 1-based position whose x is not < px (convergent: 14 trips)
                         int lo = 1, hi = nt + 1;
                         while (__ballot(lo < hi)) {
                             const int mid = (lo + hi) >> 1;
@@ -601,7 +609,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                         iL = lo - 1;
                     }
                     bool fin = !valid;
-                    for (int trip = 0; trip < sw_budget; ++trip) {
+                    for (int trip = 0; trip < budget; ++trip) {
                         if (!fin) {
 #pragma unroll
                             for (int s2 = 0; s2 < 2; ++s2) {
@@ -663,7 +671,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                             if (is_susp)
                                 wl_next[base + __popcll(ms & below)] = q;
                         }
-                        if (ml) {
+                        if (ml && last) {
                             int base = 0;
                             if (lane == 0)
                                 base = atomicAdd(&S.long_n, __popcll(ml));
@@ -675,8 +683,23 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                                                                __float_as_int(best), 0);
                             }
                         }
+                        if (ml && !last) {
+                            int base = 0;
+                            if (lane == 0)
+                                base = atomicAdd(&S.mid_n, __popcll(ml));
+                            base = __builtin_amdgcn_readfirstlane(base);
+                            if (is_long) {
+                                Q.d2[q] = best;
+                                Q.st[q] = make_int4(iL, iR, bpos | (tied ? (int)0x80000000 : 0), 0);
+                                Q.mid[base + __popcll(ml & below)] = q;
+                            }
+                        }
                     }
                 }
+                };
+                walk_pass(wl, nwork, round == 0, sw_budget_a, false);
+                __syncthreads();
+                walk_pass(Q.mid, S.mid_n, false, sw_budget, true);
                 __syncthreads();
                 SW_PROF(6);
                 const int nlong = S.long_n;
@@ -1053,7 +1076,7 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
     unsigned long long *d_gkeys = (unsigned long long *)sfe_scratch(ctx, 24, sizeof(unsigned long long) * (size_t)std::max(koff, 1LL));
     float2 *d_qxy = (float2 *)sfe_scratch(ctx, 18, sizeof(float2) * (size_t)qoff);
     int4 *d_qst = (int4 *)sfe_scratch(ctx, 19, sizeof(int4) * (size_t)qoff);
-    int *d_qwl = (int *)sfe_scratch(ctx, 21, sizeof(int) * 2 * (size_t)qoff);
+    int *d_qwl = (int *)sfe_scratch(ctx, 21, sizeof(int) * 3 * (size_t)qoff);
     int4 *d_qlong = (int4 *)sfe_scratch(ctx, 23, sizeof(int4) * 2 * (size_t)qoff);
     float *d_nn_d2 = (float *)sfe_scratch(ctx, 5, sizeof(float) * (size_t)qoff);
     int *d_nn_pos = (int *)sfe_scratch(ctx, 6, sizeof(int) * (size_t)qoff);
@@ -1078,6 +1101,7 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
     SFE_LAUNCH_CHECK(ctx);
     static const bool debug = getenv("SFE_ICP_DEBUG") != nullptr;
     const int sw_budget = getenv("SFE_SW_BUDGET") ? atoi(getenv("SFE_SW_BUDGET")) : SW_BUDGET;
+    const int sw_budget_a = getenv("SFE_SW_BUDGET_A") ? atoi(getenv("SFE_SW_BUDGET_A")) : SW_BUDGET_A;
     int *d_dbg = nullptr;
     if (debug) {
         d_dbg = (int *)sfe_scratch(ctx, 22, sizeof(int) * 8);
@@ -1093,13 +1117,13 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         hipLaunchKernelGGL((icp_sweep_kernel<8, true>), dim3(n_lds), dim3(ICP_THREADS), smem, ctx->stream, *p, d_jobs,
                            d_ids, (const float2 *)d_src, d_guess9, d_stgt, d_perm, d_snrm, d_mean, d_qxy, d_qst, d_qwl,
-                           d_qlong, d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof, d_dbg, sw_budget);
+                           d_qlong, d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof, d_dbg, sw_budget, sw_budget_a);
         SFE_LAUNCH_CHECK(ctx);
     }
     if (n_glb) {
         hipLaunchKernelGGL((icp_sweep_kernel<8, false>), dim3(n_glb), dim3(ICP_THREADS), ctl_bytes, ctx->stream, *p,
                            d_jobs, d_ids + n_lds, (const float2 *)d_src, d_guess9, d_stgt, d_perm, d_snrm, d_mean, d_qxy,
-                           d_qst, d_qwl, d_qlong, d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof, d_dbg, sw_budget);
+                           d_qst, d_qwl, d_qlong, d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof, d_dbg, sw_budget, sw_budget_a);
         SFE_LAUNCH_CHECK(ctx);
     }
     if (debug) {

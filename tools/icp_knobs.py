@@ -36,10 +36,10 @@ for mode, p in (("p2plane30", icp_config.shipped_params(minimizer=1, use_diff_ch
     kb = KeyframeBatch(ctx, fe.geometry, det.params["SOCA"], "SOCA", 65, p, B)
     kb.upload_scan_pairs(srcs, tgts, guesses)
     kbs[mode] = kb
-for refill, budget in [(0, 24), (0, 12)]:
-    os.environ["SFE_SW_PART"] = str(refill)
+for refill, budget in [(6, 24), (4, 24), (8, 24), (3, 24), (6, 32), (6, 16), (12, 24)]:
+    os.environ["SFE_SW_BUDGET_A"] = str(refill)
     os.environ["SFE_SW_BUDGET"] = str(budget)
-    line = "part %6d budget %2d:" % (refill, budget)
+    line = "budget A %2d B %2d:" % (refill, budget)
     for mode, kb in kbs.items():
         ms = timed(kb.run_icp, 3)
         cyc = (ctypes.c_longlong * 80)()
