@@ -372,6 +372,7 @@ struct SweepShared {
             atomicMax(dbg + (code), (int)blockIdx.x + 1);                                        \
         break;                                                                                   \
     }
+#define SW_NQ 8         // results fetched per lane and batch in the census / quantile / reduction loops
 #define SW_BUDGET_A 8   // first-pass trips per walk (4 candidates each)
 #define SW_BUDGET 24    // tier-1 trips (4 candidates each) before a walk is handed to the cooperative tier
 #define SW_NONE (-1)
@@ -822,10 +823,20 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                 SW_PROF(7);
                 // -- census: finite matches, and true neighbours within the cap --
                 double cnt[2] = {0, 0};
-                for (int i = tid; i < ns; i += ICP_THREADS) {
-                    const int pz = Q.pos[i];
-                    cnt[0] += (pz != SW_NONE) ? 1.0 : 0.0;
-                    cnt[1] += (pz >= 0 && Q.d2[i] <= C) ? 1.0 : 0.0;
+                for (int base = 0; base < ns; base += SW_NQ * ICP_THREADS) { // SW_NQ loads in flight, not a chain
+                    int pz[SW_NQ];
+                    float dz[SW_NQ];
+#pragma unroll
+                    for (int k = 0; k < SW_NQ; ++k) {
+                        const int i = base + k * ICP_THREADS + tid;
+                        pz[k] = i < ns ? Q.pos[i] : SW_NONE;
+                        dz[k] = i < ns ? Q.d2[i] : INFINITY;
+                    }
+#pragma unroll
+                    for (int k = 0; k < SW_NQ; ++k) {
+                        cnt[0] += (pz[k] != SW_NONE) ? 1.0 : 0.0;
+                        cnt[1] += (pz[k] >= 0 && dz[k] <= C) ? 1.0 : 0.0;
+                    }
                 }
                 block_sum<2>(cnt, S.red);
                 nfin = (unsigned)cnt[0];
@@ -877,11 +888,10 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                     __syncthreads();
                     const unsigned prefix = S.sel_prefix;
                     const unsigned himask = (shift == 24) ? 0u : (0xFFFFFFFFu << (shift + 8));
-                    for (int i0 = 0; i0 < ns; i0 += ICP_THREADS) {
-                        const int i = i0 + tid;
-                        unsigned bin = 0xFFFFFFFFu; // no contribution
-                        if (i < ns && Q.pos[i] >= 0) {
-                            const unsigned u = __float_as_uint(Q.d2[i]); // d >= 0: bit pattern order == value order
+                    auto tally = [&](int pz, float dz) { // called wave-uniformly
+                        unsigned bin = 0xFFFFFFFFu;      // no contribution
+                        if (pz >= 0) {
+                            const unsigned u = __float_as_uint(dz); // d >= 0: bit pattern order == value order
                             if ((u & himask) == prefix)
                                 bin = (u >> shift) & 255u;
                         }
@@ -902,6 +912,19 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                         } else if (bin != 0xFFFFFFFFu) {
                             atomicAdd(&S.hist[bin], 1u);
                         }
+                    };
+                    for (int base = 0; base < ns; base += SW_NQ * ICP_THREADS) {
+                        int pz[SW_NQ];
+                        float dz[SW_NQ];
+#pragma unroll
+                        for (int k = 0; k < SW_NQ; ++k) {
+                            const int i = base + k * ICP_THREADS + tid;
+                            pz[k] = i < ns ? Q.pos[i] : SW_NONE;
+                            dz[k] = i < ns ? Q.d2[i] : INFINITY;
+                        }
+#pragma unroll
+                        for (int k = 0; k < SW_NQ; ++k)
+                            tally(pz[k], dz[k]);
                     }
                     __syncthreads();
                     if (tid < 64) { // one wave: rank-in-histogram by shuffles instead of a 256-step serial walk
