@@ -14,6 +14,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libsonar_oracle.so")
+# the reference's OWN cfar.cpp compiled unmodified (oracle/Makefile `ref`); built only where
+# /root/reference exists, travels to the GPU box as a prebuilt .so
+_REF_SO = os.path.join(_HERE, "_ref", "libcfar_ref.so")
 
 ALG = {"CA": 0, "SOCA": 1, "GOCA": 2, "OS": 3}
 
@@ -253,3 +256,34 @@ def set_kdtree(on):
     """Route the NN searches of icp / match / normals2d through the oracle's exact kd-tree (same
     neighbours, O(N log N)); bench.py turns it on for the CPU baseline, the parity tests leave it off."""
     lib().orc_set_kdtree(1 if on else 0)
+
+
+_ref_lib = None
+
+
+def have_ref_cfar():
+    """True if oracle/_ref/libcfar_ref.so (the reference's own cfar.cpp, compiled unmodified against
+    the stand-in Eigen / pybind11 headers in oracle/ref_shim/) is available."""
+    return os.path.exists(_REF_SO)
+
+
+def ref_cfar(img, alg, train_hs, guard_hs, tau, k=0, want_threshold=False):
+    """The REFERENCE implementation itself: bruce_slam/src/bruce_slam/cpp/cfar.cpp:10-192 through
+    the C wrapper oracle/ref_cfar_wrap.cpp (which does what pybind11 does at the boundary: cast-copy
+    the image to a float matrix).  Used to pin ``cfar`` above and the HIP kernels."""
+    global _ref_lib
+    if _ref_lib is None:
+        L = C.CDLL(_REF_SO)
+        L.ref_cfar.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                               C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_float)]
+        _ref_lib = L
+    a = np.ascontiguousarray(img, np.float32)     # pybind11's numpy -> MatrixXf cast
+    rows, cols = a.shape
+    mask = np.zeros((rows, cols), np.uint8)
+    thr = np.zeros((rows, cols), np.float32) if want_threshold else None
+    rc = _ref_lib.ref_cfar(_p(a, C.c_float), rows, cols, ALG[alg], train_hs, guard_hs, int(k), float(tau),
+                           1 if want_threshold else 0, _p(mask, C.c_uint8),
+                           _p(thr, C.c_float) if want_threshold else None)
+    if rc:
+        raise ValueError("ref_cfar rc=%d" % rc)
+    return (mask, thr) if want_threshold else mask

@@ -8,9 +8,13 @@
  * Parity status (see DESIGN.md "Oracle"):
  *   - CFAR (ca/soca/goca/os and the *2 variants): arithmetic is fully given by
  *     bruce_slam/src/bruce_slam/cpp/cfar.cpp:10-192, restated line by line
- *     below (Eigen accessors replaced by row-major indexing).  The reference
- *     ships no tests/golden vectors; the module cannot be compiled here (no
- *     Eigen), so the pin is "restated from in-tree source".
+ *     below (Eigen accessors replaced by row-major indexing).  PINNED: the
+ *     reference's own cfar.cpp is compiled unmodified into oracle/_ref/ (stand-in
+ *     headers for the two Eigen types it uses, oracle/ref_shim/) and this
+ *     restatement equals it bit for bit (tests/test_reference_cfar.py).
+ *   - global-initialisation cost (slam.py:461-570): numpy parts transcribed,
+ *     cv2's ellipse element / dilate restated and checked against OpenCV's
+ *     documented 5x5 / 7x7 elements; otherwise parity unpinned.
  *   - cv2.remap / libpointmatcher ICP / libnabo NN live in un-vendored third
  *     parties (OpenCV unpinned; libpointmatcher@d478ef2 + libnabo HEAD,
  *     reference README.md:50-55).  Their published algorithms are restated
