@@ -108,12 +108,19 @@ def cpu_baseline(frames, srcs, tgts, guesses, n_kf, det, fe, icp_mode):
             dt = time.perf_counter() - t0
     finally:
         oracle.set_kdtree(0)
+    ref_note = ""
+    if oracle.have_ref_cfar():   # the reference's own cfar.cpp (oracle/_ref), incl. pybind's uint8 -> float cast-copy
+        t0 = time.perf_counter()
+        for j in range(2):
+            oracle.ref_cfar(frames[j], "SOCA", th, gh, tau)
+        ref_note = "; the reference's own cfar.cpp (compiled unmodified): %.1f ms/frame" % (
+            1e3 * (time.perf_counter() - t0) / 2)
     return {"value": n_kf / dt, "unit": "keyframes/s", "cores": cores, "kind": "port",
             "sample": "%d keyframes (1024x512 SOCA-CFAR+gate+remap+nonzero+px2m, 5000x5000 ICP %s with an exact "
                       "kd-tree) in %.1f s on %d worker processes; one core alone: %.2f keyframes/s "
-                      "(CFAR %.1f ms, remap+nonzero %.1f ms, ICP %.1f ms per keyframe)"
+                      "(CFAR %.1f ms, remap+nonzero %.1f ms, ICP %.1f ms per keyframe)%s"
                       % (n_kf, icp_mode, dt, cores, len(one) / dt1, 1e3 * np.mean([o[0] for o in one]),
-                         1e3 * np.mean([o[1] for o in one]), 1e3 * np.mean([o[2] for o in one]))}
+                         1e3 * np.mean([o[1] for o in one]), 1e3 * np.mean([o[2] for o in one]), ref_note)}
 
 
 def main():
