@@ -115,3 +115,36 @@ def test_gpu_shgo_runs_on_the_subroutine(ctx):
     res = shgo(func=sub, bounds=bounds, n=16, iters=1, sampling_method="sobol",
                minimizer_kwargs={"options": {"ftol": 1e-4}})
     assert len(samples) >= 16 and res.fun <= sub([0, 0, 0])
+
+
+# ---- fixtures produced by the REFERENCE's own get_matching_cost_subroutine1 (tests/golden/make_golden.py) ----
+def _golden():
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "matching_cost.npz"))
+    return g, mc.Pose2(*g["source_pose"]), mc.Pose2(0, 0, 0)
+
+
+def test_oracle_reproduces_the_reference_functions_costs():
+    """slam.py:461-570 executed from the reference source (cv2 / gtsam stood in, see make_golden.py):
+    every numpy step of it -- bounds, np.arange lengths, rounding, clipping, the BLAS dot of
+    Keyframe.transform_points, the inside test and the sum -- is the reference's own code."""
+    g, sp, tp = _golden()
+    grid, costs, (x0, y0, res) = _numpy_reference(g["src"], sp, g["tgt"], tp, float(g["point_noise"]), g["X"])
+    assert np.array_equal(costs, g["costs"])
+    assert np.array_equal(g["samples"][:, 3], g["costs"])
+    # Keyframe.transform_points goes through this image's BLAS (fused multiply-adds): our written-out
+    # float32 recipe differs from it by an ulp of the larger product (< 4e-6 m here), and no cell decision flips
+    T = tp.between(sp.compose(mc.Pose2(*g["X"][7]))).matrix().astype(np.float32)
+    mine = np.c_[(g["src"][:, 0] * T[0, 0] + g["src"][:, 1] * T[0, 1]) + T[0, 2],
+                 (g["src"][:, 0] * T[1, 0] + g["src"][:, 1] * T[1, 1]) + T[1, 2]]
+    ref = g["points_pose7"]
+    assert ref.dtype == np.float32 and np.abs(mine - ref).max() <= 4e-6
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_the_reference_functions_costs(ctx):
+    g, sp, tp = _golden()
+    sub, samples = mc.get_matching_cost_subroutine1(g["src"], sp, g["tgt"], tp, np.eye(3),
+                                                    point_noise=float(g["point_noise"]), ctx=ctx)
+    assert np.array_equal(sub.batch(g["X"]), g["costs"])
+    assert np.allclose(np.array(samples), g["samples"], rtol=0, atol=1e-12)
