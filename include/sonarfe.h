@@ -187,6 +187,16 @@ int sfe_icp_batch_dev(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_src,
                       const float *d_guess9, int n_jobs, float *d_T9, int32_t *d_status,
                       int32_t *d_iters);
 
+/* Device-resident tail of FeatureExtraction.callback (feature_extraction.py:241-249) for a batch:
+ * pcl.downsample(points, resolution) then pcl.remove_outlier(points, radius, min_points) on the
+ * float64 clouds sfe_extract_points_batch_dev left in HBM (d_pts [n_frames][cap][2], d_counts),
+ * without a host round trip.  resolution <= 0 skips the downsample (:241), min_points <= 1 the
+ * outlier filter (:245).  Output: float32 clouds d_out [n_frames][cap][2] (what pybind hands back),
+ * d_out_counts[f] points each (-1: the frame's octree is deeper than 24 levels).  cap <= 16384. */
+int sfe_cloud_filter_batch_dev(sfe_ctx *ctx, const double *d_pts, const int32_t *d_counts, int n_frames,
+                               int64_t cap, float resolution, double radius, int min_points,
+                               float *d_out, int32_t *d_out_counts);
+
 /* ---- global-initialisation matching cost: slam.py:461-570 ---------------- */
 /*
  * get_matching_cost_subroutine1 builds a dilated occupancy grid of the target cloud and hands

@@ -101,6 +101,8 @@ SIGNATURES = {
     "sfe_icp_get_profile": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_longlong)]),
     "sfe_icp_batch_dev": (C.c_int, [_vp, C.POINTER(IcpParams), _vp, _i32p, _vp, _i32p, _vp, C.c_int,
                                     _vp, _vp, _vp]),
+    "sfe_cloud_filter_batch_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_int,
+                                             _vp, _vp]),
     "sfe_costgrid_create": (C.c_int, [_vp, _i32p, _i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     "sfe_costgrid_destroy": (None, [_vp]),
     "sfe_costgrid_download": (C.c_int, [_vp, _vp, _u8p]),

@@ -1,0 +1,318 @@
+// Device-resident tail of FeatureExtraction.callback for a BATCH of pings
+// (bruce_slam/src/bruce_slam/feature_extraction.py:241-249):
+//     points = pcl.downsample(points, resolution)                   pcl.cpp:128-141
+//     points = pcl.remove_outlier(points, radius, min_points)       pcl.cpp:54-74
+// Input = what sfe_extract_points_batch_dev leaves in HBM (float64 points, per-frame counts), output =
+// the float32 feature clouds the SLAM node receives; nothing visits the host in between (SURVEY 8
+// row f4).  Same algorithms, same float recipes and the same results as the single-cloud entry
+// points sfe_downsample (sfe_downsample.hip) and sfe_remove_outlier (sfe_icp.hip); every kernel
+// takes its cloud size from the per-frame count in device memory and the frame index from
+// blockIdx.x.
+//
+// downsample = libpointmatcher OctreeGridDataPointsFilter restated without a tree (see
+// sfe_downsample.hip): 2L-bit path key per point, stable sort by (key, index), one leaf per run of
+// equal keys, medoid per leaf.  Here the stable sort is an in-LDS bitonic sort of (key << 16 | index)
+// per frame (<= 16384 points, key <= 48 bits); clouds or trees beyond that take the rank-counting
+// sort of sfe_downsample.hip.
+#include "sfe_internal.h"
+
+#include <cstdio>
+#include <cstdlib>
+
+#define CF_MAX_LEVELS 31
+#define CF_SORT_CAP 16384 // points per frame the LDS sort holds (128 KiB of 64-bit keys)
+
+struct CfHeader {
+    float cx, cy, radius;
+    int levels;
+    int n;      // points of this frame (clamped to cap)
+    int n_seg;  // leaves = points after the downsample
+    int n_out;  // points after the outlier filter
+};
+
+// one workgroup per frame: float64 -> float32 (what pybind does at pcl.cpp's boundary), bounding box,
+// octree root and depth
+__global__ __launch_bounds__(1024) void cf_cast_bbox_kernel(const double *__restrict__ pts64,
+                                                            const int32_t *__restrict__ counts, long long cap,
+                                                            float max_size, float2 *__restrict__ p32,
+                                                            CfHeader *__restrict__ hdrs)
+{
+    __shared__ float s_mn[2][16], s_mx[2][16];
+    const int f = blockIdx.x;
+    const int n = (int)min((long long)max(counts[f], 0), cap);
+    const double *src = pts64 + (size_t)f * cap * 2;
+    float2 *dst = p32 + (size_t)f * cap;
+    float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const float2 p = make_float2((float)src[2 * i], (float)src[2 * i + 1]);
+        dst[i] = p;
+        mnx = fminf(mnx, p.x);
+        mxx = fmaxf(mxx, p.x);
+        mny = fminf(mny, p.y);
+        mxy = fmaxf(mxy, p.y);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        mnx = fminf(mnx, __shfl_down(mnx, d));
+        mxx = fmaxf(mxx, __shfl_down(mxx, d));
+        mny = fminf(mny, __shfl_down(mny, d));
+        mxy = fmaxf(mxy, __shfl_down(mxy, d));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_mn[0][threadIdx.x >> 6] = mnx;
+        s_mn[1][threadIdx.x >> 6] = mny;
+        s_mx[0][threadIdx.x >> 6] = mxx;
+        s_mx[1][threadIdx.x >> 6] = mxy;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) {
+            mnx = fminf(mnx, s_mn[0][w]);
+            mny = fminf(mny, s_mn[1][w]);
+            mxx = fmaxf(mxx, s_mx[0][w]);
+            mxy = fmaxf(mxy, s_mx[1][w]);
+        }
+        CfHeader h;
+        // Octree::build: centre = min + radii*0.5, radius = max(radii)*0.5
+        const float rx = mxx - mnx, ry = mxy - mny;
+        h.cx = mnx + rx * 0.5f;
+        h.cy = mny + ry * 0.5f;
+        float radius = rx;
+        if (radius < ry)
+            radius = ry;
+        radius *= 0.5f;
+        h.radius = radius;
+        int L = 0;
+        float r = radius;
+        while (!((double)r * 2.0 <= (double)max_size) && L < CF_MAX_LEVELS) {
+            r *= 0.5f;
+            ++L;
+        }
+        h.levels = L;
+        h.n = n;
+        h.n_seg = n; // if the downsample is skipped the cloud passes through
+        h.n_out = n;
+        hdrs[f] = h;
+    }
+}
+
+__device__ __forceinline__ unsigned long long cf_path_key(float2 p, const CfHeader &h)
+{
+    float cx = h.cx, cy = h.cy, r = h.radius;
+    unsigned long long key = 0;
+    for (int l = 0; l < h.levels; ++l) {
+        const unsigned bx = p.x > cx, by = p.y > cy; // Octree::idx: bit i = pt(i) > centre(i)
+        key = (key << 2) | (bx | (by << 1));
+        const float hr = r * 0.5f;
+        cx = cx + (bx ? hr : -hr);
+        cy = cy + (by ? hr : -hr);
+        r = hr;
+    }
+    return key;
+}
+
+// one workgroup per frame: keys, stable sort in LDS, leaves, medoids
+__global__ __launch_bounds__(1024) void cf_downsample_lds_kernel(const float2 *__restrict__ p32, long long cap,
+                                                                 CfHeader *__restrict__ hdrs,
+                                                                 float2 *__restrict__ ds_out, int *__restrict__ seg_all)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_keys[]; // n2 sort keys
+    __shared__ int s_scan[1024];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const CfHeader h = hdrs[f];
+    const int n = h.n;
+    const float2 *pts = p32 + (size_t)f * cap;
+    float2 *out = ds_out + (size_t)f * cap;
+    if (n == 0)
+        return;
+    if (h.levels > 24) { // (key << 16 | index) holds 48 key bits: cells finer than extent / 2^24 are refused
+        if (tid == 0)
+            hdrs[f].n_seg = -1;
+        return;
+    }
+    unsigned n2 = 2;
+    while (n2 < (unsigned)n)
+        n2 <<= 1;
+    for (unsigned i = tid; i < n2; i += 1024)
+        s_keys[i] = i < (unsigned)n ? ((cf_path_key(pts[i], h) << 16) | i) : ~0ull;
+    __syncthreads();
+    for (unsigned k = 2; k <= n2; k <<= 1)
+        for (unsigned j = k >> 1; j > 0; j >>= 1) {
+            for (unsigned t = tid; t < n2 / 2; t += 1024) {
+                const unsigned i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const unsigned l = i | j;
+                const unsigned long long a = s_keys[i], b = s_keys[l];
+                if ((a > b) == ((i & k) == 0)) {
+                    s_keys[i] = b;
+                    s_keys[l] = a;
+                }
+            }
+            __syncthreads();
+        }
+    // leaf starts: positions whose key differs from the previous one (block scan over per-thread chunks)
+    const int per = (n + 1023) / 1024;
+    const int b0 = tid * per, e0 = min(b0 + per, n);
+    int c = 0;
+    for (int r = b0; r < e0; ++r)
+        c += (r == 0) || ((s_keys[r] >> 16) != (s_keys[r - 1] >> 16));
+    s_scan[tid] = c;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int v = (tid >= d) ? s_scan[tid - d] : 0;
+        __syncthreads();
+        s_scan[tid] += v;
+        __syncthreads();
+    }
+    const int n_seg = s_scan[1023];
+    int *s_seg = seg_all + (size_t)f * (cap + 1); // n_seg + 1 leaf starts (HBM scratch: written once, read once)
+    int s = (tid == 0) ? 0 : s_scan[tid - 1];
+    for (int r = b0; r < e0; ++r)
+        if ((r == 0) || ((s_keys[r] >> 16) != (s_keys[r - 1] >> 16)))
+            s_seg[s++] = r;
+    if (tid == 0)
+        s_seg[n_seg] = n;
+    __syncthreads(); // same workgroup: its own stores are visible to it after the barrier
+    // one thread per leaf: float centroid in original order, first point at minimum distance
+    for (int sg = tid; sg < n_seg; sg += 1024) {
+        const int r0 = s_seg[sg], r1 = s_seg[sg + 1];
+        float sx = 0.0f, sy = 0.0f;
+        for (int r = r0; r < r1; ++r) {
+            const float2 p = pts[(int)(s_keys[r] & 0xFFFFu)];
+            sx = __fadd_rn(sx, p.x);
+            sy = __fadd_rn(sy, p.y);
+        }
+        const float cnt = (float)(r1 - r0);
+        sx = __fdiv_rn(sx, cnt);
+        sy = __fdiv_rn(sy, cnt);
+        float best = 3.402823466e+38f;
+        int bi = (int)(s_keys[r0] & 0xFFFFu);
+        for (int r = r0; r < r1; ++r) {
+            const int id = (int)(s_keys[r] & 0xFFFFu);
+            const float2 p = pts[id];
+            const float dx = __fadd_rn(p.x, -sx), dy = __fadd_rn(p.y, -sy);
+            // sqrtf, not __fsqrt_rn: the intrinsic lowers to a bare v_sqrt_f32 (1 ulp), sqrtf to the correctly rounded
+        // sequence; a 1-ulp tie between two points of a leaf must fall like it does on the CPU
+        const float d = sqrtf(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+            if (d < best) {
+                best = d;
+                bi = id;
+            }
+        }
+        out[sg] = pts[bi];
+    }
+    if (tid == 0) {
+        hdrs[f].n_seg = n_seg;
+        hdrs[f].n_out = n_seg;
+    }
+}
+
+// pcl.remove_outlier: keep a point iff more than min_points points (itself included) lie within the
+// radius; order preserved.  One workgroup per frame: counts (cloud tiled through LDS), scan, gather.
+__global__ __launch_bounds__(1024) void cf_radius_filter_kernel(const float2 *__restrict__ in_all, long long cap,
+                                                                CfHeader *__restrict__ hdrs, float r2, int min_points,
+                                                                float *__restrict__ out_all,
+                                                                int32_t *__restrict__ out_counts, int do_filter)
+{
+    __shared__ float2 s_p[2048];
+    __shared__ int s_scan[1024];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int n = hdrs[f].n_seg;
+    const float2 *pts = in_all + (size_t)f * cap;
+    float2 *out = reinterpret_cast<float2 *>(out_all) + (size_t)f * cap;
+    if (n < 0) { // the downsample refused this frame (tree deeper than 24 levels)
+        if (tid == 0)
+            out_counts[f] = -1;
+        return;
+    }
+    int carry = 0; // kept points of the previous chunks of 1024
+    for (int base = 0; base < n || base == 0; base += 1024) {
+        const int i = base + tid;
+        float2 p = make_float2(0, 0);
+        if (i < n)
+            p = pts[i];
+        int cnt = 0;
+        if (do_filter) {
+            for (int tb = 0; tb < n; tb += 2048) {
+                const int tn = min(2048, n - tb);
+                __syncthreads();
+                for (int j = tid; j < tn; j += 1024)
+                    s_p[j] = pts[tb + j];
+                __syncthreads();
+                for (int j = 0; j < tn; ++j) {
+                    const float2 t = s_p[j];
+                    const float dx = __fadd_rn(p.x, -t.x), dy = __fadd_rn(p.y, -t.y);
+                    cnt += __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)) <= r2;
+                }
+            }
+        }
+        const int keep = (i < n) && (!do_filter || cnt > min_points);
+        __syncthreads();
+        s_scan[tid] = keep;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            const int v = (tid >= d) ? s_scan[tid - d] : 0;
+            __syncthreads();
+            s_scan[tid] += v;
+            __syncthreads();
+        }
+        if (keep)
+            out[carry + s_scan[tid] - 1] = p;
+        carry += s_scan[1023];
+        __syncthreads();
+        if (n == 0)
+            break;
+    }
+    if (tid == 0) {
+        hdrs[f].n_out = carry;
+        out_counts[f] = carry;
+    }
+}
+
+extern "C" int sfe_cloud_filter_batch_dev(sfe_ctx *ctx, const double *d_pts, const int32_t *d_counts, int n_frames,
+                                          int64_t cap, float resolution, double radius, int min_points, float *d_out,
+                                          int32_t *d_out_counts)
+{
+    if (int rc = sfe_use(ctx))
+        return rc;
+    SFE_ARG(ctx, n_frames >= 0 && cap >= 0 && (n_frames == 0 || cap == 0 || (d_pts && d_counts && d_out && d_out_counts)));
+    if (n_frames == 0)
+        return 0;
+    const bool do_ds = resolution > 0.0f;            // feature_extraction.py:241
+    const bool do_filter = min_points > 1;           // feature_extraction.py:245
+    if (do_ds && cap > CF_SORT_CAP)
+        return sfe_set_err(ctx, SFE_ERR_ARG, "sfe_cloud_filter_batch_dev: cap %lld exceeds %d points per frame",
+                           (long long)cap, CF_SORT_CAP);
+    // pcl.cpp:134 hands the resolution over as std::to_string(float): six decimals survive
+    char buf[64];
+    snprintf(buf, sizeof buf, "%f", (double)resolution);
+    const float max_size = strtof(buf, nullptr);
+
+    const size_t per = (size_t)std::max<int64_t>(cap, 1);
+    float2 *d_p32 = (float2 *)sfe_scratch(ctx, 25, sizeof(float2) * per * (size_t)n_frames);
+    float2 *d_ds = (float2 *)sfe_scratch(ctx, 26, sizeof(float2) * per * (size_t)n_frames);
+    CfHeader *d_hdr = (CfHeader *)sfe_scratch(ctx, 27, sizeof(CfHeader) * (size_t)n_frames);
+    if (!d_p32 || !d_ds || !d_hdr)
+        return SFE_ERR_HIP;
+    hipLaunchKernelGGL(cf_cast_bbox_kernel, dim3(n_frames), dim3(1024), 0, ctx->stream, d_pts, d_counts, (long long)cap,
+                       max_size, d_p32, d_hdr);
+    const float2 *stage = d_p32;
+    if (do_ds) {
+        // 48 key bits + 16 index bits: a frame whose tree is deeper than 24 levels reports count -1
+        size_t n2 = 2;
+        while (n2 < (size_t)cap)
+            n2 <<= 1;
+        int *d_seg = (int *)sfe_scratch(ctx, 28, sizeof(int) * (per + 1) * (size_t)n_frames);
+        if (!d_seg)
+            return SFE_ERR_HIP;
+        const size_t smem = 8 * n2;
+        SFE_HIP(ctx, hipFuncSetAttribute((const void *)cf_downsample_lds_kernel,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(cf_downsample_lds_kernel, dim3(n_frames), dim3(1024), smem, ctx->stream, d_p32, (long long)cap,
+                           d_hdr, d_ds, d_seg);
+        stage = d_ds;
+    }
+    hipLaunchKernelGGL(cf_radius_filter_kernel, dim3(n_frames), dim3(1024), 0, ctx->stream, stage, (long long)cap, d_hdr,
+                       (float)(radius * radius), min_points, d_out, d_out_counts, do_filter ? 1 : 0);
+    SFE_LAUNCH_CHECK(ctx);
+    return 0;
+}

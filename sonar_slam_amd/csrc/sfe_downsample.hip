@@ -182,7 +182,9 @@ __global__ __launch_bounds__(256) void ds_medoid_kernel(const float2 *__restrict
         const int id = sorted_idx[r];
         const float2 p = pts[id];
         const float dx = __fadd_rn(p.x, -sx), dy = __fadd_rn(p.y, -sy);
-        const float d = __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+        // sqrtf, not __fsqrt_rn: the intrinsic lowers to a bare v_sqrt_f32 (1 ulp), sqrtf to the correctly rounded
+        // sequence; a 1-ulp tie between two points of a leaf must fall like it does on the CPU
+        const float d = sqrtf(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
         if (d < best) {
             best = d;
             bi = id;

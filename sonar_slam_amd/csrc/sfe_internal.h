@@ -9,7 +9,7 @@
 
 #include "../../include/sonarfe.h"
 
-#define SFE_NSCRATCH 28
+#define SFE_NSCRATCH 32
 
 struct sfe_ctx {
     int device = -1;

@@ -33,6 +33,7 @@ class KeyframeBatch(object):
         self.d_mask = ctx.alloc(fb)
         self.d_pts = ctx.alloc(self.n * self.cap * 16)
         self.d_cnt = ctx.alloc(self.n * 4)
+        self.d_cloud = self.d_cloud_cnt = None      # filtered float32 feature clouds (run_filter)
         self.d_src = self.d_tgt = self.d_guess = None
         self.d_T = ctx.alloc(self.n * 36)
         self.d_status = ctx.alloc(self.n * 4)
@@ -74,6 +75,22 @@ class KeyframeBatch(object):
         c._check(c.lib.sfe_extract_points_batch_dev(c.handle, self.geom.handle, self.d_mask.ptr, self.n,
                                                     self.cap, self.d_pts.ptr, self.d_cnt.ptr))
 
+    def run_filter(self, resolution=0.5, radius=1.0, min_points=5):
+        """pcl.downsample + pcl.remove_outlier on the extracted clouds, device to device
+        (feature_extraction.py:241-249; defaults = config/feature.yaml)."""
+        c = self.ctx
+        if self.d_cloud is None:
+            self.d_cloud = c.alloc(self.n * self.cap * 8)
+            self.d_cloud_cnt = c.alloc(self.n * 4)
+        c._check(c.lib.sfe_cloud_filter_batch_dev(c.handle, self.d_pts.ptr, self.d_cnt.ptr, self.n, self.cap,
+                                                  float(resolution), float(radius), int(min_points),
+                                                  self.d_cloud.ptr, self.d_cloud_cnt.ptr))
+
+    def cloud(self, j):
+        """the filtered float32 feature cloud of frame j (after run_filter)"""
+        n = int(self.d_cloud_cnt.download(np.int32, 1, offset=4 * j)[0])
+        return self.d_cloud.download(np.float32, 2 * max(n, 0), offset=j * self.cap * 8).reshape(-1, 2)
+
     def run_icp(self):
         c = self.ctx
         c._check(c.lib.sfe_icp_batch_dev(c.handle, _C.byref(self.icp_params), self.d_src.ptr,
@@ -106,7 +123,8 @@ class KeyframeBatch(object):
         return self.d_mask.download(np.uint8, sz, offset=j * sz).reshape(self.rows, self.cols)
 
     def free(self):
-        for b in (self.d_img, self.d_mask, self.d_pts, self.d_cnt, self.d_src, self.d_tgt, self.d_guess,
+        for b in (self.d_img, self.d_mask, self.d_pts, self.d_cnt, self.d_cloud, self.d_cloud_cnt, self.d_src,
+                  self.d_tgt, self.d_guess,
                   self.d_T, self.d_status, self.d_iters):
             if b is not None:
                 b.free()

@@ -87,3 +87,40 @@ def test_batched_extract_device_path(ctx, shipped_cfar):
         rc = oracle.nonzero(oracle.remap_u8(masks[f], mx, my))
         assert cnt[f] == len(rc)
         assert np.array_equal(pts[f, :cnt[f]], oracle.px_to_m(rc, ranges, mx.shape[1], width, height))
+
+
+def test_resident_cloud_filters_equal_the_per_cloud_api_and_the_oracle(ctx, shipped_cfar):
+    """sfe_cloud_filter_batch_dev (downsample + remove_outlier, device to device, the tail of
+    FeatureExtraction.callback) against pcl.downsample / pcl.remove_outlier on the same clouds and
+    against the oracle; also with either stage switched off like feature_extraction.py:241,245."""
+    import oracle
+    from sonar_slam_amd import pcl
+    from sonar_slam_amd.pipeline import KeyframeBatch
+    th, gh, tau = shipped_cfar.params["SOCA"]
+    fe = FeatureExtraction(ctx)
+    fe.Ntc, fe.Ngc, fe.Pfa, fe.rank, fe.alg, fe.threshold = 40, 10, 0.1, 10, "SOCA", 65
+    fe.configure()
+    frames = np.stack([synth.sonar_frame(seed=70 + s, rows=512, cols=256, n_blobs=25) for s in range(5)])
+    frames[3] = 0                                             # a frame without detections
+    fe.generate_map_xy(SonarPing(frames[0], oculus_bearings(256), 30.0 / 512))
+    kb = KeyframeBatch(ctx, fe.geometry, (th, gh, tau), "SOCA", 65, None, len(frames), max_points=8192)
+    kb.upload_frames(frames)
+    kb.run_cfar()
+    kb.run_extract()
+    for res, rad, mp in ((0.5, 1.0, 5), (0.0, 1.0, 5), (0.5, 1.0, 1), (0.25, 0.6, 3)):
+        kb.run_filter(res, rad, mp)
+        ctx.sync()
+        for j in range(len(frames)):
+            pts = kb.points(j)                                # float64, as FeatureExtraction.extract returns them
+            want = pts.astype(np.float32)
+            want_o = want
+            if len(want) and res > 0:
+                want = pcl.downsample(want, res, ctx=ctx)
+                want_o = oracle.downsample(want_o, res)
+            if mp > 1 and len(want):
+                want = pcl.remove_outlier(want, rad, mp, ctx=ctx)
+                want_o = oracle.remove_outlier(want_o, rad, mp)
+            got = kb.cloud(j)
+            assert got.dtype == np.float32 and np.array_equal(got, want.reshape(-1, 2)), (res, rad, mp, j)
+            assert np.array_equal(got, np.asarray(want_o, np.float32).reshape(-1, 2))
+    kb.free()
