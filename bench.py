@@ -7,7 +7,8 @@
 
 A "step" = one pass of the hot path over a batch of B synthetic keyframes resident in HBM:
 B sonar pings (1024 range bins x 512 beams, uint8) through SOCA-CFAR + intensity gate +
-polar->Cartesian point extraction, and B scan pairs (5000 x 5000 points) through the 30-iteration
+polar->Cartesian point extraction + pcl.downsample + pcl.remove_outlier (= the whole of
+FeatureExtraction.callback), and B scan pairs (5000 x 5000 points) through the 30-iteration
 2-D point-to-plane ICP (BASELINE.json configs[1]).  Every rank owns one GPU and its own B jobs
 (weak scaling, no data-path collective; torch.distributed/gloo is control plane only: barrier
 and the max-over-ranks time).  Rank 0 prints ONE JSON line.
@@ -40,6 +41,7 @@ def parse():
     ap.add_argument("--cpu-keyframes", type=int, default=0,
                     help="CPU-baseline keyframes per host core (0 = about 10 s of work per core)")
     ap.add_argument("--icp-mode", choices=["p2plane30", "reference"], default="p2plane30")
+    ap.add_argument("--no-filters", action="store_true", help="leave pcl.downsample / remove_outlier out of the step")
     return ap.parse_args()
 
 
@@ -60,6 +62,29 @@ def make_inputs(rank, batch):
 _CPU = {}
 
 
+def usable_cores():
+    """CPUs this process may really use: affinity mask and cgroup quota, not the host's core count."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    return n
+
+
 def _cpu_keyframe(j):
     """One keyframe through the oracle: the reference's per-ping + per-scan-match CPU work."""
     import oracle
@@ -68,13 +93,17 @@ def _cpu_keyframe(j):
     m = oracle.gate(c["frames"][j], oracle.cfar(c["frames"][j], "SOCA", c["th"], c["gh"], c["tau"]), 65)
     t1 = time.perf_counter()
     rc = oracle.nonzero(oracle.remap_u8(m, c["map_x"], c["map_y"]))
-    oracle.px_to_m(rc, c["rows"], c["cols"], c["width"], c["height"])
+    pts = oracle.px_to_m(rc, c["rows"], c["cols"], c["width"], c["height"])
+    if c["filters"] and len(pts):
+        pts = oracle.downsample(pts.astype(np.float32), 0.5)               # feature_extraction.py:241-249
+        if len(pts):
+            oracle.remove_outlier(np.asarray(pts, np.float32), 1.0, 5)
     t2 = time.perf_counter()
     oracle.icp(c["srcs"][j], c["tgts"][j], c["guesses"][j], c["prm"])
     return t1 - t0, t2 - t1, time.perf_counter() - t2
 
 
-def cpu_baseline(frames, srcs, tgts, guesses, n_kf, det, fe, icp_mode):
+def cpu_baseline(frames, srcs, tgts, guesses, n_kf, det, fe, icp_mode, filters=True):
     """The oracle (C port of the reference path, built with the reference's flags: -O3, no -march=native)
     on a bounded sample of the same keyframes, one independent worker process per host core (the
     reference is single-threaded per node process).  NN search = the oracle's exact kd-tree, like
@@ -89,25 +118,30 @@ def cpu_baseline(frames, srcs, tgts, guesses, n_kf, det, fe, icp_mode):
         prm = oracle.shipped_icp_params(precision=0)
     oracle.set_kdtree(1)
     _CPU.update(frames=frames, srcs=srcs, tgts=tgts, guesses=guesses, th=th, gh=gh, tau=tau, map_x=fe.map_x,
-                map_y=fe.map_y, rows=fe.rows, cols=fe.cols, width=fe.width, height=fe.height, prm=prm)
-    cores = os.cpu_count() or 1
+                map_y=fe.map_y, rows=fe.rows, cols=fe.cols, width=fe.width, height=fe.height, prm=prm, filters=filters)
+    cores = usable_cores()
     nb = len(frames)
     t0 = time.perf_counter()
     one = [_cpu_keyframe(j) for j in range(min(4, nb))]            # 1 core
     dt1 = time.perf_counter() - t0
-    # about 10 s of work per core (the batch's keyframes, cycled), so that pool start-up and
-    # dispatch do not dominate on a many-core host
-    per_core = n_kf if n_kf else int(min(max(10.0 / (dt1 / len(one)), 8), 400))
-    jobs = [j % nb for j in range(per_core * cores)]
-    n_kf = len(jobs)
+    # batches of keyframes (the step's own, cycled) until about 10 s have passed, so that the sample is
+    # bounded by time whatever the host looks like
+    budget_s = 10.0 if not n_kf else 1e9
+    done = 0
     try:
         with mp.get_context("fork").Pool(cores) as pool:           # fork: the workers inherit the inputs
-            pool.map(_cpu_keyframe, jobs[:cores])                   # warm the pool
+            pool.map(_cpu_keyframe, [j % nb for j in range(cores)])  # warm the pool
             t0 = time.perf_counter()
-            pool.map(_cpu_keyframe, jobs, chunksize=max(per_core // 4, 1))
+            while True:
+                batch = [(done + j) % nb for j in range(2 * cores if not n_kf else n_kf * cores)]
+                pool.map(_cpu_keyframe, batch, chunksize=1)
+                done += len(batch)
+                if n_kf or time.perf_counter() - t0 >= budget_s:
+                    break
             dt = time.perf_counter() - t0
     finally:
         oracle.set_kdtree(0)
+    n_kf = done
     ref_note = ""
     if oracle.have_ref_cfar():   # the reference's own cfar.cpp (oracle/_ref), incl. pybind's uint8 -> float cast-copy
         t0 = time.perf_counter()
@@ -116,9 +150,9 @@ def cpu_baseline(frames, srcs, tgts, guesses, n_kf, det, fe, icp_mode):
         ref_note = "; the reference's own cfar.cpp (compiled unmodified): %.1f ms/frame" % (
             1e3 * (time.perf_counter() - t0) / 2)
     return {"value": n_kf / dt, "unit": "keyframes/s", "cores": cores, "kind": "port",
-            "sample": "%d keyframes (1024x512 SOCA-CFAR+gate+remap+nonzero+px2m, 5000x5000 ICP %s with an exact "
+            "sample": "%d keyframes (1024x512 SOCA-CFAR+gate+remap+nonzero+px2m+downsample+remove_outlier, 5000x5000 ICP %s with an exact "
                       "kd-tree) in %.1f s on %d worker processes; one core alone: %.2f keyframes/s "
-                      "(CFAR %.1f ms, remap+nonzero %.1f ms, ICP %.1f ms per keyframe)%s"
+                      "(CFAR %.1f ms, remap+nonzero+filters %.1f ms, ICP %.1f ms per keyframe)%s"
                       % (n_kf, icp_mode, dt, cores, len(one) / dt1, 1e3 * np.mean([o[0] for o in one]),
                          1e3 * np.mean([o[1] for o in one]), 1e3 * np.mean([o[2] for o in one]), ref_note)}
 
@@ -149,7 +183,7 @@ def main():
         host_fe = SimpleNamespace(map_x=map_x_, map_y=map_y_, rows=rows_, cols=cols_, width=width_, height=height_)
         cpu = cpu_baseline(frames, srcs, tgts, guesses,
                            args.cpu_keyframes, det, host_fe,
-                           args.icp_mode)
+                           args.icp_mode, not args.no_filters)
     ctx = _lib.Context(local_rank)
     fe = FeatureExtraction(ctx)
     fe.Ntc, fe.Ngc, fe.Pfa, fe.rank, fe.alg, fe.threshold = 40, 10, 0.1, 10, "SOCA", 65
@@ -170,11 +204,11 @@ def main():
             dist.barrier()
 
     for _ in range(args.warmup):
-        kb.run()
+        kb.run(not args.no_filters)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        kb.run()
+        kb.run(not args.no_filters)
     ctx.sync()
     barrier()
     dt = time.perf_counter() - t0
@@ -198,6 +232,7 @@ def main():
             return ctx.timer_stop() / reps
         ms_cfar_b = timed(kb.run_cfar, 5)
         ms_extract_b = timed(kb.run_extract, 5)
+        ms_filter_b = 0.0 if args.no_filters else timed(kb.run_filter, 5)
         ms_icp_b = timed(kb.run_icp, 2)
         iters_total = int(res["iters"].sum())
         icp_flops = 8.0 * N_PTS * N_PTS * iters_total      # 8 flop per pair evaluation
@@ -240,7 +275,9 @@ def main():
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8 (CFAR, integer-exact) + f32/f64-accumulate (ICP)", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: %d keyframes/step/GPU = 1024x512 SOCA-CFAR(Ntc40,Ngc10)+gate65"
-                                   " -> remap+nonzero+px2m -> 5000x5000-pt ICP (%s)" % (args.batch, args.icp_mode),
+                                   " -> remap+nonzero+px2m%s -> 5000x5000-pt ICP (%s)"
+                                   % (args.batch, "" if args.no_filters else " -> downsample 0.5 -> remove_outlier 1.0/5",
+                                      args.icp_mode),
                        "batch_per_gpu": args.batch, "icp_mode": args.icp_mode, "parallelism": "job farm x%d" % world,
                        "icp_converged_jobs": ok, "mean_icp_iters": iters_total / float(args.batch),
                        "mean_points_per_frame": float(res["counts"].mean())},
@@ -255,7 +292,7 @@ def main():
                            "brute_force_equivalent_tflops": icp_tflops,
                            "note": "8 flop x n_src x n_tgt x iterations / time; brute force itself reaches 51 "
                                    "TFLOP/s = 33 % of the 157.3 TFLOP/s fp32 vector peak (sfe_icp_set_tuning 4)"},
-            "stage_ms_per_step": {"cfar": ms_cfar_b, "extract": ms_extract_b, "icp": ms_icp_b},
+            "stage_ms_per_step": {"cfar": ms_cfar_b, "extract": ms_extract_b, "filters": ms_filter_b, "icp": ms_icp_b},
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu

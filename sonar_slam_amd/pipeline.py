@@ -98,10 +98,14 @@ class KeyframeBatch(object):
                                          _L.ptr(self.tgt_off, _C.c_int32), self.d_guess.ptr, self.n,
                                          self.d_T.ptr, self.d_status.ptr, self.d_iters.ptr))
 
-    def run(self):
-        """One step: all stages of all n keyframes, enqueued back to back on the stream."""
+    def run(self, filters=True):
+        """One step: all stages of all n keyframes, enqueued back to back on the stream: the whole of
+        FeatureExtraction.callback (CFAR + gate, remap + nonzero + px->m, downsample, outlier filter with
+        the config/feature.yaml defaults) and one scan match per keyframe."""
         self.run_cfar()
         self.run_extract()
+        if filters:
+            self.run_filter()
         self.run_icp()
 
     def results(self):

@@ -42,6 +42,8 @@ def main():
         if mode == "p2plane30":
             print("cfar    %8.3f ms / %d frames" % (timed(kb.run_cfar, 10), a.batch))
             print("extract %8.3f ms / %d frames" % (timed(kb.run_extract, 10), a.batch))
+            print("filter  %8.3f ms / %d frames (downsample 0.5 + remove_outlier 1.0/5, device resident)"
+                  % (timed(kb.run_filter, 5), a.batch))
         for v in [int(x) for x in a.icp_variants.split(",")]:
             ctx._check(ctx.lib.sfe_icp_set_tuning(ctx.handle, v))
             print("icp %-9s variant %d %8.3f ms / %d jobs" % (mode, v, timed(kb.run_icp, 3), a.batch))
