@@ -192,7 +192,7 @@ int sfe_icp_batch_dev(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_src,
  * float64 clouds sfe_extract_points_batch_dev left in HBM (d_pts [n_frames][cap][2], d_counts),
  * without a host round trip.  resolution <= 0 skips the downsample (:241), min_points <= 1 the
  * outlier filter (:245).  Output: float32 clouds d_out [n_frames][cap][2] (what pybind hands back),
- * d_out_counts[f] points each (-1: the frame's octree is deeper than 24 levels).  cap <= 16384. */
+ * d_out_counts[f] points each (-1: the frame's octree is deeper than 24 levels).  cap <= 65536. */
 int sfe_cloud_filter_batch_dev(sfe_ctx *ctx, const double *d_pts, const int32_t *d_counts, int n_frames,
                                int64_t cap, float resolution, double radius, int min_points,
                                float *d_out, int32_t *d_out_counts);

@@ -21,6 +21,7 @@
 
 #define CF_MAX_LEVELS 31
 #define CF_SORT_CAP 16384 // points per frame the LDS sort holds (128 KiB of 64-bit keys)
+#define CF_MAX_CAP 65536  // 16 index bits in the sort key
 
 struct CfHeader {
     float cx, cy, radius;
@@ -111,13 +112,17 @@ __device__ __forceinline__ unsigned long long cf_path_key(float2 p, const CfHead
     return key;
 }
 
-// one workgroup per frame: keys, stable sort in LDS, leaves, medoids
-__global__ __launch_bounds__(1024) void cf_downsample_lds_kernel(const float2 *__restrict__ p32, long long cap,
-                                                                 CfHeader *__restrict__ hdrs,
-                                                                 float2 *__restrict__ ds_out, int *__restrict__ seg_all)
+// one workgroup per frame: keys, stable bitonic sort (keys in LDS, or in HBM scratch for frames beyond
+// CF_SORT_CAP points: config-B pings yield ~34k detections), leaves, medoids
+template <bool IN_LDS>
+__global__ __launch_bounds__(1024) void cf_downsample_kernel(const float2 *__restrict__ p32, long long cap,
+                                                             CfHeader *__restrict__ hdrs, float2 *__restrict__ ds_out,
+                                                             int *__restrict__ seg_all,
+                                                             unsigned long long *__restrict__ gkeys_all, long long n2cap)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long s_keys[]; // n2 sort keys
+    extern __shared__ __attribute__((aligned(16))) unsigned long long lds_keys[]; // n2 sort keys (IN_LDS)
     __shared__ int s_scan[1024];
+    unsigned long long *s_keys = IN_LDS ? lds_keys : gkeys_all + (size_t)blockIdx.x * n2cap;
     const int f = blockIdx.x, tid = threadIdx.x;
     const CfHeader h = hdrs[f];
     const int n = h.n;
@@ -279,9 +284,9 @@ extern "C" int sfe_cloud_filter_batch_dev(sfe_ctx *ctx, const double *d_pts, con
         return 0;
     const bool do_ds = resolution > 0.0f;            // feature_extraction.py:241
     const bool do_filter = min_points > 1;           // feature_extraction.py:245
-    if (do_ds && cap > CF_SORT_CAP)
+    if (do_ds && cap > CF_MAX_CAP)
         return sfe_set_err(ctx, SFE_ERR_ARG, "sfe_cloud_filter_batch_dev: cap %lld exceeds %d points per frame",
-                           (long long)cap, CF_SORT_CAP);
+                           (long long)cap, CF_MAX_CAP);
     // pcl.cpp:134 hands the resolution over as std::to_string(float): six decimals survive
     char buf[64];
     snprintf(buf, sizeof buf, "%f", (double)resolution);
@@ -304,11 +309,19 @@ extern "C" int sfe_cloud_filter_batch_dev(sfe_ctx *ctx, const double *d_pts, con
         int *d_seg = (int *)sfe_scratch(ctx, 28, sizeof(int) * (per + 1) * (size_t)n_frames);
         if (!d_seg)
             return SFE_ERR_HIP;
-        const size_t smem = 8 * n2;
-        SFE_HIP(ctx, hipFuncSetAttribute((const void *)cf_downsample_lds_kernel,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL(cf_downsample_lds_kernel, dim3(n_frames), dim3(1024), smem, ctx->stream, d_p32, (long long)cap,
-                           d_hdr, d_ds, d_seg);
+        if (cap <= CF_SORT_CAP) {
+            const size_t smem = 8 * n2;
+            SFE_HIP(ctx, hipFuncSetAttribute((const void *)cf_downsample_kernel<true>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            hipLaunchKernelGGL(cf_downsample_kernel<true>, dim3(n_frames), dim3(1024), smem, ctx->stream, d_p32,
+                               (long long)cap, d_hdr, d_ds, d_seg, (unsigned long long *)nullptr, 0LL);
+        } else {
+            unsigned long long *d_gk = (unsigned long long *)sfe_scratch(ctx, 29, 8 * n2 * (size_t)n_frames);
+            if (!d_gk)
+                return SFE_ERR_HIP;
+            hipLaunchKernelGGL(cf_downsample_kernel<false>, dim3(n_frames), dim3(1024), 0, ctx->stream, d_p32,
+                               (long long)cap, d_hdr, d_ds, d_seg, d_gk, (long long)n2);
+        }
         stage = d_ds;
     }
     hipLaunchKernelGGL(cf_radius_filter_kernel, dim3(n_frames), dim3(1024), 0, ctx->stream, stage, (long long)cap, d_hdr,

@@ -124,3 +124,28 @@ def test_resident_cloud_filters_equal_the_per_cloud_api_and_the_oracle(ctx, ship
             assert got.dtype == np.float32 and np.array_equal(got, want.reshape(-1, 2)), (res, rad, mp, j)
             assert np.array_equal(got, np.asarray(want_o, np.float32).reshape(-1, 2))
     kb.free()
+
+
+def test_resident_cloud_filters_hires_frame(ctx, shipped_cfar):
+    """BASELINE configs[4] frame shape (2048 x 1024): ~34k detections per ping, beyond the LDS sort
+    capacity of the resident downsample -> its HBM-scratch sort path"""
+    from sonar_slam_amd import pcl
+    from sonar_slam_amd.pipeline import KeyframeBatch
+    th, gh, tau = shipped_cfar.params["SOCA"]
+    fe = FeatureExtraction(ctx)
+    fe.Ntc, fe.Ngc, fe.Pfa, fe.rank, fe.alg, fe.threshold = 40, 10, 0.1, 10, "SOCA", 65
+    fe.configure()
+    frames = np.stack([synth.sonar_frame(seed=90 + s, rows=2048, cols=1024, n_blobs=120) for s in range(2)])
+    fe.generate_map_xy(SonarPing(frames[0], oculus_bearings(1024), 30.0 / 2048))
+    kb = KeyframeBatch(ctx, fe.geometry, (th, gh, tau), "SOCA", 65, None, len(frames), max_points=65536)
+    kb.upload_frames(frames)
+    kb.run_cfar()
+    kb.run_extract()
+    kb.run_filter(0.5, 1.0, 5)
+    ctx.sync()
+    for j in range(len(frames)):
+        pts = kb.points(j)
+        assert len(pts) > 16384
+        want = pcl.remove_outlier(pcl.downsample(pts.astype(np.float32), 0.5, ctx=ctx), 1.0, 5, ctx=ctx)
+        assert np.array_equal(kb.cloud(j), want)
+    kb.free()
