@@ -14,17 +14,20 @@
 // oracle do), resolved by a rare second walk over the final window.  No kd-tree, no
 // approximation, no float re-association: match ids and d2 are bit-identical to brute force.
 //
-// Work per query drops from n_tgt pair evaluations to the points whose |dx| is within the
-// query's own NN distance: ~10-400 instead of 5000 on sonar clouds.  Lanes then run out of work at
-// very different times (outliers walk far), so a workgroup keeps one shared queue of queries in
-// LDS and lanes that finish pull the next query (refill when >= 16 lanes of a wave idle).
+// Work per query drops from n_tgt pair evaluations to the points whose |dx| is within the query's
+// own stop bound: ~20 instead of 5000 on converged sonar clouds, a few hundred while the clouds are
+// still far apart.  Walks differ wildly in length (a near-vertical wall puts 100+ points in one x
+// window; a query with nothing within maxDist walks its whole 10 m window), so the search is tiered
+// (details at the loop kernel): short budget for every lane -> survivors compacted into dense waves
+// with a longer budget -> what still runs is finished by a whole wave, 256 candidates per trip.
 //
-// Mapping: prep kernel = one workgroup per distinct target: mean, centre, bitonic sort of
-// (x-key, index) in LDS, sorted cloud + permutation to HBM scratch, PCA normals (k-NN by the
-// same sweep) for point-to-plane.  Loop kernel = one workgroup per job: sorted target resident
-// in LDS (<= 8192 points), all ICP iterations in one launch: transform + binary search
-// (coalesced) -> sweep (dynamic) -> trimmed quantile by exact radix select -> fp64 reduction of
-// the 9(+1) sums -> closed-form solve and checkers on one lane.
+// Mapping: prep kernel = one workgroup per distinct target (many guesses on one pair share it):
+// mean, centre, bitonic sort of (x-key, index) in LDS (HBM scratch beyond 8192 points), sorted
+// cloud + permutation to HBM scratch, PCA normals (k-NN by the same sweep) for point-to-plane.
+// Loop kernel = one workgroup per job, all ICP iterations in one launch: sorted target resident in
+// LDS (or walked through L2 beyond 8192 points), per iteration: transform + lower bound + capped
+// walks (tiers) -> census -> trimmed quantile by exact radix select -> fp64 reduction of the 9(+1)
+// sums -> closed-form solve and checkers on one lane.
 #include "sfe_icp_common.h"
 
 #include <algorithm>
