@@ -1,8 +1,8 @@
 // ICP scan matching with an exact sorted-sweep nearest-neighbour search (default ICP path).
 // Replaces bruce_slam/src/bruce_slam/cpp/pcl.cpp:198-212 (ICP.compute -> libpointmatcher chain of
 // bruce_slam/config/icp.yaml:1-31); same chain, same decisions and same arithmetic as
-// sfe_icp.hip's brute-force kernel (which stays for targets that do not fit LDS and as the A/B
-// baseline) -- only the order in which candidate pairs are visited differs.
+// sfe_icp.hip's brute-force kernel (which stays as the A/B
+// baseline and checker) -- only the order in which candidate pairs are visited differs.
 //
 // Why a sweep is exact.  The squared distance everyone on this path compares is
 //     d2 = fl( fl(dx*dx) + fl(dy*dy) ),  dx = fl(px - tx), dy = fl(py - ty)      (dist2())

@@ -1,0 +1,37 @@
+"""CPU: the host-side pieces of bench.py (input synthesis, usable-core detection, the oracle-based
+cpu_baseline leg on a tiny sample).  The GPU legs are exercised by the driver's bench run."""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from sonar_slam_amd.CFAR import CFAR  # noqa: E402
+from sonar_slam_amd.feature_extraction import build_maps, oculus_bearings  # noqa: E402
+
+
+def test_inputs_have_the_baseline_shapes():
+    frames, srcs, tgts, guesses = bench.make_inputs(0, 3)
+    assert frames.shape == (3, bench.ROWS, bench.COLS) and frames.dtype == np.uint8
+    assert all(s.shape == (bench.N_PTS, 2) and s.dtype == np.float32 for s in srcs + tgts)
+    assert guesses.shape == (3, 3, 3)
+    f2, s2, _, _ = bench.make_inputs(1, 3)            # every rank gets its own jobs
+    assert not np.array_equal(frames, f2) and not np.array_equal(srcs[0], s2[0])
+
+
+def test_usable_cores_is_sane():
+    n = bench.usable_cores()
+    assert 1 <= n <= (os.cpu_count() or 1)
+
+
+def test_cpu_baseline_leg_runs_and_reports_the_contract_fields():
+    det = CFAR(40, 10, 0.1, 10)
+    frames, srcs, tgts, guesses = bench.make_inputs(0, 2)
+    res_, height_, rows_, width_, cols_, mx, my = build_maps(oculus_bearings(bench.COLS), 30.0 / bench.ROWS, bench.ROWS)
+    fe = SimpleNamespace(map_x=mx, map_y=my, rows=rows_, cols=cols_, width=width_, height=height_)
+    out = bench.cpu_baseline(frames, srcs, tgts, guesses, 1, det, fe, "reference")
+    assert set(out) >= {"value", "unit", "cores", "kind", "sample"}
+    assert out["kind"] == "port" and out["unit"] == "keyframes/s" and out["value"] > 0
+    assert out["cores"] == bench.usable_cores()
