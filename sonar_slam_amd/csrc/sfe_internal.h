@@ -23,6 +23,7 @@ struct sfe_ctx {
     int cfar_tile_rows = 0;
     int cfar_variant = 0;
     int icp_variant = 0;
+    int extract_variant = 0;     // 0 = inverse-map scatter for binary masks (default), 1 = dense pass only (A/B)
     int icp_prof = 0;            // debug: per-phase cycle counts of workgroup 0 of the sweep kernel
     long long icp_prof_host[80] = {0};
     int n_cu = 256;
@@ -38,6 +39,10 @@ struct sfe_geom {
     unsigned rcp = 0;            // ceil(2^32 / (polar_cols+1))
     int32_t *d_tile_rows = nullptr; // per canvas tile: [ylo, yhi] polar rows tapped by its valid pixels
     int word_groups = 0, tiles_per_frame = 0, lds_bytes = 0;
+    // inverse map for sparse binary masks: for every polar pixel the canvas pixels that tap it with a
+    // non-zero weight (CSR: offsets [polar_rows * polar_cols + 1], entries = linear canvas indices)
+    int32_t *d_inv_off = nullptr;
+    uint32_t *d_inv_ent = nullptr;
 };
 
 int sfe_set_err(sfe_ctx *ctx, int code, const char *fmt, ...);

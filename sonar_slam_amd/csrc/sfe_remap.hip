@@ -120,10 +120,12 @@ __global__ __launch_bounds__(256) void extract_bits_kernel(const uint8_t *__rest
                                                            unsigned long long *__restrict__ bitmap, int prows,
                                                            int pcols, unsigned rcp, int crows, int ccols, int wpr,
                                                            int word_groups, int tiles_per_frame,
-                                                           long long words_per_frame)
+                                                           long long words_per_frame, int only_general)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_bits[];
     const int f = blockIdx.x / tiles_per_frame, tile = blockIdx.x % tiles_per_frame;
+    if (only_general && nonbinary[f] == 0) // binary frames were done by extract_scatter_kernel
+        return;
     const int w = (tile % word_groups) * 4 + (threadIdx.x >> 6); // wave-uniform
     const int r0 = (tile / word_groups) * EXTRACT_RG, r1 = min(r0 + EXTRACT_RG, crows);
     const int c = w * 64 + (threadIdx.x & 63);
@@ -300,6 +302,142 @@ __global__ __launch_bounds__(64) void extract_expand_kernel(const unsigned long 
     }
 }
 
+// pass 1 for BINARY masks, inverted: CFAR detections are sparse (~1 % of the polar pixels), so instead
+// of evaluating all ~2 M canvas pixels of a frame, walk the set polar pixels and evaluate only the
+// canvas pixels that tap them (precomputed inverse map, sfe_geom_create): ~9 candidates per set
+// pixel, each with exactly the blend of the dense pass; a detection sets its bit with atomicOr
+// (a canvas pixel reached through two of its taps is evaluated twice, idempotent).  40x less work
+// than the dense pass on sonar frames; the bitmap must be zero beforehand.  One workgroup = one frame
+// x SC_ROWS polar rows, which it stages (+1 halo row each side) as bits in LDS.
+#define SC_ROWS 16
+#define SC_LIST 256 // set pixels a wave collects before it expands them
+#define SC_U 4      // candidates per lane whose dependent loads (inverse map -> code) overlap
+__global__ __launch_bounds__(256) void extract_scatter_kernel(const uint32_t *__restrict__ bits,
+                                                              const int32_t *__restrict__ nonbinary,
+                                                              const uint32_t *__restrict__ code,
+                                                              const int32_t *__restrict__ inv_off,
+                                                              const uint32_t *__restrict__ inv_ent,
+                                                              unsigned long long *__restrict__ bitmap, int prows,
+                                                              int pcols, unsigned rcp, int crows, int ccols, int wpr,
+                                                              long long words_per_frame)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_rows[]; // (SC_ROWS + 2) x pw words, then per-wave lists
+    const int f = blockIdx.y, y0 = blockIdx.x * SC_ROWS;
+    if (nonbinary[f] != 0)
+        return;
+    const int pw = pcols >> 5;
+    const uint32_t *__restrict__ src = bits + (long long)f * words_per_frame;
+    for (int i = threadIdx.x; i < (SC_ROWS + 2) * pw; i += 256) {
+        const int r = y0 - 1 + i / pw;
+        s_rows[i] = (r >= 0 && r < prows) ? src[(long long)r * pw + (i % pw)] : 0u; // rows outside the image: no taps
+    }
+    __syncthreads();
+    auto tap = [&](int y, int x) -> int { // bit (y, x) of the mask, 0 outside the image
+        if (x < 0 || x >= pcols)
+            return 0;
+        return (s_rows[(y - (y0 - 1)) * pw + (x >> 5)] >> (x & 31)) & 1;
+    };
+    // Per wave, 64 mask words (2048 polar pixels) at a time:
+    //   1. compact the set pixels into an LDS list (ballot per bit position, no memory traffic);
+    //   2. 64 set pixels per pass: their inverse-map ranges in one batch of loads, wave prefix sum;
+    //   3. load-balanced expansion: lane k takes candidate k of the concatenated ranges (binary search in
+    //      the prefix), so the dependent loads inv_ent -> code run 64 wide instead of as a per-lane chain.
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t *s_list = s_rows + (SC_ROWS + 2) * pw + wave * (SC_LIST + 128); // set pixels collected by this wave
+    uint32_t *s_off = s_list + SC_LIST, *s_excl = s_off + 64;                // per pass: range start, exclusive prefix
+    int nset = 0;
+    auto flush = [&]() { // expand the collected set pixels (wave-uniform)
+        for (int j0 = 0; j0 < nset; j0 += 64) {
+            const int j = j0 + lane;
+            int off0 = 0, cnt = 0;
+            if (j < nset) {
+                const int pi = (int)s_list[j];
+                off0 = inv_off[pi];
+                cnt = inv_off[pi + 1] - off0;
+            }
+            int incl = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int v = __shfl_up(incl, d);
+                if (lane >= d)
+                    incl += v;
+            }
+            const int total = __shfl(incl, 63);
+            s_off[lane] = (uint32_t)off0;
+            s_excl[lane] = (uint32_t)(incl - cnt);
+            for (int k0 = lane; k0 < total; k0 += 64 * SC_U) { // SC_U independent candidates per lane in flight
+                uint32_t o[SC_U], cd[SC_U];
+                int src_pi[SC_U];
+#pragma unroll
+                for (int u = 0; u < SC_U; ++u) {
+                    const int k = k0 + 64 * u;
+                    int lo = 0, hi = 63; // largest source lane whose exclusive prefix is <= k
+                    while (lo < hi) {
+                        const int mid = (lo + hi + 1) >> 1;
+                        if ((int)s_excl[mid] <= k)
+                            lo = mid;
+                        else
+                            hi = mid - 1;
+                    }
+                    o[u] = k < total ? inv_ent[s_off[lo] + (uint32_t)(k - (int)s_excl[lo])] : 0xFFFFFFFFu;
+                    src_pi[u] = (int)s_list[j0 + lo]; // the set pixel this candidate was reached from
+                }
+#pragma unroll
+                for (int u = 0; u < SC_U; ++u)
+                    cd[u] = o[u] != 0xFFFFFFFFu ? code[o[u]] : SFE_CODE_NONE;
+#pragma unroll
+                for (int u = 0; u < SC_U; ++u) {
+                    if (o[u] == 0xFFFFFFFFu)
+                        continue;
+                    const unsigned lin = cd[u] >> 10;
+                    const int fy = (int)((cd[u] >> 5) & 31u), fx = (int)(cd[u] & 31u);
+                    const unsigned q = __umulhi(lin, rcp);
+                    const int iy = (int)q - 1, ix = (int)(lin - q * (unsigned)(pcols + 1)) - 1;
+                    // iy, iy + 1 lie within one row of the set pixel: inside the staged rows
+                    const int v00 = tap(iy, ix), v01 = tap(iy, ix + 1), v10 = tap(iy + 1, ix), v11 = tap(iy + 1, ix + 1);
+                    int w00 = (32 - fy) * (32 - fx) * 32, w01 = (32 - fy) * fx * 32;
+                    int w10 = fy * (32 - fx) * 32, w11 = fy * fx * 32;
+                    if ((fx | fy) == 0) {
+                        w00 = 32767;
+                        w11 = 1;
+                    }
+                    const int acc = w00 * v00 + w01 * v01 + w10 * v10 + w11 * v11;
+                    // a canvas pixel is reached once per set tap: only the visit through its FIRST set tap
+                    // with a non-zero weight (the taps the inverse map lists) writes, which removes the
+                    // duplicate atomics on clustered detections
+                    const int sy = src_pi[u] / pcols, sx = src_pi[u] - sy * pcols;
+                    const int t_src = (sy - iy) * 2 + (sx - ix);
+                    const int first = (v00 && w00) ? 0 : (v01 && w01) ? 1 : (v10 && w10) ? 2 : 3;
+                    if (((acc + 16384) >> 15) != 0 && t_src == first) {
+                        const unsigned row = o[u] / (unsigned)ccols, col = o[u] - row * (unsigned)ccols;
+                        atomicOr(&bitmap[((long long)f * crows + row) * wpr + (col >> 6)], 1ull << (col & 63));
+                    }
+                }
+            }
+        }
+        nset = 0;
+    };
+    for (int c0 = wave * 64; c0 < SC_ROWS * pw; c0 += 4 * 64) {
+        const int wi = c0 + lane;
+        const int r = y0 + wi / pw, w = wi % pw;
+        const uint32_t word = (wi < SC_ROWS * pw && r < prows) ? s_rows[(r - (y0 - 1)) * pw + w] : 0u;
+        if (!__ballot(word != 0))
+            continue;
+        for (int bb = 0; bb < 32; ++bb) {
+            const bool set = (word >> bb) & 1u;
+            const unsigned long long m = __ballot(set);
+            if (!m)
+                continue;
+            if (nset + 64 > SC_LIST)
+                flush();
+            if (set)
+                s_list[nset + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)(r * pcols + w * 32 + bb);
+            nset += __popcll(m);
+        }
+    }
+    flush();
+}
+
 // ---------------------------------------------------------------------------------------------
 static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_frames, long long cap,
                        long long *d_rc, double *d_pts, int32_t *d_counts)
@@ -328,9 +466,20 @@ static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_f
         SFE_HIP(ctx, hipMemsetAsync(d_nonbin, 0, (size_t)nf * 4, ctx->stream));
         hipLaunchKernelGGL(mask_pack_kernel, dim3((unsigned)((wpf + 255) / 256), nf), dim3(256), 0, ctx->stream, m,
                            d_bits, d_nonbin, px, wpf);
+        const bool scatter = g->d_inv_off != nullptr && (g->polar_cols & 31) == 0 && ctx->extract_variant == 0;
+        if (scatter) {
+            // sparse binary masks: inverse map (binary frames), dense pass only for frames with other values
+            SFE_HIP(ctx, hipMemsetAsync(d_bm, 0, (size_t)nf * crows * wpr * sizeof(unsigned long long), ctx->stream));
+            const int pw = g->polar_cols >> 5;
+            hipLaunchKernelGGL(extract_scatter_kernel, dim3((unsigned)((g->polar_rows + SC_ROWS - 1) / SC_ROWS), nf),
+                               dim3(256), ((size_t)(SC_ROWS + 2) * pw + 4 * (SC_LIST + 128)) * 4, ctx->stream, d_bits, d_nonbin,
+                               (const uint32_t *)g->d_code, g->d_inv_off, g->d_inv_ent, d_bm, g->polar_rows,
+                               g->polar_cols, g->rcp, crows, g->cart_cols, wpr, wpf);
+        }
         hipLaunchKernelGGL(extract_bits_kernel, dim3((unsigned)(nf * tiles)), dim3(256), g->lds_bytes, ctx->stream, m,
                            d_bits, d_nonbin, (const uint32_t *)g->d_code, g->d_span, g->d_tile_rows, d_bm,
-                           g->polar_rows, g->polar_cols, g->rcp, crows, g->cart_cols, wpr, word_groups, tiles, wpf);
+                           g->polar_rows, g->polar_cols, g->rcp, crows, g->cart_cols, wpr, word_groups, tiles, wpf,
+                           scatter ? 1 : 0);
         hipLaunchKernelGGL(extract_scan_kernel, dim3(nf), dim3(256), 0, ctx->stream, d_bm, d_rcnt, d_roff,
                            d_counts + f0, crows, wpr);
         hipLaunchKernelGGL(extract_expand_kernel, dim3(crows, nf), dim3(64), 0, ctx->stream, d_bm, d_rcnt, d_roff,
@@ -348,6 +497,15 @@ static inline int cv_round_f(float v)
 }
 
 extern "C" {
+
+int sfe_extract_set_tuning(sfe_ctx *ctx, int variant)
+{
+    if (!ctx)
+        return SFE_ERR_ARG;
+    SFE_ARG(ctx, variant == 0 || variant == 1);
+    ctx->extract_variant = variant;
+    return 0;
+}
 
 int sfe_geom_create(sfe_ctx *ctx, const float *map_x, const float *map_y, int cart_rows, int cart_cols,
                     int polar_rows, int polar_cols, double width, double height, sfe_geom **out)
@@ -435,6 +593,43 @@ int sfe_geom_create(sfe_ctx *ctx, const float *map_x, const float *map_y, int ca
         sfe_geom_destroy(g);
         return sfe_set_err(ctx, SFE_ERR_ARG, "geometry needs %d bytes of LDS per canvas tile (max 153600)", g->lds_bytes);
     }
+    // inverse map: polar pixel -> canvas pixels tapping it with a non-zero weight (same weights as the kernels)
+    std::vector<int32_t> inv_off((size_t)polar_rows * polar_cols + 1, 0);
+    std::vector<uint32_t> inv_ent;
+    if (n < (1ull << 32)) {
+        auto each_tap = [&](size_t o, auto &&fn) {
+            const uint32_t cd = code[o];
+            if (cd == SFE_CODE_NONE)
+                return;
+            const uint32_t lin = cd >> 10;
+            const int fy = (int)((cd >> 5) & 31u), fx = (int)(cd & 31u);
+            const int iy = (int)(lin / (uint32_t)(polar_cols + 1)) - 1, ix = (int)(lin % (uint32_t)(polar_cols + 1)) - 1;
+            int wgt[4] = {(32 - fy) * (32 - fx), (32 - fy) * fx, fy * (32 - fx), fy * fx};
+            if ((fx | fy) == 0)
+                wgt[3] = 1;
+            for (int t = 0; t < 4; ++t) {
+                const int y = iy + (t >> 1), x = ix + (t & 1);
+                if (wgt[t] > 0 && y >= 0 && y < polar_rows && x >= 0 && x < polar_cols)
+                    fn((size_t)y * polar_cols + x);
+            }
+        };
+        for (size_t o = 0; o < n; ++o)
+            each_tap(o, [&](size_t pi) { ++inv_off[pi + 1]; });
+        for (size_t i = 1; i < inv_off.size(); ++i)
+            inv_off[i] += inv_off[i - 1];
+        inv_ent.resize((size_t)inv_off.back());
+        std::vector<int32_t> cur(inv_off.begin(), inv_off.end() - 1);
+        for (size_t o = 0; o < n; ++o)
+            each_tap(o, [&](size_t pi) { inv_ent[(size_t)cur[pi]++] = (uint32_t)o; });
+        if (hipMalloc((void **)&g->d_inv_off, inv_off.size() * 4) != hipSuccess ||
+            hipMalloc((void **)&g->d_inv_ent, std::max<size_t>(inv_ent.size(), 1) * 4) != hipSuccess ||
+            hipMemcpy(g->d_inv_off, inv_off.data(), inv_off.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            (!inv_ent.empty() &&
+             hipMemcpy(g->d_inv_ent, inv_ent.data(), inv_ent.size() * 4, hipMemcpyHostToDevice) != hipSuccess)) {
+            sfe_geom_destroy(g);
+            return sfe_set_err(ctx, SFE_ERR_HIP, "inverse remap table upload failed");
+        }
+    }
     if (hipMalloc((void **)&g->d_code, n * 4) != hipSuccess ||
         hipMalloc((void **)&g->d_span, span.size() * 4) != hipSuccess ||
         hipMalloc((void **)&g->d_tile_rows, tile_rows.size() * 4) != hipSuccess) {
@@ -465,6 +660,10 @@ void sfe_geom_destroy(sfe_geom *g)
         (void)hipFree(g->d_span);
     if (g->d_tile_rows)
         (void)hipFree(g->d_tile_rows);
+    if (g->d_inv_off)
+        (void)hipFree(g->d_inv_off);
+    if (g->d_inv_ent)
+        (void)hipFree(g->d_inv_ent);
     delete g;
 }
 

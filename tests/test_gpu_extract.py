@@ -149,3 +149,30 @@ def test_resident_cloud_filters_hires_frame(ctx, shipped_cfar):
         want = pcl.remove_outlier(pcl.downsample(pts.astype(np.float32), 0.5, ctx=ctx), 1.0, 5, ctx=ctx)
         assert np.array_equal(kb.cloud(j), want)
     kb.free()
+
+
+@pytest.mark.parametrize("density", [0.002, 0.05, 0.5, 1.0])
+def test_inverse_map_extraction_equals_dense_pass_and_oracle(ctx, density):
+    """binary masks take the inverse-map (scatter) pass by default; it must produce exactly the points
+    of the dense pass (tuning 1) and of the oracle, from almost empty to completely full masks"""
+    rng = np.random.default_rng(int(density * 1000))
+    beams, ranges, res = 128, 200, 0.15
+    fe = FeatureExtraction(ctx)
+    fe.generate_map_xy(SonarPing(np.zeros((ranges, beams), np.uint8), oculus_bearings(beams), res))
+    for trial in range(3):
+        mask = (rng.random((ranges, beams)) < density).astype(np.uint8)
+        if trial == 2:
+            mask[0, :] = 1
+            mask[-1, :] = 1
+            mask[:, 0] = 1
+            mask[:, -1] = 1                                # image borders: out-of-image taps
+        out = {}
+        for variant in (0, 1):
+            ctx._check(ctx.lib.sfe_extract_set_tuning(ctx.handle, variant))
+            try:
+                out[variant] = fe.geometry.extract(mask)
+            finally:
+                ctx._check(ctx.lib.sfe_extract_set_tuning(ctx.handle, 0))
+        assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+        rc = oracle.nonzero(oracle.remap_u8(mask, fe.map_x, fe.map_y))
+        assert np.array_equal(out[0][0], rc)
