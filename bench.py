@@ -184,7 +184,8 @@ def main():
         cpu = cpu_baseline(frames, srcs, tgts, guesses,
                            args.cpu_keyframes, det, host_fe,
                            args.icp_mode, not args.no_filters)
-    ctx = _lib.Context(local_rank)
+    # one rank per GPU; SONARFE_BENCH_DEVICE pins every rank to one device (control-plane test on a 1-GPU box)
+    ctx = _lib.Context(int(os.environ.get("SONARFE_BENCH_DEVICE", local_rank)))
     fe = FeatureExtraction(ctx)
     fe.Ntc, fe.Ngc, fe.Pfa, fe.rank, fe.alg, fe.threshold = 40, 10, 0.1, 10, "SOCA", 65
     fe.configure()
