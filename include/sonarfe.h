@@ -172,6 +172,12 @@ int sfe_icp_compute(sfe_ctx *ctx, const sfe_icp_params *p, const float *src, int
 int sfe_icp_compute_guesses(sfe_ctx *ctx, const sfe_icp_params *p, const float *src, int n_src,
                             const float *tgt, int n_tgt, const float *guesses9, int n_guesses,
                             float *T_out9, int32_t *status, int32_t *iters);
+/* many INDEPENDENT scan pairs in one launch (the job farm's unit; host pointers): clouds concatenated,
+ * job j = src[src_off[j]..src_off[j+1]) against tgt[tgt_off[j]..tgt_off[j+1]) with guess 9*j.  Per job:
+ * T_out9 (= the guess on a nonzero status, like pcl.cpp:203,207-210), status (SFE_ICP_*), iterations. */
+int sfe_icp_compute_pairs(sfe_ctx *ctx, const sfe_icp_params *p, const float *src, const int32_t *src_off,
+                          const float *tgt, const int32_t *tgt_off, const float *guesses9, int n_jobs,
+                          float *T_out9, int32_t *status, int32_t *iters);
 /* A-B knob for the ICP kernels.  bit 2: 0 = sorted-sweep exact NN search (default; targets of up to
  * 8192 points, larger ones take the brute-force kernel), 1 = brute-force tile scan for everything.
  * Brute-force only: bit 0: 0 = packed fp32 NN loop, 1 = scalar fp32; bit 1: 0 = 64-VGPR build,

@@ -765,6 +765,37 @@ int sfe_icp_compute_guesses(sfe_ctx *ctx, const sfe_icp_params *p, const float *
     return 0;
 }
 
+int sfe_icp_compute_pairs(sfe_ctx *ctx, const sfe_icp_params *p, const float *src, const int32_t *src_off,
+                          const float *tgt, const int32_t *tgt_off, const float *guesses9, int n_jobs, float *T_out9,
+                          int32_t *status, int32_t *iters)
+{
+    if (int rc = sfe_use(ctx))
+        return rc;
+    SFE_ARG(ctx, n_jobs >= 0 && (n_jobs == 0 || (src && tgt && src_off && tgt_off && guesses9 && T_out9 && status)));
+    if (n_jobs == 0)
+        return 0;
+    const size_t ns = (size_t)src_off[n_jobs], nt = (size_t)tgt_off[n_jobs];
+    float *d_src = (float *)sfe_scratch(ctx, 0, sizeof(float) * 2 * std::max<size_t>(ns, 1));
+    float *d_tgt = (float *)sfe_scratch(ctx, 1, sizeof(float) * 2 * std::max<size_t>(nt, 1));
+    float *d_g = (float *)sfe_scratch(ctx, 2, sizeof(float) * 9 * (size_t)n_jobs);
+    float *d_T = (float *)sfe_scratch(ctx, 3, sizeof(float) * 9 * (size_t)n_jobs);
+    int32_t *d_st = (int32_t *)sfe_scratch(ctx, 8, sizeof(int32_t) * 2 * (size_t)n_jobs);
+    if (!d_src || !d_tgt || !d_g || !d_T || !d_st)
+        return SFE_ERR_HIP;
+    SFE_HIP(ctx, hipMemcpyAsync(d_src, src, sizeof(float) * 2 * ns, hipMemcpyHostToDevice, ctx->stream));
+    SFE_HIP(ctx, hipMemcpyAsync(d_tgt, tgt, sizeof(float) * 2 * nt, hipMemcpyHostToDevice, ctx->stream));
+    SFE_HIP(ctx, hipMemcpyAsync(d_g, guesses9, sizeof(float) * 9 * (size_t)n_jobs, hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = sfe_icp_batch_dev(ctx, p, d_src, src_off, d_tgt, tgt_off, d_g, n_jobs, d_T, d_st, d_st + n_jobs))
+        return rc;
+    SFE_HIP(ctx, hipMemcpyAsync(T_out9, d_T, sizeof(float) * 9 * (size_t)n_jobs, hipMemcpyDeviceToHost, ctx->stream));
+    SFE_HIP(ctx, hipMemcpyAsync(status, d_st, sizeof(int32_t) * (size_t)n_jobs, hipMemcpyDeviceToHost, ctx->stream));
+    if (iters)
+        SFE_HIP(ctx, hipMemcpyAsync(iters, d_st + n_jobs, sizeof(int32_t) * (size_t)n_jobs, hipMemcpyDeviceToHost,
+                                    ctx->stream));
+    SFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 int sfe_icp_compute(sfe_ctx *ctx, const sfe_icp_params *p, const float *src, int n_src, const float *tgt, int n_tgt,
                     const float *guess9, float *T_out9, int *iters)
 {

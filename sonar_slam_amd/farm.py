@@ -17,6 +17,8 @@ import os
 
 import numpy as np
 
+CHUNK = 1024  # scan matches per launch inside a farm worker
+
 
 def shard(n_jobs, rank, world):
     """Static round-robin: the job indices rank ``rank`` of ``world`` processes."""
@@ -67,10 +69,19 @@ def _icp_worker(device, params_dict, jobs, conn):
         ctx = _lib.Context(device)
         icp = pcl.ICP(ctx)
         icp.setParams(_lib.IcpParams(**params_dict))
-        out = []
+        # flatten (pair, guess) into independent scan matches and run them CHUNK at a time in one launch
+        flat = [(j, src, tgt, g) for j, (src, tgt, guesses) in enumerate(jobs) for g in guesses]
+        res = []
+        for c0 in range(0, len(flat), CHUNK):
+            part = flat[c0:c0 + CHUNK]
+            msgs, T, it = icp.compute_pairs([f[1] for f in part], [f[2] for f in part], [f[3] for f in part])
+            res.extend(zip(msgs, T, it))
+        out, k = [], 0
         for src, tgt, guesses in jobs:
-            msgs, T, it = icp.compute_batch(src, tgt, guesses)
-            out.append((msgs, T, it))
+            n = len(guesses)
+            out.append(([r[0] for r in res[k:k + n]], np.stack([r[1] for r in res[k:k + n]]) if n else
+                        np.zeros((0, 3, 3), np.float32), np.array([r[2] for r in res[k:k + n]], np.int32)))
+            k += n
         conn.send(("ok", out))
     except Exception as e:  # surfaced in the parent, never swallowed
         conn.send(("error", "%s: %s" % (type(e).__name__, e)))

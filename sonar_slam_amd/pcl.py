@@ -157,6 +157,37 @@ class ICP(object):
         msgs = [_L.ICP_STATUS_MESSAGES.get(int(s), "ICP failure %d" % s) for s in st]
         return msgs, T, it
 
+    def compute_pairs(self, sources, targets, guesses):
+        """Many independent (source, target, guess) scan matches in ONE launch (extension; the job
+        farm's unit).  -> (messages [n], T [n x 3 x 3] float32, iterations [n])"""
+        ctx = self._ctx or _L.default_context()
+        n = len(sources)
+        if not (len(targets) == n and len(guesses) == n):
+            raise TypeError("compute_pairs: %d sources, %d targets, %d guesses" % (n, len(targets), len(guesses)))
+        if n == 0:
+            return [], _np.zeros((0, 3, 3), _np.float32), _np.zeros(0, _np.int32)
+        srcs = [_cloud(s, "ICP.compute_pairs(source)") for s in sources]
+        tgts = [_cloud(t, "ICP.compute_pairs(target)") for t in targets]
+        if any(len(s) == 0 for s in srcs) or any(len(t) == 0 for t in tgts):
+            raise RuntimeError("ICP.compute_pairs: empty point cloud (libpointmatcher would throw)")
+        so = _np.zeros(n + 1, _np.int32)
+        to = _np.zeros(n + 1, _np.int32)
+        so[1:] = _np.cumsum([len(s) for s in srcs])
+        to[1:] = _np.cumsum([len(t) for t in tgts])
+        src = _np.ascontiguousarray(_np.concatenate(srcs), _np.float32)
+        tgt = _np.ascontiguousarray(_np.concatenate(tgts), _np.float32)
+        g = _np.ascontiguousarray(_np.stack([self._guess(x) for x in guesses]), _np.float32)
+        T = _np.zeros((n, 3, 3), _np.float32)
+        st = _np.zeros(n, _np.int32)
+        it = _np.zeros(n, _np.int32)
+        with ctx.lock:
+            ctx._check(ctx.lib.sfe_icp_compute_pairs(
+                ctx.handle, _C.byref(self.params), _L.ptr(src, _C.c_float), _L.ptr(so, _C.c_int32),
+                _L.ptr(tgt, _C.c_float), _L.ptr(to, _C.c_int32), _L.ptr(g, _C.c_float), n, _L.ptr(T, _C.c_float),
+                _L.ptr(st, _C.c_int32), _L.ptr(it, _C.c_int32)))
+        msgs = [_L.ICP_STATUS_MESSAGES.get(int(s), "ICP failure %d" % s) for s in st]
+        return msgs, T, it
+
     def getCovariance(self):
         """errorMinimizer->getCovariance() (pcl.cpp:213).  libpointmatcher's base ErrorMinimizer
         returns a zero dim x dim matrix unless the point-to-plane minimiser estimated one; no

@@ -321,3 +321,22 @@ def test_sweep_vs_brute_force_fuzz(ctx):
         assert same, (case, ns, nt, p.as_dict(), a[0], b[0], a[2], b[2])
         n_fail += sum(m != "success" for m in a[0])
     assert 0 < n_fail < 200      # the fuzz reaches both the success and the failure paths
+
+
+def test_compute_pairs_and_the_farm_equal_single_calls(ctx):
+    """ICP.compute_pairs (many independent pairs per launch) and farm.IcpFarm (one worker process per
+    device, chunks of pairs per launch) return what one ICP.compute per pair returns"""
+    from sonar_slam_amd.farm import IcpFarm
+    p = icp_config.shipped_params()
+    pairs = [synth.scan_pair(seed=300 + i, n_src=400 + 37 * i, n_tgt=500 + 11 * i) for i in range(7)]
+    icp = _icp(p, ctx)
+    single = [icp.compute(s, t, g) for s, t, g, _ in pairs]
+    msgs, T, it = icp.compute_pairs([q[0] for q in pairs], [q[1] for q in pairs], [q[2] for q in pairs])
+    for (m1, T1), m2, T2 in zip(single, msgs, T):
+        assert m1 == m2 and np.array_equal(T1, T2)
+    jobs = [(s, t, [g, g @ synth.pose_matrix(0.1, 0.0, 0.01).astype(np.float32)]) for s, t, g, _ in pairs[:4]]
+    out = IcpFarm(p, devices=[ctx.device]).run(jobs)
+    assert len(out) == 4
+    for (s, t, gs), (m, Tf, itf) in zip(jobs, out):
+        mb, Tb, itb = icp.compute_batch(s, t, gs)
+        assert m == mb and np.array_equal(Tf, Tb) and np.array_equal(itf, itb)
