@@ -83,6 +83,7 @@ class FrontEnd(object):
         self.ssm_max_translation = ssm_max_translation
         self.ssm_max_rotation = ssm_max_rotation
         self.ssm_target_frames = ssm_target_frames
+        self.icp_odom_sigmas = np.array([0.1, 0.1, 0.01])        # slam.yaml: icp_odom_sigmas
         self.keyframes = []
         self.current_frame = None
         self.log = []
@@ -124,6 +125,44 @@ class FrontEnd(object):
         x, y = T[:2, 2]
         theta = np.arctan2(T[1, 0], T[0, 0])
         return message, Pose2(x, y, theta)
+
+    def compute_icp_with_cov(self, source_points, target_points, guesses, max_seconds=2.0):
+        """slam.py:325-387: many ICP runs on ONE cloud pair from different initial guesses, the spread of
+        the converged transforms (MinCovDet) as the covariance of the registration.  The reference loops
+        over the guesses in Python with a 2 s budget (:346-358); here all of them are one launch
+        (``pcl.ICP.compute_batch``), which never gets near the budget, so every guess is used.
+        -> (message, odom Pose2, cov 3x3, sample_transforms [n x 3]) like the reference."""
+        from sklearn.covariance import MinCovDet
+        source_points = np.array(source_points, np.float32)
+        target_points = np.array(target_points, np.float32)
+        msgs, Ts, _ = self.icp.compute_batch(source_points, target_points, [g.matrix() for g in guesses])
+        sample_transforms = []
+        for message, T in zip(msgs, Ts):                          # :351-355
+            if message == "success":
+                x, y = T[:2, 2]
+                theta = np.arctan2(T[1, 0], T[0, 0])
+                sample_transforms.append((x, y, theta))
+        sample_transforms = np.array(sample_transforms)
+        if len(sample_transforms) < 5:                            # :364-365
+            return "Too few samples for covariance computation", None, None, None
+        try:                                                      # :368-376
+            fcov = MinCovDet(store_precision=False, support_fraction=0.8).fit(sample_transforms)
+        except ValueError:
+            return "Failed to calculate covariance", None, None, None
+        m = self._as_pose(fcov.location_)
+        cov = fcov.covariance_
+        c, s = np.cos(m.theta()), np.sin(m.theta())               # :379-382 unrotate to the local frame
+        R = np.array([[c, -s], [s, c]])                           # m.rotation().matrix()
+        cov[:2, :] = R.T.dot(cov[:2, :])
+        cov[:, :2] = cov[:, :2].dot(R)
+        default_cov = np.diag(self.icp_odom_sigmas) ** 2
+        if np.linalg.det(cov) < np.linalg.det(default_cov):       # :384-386
+            cov = default_cov
+        return "success", m, cov, sample_transforms
+
+    @staticmethod
+    def _as_pose(xytheta):
+        return Pose2(float(xytheta[0]), float(xytheta[1]), float(xytheta[2]))
 
     def get_overlap(self, source_points, target_points, source_pose):
         """slam.py:389-424"""

@@ -54,3 +54,22 @@ def test_replay_closed_loop_beats_odometry(ctx):
         est_err.append(np.hypot(got.x() - want.x(), got.y() - want.y()))
         dr_err.append(np.hypot(odo.x() - want.x(), odo.y() - want.y()))
     assert est_err[-1] < 0.5 * max(dr_err[-1], 0.3), (est_err, dr_err)
+
+
+@pytest.mark.gpu
+def test_compute_icp_with_cov_many_guesses_one_launch(ctx):
+    """slam.py:325-387 on the batched path: 30 guesses (slam.yaml nssm.cov_samples) on one pair"""
+    from sonar_slam_amd.replay import FrontEnd
+    src, tgt, guess, truth = synth.scan_pair(seed=9, n_src=2000, n_tgt=2000)
+    fe = FrontEnd(ctx)
+    rng = np.random.default_rng(1)
+    gx, gy, gt = synth.pose_of(guess)
+    guesses = [Pose2(gx + dx, gy + dy, gt + dt) for dx, dy, dt in rng.normal(0, [0.2, 0.2, 0.02], (30, 3))]
+    msg, odom, cov, samples = fe.compute_icp_with_cov(src, tgt, guesses)
+    assert msg == "success" and len(samples) >= 25 and cov.shape == (3, 3)
+    tx, ty, tt = synth.pose_of(truth)
+    assert abs(odom.x() - tx) < 0.3 and abs(odom.y() - ty) < 0.3 and abs(odom.theta() - tt) < 0.03   # ICP on 20 % outliers
+    assert np.linalg.det(cov) >= np.linalg.det(np.diag([0.1, 0.1, 0.01]) ** 2) - 1e-18
+    # too few successes -> the reference's message
+    msg2, *_ = fe.compute_icp_with_cov(src, tgt, guesses[:3])
+    assert msg2 == "Too few samples for covariance computation"
