@@ -33,6 +33,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <map>
+#include <type_traits>
 #include <utility>
 
 #define SW_TCAP 8192   // target points resident in LDS
@@ -348,8 +349,16 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_sweep_prep_kernel(sfe_icp_
 // starts from the previous iteration's limit, so far outliers cost a handful of steps instead of
 // a walk across the whole cloud.  Decisions and results are identical to the exhaustive search.
 // control block of a job; the LDS-resident variant places the sorted target right behind it
+// wave-uniform float held in an SGPR instead of one VGPR per lane (the loop kernel runs at the
+// 64-VGPR budget: every uniform value kept out of the vector file is one spill less)
+__device__ __forceinline__ float sw_uniform(float v)
+{
+    return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v)));
+}
+
 struct SweepShared {
     double red[ICP_WAVES * 10 + 10];
+    double acc[10];  // the reduced error-minimiser sums (read by the solving lane)
     unsigned hist[256];
     unsigned sel_prefix, sel_k;
     int long_n, mid_n, wl_n[2];
@@ -476,7 +485,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
     Q.nt = nt;
     const float *guess = guess_all + 9 * (size_t)jb;
     const int tid = threadIdx.x, lane = threadIdx.x & 63;
-    const float mx = mean_all[2 * J.prep], my = mean_all[2 * J.prep + 1];
+    const float mx = sw_uniform(mean_all[2 * J.prep]), my = sw_uniform(mean_all[2 * J.prep + 1]);
 
     if (prof != nullptr && tid == 0) {
         for (int i = 0; i < 16; ++i)
@@ -498,6 +507,9 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
         for (int i = 0; i < 9; ++i)
             g[i] = guess[i];
         mat3_mul(Tinv, g, T0);
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+            T0[i] = sw_uniform(T0[i]);
     }
     IcpCheck chk = {S.hist_c, S.hist_s, S.hist_x, S.hist_y, 1, 0, 0};
     if (tid == 0) {
@@ -513,8 +525,8 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
     }
     __syncthreads();
 
-    const float r2_match = f_mul(P.matcher_max_dist, P.matcher_max_dist);
-    const float r2_filter = f_mul(P.max_dist_filter, P.max_dist_filter);
+    const float r2_match = sw_uniform(f_mul(P.matcher_max_dist, P.matcher_max_dist));
+    const float r2_filter = sw_uniform(f_mul(P.max_dist_filter, P.max_dist_filter));
     // best starts just above maxDist^2 so that `d < best` accepts d == maxDist^2
     const float r2m_up = __uint_as_float(__float_as_uint(r2_match) + 1u);
     // no pair beyond Cmax can get weight 1
@@ -526,6 +538,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
         Cinit = h * h;
         if (!(Cinit > 1e-30f) || !(Cinit < Cmax))
             Cinit = Cmax;
+        Cinit = sw_uniform(Cinit);
     }
     float Cnext = P.use_trimmed_filter ? Cinit : Cmax; // cap the next iteration starts with
     SW_PROF(0);
@@ -536,7 +549,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
         float Ti[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i)
-            Ti[i] = S.Ti[i];
+            Ti[i] = sw_uniform(S.Ti[i]);
 
         // ---- A+B: cur = Ti * (T0 * src); exact NN for every pair that can matter.  Round 0 walks
         // every query (lane i handles queries i, i + 1024, ...: transform, lower bound of cur.x in the
@@ -860,7 +873,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                 }
                 if (done)
                     break;
-                C = (round >= 12) ? Cmax : fminf(fmaxf(4.0f * C, Cinit), Cmax);
+                C = sw_uniform((round >= 12) ? Cmax : fminf(fmaxf(4.0f * C, Cinit), Cmax));
                 cur ^= 1;
                 nwork = nsusp;
             }
@@ -963,7 +976,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                     }
                     __syncthreads();
                 }
-                limit = __uint_as_float(S.sel_prefix);
+                limit = sw_uniform(__uint_as_float(S.sel_prefix));
             }
         }
         __syncthreads();
@@ -972,54 +985,70 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
         Cnext = P.use_trimmed_filter ? ((limit < Cmax) ? fmaxf(limit, Cinit * 0.0625f) : Cmax) : Cmax;
         SW_PROF(3);
 
-        // ---- D: error minimiser sums over the kept pairs ----
-        double acc[10];
+        // ---- D: error minimiser sums over the kept pairs, in two halves of five accumulators: ten fp64
+        // accumulators per lane do not fit the 64-VGPR budget next to the loop state (they spilled) ----
+        auto sums = [&](auto lo_tag) {
+            constexpr int LO = decltype(lo_tag)::value;
+            double a5[5] = {0, 0, 0, 0, 0};
+            for (int i = tid; i < ns; i += ICP_THREADS) {
+                const int id = Q.pos[i];
+                const float d = Q.d2[i];
+                const bool ok = id >= 0 && (!P.use_max_dist_filter || d <= r2_filter) &&
+                                (!P.use_trimmed_filter || d <= limit);
+                if (!ok)
+                    continue;
+                const float2 p = Q.xy[i];
+                const double px = p.x, py = p.y;
+                const float2 q = T[id + 1];
+                const double qx = q.x, qy = q.y;
+                double t[10];
+                t[0] = 1.0;
+                if (P.minimizer == 0) {
+                    t[1] = px;
+                    t[2] = py;
+                    t[3] = qx;
+                    t[4] = qy;
+                    t[5] = qx * px;
+                    t[6] = qx * py;
+                    t[7] = qy * px;
+                    t[8] = qy * py;
+                    t[9] = 0.0;
+                } else {
+                    const float2 n = snrm[id];
+                    const double nx = n.x, ny = n.y;
+                    const double a0 = px * ny - py * nx;
+                    const double e = nx * (px - qx) + ny * (py - qy);
+                    t[1] = a0 * a0;
+                    t[2] = a0 * nx;
+                    t[3] = a0 * ny;
+                    t[4] = nx * nx;
+                    t[5] = nx * ny;
+                    t[6] = ny * ny;
+                    t[7] = -(a0 * e);
+                    t[8] = -(nx * e);
+                    t[9] = -(ny * e);
+                }
 #pragma unroll
-        for (int i = 0; i < 10; ++i)
-            acc[i] = 0;
-        for (int i = tid; i < ns; i += ICP_THREADS) {
-            const int id = Q.pos[i];
-            const float d = Q.d2[i];
-            const bool ok = id >= 0 && (!P.use_max_dist_filter || d <= r2_filter) &&
-                            (!P.use_trimmed_filter || d <= limit);
-            if (!ok)
-                continue;
-            const float2 p = Q.xy[i];
-            const double px = p.x, py = p.y;
-            const float2 q = T[id + 1];
-            const double qx = q.x, qy = q.y;
-            acc[0] += 1.0;
-            if (P.minimizer == 0) {
-                acc[1] += px;
-                acc[2] += py;
-                acc[3] += qx;
-                acc[4] += qy;
-                acc[5] += qx * px;
-                acc[6] += qx * py;
-                acc[7] += qy * px;
-                acc[8] += qy * py;
-            } else {
-                const float2 n = snrm[id];
-                const double nx = n.x, ny = n.y;
-                const double a0 = px * ny - py * nx;
-                const double e = nx * (px - qx) + ny * (py - qy);
-                acc[1] += a0 * a0;
-                acc[2] += a0 * nx;
-                acc[3] += a0 * ny;
-                acc[4] += nx * nx;
-                acc[5] += nx * ny;
-                acc[6] += ny * ny;
-                acc[7] -= a0 * e;
-                acc[8] -= nx * e;
-                acc[9] -= ny * e;
+                for (int k = 0; k < 5; ++k)
+                    a5[k] += t[LO + k];
             }
-        }
-        block_sum<10>(acc, S.red);
+            block_sum<5>(a5, S.red);
+            if (tid == 0) {
+#pragma unroll
+                for (int k = 0; k < 5; ++k)
+                    S.acc[LO + k] = a5[k];
+            }
+        };
+        sums(std::integral_constant<int, 0>());
+        sums(std::integral_constant<int, 5>());
         SW_PROF(4);
 
         // ---- E: solve, compose, check (one lane) ----
         if (tid == 0) {
             int status, iterate;
+            double acc[10];
+            for (int i = 0; i < 10; ++i)
+                acc[i] = S.acc[i];
             icp_solve_and_check(P, acc, Ti, S.Ti, chk, status, iterate);
             S.flag_status = status;
             S.flag_iterate = (status == SFE_ICP_OK) ? iterate : 0;
