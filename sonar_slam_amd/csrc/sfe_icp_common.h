@@ -27,12 +27,32 @@ __device__ __forceinline__ float affine1(float a, float b, float c, float x, flo
     return f_add(f_add(f_mul(a, x), f_mul(b, y)), c);
 }
 
+// v + (v of the lane `SHR` places to the left in the same row of 16 lanes, 0.0 where there is none): DPP
+// row_shr, no address register and no LDS crossbar (the __shfl form kept six loop-invariant address
+// VGPRs alive, which the 64-VGPR ICP kernels spilled and re-loaded around every reduction)
+template <int SHR>
+__device__ __forceinline__ double dpp_row_shr_add(double v)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x110 + SHR, 0xf, 0xf, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x110 + SHR, 0xf, 0xf, false);
+    return v + __hiloint2double(hi2, lo2);
+}
+
+// sum over the 64 lanes, same value in every lane; fixed order (deterministic): inclusive scan inside
+// each row of 16 lanes, then the four row totals left to right
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1)
-        v += __shfl_down(v, d);
-    return v;
+    v = dpp_row_shr_add<1>(v);
+    v = dpp_row_shr_add<2>(v);
+    v = dpp_row_shr_add<4>(v);
+    v = dpp_row_shr_add<8>(v);
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    double s = __hiloint2double(__builtin_amdgcn_readlane(hi, 15), __builtin_amdgcn_readlane(lo, 15));
+    s += __hiloint2double(__builtin_amdgcn_readlane(hi, 31), __builtin_amdgcn_readlane(lo, 31));
+    s += __hiloint2double(__builtin_amdgcn_readlane(hi, 47), __builtin_amdgcn_readlane(lo, 47));
+    s += __hiloint2double(__builtin_amdgcn_readlane(hi, 63), __builtin_amdgcn_readlane(lo, 63));
+    return s;
 }
 
 // block-wide sum of NV doubles per thread; result valid in every thread
