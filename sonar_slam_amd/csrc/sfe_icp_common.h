@@ -55,6 +55,43 @@ __device__ __forceinline__ double wave_sum(double v)
     return s;
 }
 
+// minimum over the 64 lanes (NaN-free inputs), same value in every lane; DPP like wave_sum
+template <int SHR>
+__device__ __forceinline__ float dpp_row_shr_min(float v)
+{
+    const int o = __builtin_amdgcn_update_dpp(0x7F800000 /* +inf where there is no source lane */, __float_as_int(v),
+                                              0x110 + SHR, 0xf, 0xf, false);
+    return fminf(v, __int_as_float(o));
+}
+__device__ __forceinline__ float wave_min(float v)
+{
+    v = dpp_row_shr_min<1>(v);
+    v = dpp_row_shr_min<2>(v);
+    v = dpp_row_shr_min<4>(v);
+    v = dpp_row_shr_min<8>(v);
+    const int b = __float_as_int(v);
+    return fminf(fminf(__int_as_float(__builtin_amdgcn_readlane(b, 15)), __int_as_float(__builtin_amdgcn_readlane(b, 31))),
+                 fminf(__int_as_float(__builtin_amdgcn_readlane(b, 47)), __int_as_float(__builtin_amdgcn_readlane(b, 63))));
+}
+
+// inclusive prefix sum over the 64 lanes (unsigned), DPP inside the rows + the row totals of the rows before
+template <int SHR>
+__device__ __forceinline__ unsigned dpp_row_shr_addu(unsigned v)
+{
+    return v + (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + SHR, 0xf, 0xf, false);
+}
+__device__ __forceinline__ unsigned wave_inclusive_scan(unsigned v)
+{
+    v = dpp_row_shr_addu<1>(v);
+    v = dpp_row_shr_addu<2>(v);
+    v = dpp_row_shr_addu<4>(v);
+    v = dpp_row_shr_addu<8>(v);
+    const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)v, 15), r1 = (unsigned)__builtin_amdgcn_readlane((int)v, 31),
+                   r2 = (unsigned)__builtin_amdgcn_readlane((int)v, 47);
+    const int row = (threadIdx.x & 63) >> 4;
+    return v + (row > 0 ? r0 : 0u) + (row > 1 ? r1 : 0u) + (row > 2 ? r2 : 0u);
+}
+
 // block-wide sum of NV doubles per thread; result valid in every thread
 template <int NV>
 __device__ __forceinline__ void block_sum(double (&v)[NV], double *s_red /* ICP_WAVES*NV + NV */)

@@ -787,10 +787,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                             }
                             float wmin = INFINITY;
                             if (__ballot(d <= best)) { // rare for far queries: only then pay for the wave reduction
-                                wmin = d;
-#pragma unroll
-                                for (int o = 32; o >= 1; o >>= 1)
-                                    wmin = fminf(wmin, __shfl_xor(wmin, o));
+                                wmin = wave_min(d); // d never holds a NaN (only `du < d` updates it)
                             }
                             if (wmin < best) {
                                 const unsigned long long who = __ballot(d == wmin);
@@ -948,13 +945,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                         const unsigned h0 = S.hist[4 * lane], h1 = S.hist[4 * lane + 1], h2 = S.hist[4 * lane + 2],
                                        h3 = S.hist[4 * lane + 3];
                         const unsigned tot = h0 + h1 + h2 + h3;
-                        unsigned incl = tot;
-#pragma unroll
-                        for (int d = 1; d < 64; d <<= 1) {
-                            const unsigned o = __shfl_up(incl, d);
-                            if (lane >= d)
-                                incl += o;
-                        }
+                        const unsigned incl = wave_inclusive_scan(tot);
                         const unsigned excl = incl - tot;
                         if (k >= excl && k < incl) { // exactly one lane
                             unsigned r = k - excl, b = 4 * lane;
