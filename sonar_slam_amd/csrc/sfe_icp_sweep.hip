@@ -96,17 +96,18 @@ struct PrepShared {
 // PCA normals of the centred target: K nearest incl. the point itself, ordered by (d2, original
 // index) exactly like the brute-force scan (sfe_icp.hip).  s_tgt = sorted cloud with sentinels
 // (1-based positions), in LDS or in HBM scratch.
+template <int KM> // capacity of the neighbour list (>= K): its loops are fully unrolled, so a snug KM pays
 __device__ __forceinline__ void sweep_knn_normals(const sfe_icp_params &P, const float2 *__restrict__ s_tgt,
                                                   const int *__restrict__ perm, float2 *__restrict__ snrm, int nt)
 {
     const int tid = threadIdx.x;
-    const int K = min(min(P.normals_knn, ICP_KMAX), nt);
+    const int K = min(min(P.normals_knn, KM), nt);
     for (int c = tid; c < nt; c += ICP_THREADS) {
         const float2 q = s_tgt[c + 1];
-        float bd[ICP_KMAX];
-        int bj[ICP_KMAX];
+        float bd[KM];
+        int bj[KM];
 #pragma unroll
-        for (int k = 0; k < ICP_KMAX; ++k) {
+        for (int k = 0; k < KM; ++k) {
             bd[k] = INFINITY;
             bj[k] = 0;
         }
@@ -118,27 +119,27 @@ __device__ __forceinline__ void sweep_knn_normals(const sfe_icp_params &P, const
             int p = 0;
             bool eq = false;
 #pragma unroll
-            for (int k = 0; k < ICP_KMAX; ++k) {
+            for (int k = 0; k < KM; ++k) {
                 p += (k < K && bd[k] < d) ? 1 : 0;
                 eq |= (k < K && bd[k] == d);
             }
             if (eq) { // ties: lower original index first
                 const int o = perm[j - 1];
 #pragma unroll
-                for (int k = 0; k < ICP_KMAX; ++k)
+                for (int k = 0; k < KM; ++k)
                     if (k < K && bd[k] == d && perm[bj[k] - 1] < o)
                         ++p;
             }
             if (p >= K)
                 return;
 #pragma unroll
-            for (int k = ICP_KMAX - 1; k >= 1; --k)
+            for (int k = KM - 1; k >= 1; --k)
                 if (k < K && k > p) {
                     bd[k] = bd[k - 1];
                     bj[k] = bj[k - 1];
                 }
 #pragma unroll
-            for (int k = 0; k < ICP_KMAX; ++k) {
+            for (int k = 0; k < KM; ++k) {
                 if (k == p) {
                     bd[k] = d;
                     bj[k] = j;
@@ -165,7 +166,7 @@ __device__ __forceinline__ void sweep_knn_normals(const sfe_icp_params &P, const
         }
         double sx = 0, sy = 0;
 #pragma unroll
-        for (int k = 0; k < ICP_KMAX; ++k)
+        for (int k = 0; k < KM; ++k)
             if (k < K) {
                 const float2 t = s_tgt[bj[k]];
                 sx += (double)t.x;
@@ -175,7 +176,7 @@ __device__ __forceinline__ void sweep_knn_normals(const sfe_icp_params &P, const
         sy /= K;
         double a = 0, b = 0, d = 0;
 #pragma unroll
-        for (int k = 0; k < ICP_KMAX; ++k)
+        for (int k = 0; k < KM; ++k)
             if (k < K) {
                 const float2 t = s_tgt[bj[k]];
                 const double ux = (double)t.x - sx, uy = (double)t.y - sy;
@@ -317,8 +318,12 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_sweep_prep_kernel(sfe_icp_
             s_tgt[nt + 1] = make_float2(qnan, qnan);
         }
         __syncthreads();
-        if (P.minimizer == 1)
-            sweep_knn_normals(P, s_tgt, perm, snrm_all + J.off, nt);
+        if (P.minimizer == 1) {
+            if (P.normals_knn <= 12)
+                sweep_knn_normals<12>(P, s_tgt, perm, snrm_all + J.off, nt);
+            else
+                sweep_knn_normals<ICP_KMAX>(P, s_tgt, perm, snrm_all + J.off, nt);
+        }
     } else {
         bitonic_sort_global(keys, n2);
         for (int pos = tid; pos < nt; pos += ICP_THREADS) {
@@ -328,8 +333,12 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_sweep_prep_kernel(sfe_icp_
             perm[pos] = id;
         }
         __syncthreads();
-        if (P.minimizer == 1)
-            sweep_knn_normals(P, stgt, perm, snrm_all + J.off, nt);
+        if (P.minimizer == 1) {
+            if (P.normals_knn <= 12)
+                sweep_knn_normals<12>(P, stgt, perm, snrm_all + J.off, nt);
+            else
+                sweep_knn_normals<ICP_KMAX>(P, stgt, perm, snrm_all + J.off, nt);
+        }
     }
 }
 

@@ -313,7 +313,7 @@ def test_sweep_vs_brute_force_fuzz(ctx):
                       max_dist_filter=float(rng.choice([0.3, 3.0, 20.0])), use_trimmed_filter=int(rng.integers(0, 2)),
                       trim_ratio=float(rng.choice([0.3, 0.8, 1.0])), minimizer=int(rng.integers(0, 2)),
                       max_iter=int(rng.integers(1, 15)), use_diff_checker=int(rng.integers(0, 2)), min_diff_rot=0.001,
-                      min_diff_trans=0.01, smooth_len=int(rng.integers(1, 4)), normals_knn=int(rng.integers(2, 12)))
+                      min_diff_trans=0.01, smooth_len=int(rng.integers(1, 4)), normals_knn=int(rng.integers(2, 17)))
         guesses = [synth.pose_matrix(*rng.normal(0, [0.3, 0.3, 0.05])).astype(np.float32) for _ in range(3)]
         a = _with_variant(ctx, 0, lambda: _icp(p, ctx).compute_batch(src, tgt, guesses))
         b = _with_variant(ctx, 4, lambda: _icp(p, ctx).compute_batch(src, tgt, guesses))
