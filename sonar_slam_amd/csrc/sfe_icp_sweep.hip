@@ -319,7 +319,11 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_sweep_prep_kernel(sfe_icp_
         }
         __syncthreads();
         if (P.minimizer == 1) {
-            if (P.normals_knn <= 12)
+            if (P.normals_knn <= 8)
+                sweep_knn_normals<8>(P, s_tgt, perm, snrm_all + J.off, nt);
+            else if (P.normals_knn <= 10)
+                sweep_knn_normals<10>(P, s_tgt, perm, snrm_all + J.off, nt);
+            else if (P.normals_knn <= 12)
                 sweep_knn_normals<12>(P, s_tgt, perm, snrm_all + J.off, nt);
             else
                 sweep_knn_normals<ICP_KMAX>(P, s_tgt, perm, snrm_all + J.off, nt);
@@ -334,7 +338,11 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_sweep_prep_kernel(sfe_icp_
         }
         __syncthreads();
         if (P.minimizer == 1) {
-            if (P.normals_knn <= 12)
+            if (P.normals_knn <= 8)
+                sweep_knn_normals<8>(P, stgt, perm, snrm_all + J.off, nt);
+            else if (P.normals_knn <= 10)
+                sweep_knn_normals<10>(P, stgt, perm, snrm_all + J.off, nt);
+            else if (P.normals_knn <= 12)
                 sweep_knn_normals<12>(P, stgt, perm, snrm_all + J.off, nt);
             else
                 sweep_knn_normals<ICP_KMAX>(P, stgt, perm, snrm_all + J.off, nt);
