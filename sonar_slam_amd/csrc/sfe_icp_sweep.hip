@@ -373,6 +373,13 @@ __device__ __forceinline__ float sw_uniform(float v)
     return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v)));
 }
 
+__device__ __forceinline__ long long sw_uniform_ll(long long v)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v & 0xFFFFFFFFll));
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
 struct SweepShared {
     double red[ICP_WAVES * 10 + 10];
     double acc[10];  // the reduced error-minimiser sums (read by the solving lane)
@@ -481,8 +488,15 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     SweepShared &S = *reinterpret_cast<SweepShared *>(smem_raw);
 
-    const int jb = job_ids[blockIdx.x];
-    const SweepJob J = jobs[jb];
+    const int jb = __builtin_amdgcn_readfirstlane(job_ids[blockIdx.x]);
+    SweepJob J = jobs[jb];
+    // the job record is the same for every lane: keep it (and every pointer derived from it) in SGPRs
+    J.src_start = __builtin_amdgcn_readfirstlane(J.src_start);
+    J.n_src = __builtin_amdgcn_readfirstlane(J.n_src);
+    J.n_tgt = __builtin_amdgcn_readfirstlane(J.n_tgt);
+    J.prep = __builtin_amdgcn_readfirstlane(J.prep);
+    J.tgt_off = sw_uniform_ll(J.tgt_off);
+    J.q_off = sw_uniform_ll(J.q_off);
     const int ns = J.n_src, nt = J.n_tgt;
     const float2 *__restrict__ src = src_all + J.src_start;
     const float2 *__restrict__ stgt = stgt_all + J.tgt_off;
