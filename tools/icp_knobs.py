@@ -11,7 +11,7 @@ from sonar_slam_amd.CFAR import CFAR  # noqa: E402
 from sonar_slam_amd.feature_extraction import FeatureExtraction, SonarPing, oculus_bearings  # noqa: E402
 from sonar_slam_amd.pipeline import KeyframeBatch  # noqa: E402
 
-B = 256
+B = 512
 ctx = _lib.default_context()
 det = CFAR(40, 10, 0.1, 10)
 fe = FeatureExtraction(ctx)
@@ -36,7 +36,7 @@ for mode, p in (("p2plane30", icp_config.shipped_params(minimizer=1, use_diff_ch
     kb = KeyframeBatch(ctx, fe.geometry, det.params["SOCA"], "SOCA", 65, p, B)
     kb.upload_scan_pairs(srcs, tgts, guesses)
     kbs[mode] = kb
-for refill, budget in [(6, 24), (4, 24), (8, 24), (3, 24), (6, 32), (6, 16), (12, 24)]:
+for refill, budget in [(8, 24), (6, 24), (10, 24), (12, 24), (8, 16), (8, 32), (12, 32), (16, 32)]:
     os.environ["SFE_SW_BUDGET_A"] = str(refill)
     os.environ["SFE_SW_BUDGET"] = str(budget)
     line = "budget A %2d B %2d:" % (refill, budget)
