@@ -385,7 +385,7 @@ struct SweepShared {
     double acc[10];  // the reduced error-minimiser sums (read by the solving lane)
     unsigned hist[256];
     unsigned sel_prefix, sel_k;
-    int long_n, mid_n, wl_n[2];
+    int long_n, long_next, mid_n, wl_n[2];
     int flag_iterate, flag_status;
     float Ti[9];
     float hist_c[ICP_MAX_HIST], hist_s[ICP_MAX_HIST], hist_x[ICP_MAX_HIST], hist_y[ICP_MAX_HIST];
@@ -602,6 +602,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                 }
                 if (tid == 0) {
                     S.long_n = 0;
+                    S.long_next = 0;
                     S.mid_n = 0;
                     S.wl_n[cur ^ 1] = 0;
                 }
@@ -761,7 +762,16 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                 if (nlong > 0) {
                     const int wave = tid >> 6;
                     const bool left = lane < 32;
-                    int slot = wave;
+                    // walks are handed out dynamically (their lengths differ by orders of magnitude): the first
+                    // ICP_WAVES slots are the waves' own, further ones come from the LDS counter
+                    (void)wave;
+                    auto next_slot = [&]() {
+                        int v = 0;
+                        if (lane == 0)
+                            v = atomicAdd(&S.long_next, 1);
+                        return __builtin_amdgcn_readfirstlane(v);
+                    };
+                    int slot = next_slot();
                     int4 e0 = make_int4(0, 0, 0, 0), e1 = make_int4(0, 0, 0, 0);
                     if (slot < nlong) {
                         e0 = Q.longe[2 * slot];
@@ -776,7 +786,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                         bool tied = e0.w < 0;
                         const float px = __int_as_float(e1.x), py = __int_as_float(e1.y);
                         float best = __int_as_float(e1.z);
-                        slot += ICP_WAVES;
+                        slot = next_slot();
                         if (slot < nlong) { // prefetch the next walk
                             e0 = Q.longe[2 * slot];
                             e1 = Q.longe[2 * slot + 1];
