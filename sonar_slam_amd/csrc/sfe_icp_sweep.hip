@@ -614,16 +614,22 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                 // waves for pass B with the long budget, so lanes that finished early do not sit idle
                 // through the long walks of their neighbours.  What still runs on goes to tier 2. --
                 auto walk_pass = [&](const int *list, int n, bool fresh, int budget, bool last) {
+                float2 sp_next = make_float2(0, 0); // fresh pass: the next slice's source point is fetched a slice ahead
+                if (fresh && tid < n)
+                    sp_next = src[tid];
                 for (int k0 = 0; k0 < n; k0 += ICP_THREADS) {
                     const int slot = k0 + tid;
                     const bool valid = slot < n;
+                    const float2 sp_cur = sp_next;
+                    if (fresh && slot + ICP_THREADS < n)
+                        sp_next = src[slot + ICP_THREADS];
                     int q = 0, iL = 0, iR = 0, bpos = 0;
                     float px = 0, py = 0, best = r2m_up;
                     bool tied = false;
                     if (valid) {
                         if (fresh) {
                             q = slot;
-                            const float2 sp = src[q];
+                            const float2 sp = sp_cur;
                             const float rx = affine1(T0[0], T0[1], T0[2], sp.x, sp.y);
                             const float ry = affine1(T0[3], T0[4], T0[5], sp.x, sp.y);
                             px = affine1(Ti[0], Ti[1], Ti[2], rx, ry);
