@@ -673,7 +673,8 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                                 const float dyl = f_add(py, -tl.y), dl = f_add(el, f_mul(dyl, dyl));
                                 const float dxr = f_add(px, -tr.x), er = f_mul(dxr, dxr);
                                 const float dyr = f_add(py, -tr.y), dr = f_add(er, f_mul(dyr, dyr));
-                                const float sb = bpos ? fminf(best, C) : best; // stop bound
+                                const float capv = bpos ? C : best;            // nothing found yet: only maxDist bounds the walk
+                                const float sb = best < capv ? best : capv;    // stop bound (no NaNs here: plain select)
                                 const bool okl = el <= sb, okr = er <= sb;    // NaN sentinel -> false
                                 // only consumed candidates (cursor moves past them) may update the state:
                                 // nothing is ever evaluated twice, so `tied` flags real ties only
@@ -806,7 +807,8 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                         constexpr int U = 4; // candidates per lane and trip: four independent LDS reads in flight
                         const int lo = left ? lane : lane - 32;
                         for (int guard = 0; guard <= nt / (32 * U) + 2; ++guard) { // bounded by construction
-                            const float sb = bpos ? fminf(best, C) : best; // stop bound at the start of the trip
+                            const float capv = bpos ? C : best;
+                            const float sb = best < capv ? best : capv; // stop bound at the start of the trip
                             const bool on = left ? !doneL : !doneR;
                             float d = INFINITY;
                             int jb = 0, nL = 0, nR = 0;
