@@ -126,3 +126,25 @@ def test_batched_device_path_full_size(shipped_cfar, ctx):
     assert np.array_equal(cfar.soca(big, th, gh, tau), oracle.cfar(big, "SOCA", th, gh, tau))
     d_img.free()
     d_mask.free()
+
+
+@pytest.mark.parametrize("alg", ["CA", "SOCA", "GOCA"])
+@pytest.mark.parametrize("shape,frames", [((2048, 1024), 3), ((1024, 512), 19), ((157, 256), 9), ((104, 260), 8)])
+def test_ring_kernel_xcd_map_and_march_direction(alg, shape, frames, shipped_cfar, ctx):
+    """The ring kernel maps frame f to XCD f % 8 (frame count padded to 8) and marches even tiles up,
+    odd tiles down: batches whose frame count is not a multiple of 8, the config-B frame shape, tile
+    counts that are odd / a single shifted tile -- every frame must equal the oracle."""
+    rng = np.random.default_rng(frames * 1000 + shape[0])
+    imgs = np.stack([synth.sonar_frame(seed=int(s), rows=shape[0], cols=shape[1], n_blobs=20)
+                     for s in rng.integers(0, 1 << 30, frames)])
+    p = _args(shipped_cfar, alg)
+    d_in, d_out = ctx.alloc(imgs.nbytes), ctx.alloc(imgs.nbytes)
+    d_in.upload(imgs)
+    from sonar_slam_amd import _lib
+    ctx._check(ctx.lib.sfe_cfar_u8_batch_dev(ctx.handle, d_in.ptr, frames, shape[0], shape[1], _lib.ALG[alg], p[0], p[1],
+                                             0, float(p[-1]), -1, d_out.ptr, None))
+    got = d_out.download(np.uint8, imgs.size).reshape(imgs.shape)
+    for f in range(frames):
+        assert np.array_equal(got[f], _oracle(imgs[f], alg, p)), f
+    d_in.free()
+    d_out.free()
