@@ -116,6 +116,29 @@ __device__ __forceinline__ void sweep_knn_normals(const sfe_icp_params &P, const
         auto consider = [&](float d, int j) {
             if (!(d <= kth) || d == INFINITY)
                 return;
+            if (K == KM) {
+                // full list (the usual case, KM == k): the newcomer replaces the last entry and bubbles up
+                // with KM-1 compare-exchanges -- half the work of the count / shift / place form below.
+                // Equal distances order by original index (rare: the permutation is only read then).
+                if (d == kth && !(perm[j - 1] < perm[bj[KM - 1] - 1]))
+                    return;
+                bd[KM - 1] = d;
+                bj[KM - 1] = j;
+#pragma unroll
+                for (int k = KM - 1; k >= 1; --k) {
+                    bool up = bd[k] < bd[k - 1];
+                    if (bd[k] == bd[k - 1] && bj[k - 1] != 0)
+                        up = perm[bj[k] - 1] < perm[bj[k - 1] - 1];
+                    const float td = up ? bd[k - 1] : bd[k];
+                    const int tj = up ? bj[k - 1] : bj[k];
+                    bd[k - 1] = up ? bd[k] : bd[k - 1];
+                    bj[k - 1] = up ? bj[k] : bj[k - 1];
+                    bd[k] = td;
+                    bj[k] = tj;
+                }
+                kth = bd[KM - 1];
+                return;
+            }
             int p = 0;
             bool eq = false;
 #pragma unroll
