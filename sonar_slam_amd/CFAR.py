@@ -5,17 +5,11 @@ Same constructor, attributes (``threshold_factor_*``, ``params``, ``detector``,
 bruce_slam/src/bruce_slam/CFAR.py:9-133, so FeatureExtraction code written against the
 reference runs unchanged; the native module behind it is ``sonar_slam_amd.cfar`` (HIP).
 
-The threshold factors are the white-Gaussian-noise P_fa inversions of CFAR.py:71-121: CA in
-closed form, SOCA / GOCA / OS as roots (scipy.optimize.root from ten log-spaced starting
-points, first converged one wins -- the iteration must be identical because tau enters the
-detector's compare to the last bit).
+The threshold factors (CFAR.py:71-121) are computed in ``wgn_threshold``; the ``calc_WGN_*``
+methods are kept as thin bindings for code that calls them on the object.
 """
-import math
-
-import numpy as np
-from scipy.optimize import root
-
 from . import cfar
+from . import wgn_threshold as wgn
 
 
 class CFAR(object):
@@ -31,9 +25,9 @@ class CFAR(object):
                 raise AssertionError("rank out of range")
 
         self.threshold_factor_CA = self.calc_WGN_threshold_factor_CA()
-        self.threshold_factor_SOCA = self._solve(self.calc_WGN_pfa_SOCA, "SOCA")
-        self.threshold_factor_GOCA = self._solve(self.calc_WGN_pfa_GOCA, "GOCA")
-        self.threshold_factor_OS = self._solve(self.calc_WGN_pfa_OS, "OS")
+        self.threshold_factor_SOCA = self.calc_WGN_threshold_factor_SOCA()
+        self.threshold_factor_GOCA = self.calc_WGN_threshold_factor_GOCA()
+        self.threshold_factor_OS = self.calc_WGN_threshold_factor_OS()
 
         hs, gs = self.Ntc // 2, self.Ngc // 2  # CFAR.py:35-40
         self.params = {
@@ -54,54 +48,30 @@ class CFAR(object):
                     self.Ntc, self.Ngc, self.Pfa, self.rank, self.threshold_factor_CA,
                     self.threshold_factor_SOCA, self.threshold_factor_GOCA, self.threshold_factor_OS)
 
-    # ---- threshold factors (CFAR.py:71-121) ----
+    # ---- threshold factors: the arithmetic lives in wgn_threshold.py ----
     def calc_WGN_threshold_factor_CA(self):
-        return self.Ntc * (self.Pfa ** (-1.0 / self.Ntc) - 1)
-
-    def _solve(self, fun, name):
-        x0 = self.calc_WGN_threshold_factor_CA()
-        for ratio in np.logspace(-2, 2, 10):
-            ret = root(fun, x0 * ratio)
-            if ret.success:
-                return ret.x[0]
-        raise ValueError("Threshold factor of %s not found" % name)
-
-    def calc_WGN_threshold_factor_SOCA(self):
-        return self._solve(self.calc_WGN_pfa_SOCA, "SOCA")
-
-    def calc_WGN_threshold_factor_GOCA(self):
-        return self._solve(self.calc_WGN_pfa_GOCA, "GOCA")
-
-    def calc_WGN_threshold_factor_OS(self):
-        return self._solve(self.calc_WGN_pfa_OS, "OS")
-
-    @staticmethod
-    def _scalar(x):
-        # scipy.optimize.root hands the residual a length-1 array (the reference does float(x))
-        return float(np.asarray(x, dtype=float).reshape(-1)[0])
+        return wgn.ca_factor(self.Ntc, self.Pfa)
 
     def calc_WGN_pfa_GOSOCA_core(self, x):
-        x = self._scalar(x)
-        half = self.Ntc / 2
-        acc = 0.0
-        for k in range(int(half)):
-            acc += math.exp(math.lgamma(half + k) - math.lgamma(k + 1) - math.lgamma(half)) \
-                * (2 + x / half) ** (-k)
-        return acc * (2 + x / half) ** (-half)
+        return wgn.half_window_tail(x, self.Ntc)
 
     def calc_WGN_pfa_SOCA(self, x):
-        return self.calc_WGN_pfa_GOSOCA_core(x) - self.Pfa / 2
+        return wgn.residual_soca(x, self.Ntc, self.Pfa)
 
     def calc_WGN_pfa_GOCA(self, x):
-        x = self._scalar(x)
-        half = self.Ntc / 2
-        return (1.0 + x / half) ** (-half) - self.calc_WGN_pfa_GOSOCA_core(x) - self.Pfa / 2
+        return wgn.residual_goca(x, self.Ntc, self.Pfa)
 
     def calc_WGN_pfa_OS(self, x):
-        x = self._scalar(x)
-        n, r = self.Ntc, self.rank
-        return math.exp(math.lgamma(n + 1) - math.lgamma(n - r + 1)
-                        + math.lgamma(x + n - r + 1) - math.lgamma(x + n + 1)) - self.Pfa
+        return wgn.residual_os(x, self.Ntc, self.Pfa, self.rank)
+
+    def calc_WGN_threshold_factor_SOCA(self):
+        return wgn.first_root(self.calc_WGN_pfa_SOCA, self.Ntc, self.Pfa, "SOCA")
+
+    def calc_WGN_threshold_factor_GOCA(self):
+        return wgn.first_root(self.calc_WGN_pfa_GOCA, self.Ntc, self.Pfa, "GOCA")
+
+    def calc_WGN_threshold_factor_OS(self):
+        return wgn.first_root(self.calc_WGN_pfa_OS, self.Ntc, self.Pfa, "OS")
 
     # ---- detection (CFAR.py:123-133) ----
     def detect(self, mat, alg="CA"):
