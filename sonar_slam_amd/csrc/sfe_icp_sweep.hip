@@ -435,13 +435,16 @@ struct SweepShared {
 #define SW_BUDGET_A 8   // first-pass trips per walk (4 candidates each)
 #define SW_BUDGET 24    // tier-1 trips (4 candidates each) before a walk is handed to the cooperative tier
 #define SW_NONE (-1)
-#define SW_INEXACT (-2)
+// a suspended (inexact) query is stored as pos = -2 - bpos (<= -3): the target it holds doubles as the
+// next iteration's witness
+#define SW_INEXACT_OF(bpos) (-2 - (bpos))
 
 struct SweepQ { // per-job views of the per-query scratch
     float2 *xy;   // transformed query
-    int4 *st;     // suspended walk: x = iL, y = iR, z = bpos | tied << 31
+    int4 *st;     // suspended walk: x = iL, y = iR, z = bpos | tied << 31; a `none` query keeps its
+                  // clearance record here instead: (px, py, clearance) as float bits
     float *d2;    // best so far / final d2
-    int *pos;     // >= 0 sorted position of the NN, SW_NONE, SW_INEXACT
+    int *pos;     // >= 0 sorted position of the NN, SW_NONE, <= -3 inexact (SW_INEXACT_OF)
     int *wl[2];   // work lists of suspended queries (ping-pong between rounds)
     int *mid;     // walks that outlived the short first pass (compacted for the second)
     int4 *longe;  // walks handed to the cooperative tier this round: (q, iL, iR, bpos|tied), (px, py, best, -)
@@ -506,7 +509,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
     const float2 *__restrict__ snrm_all, const float *__restrict__ mean_all, float2 *__restrict__ q_xy_all,
     int4 *__restrict__ q_st_all, int *__restrict__ q_wl_all, int4 *__restrict__ q_long_all, float *__restrict__ nn_d2_all,
     int *__restrict__ nn_pos_all, float *__restrict__ T_out, int *__restrict__ status_out,
-    int *__restrict__ iters_out, long long *prof, int *dbg, int sw_budget, int sw_budget_a)
+    int *__restrict__ iters_out, long long *prof, int *dbg, int sw_budget, int sw_budget_a, int sw_cache)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     SweepShared &S = *reinterpret_cast<SweepShared *>(smem_raw);
@@ -581,8 +584,14 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
 
     const float r2_match = sw_uniform(f_mul(P.matcher_max_dist, P.matcher_max_dist));
     const float r2_filter = sw_uniform(f_mul(P.max_dist_filter, P.max_dist_filter));
-    // best starts just above maxDist^2 so that `d < best` accepts d == maxDist^2
-    const float r2m_up = __uint_as_float(__float_as_uint(r2_match) + 1u);
+    // A walk that has not met a target within maxDist yet is bounded by `best`, which starts at W2 = a
+    // little MORE than maxDist^2 (found <=> best < r2m_up <=> best <= maxDist^2; with an unbounded
+    // matcher: best finite): a query that ends `none` then knows its
+    // nearest target is at least sqrt(best) > maxDist away, and that margin lets later iterations prove
+    // "still none" from how far the query has moved instead of walking its whole maxDist window again.
+    const float r2m_up = sw_uniform((r2_match < INFINITY) ? __uint_as_float(__float_as_uint(r2_match) + 1u) : INFINITY);
+    const float W2 = sw_uniform(fmaxf(r2m_up, f_mul(r2_match, 1.1025f)));
+    const float md_hi = sw_uniform(f_mul(P.matcher_max_dist, 1.00001f));
     // no pair beyond Cmax can get weight 1
     const float Cmax = P.use_max_dist_filter ? fminf(r2_filter, r2_match) : r2_match;
     float Cinit;
@@ -598,6 +607,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
     SW_PROF(0);
 
     int wd_outer = 0;
+    bool use_cache = false; // from the second iteration on: Q.pos / Q.st hold the previous iteration's results
     while (true) {
         SW_WATCH(wd_outer, P.max_iter + 2, 0)
         float Ti[9];
@@ -638,16 +648,24 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                 // through the long walks of their neighbours.  What still runs on goes to tier 2. --
                 auto walk_pass = [&](const int *list, int n, bool fresh, int budget, bool last) {
                 float2 sp_next = make_float2(0, 0); // fresh pass: the next slice's source point is fetched a slice ahead
-                if (fresh && tid < n)
+                int prev_next = 0;                  // ... and so is last iteration's result of that query
+                if (fresh && tid < n) {
                     sp_next = src[tid];
+                    if (use_cache)
+                        prev_next = Q.pos[tid];
+                }
                 for (int k0 = 0; k0 < n; k0 += ICP_THREADS) {
                     const int slot = k0 + tid;
                     const bool valid = slot < n;
                     const float2 sp_cur = sp_next;
-                    if (fresh && slot + ICP_THREADS < n)
+                    const int prev = prev_next;
+                    if (fresh && slot + ICP_THREADS < n) {
                         sp_next = src[slot + ICP_THREADS];
+                        if (use_cache)
+                            prev_next = Q.pos[slot + ICP_THREADS];
+                    }
                     int q = 0, iL = 0, iR = 0, bpos = 0;
-                    float px = 0, py = 0, best = r2m_up;
+                    float px = 0, py = 0, best = W2;
                     bool tied = false;
                     if (valid) {
                         if (fresh) {
@@ -686,7 +704,33 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                         iR = lo;
                         iL = lo - 1;
                     }
-                    bool fin = !valid;
+                    // What the previous iteration knew about this query (the cloud moves little between
+                    // iterations).  Its neighbour -- exact or not -- is evaluated first as a WITNESS: a real
+                    // target at distance dw, so the walk is "found" at once and bounded by min(dw, C)
+                    // instead of running on until it meets some target within maxDist.  The witness counts
+                    // as evaluated; the walk skips it when the cursors reach it (`!= bpos` below).
+                    // A `none` query stays none as long as it has moved less than its recorded clearance:
+                    // |p - t| >= |p0 - t| - |p - p0| > maxDist for every target t (1e-5 relative slop on
+                    // each term, two orders above the rounding of the fp32 distances involved).
+                    bool skip = false;
+                    if (fresh && use_cache && valid) {
+                        const int w = prev >= 0 ? prev + 1 : (prev <= -3 ? -2 - prev : 0);
+                        if (w) {
+                            const float2 t = T[w];
+                            const float dxw = f_add(px, -t.x), dyw = f_add(py, -t.y);
+                            const float dw = f_add(f_mul(dxw, dxw), f_mul(dyw, dyw));
+                            if (dw < best) {
+                                best = dw;
+                                bpos = w;
+                            }
+                        } else if (prev == SW_NONE) {
+                            const int4 r = Q.st[q];
+                            const float mx0 = f_add(px, -__int_as_float(r.x)), my0 = f_add(py, -__int_as_float(r.y));
+                            const float mv = sqrtf(f_add(f_mul(mx0, mx0), f_mul(my0, my0)));
+                            skip = f_mul(mv, 1.00001f) < __int_as_float(r.z); // NaN -> walk
+                        }
+                    }
+                    bool fin = !valid || skip;
                     for (int trip = 0; trip < budget; ++trip) {
                         if (!fin) {
 #pragma unroll
@@ -696,17 +740,17 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                                 const float dyl = f_add(py, -tl.y), dl = f_add(el, f_mul(dyl, dyl));
                                 const float dxr = f_add(px, -tr.x), er = f_mul(dxr, dxr);
                                 const float dyr = f_add(py, -tr.y), dr = f_add(er, f_mul(dyr, dyr));
-                                const float capv = bpos ? C : best;            // nothing found yet: only maxDist bounds the walk
+                                const float capv = (best < r2m_up) ? C : best; // nothing within maxDist yet: only `best` bounds the walk
                                 const float sb = best < capv ? best : capv;    // stop bound (no NaNs here: plain select)
                                 const bool okl = el <= sb, okr = er <= sb;    // NaN sentinel -> false
                                 // only consumed candidates (cursor moves past them) may update the state:
                                 // nothing is ever evaluated twice, so `tied` flags real ties only
-                                tied |= okl && (dl == best);
+                                tied |= okl && (dl == best) && (iL != bpos);
                                 if (okl && dl < best) {
                                     best = dl;
                                     bpos = iL;
                                 }
-                                tied |= okr && (dr == best);
+                                tied |= okr && (dr == best) && (iR != bpos);
                                 if (okr && dr < best) {
                                     best = dr;
                                     bpos = iR;
@@ -721,12 +765,16 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                     }
                     // classify: none / exact / suspended (inexact) / long (budget exhausted)
                     const bool is_long = valid && !fin;
-                    const bool is_none = valid && fin && bpos == 0;
-                    const bool is_exact = valid && fin && bpos != 0 && best <= C;
-                    const bool is_susp = valid && fin && bpos != 0 && !(best <= C);
+                    const bool found = best < r2m_up; // <=> some target with d2 <= maxDist^2 was met (best starts at W2 >= r2m_up)
+                    const bool is_none = valid && fin && !found;
+                    const bool is_exact = valid && fin && found && best <= C;
+                    const bool is_susp = valid && fin && found && !(best <= C);
                     if (is_none) {
                         Q.d2[q] = INFINITY;
                         Q.pos[q] = SW_NONE;
+                        if (!skip) // a full walk: every target is at least sqrt(best) away from (px, py)
+                            Q.st[q] = make_int4(__float_as_int(px), __float_as_int(py),
+                                                __float_as_int(f_add(f_mul(sqrtf(best), 0.99999f), -md_hi)), 0);
                     }
                     if (is_exact) {
                         if (tied)
@@ -736,7 +784,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                     }
                     if (is_susp) {
                         Q.d2[q] = best;
-                        Q.pos[q] = SW_INEXACT;
+                        Q.pos[q] = SW_INEXACT_OF(bpos);
                         Q.st[q] = make_int4(iL, iR, bpos | (tied ? (int)0x80000000 : 0), 0);
                     }
                     { // wave-aggregated appends
@@ -830,7 +878,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                         constexpr int U = 4; // candidates per lane and trip: four independent LDS reads in flight
                         const int lo = left ? lane : lane - 32;
                         for (int guard = 0; guard <= nt / (32 * U) + 2; ++guard) { // bounded by construction
-                            const float capv = bpos ? C : best;
+                            const float capv = (best < r2m_up) ? C : best;
                             const float sb = best < capv ? best : capv; // stop bound at the start of the trip
                             const bool on = left ? !doneL : !doneR;
                             float d = INFINITY;
@@ -849,11 +897,12 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                                 const unsigned long long mc = __ballot(cons);
                                 nL += __popcll(mc & 0xFFFFFFFFull);
                                 nR += __popcll(mc >> 32);
-                                if (cons && du < d) { // NaN never passes
+                                const bool use = cons && j != bpos; // the witness is already accounted for
+                                if (use && du < d) { // NaN never passes
                                     d = du;
                                     jb = j;
                                     eqf = false;
-                                } else if (cons && du == d && du < INFINITY) {
+                                } else if (use && du == d && du < INFINITY) {
                                     eqf = true; // two of this lane's candidates at the same distance
                                 }
                             }
@@ -885,9 +934,11 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                             tp0 = t_;
                         }
                         if (lane == 0) {
-                            if (bpos == 0) {
+                            if (!(best < r2m_up)) {
                                 Q.d2[q] = INFINITY;
                                 Q.pos[q] = SW_NONE;
+                                Q.st[q] = make_int4(__float_as_int(px), __float_as_int(py),
+                                                    __float_as_int(f_add(f_mul(sqrtf(best), 0.99999f), -md_hi)), 0);
                             } else if (best <= C) {
                                 if (tied)
                                     bpos = sweep_resolve_tie(T, Q, px, py, best, iL, iR);
@@ -895,7 +946,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                                 Q.pos[q] = bpos - 1;
                             } else {
                                 Q.d2[q] = best;
-                                Q.pos[q] = SW_INEXACT;
+                                Q.pos[q] = SW_INEXACT_OF(bpos);
                                 Q.st[q] = make_int4(iL, iR, bpos | (tied ? (int)0x80000000 : 0), 0);
                                 wl_next[atomicAdd(&S.wl_n[cur ^ 1], 1)] = q;
                             }
@@ -1120,6 +1171,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
         SW_PROF(5);
         if (!S.flag_iterate)
             break;
+        use_cache = sw_cache != 0;
     }
 
     if (tid == 0) {
@@ -1220,6 +1272,7 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
     static const bool debug = getenv("SFE_ICP_DEBUG") != nullptr;
     const int sw_budget = getenv("SFE_SW_BUDGET") ? atoi(getenv("SFE_SW_BUDGET")) : SW_BUDGET;
     const int sw_budget_a = getenv("SFE_SW_BUDGET_A") ? atoi(getenv("SFE_SW_BUDGET_A")) : SW_BUDGET_A;
+    const int sw_cache = getenv("SFE_SW_CACHE") ? atoi(getenv("SFE_SW_CACHE")) : 1; // 0: A/B without the witness / clearance cache
     int *d_dbg = nullptr;
     if (debug) {
         d_dbg = (int *)sfe_scratch(ctx, 22, sizeof(int) * 8);
@@ -1238,13 +1291,13 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             hipLaunchKernelGGL((icp_sweep_kernel<4, true>), dim3(n_lds), dim3(ICP_THREADS), smem, ctx->stream, *p, d_jobs,
                                d_ids, (const float2 *)d_src, d_guess9, d_stgt, d_perm, d_snrm, d_mean, d_qxy, d_qst, d_qwl,
-                               d_qlong, d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof, d_dbg, sw_budget, sw_budget_a);
+                               d_qlong, d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof, d_dbg, sw_budget, sw_budget_a, sw_cache);
         } else {
             SFE_HIP(ctx, hipFuncSetAttribute((const void *)icp_sweep_kernel<8, true>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             hipLaunchKernelGGL((icp_sweep_kernel<8, true>), dim3(n_lds), dim3(ICP_THREADS), smem, ctx->stream, *p, d_jobs,
                                d_ids, (const float2 *)d_src, d_guess9, d_stgt, d_perm, d_snrm, d_mean, d_qxy, d_qst, d_qwl,
-                               d_qlong, d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof, d_dbg, sw_budget, sw_budget_a);
+                               d_qlong, d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof, d_dbg, sw_budget, sw_budget_a, sw_cache);
         }
         SFE_LAUNCH_CHECK(ctx);
     }
@@ -1253,12 +1306,12 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
             hipLaunchKernelGGL((icp_sweep_kernel<4, false>), dim3(n_glb), dim3(ICP_THREADS), ctl_bytes, ctx->stream, *p,
                                d_jobs, d_ids + n_lds, (const float2 *)d_src, d_guess9, d_stgt, d_perm, d_snrm, d_mean,
                                d_qxy, d_qst, d_qwl, d_qlong, d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof, d_dbg,
-                               sw_budget, sw_budget_a);
+                               sw_budget, sw_budget_a, sw_cache);
         else
             hipLaunchKernelGGL((icp_sweep_kernel<8, false>), dim3(n_glb), dim3(ICP_THREADS), ctl_bytes, ctx->stream, *p,
                                d_jobs, d_ids + n_lds, (const float2 *)d_src, d_guess9, d_stgt, d_perm, d_snrm, d_mean,
                                d_qxy, d_qst, d_qwl, d_qlong, d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof, d_dbg,
-                               sw_budget, sw_budget_a);
+                               sw_budget, sw_budget_a, sw_cache);
         SFE_LAUNCH_CHECK(ctx);
     }
     if (debug) {

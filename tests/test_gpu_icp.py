@@ -323,6 +323,79 @@ def test_sweep_vs_brute_force_fuzz(ctx):
     assert 0 < n_fail < 200      # the fuzz reaches both the success and the failure paths
 
 
+def _sweep_vs_brute(ctx, p, src, tgt, guesses):
+    a = _with_variant(ctx, 0, lambda: _icp(p, ctx).compute_batch(src, tgt, guesses))
+    b = _with_variant(ctx, 4, lambda: _icp(p, ctx).compute_batch(src, tgt, guesses))
+    same = a[0] == b[0] and np.array_equal(a[1], b[1], equal_nan=True) and np.array_equal(a[2], b[2])
+    return same, a, b
+
+
+def test_sweep_iteration_cache_at_the_maxdist_boundary(ctx, monkeypatch):
+    """From the second iteration on the sweep reuses what the previous iteration knew: the old
+    neighbour as a witness, and for queries without any target within maxDist a clearance that
+    proves "still none" while the query has moved less than it.  Source points are placed in a thin
+    shell around maxDist from the target and the guess is off, so queries cross the boundary in both
+    directions while the pose converges; results must stay identical to the brute-force kernel, with
+    the cache on and off, for a finite and for an unbounded matcher."""
+    from sonar_slam_amd._lib import IcpParams
+    rng = np.random.default_rng(77)
+    world = synth._structure(rng, 1500, max_range=12.0)
+    tgt = (world + rng.normal(0, 0.02, world.shape)).astype(np.float32)
+    inl = world[rng.permutation(len(world))[:900]] + rng.normal(0, 0.02, (900, 2))
+    for md in (1.5, float("inf")):
+        r = (md if np.isfinite(md) else 3.0) + rng.uniform(-0.08, 0.25, 1200)
+        a = rng.uniform(0, 2 * np.pi, 1200)
+        shell = world[rng.integers(0, len(world), 1200)] + np.c_[r * np.cos(a), r * np.sin(a)]
+        far = rng.uniform(-60, 60, (100, 2))
+        src_t = np.concatenate([inl, shell, far])
+        T = synth.pose_matrix(0.5, -0.2, 0.06)
+        Tinv = np.linalg.inv(T)
+        src = (src_t @ Tinv[:2, :2].T + Tinv[:2, 2]).astype(np.float32)
+        guesses = [synth.pose_matrix(0.5 + dx, -0.2 + dy, 0.06 + dt).astype(np.float32)
+                   for dx, dy, dt in rng.normal(0, [0.15, 0.15, 0.03], (4, 3))]
+        for mz in (0, 1):
+            p = IcpParams(matcher_max_dist=md, use_max_dist_filter=1, max_dist_filter=1.0, use_trimmed_filter=1,
+                          trim_ratio=0.7, minimizer=mz, max_iter=25, use_diff_checker=0, min_diff_rot=0.001,
+                          min_diff_trans=0.01, smooth_len=3, normals_knn=10)
+            for cache in ("1", "0"):
+                monkeypatch.setenv("SFE_SW_CACHE", cache)
+                same, x, y = _sweep_vs_brute(ctx, p, src, tgt, guesses)
+                assert same, (md, mz, cache, x[0], y[0], x[2], y[2])
+                assert all(m == "success" for m in x[0]) and (x[2] == 25).all()
+            st, To, ito = oracle.icp(src, tgt, guesses[0], oracle.shipped_icp_params(
+                minimizer=mz, precision=1, matcher_max_dist=md, max_dist_filter=1.0, trim_ratio=0.7, max_iter=25,
+                use_diff_checker=0, min_diff_rot=0.001, min_diff_trans=0.01, smooth_len=3))
+            assert st == 0 and ito == 25 and _pose_diff(x[1][0], To) < TOL_REF
+
+
+def test_sweep_vs_brute_force_fuzz_many_iterations(ctx):
+    """second differential fuzz: larger clouds, 10-25 iterations (the iteration-to-iteration cache is
+    exercised over many steps), small / unbounded matcher radii"""
+    from sonar_slam_amd._lib import IcpParams
+    rng = np.random.default_rng(909)
+    for case in range(24):
+        ns, nt = int(rng.integers(200, 1500)), int(rng.integers(200, 1500))
+        world = synth._structure(rng, max(ns, nt), max_range=float(rng.choice([6.0, 15.0, 30.0])))
+        tgt = (world[rng.permutation(len(world))[:nt]] + rng.normal(0, 0.03, (nt, 2))).astype(np.float32)
+        if case % 4 == 0:
+            tgt[:, case % 8 // 4] = np.round(tgt[:, case % 8 // 4] * 2) / 2      # walls on a half-metre raster
+        T = synth.pose_matrix(*rng.normal(0, [0.4, 0.4, 0.05]))
+        Tinv = np.linalg.inv(T)
+        base = world[rng.permutation(len(world))[:ns]] + rng.normal(0, 0.03, (ns, 2))
+        src = base @ Tinv[:2, :2].T + Tinv[:2, 2]
+        k = ns // 4
+        src[:k] = rng.uniform(-35, 35, (k, 2))                                   # outliers, some beyond everything
+        src = src.astype(np.float32)
+        p = IcpParams(matcher_max_dist=float(rng.choice([0.4, 1.0, 10.0, np.inf])),
+                      use_max_dist_filter=int(rng.integers(0, 2)), max_dist_filter=float(rng.choice([0.3, 3.0])),
+                      use_trimmed_filter=int(rng.integers(0, 4) > 0), trim_ratio=float(rng.choice([0.5, 0.8, 0.95])),
+                      minimizer=int(rng.integers(0, 2)), max_iter=int(rng.integers(10, 26)), use_diff_checker=0,
+                      min_diff_rot=0.001, min_diff_trans=0.01, smooth_len=3, normals_knn=10)
+        guesses = [(T @ synth.pose_matrix(*rng.normal(0, [0.2, 0.2, 0.04]))).astype(np.float32) for _ in range(3)]
+        same, a, b = _sweep_vs_brute(ctx, p, src, tgt, guesses)
+        assert same, (case, ns, nt, p.as_dict(), a[0], b[0], a[2], b[2])
+
+
 def test_compute_pairs_and_the_farm_equal_single_calls(ctx):
     """ICP.compute_pairs (many independent pairs per launch) and farm.IcpFarm (one worker process per
     device, chunks of pairs per launch) return what one ICP.compute per pair returns"""

@@ -36,7 +36,10 @@ for mode, p in (("p2plane30", icp_config.shipped_params(minimizer=1, use_diff_ch
     kb = KeyframeBatch(ctx, fe.geometry, det.params["SOCA"], "SOCA", 65, p, B)
     kb.upload_scan_pairs(srcs, tgts, guesses)
     kbs[mode] = kb
-for refill, budget in [(8, 24), (6, 24), (10, 24), (12, 24), (8, 16), (8, 32), (12, 32), (16, 32)]:
+combos = [(8, 24), (6, 24), (10, 24), (12, 24), (8, 16), (8, 32), (12, 32), (16, 32)]
+if len(sys.argv) > 1:  # e.g. "4,24 6,24 8,40"
+    combos = [tuple(int(v) for v in c.split(",")) for c in " ".join(sys.argv[1:]).split()]
+for refill, budget in combos:
     os.environ["SFE_SW_BUDGET_A"] = str(refill)
     os.environ["SFE_SW_BUDGET"] = str(budget)
     line = "budget A %2d B %2d:" % (refill, budget)

@@ -59,6 +59,8 @@ def main():
                 it = int(kb.results()["iters"][0])
                 print("   workgroup 0, %d iterations: " % it +
                       ", ".join("%s %d" % (n, c) for n, c in zip(names, list(cyc)[:12]) if n != "-"))
+                print("   tier 2: %d trips over %d walks; wave 0 of workgroup 0: fetch %d, walk %d, finish %d cycles"
+                      % (cyc[12], cyc[10], cyc[13], cyc[14], cyc[15]))
                 import struct
                 print("   per iteration (kcycles search, cap C, n_exact): " + " ".join(
                     "%d/%.3g/%d" % (cyc[16 + 2 * i] // 1000, struct.unpack("f", struct.pack("I", (cyc[17 + 2 * i] >> 32) & 0xFFFFFFFF))[0],
