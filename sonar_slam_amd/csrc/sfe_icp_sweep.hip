@@ -1,4 +1,4 @@
-// ICP scan matching with an exact sorted-sweep nearest-neighbour search (default ICP path).
+// ICP scan matching with an exact strip-sweep nearest-neighbour search (default ICP path).
 // Replaces bruce_slam/src/bruce_slam/cpp/pcl.cpp:198-212 (ICP.compute -> libpointmatcher chain of
 // bruce_slam/config/icp.yaml:1-31); same chain, same decisions and same arithmetic as
 // sfe_icp.hip's brute-force kernel (which stays as the A/B
@@ -6,28 +6,35 @@
 //
 // Why a sweep is exact.  The squared distance everyone on this path compares is
 //     d2 = fl( fl(dx*dx) + fl(dy*dy) ),  dx = fl(px - tx), dy = fl(py - ty)      (dist2())
-// Rounding is monotone, so d2 >= fl(dx*dx) =: e, and e is non-decreasing in |px - tx|.  With the
-// centred target sorted by x, a query walks outwards from its own x position in both directions
-// and may stop a direction as soon as e > best: every point further out has d2 >= e > best and
-// can neither win nor tie.  All surviving candidates are evaluated with dist2()'s exact
-// expression; ties go to the lowest ORIGINAL target index (what the brute-force scan and the
-// oracle do), resolved by a rare second walk over the final window.  No kd-tree, no
-// approximation, no float re-association: match ids and d2 are bit-identical to brute force.
+// Rounding is monotone, so d2 >= fl(dx*dx) =: e and d2 >= fl(dy*dy), and both grow with |dx|, |dy|.
+// The centred target is cut into horizontal STRIPS (uniform y intervals, <= 64 of them) and sorted by
+// x inside each strip.  A query visits its own strip, then the strips above, then the strips below:
+//   * a strip (and every strip beyond it) is skipped once fl(ylb*ylb) > bound, ylb = distance from the
+//     query's y to the nearest y any point of those strips has (min / max taken from the data, so no
+//     cell-boundary rounding enters);
+//   * inside a strip the query walks outwards from its own x position in both directions and stops a
+//     direction as soon as e > bound.
+// Whatever is skipped has d2 > bound and can neither win nor tie.  All surviving candidates are
+// evaluated with dist2()'s exact expression; ties go to the lowest ORIGINAL target index (what the
+// brute-force scan and the oracle do), resolved by a rare second pass over the final window.  No
+// kd-tree, no approximation, no float re-association: match ids and d2 are bit-identical to brute
+// force.
 //
-// Work per query drops from n_tgt pair evaluations to the points whose |dx| is within the query's
-// own stop bound: ~20 instead of 5000 on converged sonar clouds, a few hundred while the clouds are
-// still far apart.  Walks differ wildly in length (a near-vertical wall puts 100+ points in one x
-// window; a query with nothing within maxDist walks its whole 10 m window), so the search is tiered
-// (details at the loop kernel): short budget for every lane -> survivors compacted into dense waves
-// with a longer budget -> what still runs is finished by a whole wave, 256 candidates per trip.
+// Work per query drops from n_tgt pair evaluations to the points inside a (2r x strip height) box per
+// visited strip: ~4 instead of 5000 on converged sonar clouds, a few dozen while the clouds are still
+// far apart (a single x-sorted sweep -- the first version of this file -- needed ~17 and ~200: a wall
+// along y puts its whole length into one x window).  Walks still differ in length, so the search is
+// tiered (details at the loop kernel): own strip with a short budget for every lane -> survivors
+// compacted into dense waves that go through all their strips -> what still runs is finished by a whole
+// wave, 256 candidates per trip.
 //
 // Mapping: prep kernel = one workgroup per distinct target (many guesses on one pair share it):
-// mean, centre, bitonic sort of (x-key, index) in LDS (HBM scratch beyond 8192 points), sorted
-// cloud + permutation to HBM scratch, PCA normals (k-NN by the same sweep) for point-to-plane.
-// Loop kernel = one workgroup per job, all ICP iterations in one launch: sorted target resident in
-// LDS (or walked through L2 beyond 8192 points), per iteration: transform + lower bound + capped
-// walks (tiers) -> census -> trimmed quantile by exact radix select -> fp64 reduction of the 9(+1)
-// sums -> closed-form solve and checkers on one lane.
+// mean, centre, strip table, bitonic sort of (strip, x-key, index) in LDS (HBM scratch beyond 8192
+// points), sorted cloud + permutation to HBM scratch, PCA normals (k-NN by the same strip sweep) for
+// point-to-plane.  Loop kernel = one workgroup per job, all ICP iterations in one launch: sorted target
+// resident in LDS (or walked through L2 beyond 8192 points), per iteration: transform + capped walks
+// (tiers) -> census -> trimmed quantile by exact radix select -> fp64 reduction of the 9(+1) sums ->
+// closed-form solve and checkers on one lane.
 #include "sfe_icp_common.h"
 
 #include <algorithm>
@@ -37,10 +44,28 @@
 #include <utility>
 
 #define SW_TCAP 8192   // target points resident in LDS
+#define SW_NS_MAX 64   // strips per target
+#define SW_PAD (SW_NS_MAX + 4) // sentinels: one in front, one behind every strip, two spare behind the last
+
+// Strip table of one target (built by the prep kernel, read by every job on that target).
+// Sorted-cloud layout (float2 positions): [0] NaN, then for every strip s its points ascending in x
+// followed by one NaN sentinel; sbeg[s] = position of the first point of strip s, its points are
+// [sbeg[s], sbeg[s+1] - 1), the sentinel behind them sits at sbeg[s+1] - 1 (and is the sentinel in front
+// of strip s+1); len = sbeg[ns] = n_tgt + ns + 1, positions len and len+1 hold two more NaNs.  perm /
+// snrm use the same positions: entry p-1 belongs to position p.
+struct StripTab {
+    int ns, len;
+    float ylo, inv_g;         // strip(y) = clamp(int((y - ylo) * inv_g), 0, ns - 1)
+    float ext_x;              // x extent of the finite points (initial cap of the search)
+    int pad_[3];
+    int sbeg[SW_NS_MAX + 1];
+    float smin[SW_NS_MAX];    // smallest y of any point in strips >= s (+inf if none)
+    float smax[SW_NS_MAX];    // largest y of any point in strips <= s (-inf if none)
+};
 
 struct SweepPrep {
-    int tgt_start, n_tgt;
-    long long off;     // offset (points) of this target's slice of the sorted-cloud scratch (stride n_tgt + 4)
+    int tgt_start, n_tgt, ns, pad_;
+    long long off;     // offset (points) of this target's slice of the sorted-cloud scratch (stride n_tgt + SW_PAD)
     long long key_off; // targets beyond the LDS capacity: offset of their sort keys in HBM scratch
 };
 
@@ -61,6 +86,69 @@ __device__ __forceinline__ unsigned mono_key(float x)
 __device__ __forceinline__ float mono_inv(unsigned k)
 {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+__device__ __forceinline__ int strip_of(float y, float ylo, float inv_g, int ns)
+{
+    float v = f_mul(f_add(y, -ylo), inv_g);
+    v = fminf(fmaxf(v, 0.0f), (float)(ns - 1)); // NaN -> 0
+    return (int)v;
+}
+
+// first position in [lo, hi) whose x is not < px (hi if there is none; NaN x counts as "not <").
+// Convergent form: every lane of the wave must call it, lanes without work pass lo == hi.
+__device__ __forceinline__ int strip_lower_bound(const float2 *__restrict__ T, int lo, int hi, float px)
+{
+    while (__ballot(lo < hi)) {
+        const int mid = (lo + hi) >> 1;
+        const bool lt = T[mid].x < px;
+        if (lo < hi) {
+            if (lt)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+    }
+    return lo;
+}
+
+// the same for one lane on its own (rare paths)
+__device__ __forceinline__ int strip_lower_bound_lane(const float2 *__restrict__ T, int lo, int hi, float px)
+{
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (T[mid].x < px)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+// Next strip of a search that has covered strips [so, s_up) upwards and (s_dn, so) downwards: upwards
+// first (the own strip `so` is the first of them), then downwards; -1 when every remaining strip is
+// farther than `sb` in y.  smin / smax are monotone in s, so a direction that is pruned once stays pruned.
+__device__ __forceinline__ int next_strip(const StripTab &tab, int ns, int so, int &s_up, int &s_dn, float py, float sb)
+{
+    bool upok = s_up < ns;
+    if (upok && s_up != so) {
+        const float yl = f_add(tab.smin[s_up], -py);
+        upok = !(yl > 0.0f && f_mul(yl, yl) > sb);
+    }
+    if (!upok)
+        s_up = ns;
+    bool dnok = s_dn >= 0;
+    if (dnok) {
+        const float yl = f_add(py, -tab.smax[s_dn]);
+        dnok = !(yl > 0.0f && f_mul(yl, yl) > sb);
+    }
+    if (!dnok)
+        s_dn = -1;
+    if (upok)
+        return s_up++;
+    if (dnok)
+        return s_dn--;
+    return -1;
 }
 
 // in-LDS bitonic sort of n2 (power of two) 64-bit keys, ascending
@@ -84,26 +172,35 @@ __device__ __forceinline__ void bitonic_sort_lds(unsigned long long *keys, unsig
 }
 
 struct PrepShared {
-    // first the sort keys, then (same bytes) the sorted cloud with one NaN sentinel at each end
-    unsigned long long buf[SW_TCAP + 2];
+    // first the sort keys, then (same bytes) the sorted cloud with its sentinels
+    unsigned long long buf[SW_TCAP + SW_PAD + 4];
     double red[ICP_WAVES * 2 + 2];
     float mean[2];
+    unsigned ykey[2], xkey[2]; // min / max order keys of the finite centred coordinates
+    int cnt[SW_NS_MAX];
+    unsigned smin_k[SW_NS_MAX], smax_k[SW_NS_MAX];
+    StripTab tab;
 };
 
 // ---------------------------------------------------------------------------------------------
 // prep: one workgroup per distinct target cloud
 // ---------------------------------------------------------------------------------------------
 // PCA normals of the centred target: K nearest incl. the point itself, ordered by (d2, original
-// index) exactly like the brute-force scan (sfe_icp.hip).  s_tgt = sorted cloud with sentinels
-// (1-based positions), in LDS or in HBM scratch.
+// index) exactly like the brute-force scan (sfe_icp.hip).  s_tgt = sorted cloud in the strip layout
+// (in LDS or in HBM scratch).
 template <int KM> // capacity of the neighbour list (>= K): its loops are fully unrolled, so a snug KM pays
-__device__ __forceinline__ void sweep_knn_normals(const sfe_icp_params &P, const float2 *__restrict__ s_tgt,
-                                                  const int *__restrict__ perm, float2 *__restrict__ snrm, int nt)
+__device__ __forceinline__ void sweep_knn_normals(const sfe_icp_params &P, const StripTab &tab,
+                                                  const float2 *__restrict__ s_tgt, const int *__restrict__ perm,
+                                                  float2 *__restrict__ snrm, int nt)
 {
     const int tid = threadIdx.x;
     const int K = min(min(P.normals_knn, KM), nt);
-    for (int c = tid; c < nt; c += ICP_THREADS) {
-        const float2 q = s_tgt[c + 1];
+    const int ns = tab.ns, len = tab.len;
+    for (int c = tid + 1; c < len; c += ICP_THREADS) { // positions; sentinels are skipped
+        const float2 q = s_tgt[c];
+        if (q.x != q.x && q.y != q.y)
+            continue; // a sentinel (a cloud point that is NaN in both coordinates gets no normal either:
+                      // nothing can ever match it)
         float bd[KM];
         int bj[KM];
 #pragma unroll
@@ -112,7 +209,6 @@ __device__ __forceinline__ void sweep_knn_normals(const sfe_icp_params &P, const
             bj[k] = 0;
         }
         float kth = INFINITY; // bd[K-1]
-        int iL = c, iR = c + 1;  // 1-based positions: the point itself is the first right candidate
         auto consider = [&](float d, int j) {
             if (!(d <= kth) || d == INFINITY)
                 return;
@@ -171,21 +267,30 @@ __device__ __forceinline__ void sweep_knn_normals(const sfe_icp_params &P, const
                     kth = bd[k];
             }
         };
-        while (true) {
-            const float2 tl = s_tgt[iL], tr = s_tgt[iR];
-            const float dxl = f_add(q.x, -tl.x), el = f_mul(dxl, dxl);
-            const float dyl = f_add(q.y, -tl.y), dl = f_add(el, f_mul(dyl, dyl));
-            const float dxr = f_add(q.x, -tr.x), er = f_mul(dxr, dxr);
-            const float dyr = f_add(q.y, -tr.y), dr = f_add(er, f_mul(dyr, dyr));
-            const bool okl = el <= kth, okr = er <= kth; // NaN sentinel -> false
-            if (!(okl || okr))
+        const int so = strip_of(q.y, tab.ylo, tab.inv_g, ns);
+        int s_up = so, s_dn = so - 1;
+        for (int guard = 0; guard < 2 * SW_NS_MAX + 2; ++guard) {
+            const int s = next_strip(tab, ns, so, s_up, s_dn, q.y, kth);
+            if (s < 0)
                 break;
-            if (okr)
-                consider(dr, iR);
-            if (okl)
-                consider(dl, iL);
-            iL -= okl ? 1 : 0;
-            iR += okr ? 1 : 0;
+            int iR = (s == so) ? c : strip_lower_bound_lane(s_tgt, tab.sbeg[s], tab.sbeg[s + 1] - 1, q.x);
+            int iL = iR - 1; // own strip: the point itself is the first right candidate
+            while (true) {
+                const float2 tl = s_tgt[iL], tr = s_tgt[iR];
+                const float dxl = f_add(q.x, -tl.x), el = f_mul(dxl, dxl);
+                const float dyl = f_add(q.y, -tl.y), dl = f_add(el, f_mul(dyl, dyl));
+                const float dxr = f_add(q.x, -tr.x), er = f_mul(dxr, dxr);
+                const float dyr = f_add(q.y, -tr.y), dr = f_add(er, f_mul(dyr, dyr));
+                const bool okl = el <= kth, okr = er <= kth; // NaN sentinel -> false
+                if (!(okl || okr))
+                    break;
+                if (okr)
+                    consider(dr, iR);
+                if (okl)
+                    consider(dl, iL);
+                iL -= okl ? 1 : 0;
+                iR += okr ? 1 : 0;
+            }
         }
         double sx = 0, sy = 0;
 #pragma unroll
@@ -225,7 +330,7 @@ __device__ __forceinline__ void sweep_knn_normals(const sfe_icp_params &P, const
             ty = 0;
             nn = 1;
         }
-        snrm[c] = make_float2((float)(-ty / nn), (float)(tx / nn));
+        snrm[c - 1] = make_float2((float)(-ty / nn), (float)(tx / nn));
     }
 }
 
@@ -250,9 +355,12 @@ __device__ __forceinline__ void bitonic_sort_global(unsigned long long *keys, un
     }
 }
 
-// Sorted-cloud scratch layout per target (stride n_tgt + 4 points): [0] NaN sentinel,
-// [1 .. n_tgt] centred points ascending in x, [n_tgt+1], [n_tgt+2] NaN sentinels.  perm / snrm
-// use the same stride, entry p-1 belongs to sorted position p.
+// sort key: strip (8 bits) | order key of x (32 bits) | original index (24 bits)
+#define SW_KEY(s, xk, i) (((unsigned long long)(unsigned)(s) << 56) | ((unsigned long long)(xk) << 24) | (unsigned long long)(i))
+#define SW_KEY_STRIP(k) ((int)((k) >> 56))
+#define SW_KEY_X(k) ((unsigned)(((k) >> 24) & 0xFFFFFFFFull))
+#define SW_KEY_ID(k) ((int)((k) & 0xFFFFFFull))
+
 __global__ __launch_bounds__(ICP_THREADS, 4) void icp_sweep_prep_kernel(sfe_icp_params P,
                                                                         const SweepPrep *__restrict__ preps,
                                                                         const float2 *__restrict__ tgt_all,
@@ -260,12 +368,13 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_sweep_prep_kernel(sfe_icp_
                                                                         int *__restrict__ perm_all,
                                                                         float2 *__restrict__ snrm_all,
                                                                         float *__restrict__ mean_all,
-                                                                        unsigned long long *__restrict__ gkeys_all)
+                                                                        unsigned long long *__restrict__ gkeys_all,
+                                                                        StripTab *__restrict__ tab_all)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     PrepShared &S = *reinterpret_cast<PrepShared *>(smem_raw);
     const SweepPrep J = preps[blockIdx.x];
-    const int nt = J.n_tgt, tid = threadIdx.x;
+    const int nt = J.n_tgt, ns = J.ns, tid = threadIdx.x, lane = threadIdx.x & 63;
     const float2 *__restrict__ tgt = tgt_all + J.tgt_start;
     float2 *__restrict__ stgt = stgt_all + J.off;
     int *__restrict__ perm = perm_all + J.off;
@@ -285,12 +394,59 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_sweep_prep_kernel(sfe_icp_
             S.mean[1] = (float)(m[1] / nt);
             mean_all[2 * blockIdx.x] = S.mean[0];
             mean_all[2 * blockIdx.x + 1] = S.mean[1];
+            S.ykey[0] = S.xkey[0] = 0xFFFFFFFFu;
+            S.ykey[1] = S.xkey[1] = 0u;
+        }
+        if (tid < SW_NS_MAX) {
+            S.cnt[tid] = 0;
+            S.smin_k[tid] = 0xFFFFFFFFu;
+            S.smax_k[tid] = 0u;
         }
         __syncthreads();
     }
     const float mx = S.mean[0], my = S.mean[1];
 
-    // sort (key(x - mean_x), index)
+    // extent of the finite centred coordinates -> strip geometry
+    {
+        float ylo = INFINITY, yhi = -INFINITY, xlo = INFINITY, xhi = -INFINITY;
+        for (int i = tid; i < nt; i += ICP_THREADS) {
+            const float2 t = tgt[i];
+            const float x = f_add(t.x, -mx), y = f_add(t.y, -my);
+            if (fabsf(y) < INFINITY) {
+                ylo = fminf(ylo, y);
+                yhi = fmaxf(yhi, y);
+            }
+            if (fabsf(x) < INFINITY) {
+                xlo = fminf(xlo, x);
+                xhi = fmaxf(xhi, x);
+            }
+        }
+        ylo = wave_min(ylo);
+        yhi = -wave_min(-yhi);
+        xlo = wave_min(xlo);
+        xhi = -wave_min(-xhi);
+        if (lane == 0) {
+            atomicMin(&S.ykey[0], mono_key(ylo));
+            atomicMax(&S.ykey[1], mono_key(yhi));
+            atomicMin(&S.xkey[0], mono_key(xlo));
+            atomicMax(&S.xkey[1], mono_key(xhi));
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const float y0 = mono_inv(S.ykey[0]), y1 = mono_inv(S.ykey[1]);
+            const float x0 = mono_inv(S.xkey[0]), x1 = mono_inv(S.xkey[1]);
+            S.tab.ns = ns;
+            S.tab.len = nt + ns + 1;
+            S.tab.ylo = (y1 >= y0) ? y0 : 0.0f; // no finite point: everything lands in strip 0
+            const float inv = (y1 > y0) ? (float)ns / f_add(y1, -y0) : 0.0f;
+            S.tab.inv_g = (inv < INFINITY) ? inv : 0.0f;
+            S.tab.ext_x = (x1 >= x0) ? f_add(x1, -x0) : 0.0f;
+        }
+        __syncthreads();
+    }
+    const float ylo = S.tab.ylo, inv_g = S.tab.inv_g;
+
+    // sort (strip, key(x - mean_x), index); strip population and y range on the way
     unsigned n2 = 2;
     while (n2 < (unsigned)nt)
         n2 <<= 1;
@@ -298,77 +454,118 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_sweep_prep_kernel(sfe_icp_
     unsigned long long *keys = in_lds ? S.buf : gkeys_all + J.key_off;
     for (unsigned i = tid; i < n2; i += ICP_THREADS) {
         unsigned long long k = ~0ull;
-        if (i < (unsigned)nt)
-            k = ((unsigned long long)mono_key(f_add(tgt[i].x, -mx)) << 32) | i;
+        if (i < (unsigned)nt) {
+            const float2 t = tgt[i];
+            const float x = f_add(t.x, -mx), y = f_add(t.y, -my);
+            const int s = strip_of(y, ylo, inv_g, ns);
+            k = SW_KEY(s, mono_key(x), i);
+            atomicAdd(&S.cnt[s], 1);
+            if (y == y) {
+                atomicMin(&S.smin_k[s], mono_key(y));
+                atomicMax(&S.smax_k[s], mono_key(y));
+            }
+        }
         keys[i] = k;
     }
     __syncthreads();
     if (tid == 0) {
-        stgt[0] = make_float2(qnan, qnan);
-        stgt[nt + 1] = make_float2(qnan, qnan);
-        stgt[nt + 2] = make_float2(qnan, qnan);
+        int pos = 1;
+        for (int s = 0; s < ns; ++s) {
+            S.tab.sbeg[s] = pos;
+            pos += S.cnt[s] + 1;
+        }
+        for (int s = ns; s <= SW_NS_MAX; ++s)
+            S.tab.sbeg[s] = pos;
+        float m = INFINITY;
+        for (int s = SW_NS_MAX - 1; s >= 0; --s) {
+            if (s < ns && S.smin_k[s] != 0xFFFFFFFFu)
+                m = fminf(m, mono_inv(S.smin_k[s]));
+            S.tab.smin[s] = m;
+        }
+        m = -INFINITY;
+        for (int s = 0; s < SW_NS_MAX; ++s) {
+            if (s < ns && S.smax_k[s] != 0u)
+                m = fmaxf(m, mono_inv(S.smax_k[s]));
+            S.tab.smax[s] = m;
+        }
     }
+    __syncthreads();
+    { // the table travels to HBM for the loop kernel
+        const int *src = reinterpret_cast<const int *>(&S.tab);
+        int *dst = reinterpret_cast<int *>(tab_all + blockIdx.x);
+        for (int i = tid; i < (int)(sizeof(StripTab) / sizeof(int)); i += ICP_THREADS)
+            dst[i] = src[i];
+    }
+    const int len = S.tab.len;
+    // sentinels of the HBM copy
+    for (int s = tid; s <= ns; s += ICP_THREADS)
+        stgt[s == 0 ? 0 : S.tab.sbeg[s] - 1] = make_float2(qnan, qnan);
+    if (tid < 2)
+        stgt[len + tid] = make_float2(qnan, qnan);
+
+    float2 *nrm = snrm_all ? snrm_all + J.off : nullptr;
     if (in_lds) {
         bitonic_sort_lds(S.buf, n2);
-        // keys -> sorted centred cloud (registers -> same LDS bytes, shifted by the left sentinel)
+        // keys -> sorted centred cloud (registers -> same LDS bytes, in the strip layout)
         constexpr int PER = SW_TCAP / ICP_THREADS;
         float2 v[PER];
-        int id[PER];
+        int id[PER], ps[PER];
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
-            const int pos = k * ICP_THREADS + tid;
+            const int r = k * ICP_THREADS + tid;
             v[k] = make_float2(0, 0);
             id[k] = 0;
-            if (pos < nt) {
-                const unsigned long long key = S.buf[pos];
-                id[k] = (int)(unsigned)(key & 0xFFFFFFFFu);
-                v[k] = make_float2(mono_inv((unsigned)(key >> 32)), f_add(tgt[id[k]].y, -my));
+            ps[k] = 0;
+            if (r < nt) {
+                const unsigned long long key = S.buf[r];
+                id[k] = SW_KEY_ID(key);
+                ps[k] = r + SW_KEY_STRIP(key) + 1;
+                v[k] = make_float2(mono_inv(SW_KEY_X(key)), f_add(tgt[id[k]].y, -my));
             }
         }
         __syncthreads();
         float2 *s_tgt = reinterpret_cast<float2 *>(S.buf);
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
-            const int pos = k * ICP_THREADS + tid;
-            if (pos < nt) {
-                s_tgt[pos + 1] = v[k];
-                stgt[pos + 1] = v[k];
-                perm[pos] = id[k];
+            if (k * ICP_THREADS + tid < nt) {
+                s_tgt[ps[k]] = v[k];
+                stgt[ps[k]] = v[k];
+                perm[ps[k] - 1] = id[k];
             }
         }
-        if (tid == 0) {
-            s_tgt[0] = make_float2(qnan, qnan);
-            s_tgt[nt + 1] = make_float2(qnan, qnan);
-        }
+        for (int s = tid; s <= ns; s += ICP_THREADS)
+            s_tgt[s == 0 ? 0 : S.tab.sbeg[s] - 1] = make_float2(qnan, qnan);
+        if (tid < 2)
+            s_tgt[len + tid] = make_float2(qnan, qnan);
         __syncthreads();
         if (P.minimizer == 1) {
             if (P.normals_knn <= 8)
-                sweep_knn_normals<8>(P, s_tgt, perm, snrm_all + J.off, nt);
+                sweep_knn_normals<8>(P, S.tab, s_tgt, perm, nrm, nt);
             else if (P.normals_knn <= 10)
-                sweep_knn_normals<10>(P, s_tgt, perm, snrm_all + J.off, nt);
+                sweep_knn_normals<10>(P, S.tab, s_tgt, perm, nrm, nt);
             else if (P.normals_knn <= 12)
-                sweep_knn_normals<12>(P, s_tgt, perm, snrm_all + J.off, nt);
+                sweep_knn_normals<12>(P, S.tab, s_tgt, perm, nrm, nt);
             else
-                sweep_knn_normals<ICP_KMAX>(P, s_tgt, perm, snrm_all + J.off, nt);
+                sweep_knn_normals<ICP_KMAX>(P, S.tab, s_tgt, perm, nrm, nt);
         }
     } else {
         bitonic_sort_global(keys, n2);
-        for (int pos = tid; pos < nt; pos += ICP_THREADS) {
-            const unsigned long long key = keys[pos];
-            const int id = (int)(unsigned)(key & 0xFFFFFFFFu);
-            stgt[pos + 1] = make_float2(mono_inv((unsigned)(key >> 32)), f_add(tgt[id].y, -my));
-            perm[pos] = id;
+        for (int r = tid; r < nt; r += ICP_THREADS) {
+            const unsigned long long key = keys[r];
+            const int id = SW_KEY_ID(key), pos = r + SW_KEY_STRIP(key) + 1;
+            stgt[pos] = make_float2(mono_inv(SW_KEY_X(key)), f_add(tgt[id].y, -my));
+            perm[pos - 1] = id;
         }
         __syncthreads();
         if (P.minimizer == 1) {
             if (P.normals_knn <= 8)
-                sweep_knn_normals<8>(P, stgt, perm, snrm_all + J.off, nt);
+                sweep_knn_normals<8>(P, S.tab, stgt, perm, nrm, nt);
             else if (P.normals_knn <= 10)
-                sweep_knn_normals<10>(P, stgt, perm, snrm_all + J.off, nt);
+                sweep_knn_normals<10>(P, S.tab, stgt, perm, nrm, nt);
             else if (P.normals_knn <= 12)
-                sweep_knn_normals<12>(P, stgt, perm, snrm_all + J.off, nt);
+                sweep_knn_normals<12>(P, S.tab, stgt, perm, nrm, nt);
             else
-                sweep_knn_normals<ICP_KMAX>(P, stgt, perm, snrm_all + J.off, nt);
+                sweep_knn_normals<ICP_KMAX>(P, S.tab, stgt, perm, nrm, nt);
         }
     }
 }
@@ -380,15 +577,16 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_sweep_prep_kernel(sfe_icp_
 // limit (and <= MaxDist^2).  A search is therefore exhaustive only out to a cap C (squared
 // radius), and merely keeps going until it has seen SOME target within KDTreeMatcher.maxDist so
 // that the count of finite matches is exact.  A query ends as
-//   none    : no target within maxDist (exact: its whole maxDist window was walked)
-//   exact   : best <= C, every candidate with fl(dx*dx) <= best was evaluated
-//   inexact : finite, C < d2_NN <= best            (its walk is suspended, state kept)
+//   none    : no target within maxDist (exact: its whole maxDist window was searched)
+//   exact   : best <= C, every candidate that could beat or tie `best` was evaluated
+//   inexact : finite, C < d2_NN <= best            (suspended: best and its position are kept)
 // If the exact set holds more than k = floor(n_finite * ratio) values, the k-th smallest of them
 // IS the k-th smallest of all (everything else is > C), the limit is exact and so are all
-// weight-1 pairs.  Otherwise C grows 4x and the suspended walks resume where they stopped.  C
-// starts from the previous iteration's limit, so far outliers cost a handful of steps instead of
-// a walk across the whole cloud.  Decisions and results are identical to the exhaustive search.
-// control block of a job; the LDS-resident variant places the sorted target right behind it
+// weight-1 pairs.  Otherwise C grows 4x and the suspended queries search again (from scratch, but
+// bounded by the best they already hold; a candidate is never mistaken for a tie with itself because
+// the position of the current best is excluded).  C starts from the previous iteration's limit, so far
+// outliers cost a handful of steps.  Decisions and results are identical to the exhaustive search.
+//
 // wave-uniform float held in an SGPR instead of one VGPR per lane (the loop kernel runs at the
 // 64-VGPR budget: every uniform value kept out of the vector file is one spill less)
 __device__ __forceinline__ float sw_uniform(float v)
@@ -403,6 +601,7 @@ __device__ __forceinline__ long long sw_uniform_ll(long long v)
     return (long long)(((unsigned long long)hi << 32) | lo);
 }
 
+// control block of a job; the LDS-resident variant places the sorted target right behind it
 struct SweepShared {
     double red[ICP_WAVES * 10 + 10];
     double acc[10];  // the reduced error-minimiser sums (read by the solving lane)
@@ -413,6 +612,7 @@ struct SweepShared {
     float Ti[9];
     float hist_c[ICP_MAX_HIST], hist_s[ICP_MAX_HIST], hist_x[ICP_MAX_HIST], hist_y[ICP_MAX_HIST];
     long long prof_t, prof[16], prof_it[64], prof_b0;
+    StripTab tab;
 };
 
 #define SW_PROF(k)                                                                               \
@@ -432,68 +632,57 @@ struct SweepShared {
         break;                                                                                   \
     }
 #define SW_NQ 8         // results fetched per lane and batch in the census / quantile / reduction loops
-#define SW_BUDGET_A 8   // first-pass trips per walk (4 candidates each)
-#define SW_BUDGET 24    // tier-1 trips (4 candidates each) before a walk is handed to the cooperative tier
+#define SW_BUDGET_A 6   // first pass (own strip): walk trips (4 candidates each) before a query is handed on
+#define SW_BUDGET 256   // second pass (all strips): trips + strips before a query is handed to the cooperative tier
+#define SW_ROUND_TRIPS 4 // second pass: walk trips between two chances to move on to the next strip
 #define SW_NONE (-1)
-// a suspended (inexact) query is stored as pos = -2 - bpos (<= -3): the target it holds doubles as the
-// next iteration's witness
+// an unfinished / suspended (inexact) query is stored as pos = -2 - bpos (<= -2; bpos = 0: nothing met
+// yet): the target it holds bounds its next search and doubles as the next iteration's witness
 #define SW_INEXACT_OF(bpos) (-2 - (bpos))
+#define SW_OWN_DONE 0x80000000u // list entry flags of queries handed from the first to the second pass:
+#define SW_TIED 0x40000000u     // own strip finished / a tie with the current best was seen there
+#define SW_QMASK 0x3FFFFFFFu
 
 struct SweepQ { // per-job views of the per-query scratch
     float2 *xy;   // transformed query
-    int4 *st;     // suspended walk: x = iL, y = iR, z = bpos | tied << 31; a `none` query keeps its
-                  // clearance record here instead: (px, py, clearance) as float bits
+    int4 *st;     // clearance record of a `none` query: (px, py, clearance) as float bits
     float *d2;    // best so far / final d2
-    int *pos;     // >= 0 sorted position of the NN, SW_NONE, <= -3 inexact (SW_INEXACT_OF)
+    int *pos;     // >= 0 sorted position - 1 of the NN, SW_NONE, <= -2 inexact (SW_INEXACT_OF)
     int *wl[2];   // work lists of suspended queries (ping-pong between rounds)
-    int *mid;     // walks that outlived the short first pass (compacted for the second)
-    int4 *longe;  // walks handed to the cooperative tier this round: (q, iL, iR, bpos|tied), (px, py, best, -)
+    int *mid;     // queries that outlived the first pass (compacted for the second)
+    int *lng;     // queries handed to the cooperative tier this round
+    int *order;   // all queries, neighbours in space next to each other (see the sort at the kernel start)
+    float2 *ssrc; // their source points in that order
     const int *perm;
-    int nt;
 };
 
 // ties at the final best: lowest original index among the points at distance `best`, found by
-// walking the final window once more (rare)
-__device__ __forceinline__ int sweep_resolve_tie(const float2 *__restrict__ s_tgt, const SweepQ &Q, float px,
-                                                 float py, float best, int iL, int iR)
+// searching the final window once more (rare)
+__device__ __forceinline__ int sweep_resolve_tie(const float2 *__restrict__ T, const StripTab &tab, const SweepQ &Q,
+                                                 float px, float py, float best)
 {
-    // the walk window is bounded by the suspended cursors: everything with e <= best lies inside
     int bo = 0x7FFFFFFF, bp = 0;
-    int lo = 1, hi = Q.nt + 1; // first position with x >= px
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (s_tgt[mid].x < px)
-            lo = mid + 1;
-        else
-            hi = mid;
-    }
-    (void)iL;
-    (void)iR;
-    for (int j = lo - 1; j >= 1; --j) {
-        const float2 t = s_tgt[j];
-        const float dx = f_add(px, -t.x), e = f_mul(dx, dx);
-        if (!(e <= best))
+    const int ns = tab.ns, so = strip_of(py, tab.ylo, tab.inv_g, ns);
+    int s_up = so, s_dn = so - 1;
+    for (int guard = 0; guard < 2 * SW_NS_MAX + 2; ++guard) {
+        const int s = next_strip(tab, ns, so, s_up, s_dn, py, best);
+        if (s < 0)
             break;
-        const float dy = f_add(py, -t.y);
-        if (f_add(e, f_mul(dy, dy)) == best) {
-            const int o = Q.perm[j - 1];
-            if (o < bo) {
-                bo = o;
-                bp = j;
-            }
-        }
-    }
-    for (int j = lo; j <= Q.nt; ++j) {
-        const float2 t = s_tgt[j];
-        const float dx = f_add(px, -t.x), e = f_mul(dx, dx);
-        if (!(e <= best))
-            break;
-        const float dy = f_add(py, -t.y);
-        if (f_add(e, f_mul(dy, dy)) == best) {
-            const int o = Q.perm[j - 1];
-            if (o < bo) {
-                bo = o;
-                bp = j;
+        const int lo = strip_lower_bound_lane(T, tab.sbeg[s], tab.sbeg[s + 1] - 1, px);
+        for (int dir = 0; dir < 2; ++dir) {
+            for (int j = dir ? lo : lo - 1;; j += dir ? 1 : -1) { // the strip's NaN sentinels end both walks
+                const float2 t = T[j];
+                const float dx = f_add(px, -t.x), e = f_mul(dx, dx);
+                if (!(e <= best))
+                    break;
+                const float dy = f_add(py, -t.y);
+                if (f_add(e, f_mul(dy, dy)) == best) {
+                    const int o = Q.perm[j - 1];
+                    if (o < bo) {
+                        bo = o;
+                        bp = j;
+                    }
+                }
             }
         }
     }
@@ -506,8 +695,9 @@ template <int MINW, bool LDS_TGT>
 __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
     sfe_icp_params P, const SweepJob *__restrict__ jobs, const int *__restrict__ job_ids, const float2 *__restrict__ src_all,
     const float *__restrict__ guess_all, const float2 *__restrict__ stgt_all, const int *__restrict__ perm_all,
-    const float2 *__restrict__ snrm_all, const float *__restrict__ mean_all, float2 *__restrict__ q_xy_all,
-    int4 *__restrict__ q_st_all, int *__restrict__ q_wl_all, int4 *__restrict__ q_long_all, float *__restrict__ nn_d2_all,
+    const float2 *__restrict__ snrm_all, const float *__restrict__ mean_all, const StripTab *__restrict__ tab_all,
+    float2 *__restrict__ q_xy_all, int4 *__restrict__ q_st_all, int *__restrict__ q_wl_all, float2 *__restrict__ q_ssrc_all,
+    float *__restrict__ nn_d2_all,
     int *__restrict__ nn_pos_all, float *__restrict__ T_out, int *__restrict__ status_out,
     int *__restrict__ iters_out, long long *prof, int *dbg, int sw_budget, int sw_budget_a, int sw_cache)
 {
@@ -534,12 +724,13 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
     Q.st = q_st_all + J.q_off;
     Q.d2 = nn_d2_all + J.q_off;
     Q.pos = nn_pos_all + J.q_off;
-    Q.wl[0] = q_wl_all + 3 * J.q_off;
+    Q.wl[0] = q_wl_all + 5 * J.q_off;
     Q.wl[1] = Q.wl[0] + ns;
     Q.mid = Q.wl[1] + ns;
-    Q.longe = q_long_all + 2 * J.q_off;
+    Q.lng = Q.mid + ns;
+    Q.order = Q.lng + ns;
+    Q.ssrc = q_ssrc_all + J.q_off;
     Q.perm = perm_all + J.tgt_off;
-    Q.nt = nt;
     const float *guess = guess_all + 9 * (size_t)jb;
     const int tid = threadIdx.x, lane = threadIdx.x & 63;
     const float mx = sw_uniform(mean_all[2 * J.prep]), my = sw_uniform(mean_all[2 * J.prep + 1]);
@@ -549,10 +740,11 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
             S.prof[i] = 0;
         S.prof_t = clock64();
     }
-    // sorted centred target (with its NaN sentinels: a NaN stops a walk direction) -> LDS
-    if (LDS_TGT) {
-        for (int i = tid; i < nt + 3; i += ICP_THREADS)
-            lds_tgt[i] = stgt[i];
+    { // strip table -> LDS
+        const int *tsrc = reinterpret_cast<const int *>(tab_all + J.prep);
+        int *tdst = reinterpret_cast<int *>(&S.tab);
+        for (int i = tid; i < (int)(sizeof(StripTab) / sizeof(int)); i += ICP_THREADS)
+            tdst[i] = tsrc[i];
     }
 
     // ---- T0 = T_refIn_refMean^-1 * guess ; T_iter = I ----
@@ -568,6 +760,46 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
         for (int i = 0; i < 9; ++i)
             T0[i] = sw_uniform(T0[i]);
     }
+    __syncthreads(); // strip table in place
+
+    // ---- processing order of the queries: sorted by (strip, x) of their position under the guess, so that
+    // the 64 lanes of a wave search for neighbours in space: same strips, windows of similar length, same LDS
+    // lines -- the lockstep rounds below lose little to their slowest lane.  (A cloud in arbitrary order puts
+    // a wall point next to an outlier in the same wave.)  The order only steers which lane searches for which
+    // query: results are stored under the query's own index, and the sums of the error minimiser run in the
+    // original order.  Sorted once per job, in the LDS that will hold the target (chunks of 8192). ----
+    {
+        unsigned long long *skeys = reinterpret_cast<unsigned long long *>(lds_tgt);
+        for (int c0 = 0; c0 < ns; c0 += SW_TCAP) {
+            const int n = min(SW_TCAP, ns - c0);
+            unsigned n2 = 2;
+            while (n2 < (unsigned)n)
+                n2 <<= 1;
+            for (unsigned i = tid; i < n2; i += ICP_THREADS) {
+                unsigned long long k = ~0ull;
+                if (i < (unsigned)n) {
+                    const float2 sp = src[c0 + i];
+                    const float rx = affine1(T0[0], T0[1], T0[2], sp.x, sp.y);
+                    const float ry = affine1(T0[3], T0[4], T0[5], sp.x, sp.y);
+                    k = SW_KEY(strip_of(ry, S.tab.ylo, S.tab.inv_g, S.tab.ns), mono_key(rx), c0 + i);
+                }
+                skeys[i] = k;
+            }
+            __syncthreads();
+            bitonic_sort_lds(skeys, n2);
+            for (int i = tid; i < n; i += ICP_THREADS) {
+                const int q = SW_KEY_ID(skeys[i]);
+                Q.order[c0 + i] = q;
+                Q.ssrc[c0 + i] = src[q];
+            }
+            __syncthreads();
+        }
+    }
+    // sorted centred target (with its NaN sentinels: a NaN stops a walk direction) -> LDS
+    if (LDS_TGT) {
+        for (int i = tid; i < nt + SW_PAD; i += ICP_THREADS)
+            lds_tgt[i] = stgt[i];
+    }
     IcpCheck chk = {S.hist_c, S.hist_s, S.hist_x, S.hist_y, 1, 0, 0};
     if (tid == 0) {
         const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -581,14 +813,17 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
         S.hist_y[0] = 0.0f;
     }
     __syncthreads();
+    const StripTab &tab = S.tab;
+    const int nst = __builtin_amdgcn_readfirstlane(tab.ns);
+    const float ylo = sw_uniform(tab.ylo), inv_g = sw_uniform(tab.inv_g);
 
     const float r2_match = sw_uniform(f_mul(P.matcher_max_dist, P.matcher_max_dist));
     const float r2_filter = sw_uniform(f_mul(P.max_dist_filter, P.max_dist_filter));
-    // A walk that has not met a target within maxDist yet is bounded by `best`, which starts at W2 = a
+    // A search that has not met a target within maxDist yet is bounded by `best`, which starts at W2 = a
     // little MORE than maxDist^2 (found <=> best < r2m_up <=> best <= maxDist^2; with an unbounded
     // matcher: best finite): a query that ends `none` then knows its
     // nearest target is at least sqrt(best) > maxDist away, and that margin lets later iterations prove
-    // "still none" from how far the query has moved instead of walking its whole maxDist window again.
+    // "still none" from how far the query has moved instead of searching its whole maxDist window again.
     const float r2m_up = sw_uniform((r2_match < INFINITY) ? __uint_as_float(__float_as_uint(r2_match) + 1u) : INFINITY);
     const float W2 = sw_uniform(fmaxf(r2m_up, f_mul(r2_match, 1.1025f)));
     const float md_hi = sw_uniform(f_mul(P.matcher_max_dist, 1.00001f));
@@ -596,8 +831,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
     const float Cmax = P.use_max_dist_filter ? fminf(r2_filter, r2_match) : r2_match;
     float Cinit;
     {
-        const float ext = f_add(T[nt].x, -T[1].x); // x extent of the sorted target
-        const float h = 8.0f * ext / (float)nt;
+        const float h = 8.0f * tab.ext_x / (float)nt; // a few point spacings of a cloud spread along x
         Cinit = h * h;
         if (!(Cinit > 1e-30f) || !(Cinit < Cmax))
             Cinit = Cmax;
@@ -606,6 +840,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
     float Cnext = P.use_trimmed_filter ? Cinit : Cmax; // cap the next iteration starts with
     SW_PROF(0);
 
+    const int sw_rtrips = (sw_cache >> 8) & 255;
     int wd_outer = 0;
     bool use_cache = false; // from the second iteration on: Q.pos / Q.st hold the previous iteration's results
     while (true) {
@@ -615,11 +850,9 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
         for (int i = 0; i < 9; ++i)
             Ti[i] = sw_uniform(S.Ti[i]);
 
-        // ---- A+B: cur = Ti * (T0 * src); exact NN for every pair that can matter.  Round 0 walks
-        // every query (lane i handles queries i, i + 1024, ...: transform, lower bound of cur.x in the
-        // sorted x, two-sided walk of at most `sw_budget` trips), later rounds resume the suspended
-        // walks with a 4x larger cap.  Walks that exhaust their budget are finished by an exhaustive
-        // scan (tier 2), which yields their true neighbour. ----
+        // ---- A+B: cur = Ti * (T0 * src); exact NN for every pair that can matter.  Round 0 searches
+        // for every query (lane i handles queries i, i + 1024, ...), later rounds search again for the
+        // suspended ones with a 4x larger cap. ----
         if (prof != nullptr && tid == 0)
             S.prof_b0 = clock64();
         float C = Cnext;
@@ -642,34 +875,38 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                 __syncthreads();
                 const int *wl = Q.wl[cur];
                 int *wl_next = Q.wl[cur ^ 1];
-                // -- tier 1: one lane per query, two passes.  Pass A gives every walk a short budget (most
-                // finish: the typical window holds ~20 candidates); the rest is COMPACTED into dense
-                // waves for pass B with the long budget, so lanes that finished early do not sit idle
-                // through the long walks of their neighbours.  What still runs on goes to tier 2. --
+                // -- tier 1: one lane per query.  The first pass (fresh queries only) transforms the query,
+                // evaluates last iteration's neighbour as a witness and walks the query's OWN strip with a
+                // short budget: on converged clouds that settles ~85 % of the queries.  Whoever needs more
+                // strips or more trips is COMPACTED into dense waves for the second pass, which goes through
+                // all strips in lockstep rounds (pick a strip -> lower bound -> walk), so lanes that finished
+                // early do not sit idle through the long searches of their neighbours.  What exhausts the
+                // second budget too goes to tier 2. --
                 auto walk_pass = [&](const int *list, int n, bool fresh, int budget, bool last) {
                 float2 sp_next = make_float2(0, 0); // fresh pass: the next slice's source point is fetched a slice ahead
-                int prev_next = 0;                  // ... and so is last iteration's result of that query
+                int q_next = 0;                     // ... and so is its index
                 if (fresh && tid < n) {
-                    sp_next = src[tid];
-                    if (use_cache)
-                        prev_next = Q.pos[tid];
+                    sp_next = Q.ssrc[tid];
+                    q_next = Q.order[tid];
                 }
                 for (int k0 = 0; k0 < n; k0 += ICP_THREADS) {
                     const int slot = k0 + tid;
                     const bool valid = slot < n;
                     const float2 sp_cur = sp_next;
-                    const int prev = prev_next;
+                    const int q_cur = q_next;
+                    int prev = 0;
+                    if (fresh && use_cache && valid)
+                        prev = Q.pos[q_cur]; // last iteration's result of this query (used after the transform)
                     if (fresh && slot + ICP_THREADS < n) {
-                        sp_next = src[slot + ICP_THREADS];
-                        if (use_cache)
-                            prev_next = Q.pos[slot + ICP_THREADS];
+                        sp_next = Q.ssrc[slot + ICP_THREADS];
+                        q_next = Q.order[slot + ICP_THREADS];
                     }
-                    int q = 0, iL = 0, iR = 0, bpos = 0;
+                    int q = 0, bpos = 0;
                     float px = 0, py = 0, best = W2;
-                    bool tied = false;
+                    bool tied = false, own_done = false;
                     if (valid) {
                         if (fresh) {
-                            q = slot;
+                            q = q_cur;
                             const float2 sp = sp_cur;
                             const float rx = affine1(T0[0], T0[1], T0[2], sp.x, sp.y);
                             const float ry = affine1(T0[3], T0[4], T0[5], sp.x, sp.y);
@@ -677,36 +914,20 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                             py = affine1(Ti[3], Ti[4], Ti[5], rx, ry);
                             Q.xy[q] = make_float2(px, py);
                         } else {
-                            q = list[slot];
+                            const unsigned e = (unsigned)list[slot];
+                            q = (int)(e & SW_QMASK);
+                            own_done = (e & SW_OWN_DONE) != 0;
+                            tied = (e & SW_TIED) != 0;
                             const float2 p = Q.xy[q];
-                            const int4 st = Q.st[q];
                             px = p.x;
                             py = p.y;
-                            iL = st.x;
-                            iR = st.y;
-                            bpos = st.z & 0x7FFFFFFF;
-                            tied = st.z < 0;
+                            bpos = -2 - Q.pos[q];
                             best = Q.d2[q];
                         }
                     }
-                    if (fresh) { // first 1-based position whose x is not < px (convergent: 14 trips)
-                        int lo = 1, hi = nt + 1;
-                        while (__ballot(lo < hi)) {
-                            const int mid = (lo + hi) >> 1;
-                            const bool lt = T[min(mid, nt + 1)].x < px;
-                            if (lo < hi) {
-                                if (lt)
-                                    lo = mid + 1;
-                                else
-                                    hi = mid;
-                            }
-                        }
-                        iR = lo;
-                        iL = lo - 1;
-                    }
                     // What the previous iteration knew about this query (the cloud moves little between
                     // iterations).  Its neighbour -- exact or not -- is evaluated first as a WITNESS: a real
-                    // target at distance dw, so the walk is "found" at once and bounded by min(dw, C)
+                    // target at distance dw, so the search is "found" at once and bounded by min(dw, C)
                     // instead of running on until it meets some target within maxDist.  The witness counts
                     // as evaluated; the walk skips it when the cursors reach it (`!= bpos` below).
                     // A `none` query stays none as long as it has moved less than its recorded clearance:
@@ -727,65 +948,111 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                             const int4 r = Q.st[q];
                             const float mx0 = f_add(px, -__int_as_float(r.x)), my0 = f_add(py, -__int_as_float(r.y));
                             const float mv = sqrtf(f_add(f_mul(mx0, mx0), f_mul(my0, my0)));
-                            skip = f_mul(mv, 1.00001f) < __int_as_float(r.z); // NaN -> walk
+                            skip = f_mul(mv, 1.00001f) < __int_as_float(r.z); // NaN -> search
                         }
                     }
-                    bool fin = !valid || skip;
-                    for (int trip = 0; trip < budget; ++trip) {
-                        if (!fin) {
-#pragma unroll
-                            for (int s2 = 0; s2 < 2; ++s2) {
-                                const float2 tl = T[iL], tr = T[iR];
-                                const float dxl = f_add(px, -tl.x), el = f_mul(dxl, dxl);
-                                const float dyl = f_add(py, -tl.y), dl = f_add(el, f_mul(dyl, dyl));
-                                const float dxr = f_add(px, -tr.x), er = f_mul(dxr, dxr);
-                                const float dyr = f_add(py, -tr.y), dr = f_add(er, f_mul(dyr, dyr));
-                                const float capv = (best < r2m_up) ? C : best; // nothing within maxDist yet: only `best` bounds the walk
-                                const float sb = best < capv ? best : capv;    // stop bound (no NaNs here: plain select)
-                                const bool okl = el <= sb, okr = er <= sb;    // NaN sentinel -> false
-                                // only consumed candidates (cursor moves past them) may update the state:
-                                // nothing is ever evaluated twice, so `tied` flags real ties only
-                                tied |= okl && (dl == best) && (iL != bpos);
-                                if (okl && dl < best) {
-                                    best = dl;
-                                    bpos = iL;
-                                }
-                                tied |= okr && (dr == best) && (iR != bpos);
-                                if (okr && dr < best) {
-                                    best = dr;
-                                    bpos = iR;
-                                }
-                                iL -= okl ? 1 : 0;
-                                iR += okr ? 1 : 0;
-                                fin = !(okl || okr);
+                    const int so = strip_of(py, ylo, inv_g, nst);
+                    int s_up = own_done ? so + 1 : so, s_dn = so - 1;
+                    // a query with a NaN coordinate has no neighbour (every d2 is NaN): nothing to visit
+                    bool lane_done = !valid || skip || !(px == px && py == py);
+                    bool pending = false; // holds a strip it could not start or finish within the budget
+                    bool own_fin = own_done;
+                    int used = 0;
+                    auto pick = [&]() { // the lane's next strip, -1 (and lane_done) when nothing is left within its bound
+                        int s = -1;
+                        if (!lane_done) {
+                            const float capv = (best < r2m_up) ? C : best; // nothing within maxDist yet: only `best` bounds the search
+                            const float sb = best < capv ? best : capv;
+                            s = next_strip(tab, nst, so, s_up, s_dn, py, sb);
+                            lane_done = s < 0;
+                        }
+                        return s;
+                    };
+                    // Rounds: lanes that are between strips pick their next one and find their x position in it
+                    // (lower bound), then everybody walks for at most `rtrips` trips; a lane that is not through
+                    // its strip by then simply keeps walking in the next round while its neighbours move on to
+                    // their next strips -- the wave pays for its slowest LANE (sum over that lane's strips), not
+                    // for the slowest lane of every round.
+                    const int rtrips = fresh ? budget : sw_rtrips;
+                    int s = pick();
+                    int iL = 0, iR = 0;
+                    bool fin = true; // not inside a strip
+                    for (int rnd = 0; rnd < 4096; ++rnd) {
+                        if (!__ballot(s >= 0))
+                            break;
+                        if ((fresh && rnd >= 1) || used >= budget) { // out of budget: whoever still holds a strip is handed on
+                            pending = s >= 0;
+                            break;
+                        }
+                        ++used;
+                        const bool start = fin && s >= 0;
+                        if (__ballot(start)) {
+                            const int lo = strip_lower_bound(T, start ? tab.sbeg[s] : 0, start ? tab.sbeg[s + 1] - 1 : 0, px);
+                            if (start) {
+                                iR = lo;
+                                iL = lo - 1;
+                                fin = false;
                             }
                         }
-                        if (!__ballot(!fin))
-                            break;
+                        for (int trip = 0; trip < rtrips && __ballot(!fin); ++trip) {
+                            ++used;
+                            if (!fin) {
+#pragma unroll
+                                for (int s2 = 0; s2 < 2; ++s2) {
+                                    const float2 tl = T[iL], tr = T[iR];
+                                    const float dxl = f_add(px, -tl.x), el = f_mul(dxl, dxl);
+                                    const float dyl = f_add(py, -tl.y), dl = f_add(el, f_mul(dyl, dyl));
+                                    const float dxr = f_add(px, -tr.x), er = f_mul(dxr, dxr);
+                                    const float dyr = f_add(py, -tr.y), dr = f_add(er, f_mul(dyr, dyr));
+                                    const float capv = (best < r2m_up) ? C : best;
+                                    const float sb = best < capv ? best : capv;   // stop bound (no NaNs here: plain select)
+                                    const bool okl = el <= sb, okr = er <= sb;   // NaN sentinel -> false
+                                    // a candidate at the position of the current best is the best itself (a witness,
+                                    // or a point met again by a search that started over): never a tie
+                                    tied |= okl && (dl == best) && (iL != bpos);
+                                    if (okl && dl < best) {
+                                        best = dl;
+                                        bpos = iL;
+                                    }
+                                    tied |= okr && (dr == best) && (iR != bpos);
+                                    if (okr && dr < best) {
+                                        best = dr;
+                                        bpos = iR;
+                                    }
+                                    iL -= okl ? 1 : 0;
+                                    iR += okr ? 1 : 0;
+                                    fin = !(okl || okr);
+                                }
+                            }
+                        }
+                        if (fin && s >= 0) { // through this strip: the next one, or done
+                            own_fin |= s == so;
+                            s = pick();
+                        }
                     }
-                    // classify: none / exact / suspended (inexact) / long (budget exhausted)
-                    const bool is_long = valid && !fin;
+                    // classify: none / exact / suspended (inexact) / unfinished (handed to the next tier)
+                    const bool is_long = valid && pending;
+                    const bool settled = valid && !is_long;
                     const bool found = best < r2m_up; // <=> some target with d2 <= maxDist^2 was met (best starts at W2 >= r2m_up)
-                    const bool is_none = valid && fin && !found;
-                    const bool is_exact = valid && fin && found && best <= C;
-                    const bool is_susp = valid && fin && found && !(best <= C);
+                    const bool is_none = settled && !found;
+                    const bool is_exact = settled && found && best <= C;
+                    const bool is_susp = settled && found && !(best <= C);
                     if (is_none) {
                         Q.d2[q] = INFINITY;
                         Q.pos[q] = SW_NONE;
-                        if (!skip) // a full walk: every target is at least sqrt(best) away from (px, py)
+                        if (!skip) // a full search: every target is at least sqrt(best) away from (px, py)
                             Q.st[q] = make_int4(__float_as_int(px), __float_as_int(py),
                                                 __float_as_int(f_add(f_mul(sqrtf(best), 0.99999f), -md_hi)), 0);
                     }
                     if (is_exact) {
                         if (tied)
-                            bpos = sweep_resolve_tie(T, Q, px, py, best, iL, iR);
+                            bpos = sweep_resolve_tie(T, tab, Q, px, py, best);
                         Q.d2[q] = best;
                         Q.pos[q] = bpos - 1;
                     }
-                    if (is_susp) {
+                    if (is_susp || is_long) {
                         Q.d2[q] = best;
                         Q.pos[q] = SW_INEXACT_OF(bpos);
-                        Q.st[q] = make_int4(iL, iR, bpos | (tied ? (int)0x80000000 : 0), 0);
                     }
                     { // wave-aggregated appends
                         const unsigned long long ms = __ballot(is_susp), ml = __ballot(is_long);
@@ -798,51 +1065,44 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                             if (is_susp)
                                 wl_next[base + __popcll(ms & below)] = q;
                         }
-                        if (ml && last) {
+                        if (ml) {
                             int base = 0;
                             if (lane == 0)
-                                base = atomicAdd(&S.long_n, __popcll(ml));
+                                base = atomicAdd(last ? &S.long_n : &S.mid_n, __popcll(ml));
                             base = __builtin_amdgcn_readfirstlane(base);
                             if (is_long) {
-                                const int e = base + __popcll(ml & below);
-                                Q.longe[2 * e] = make_int4(q, iL, iR, bpos | (tied ? (int)0x80000000 : 0));
-                                Q.longe[2 * e + 1] = make_int4(__float_as_int(px), __float_as_int(py),
-                                                               __float_as_int(best), 0);
-                            }
-                        }
-                        if (ml && !last) {
-                            int base = 0;
-                            if (lane == 0)
-                                base = atomicAdd(&S.mid_n, __popcll(ml));
-                            base = __builtin_amdgcn_readfirstlane(base);
-                            if (is_long) {
-                                Q.d2[q] = best;
-                                Q.st[q] = make_int4(iL, iR, bpos | (tied ? (int)0x80000000 : 0), 0);
-                                Q.mid[base + __popcll(ml & below)] = q;
+                                // the own strip may be skipped by the next pass only if it was finished here
+                                // (everything in it within the then larger bound has been evaluated)
+                                const unsigned e = (unsigned)q | (own_fin ? SW_OWN_DONE : 0u) | (tied ? SW_TIED : 0u);
+                                (last ? Q.lng : Q.mid)[base + __popcll(ml & below)] = (int)e;
                             }
                         }
                     }
                 }
                 };
-                walk_pass(wl, nwork, round == 0, sw_budget_a, false);
-                __syncthreads();
-                walk_pass(Q.mid, S.mid_n, false, sw_budget, true);
+                if (round == 0) {
+                    walk_pass(wl, nwork, true, sw_budget_a, false);
+                    __syncthreads();
+                    SW_PROF(1);
+                    if (prof != nullptr && tid == 0)
+                        S.prof[11] += S.mid_n;
+                    walk_pass(Q.mid, S.mid_n, false, sw_budget, true);
+                } else {
+                    walk_pass(wl, nwork, false, sw_budget, true);
+                }
                 __syncthreads();
                 SW_PROF(6);
                 const int nlong = S.long_n;
                 if (prof != nullptr && tid == 0) {
                     S.prof[9] += 1;
                     S.prof[10] += nlong;
-                    S.prof[11] += nwork;
                 }
-                // -- tier 2: one wave per long walk, 32 candidates per side and trip; the walk's state
-                // travels in the list entry and the next entry is fetched while this one is walked --
+                // -- tier 2: one wave per long search, from scratch but bounded by the best it holds: strip
+                // by strip (wave-uniform control flow), 64-ary lower bound, then 128 candidates per side and
+                // trip; the next query is fetched while this one is searched --
                 if (nlong > 0) {
-                    const int wave = tid >> 6;
                     const bool left = lane < 32;
-                    // walks are handed out dynamically (their lengths differ by orders of magnitude): the first
-                    // ICP_WAVES slots are the waves' own, further ones come from the LDS counter
-                    (void)wave;
+                    // queries are handed out dynamically (their lengths differ by orders of magnitude)
                     auto next_slot = [&]() {
                         int v = 0;
                         if (lane == 0)
@@ -850,83 +1110,130 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                         return __builtin_amdgcn_readfirstlane(v);
                     };
                     int slot = next_slot();
-                    int4 e0 = make_int4(0, 0, 0, 0), e1 = make_int4(0, 0, 0, 0);
-                    if (slot < nlong) {
-                        e0 = Q.longe[2 * slot];
-                        e1 = Q.longe[2 * slot + 1];
-                    }
+                    int qn = 0, posn = 0;
+                    float2 pn = make_float2(0, 0);
+                    float bn = 0;
+                    auto fetch = [&](int sl) {
+                        qn = (int)((unsigned)Q.lng[sl] & SW_QMASK);
+                        pn = Q.xy[qn];
+                        bn = Q.d2[qn];
+                        posn = Q.pos[qn];
+                    };
+                    if (slot < nlong)
+                        fetch(slot);
+                    int wd2 = 0;
                     while (slot < nlong) {
+                        SW_WATCH(wd2, ns + 2, 5)
                         long long tp0 = 0;
                         if (prof != nullptr && tid == 0)
                             tp0 = clock64();
-                        const int q = e0.x;
-                        int iL = e0.y, iR = e0.z, bpos = e0.w & 0x7FFFFFFF;
-                        bool tied = e0.w < 0;
-                        const float px = __int_as_float(e1.x), py = __int_as_float(e1.y);
-                        float best = __int_as_float(e1.z);
+                        const int q = __builtin_amdgcn_readfirstlane(qn);
+                        const float px = sw_uniform(pn.x), py = sw_uniform(pn.y);
+                        float best = sw_uniform(bn);
+                        int bpos = -2 - __builtin_amdgcn_readfirstlane(posn);
+                        bool tied = false;
                         slot = next_slot();
-                        if (slot < nlong) { // prefetch the next walk
-                            e0 = Q.longe[2 * slot];
-                            e1 = Q.longe[2 * slot + 1];
-                        }
+                        if (slot < nlong) // prefetch the next query
+                            fetch(slot);
                         if (prof != nullptr && tid == 0) {
                             const long long t_ = clock64();
                             S.prof[13] += t_ - tp0;
                             tp0 = t_;
                         }
-                        bool doneL = false, doneR = false;
                         constexpr int U = 4; // candidates per lane and trip: four independent LDS reads in flight
-                        const int lo = left ? lane : lane - 32;
-                        for (int guard = 0; guard <= nt / (32 * U) + 2; ++guard) { // bounded by construction
-                            const float capv = (best < r2m_up) ? C : best;
-                            const float sb = best < capv ? best : capv; // stop bound at the start of the trip
-                            const bool on = left ? !doneL : !doneR;
-                            float d = INFINITY;
-                            int jb = 0, nL = 0, nR = 0;
-                            bool eqf = false;
-#pragma unroll
-                            for (int u = 0; u < U; ++u) {
-                                const int j = left ? max(iL - lo - 32 * u, 0) : min(iR + lo + 32 * u, nt + 1);
-                                const float2 t = T[j];
-                                const float dx = f_add(px, -t.x), e = f_mul(dx, dx);
-                                const float dy = f_add(py, -t.y);
-                                const float du = f_add(e, f_mul(dy, dy));
-                                // consumed = within the stop bound (a prefix of each side: e is monotone
-                                // outwards); only consumed candidates count, the cursors move past exactly those
-                                const bool cons = on && (e <= sb);
-                                const unsigned long long mc = __ballot(cons);
-                                nL += __popcll(mc & 0xFFFFFFFFull);
-                                nR += __popcll(mc >> 32);
-                                const bool use = cons && j != bpos; // the witness is already accounted for
-                                if (use && du < d) { // NaN never passes
-                                    d = du;
-                                    jb = j;
-                                    eqf = false;
-                                } else if (use && du == d && du < INFINITY) {
-                                    eqf = true; // two of this lane's candidates at the same distance
+                        const int lo32 = left ? lane : lane - 32;
+                        const int so = strip_of(py, ylo, inv_g, nst);
+                        int s_up = so, s_dn = so - 1;
+                        for (int rnd = 0; rnd < 2 * SW_NS_MAX + 4; ++rnd) {
+                            int s;
+                            {
+                                const float capv = (best < r2m_up) ? C : best;
+                                const float sb = best < capv ? best : capv;
+                                s = __builtin_amdgcn_readfirstlane(next_strip(tab, nst, so, s_up, s_dn, py, sb));
+                                s_up = __builtin_amdgcn_readfirstlane(s_up);
+                                s_dn = __builtin_amdgcn_readfirstlane(s_dn);
+                            }
+                            if (s < 0)
+                                break;
+                            const int first = tab.sbeg[s], sent = tab.sbeg[s + 1] - 1; // points [first, sent)
+                            if (sent <= first)
+                                continue;
+                            // 64-ary lower bound of px in the strip
+                            int lo = first, hi = sent;
+                            for (int g2 = 0; g2 < 8 && hi - lo > 64; ++g2) {
+                                const int step = (hi - lo + 63) >> 6;
+                                const int pp = lo + lane * step;
+                                const bool inb = pp < hi;
+                                const float x = T[inb ? pp : lo].x;
+                                const int c = __popcll(__ballot(inb && x < px));
+                                if (c == 0) {
+                                    hi = lo;
+                                } else {
+                                    const int nlo = lo + (c - 1) * step + 1;
+                                    hi = min(lo + c * step, hi);
+                                    lo = nlo;
                                 }
                             }
-                            float wmin = INFINITY;
-                            if (__ballot(d <= best)) { // rare for far queries: only then pay for the wave reduction
-                                wmin = wave_min(d); // d never holds a NaN (only `du < d` updates it)
+                            {
+                                const int pp = lo + lane;
+                                const bool inb = pp < hi;
+                                const float x = T[inb ? pp : lo].x;
+                                lo += __popcll(__ballot(inb && x < px));
                             }
-                            if (wmin < best) {
-                                const unsigned long long who = __ballot(d == wmin);
-                                tied = __popcll(who) > 1 || __ballot(eqf && d == wmin) != 0;
-                                const int first = __builtin_amdgcn_readfirstlane(__ffsll((long long)who) - 1);
-                                bpos = __builtin_amdgcn_readlane(jb, first);
-                                best = wmin;
-                            } else if (wmin == best && wmin < INFINITY) {
-                                tied = true;
+                            int iL = lo - 1, iR = lo;
+                            bool doneL = false, doneR = false;
+                            for (int guard = 0; guard <= (sent - first) / (32 * U) + 2; ++guard) { // bounded by construction
+                                const float capv = (best < r2m_up) ? C : best;
+                                const float sb = best < capv ? best : capv; // stop bound at the start of the trip
+                                const bool on = left ? !doneL : !doneR;
+                                float d = INFINITY;
+                                int jbest = 0, nL = 0, nR = 0;
+                                bool eqf = false;
+#pragma unroll
+                                for (int u = 0; u < U; ++u) {
+                                    // clamped onto the strip's own sentinels
+                                    const int j = left ? max(iL - lo32 - 32 * u, first - 1) : min(iR + lo32 + 32 * u, sent);
+                                    const float2 t = T[j];
+                                    const float dx = f_add(px, -t.x), e = f_mul(dx, dx);
+                                    const float dy = f_add(py, -t.y);
+                                    const float du = f_add(e, f_mul(dy, dy));
+                                    // consumed = within the stop bound (a prefix of each side: e is monotone
+                                    // outwards); only consumed candidates count, the cursors move past exactly those
+                                    const bool cons = on && (e <= sb);
+                                    const unsigned long long mc = __ballot(cons);
+                                    nL += __popcll(mc & 0xFFFFFFFFull);
+                                    nR += __popcll(mc >> 32);
+                                    const bool use = cons && j != bpos; // the best it holds is already accounted for
+                                    if (use && du < d) { // NaN never passes
+                                        d = du;
+                                        jbest = j;
+                                        eqf = false;
+                                    } else if (use && du == d && du < INFINITY) {
+                                        eqf = true; // two of this lane's candidates at the same distance
+                                    }
+                                }
+                                float wmin = INFINITY;
+                                if (__ballot(d <= best)) { // rare for far queries: only then pay for the wave reduction
+                                    wmin = wave_min(d); // d never holds a NaN (only `du < d` updates it)
+                                }
+                                if (wmin < best) {
+                                    const unsigned long long who = __ballot(d == wmin);
+                                    tied = __popcll(who) > 1 || __ballot(eqf && d == wmin) != 0;
+                                    const int firstl = __builtin_amdgcn_readfirstlane(__ffsll((long long)who) - 1);
+                                    bpos = __builtin_amdgcn_readlane(jbest, firstl);
+                                    best = wmin;
+                                } else if (wmin == best && wmin < INFINITY) {
+                                    tied = true;
+                                }
+                                iL -= nL;
+                                iR += nR;
+                                doneL |= nL < 32 * U;
+                                doneR |= nR < 32 * U;
+                                if (prof != nullptr && lane == 0)
+                                    atomicAdd((unsigned long long *)&S.prof[12], 1ull);
+                                if (doneL && doneR)
+                                    break;
                             }
-                            iL -= nL;
-                            iR += nR;
-                            doneL |= nL < 32 * U;
-                            doneR |= nR < 32 * U;
-                            if (prof != nullptr && lane == 0)
-                                atomicAdd((unsigned long long *)&S.prof[12], 1ull);
-                            if (doneL && doneR)
-                                break;
                         }
                         if (prof != nullptr && tid == 0) {
                             const long long t_ = clock64();
@@ -941,13 +1248,12 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                                                     __float_as_int(f_add(f_mul(sqrtf(best), 0.99999f), -md_hi)), 0);
                             } else if (best <= C) {
                                 if (tied)
-                                    bpos = sweep_resolve_tie(T, Q, px, py, best, iL, iR);
+                                    bpos = sweep_resolve_tie(T, tab, Q, px, py, best);
                                 Q.d2[q] = best;
                                 Q.pos[q] = bpos - 1;
                             } else {
                                 Q.d2[q] = best;
                                 Q.pos[q] = SW_INEXACT_OF(bpos);
-                                Q.st[q] = make_int4(iL, iR, bpos | (tied ? (int)0x80000000 : 0), 0);
                                 wl_next[atomicAdd(&S.wl_n[cur ^ 1], 1)] = q;
                             }
                         }
@@ -957,6 +1263,13 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                 }
                 __syncthreads();
                 SW_PROF(7);
+                if (prof != nullptr && tid == 0 && chk.iters == 0 && round < 8) { // first iteration, round by round
+                    const long long t_ = clock64();
+                    S.prof_it[24 + 4 * round] = nwork;
+                    S.prof_it[25 + 4 * round] = (round == 0) ? S.mid_n : 0;
+                    S.prof_it[26 + 4 * round] = nlong;
+                    S.prof_it[27 + 4 * round] = t_ - S.prof_b0;
+                }
                 // -- census: finite matches, and true neighbours within the cap --
                 double cnt[2] = {0, 0};
                 for (int base = 0; base < ns; base += SW_NQ * ICP_THREADS) { // SW_NQ loads in flight, not a chain
@@ -1171,7 +1484,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
         SW_PROF(5);
         if (!S.flag_iterate)
             break;
-        use_cache = sw_cache != 0;
+        use_cache = (sw_cache & 1) != 0;
     }
 
     if (tid == 0) {
@@ -1226,8 +1539,10 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
                 while (n2 < q[3])
                     n2 <<= 1;
             }
-            preps.push_back({q[2], q[3], toff, koff});
-            toff += q[3] + 4;
+            // ~64 points per strip on average, one strip (= a plain x sweep) for small clouds
+            const int n_strips = std::max(1, std::min(SW_NS_MAX, (int)q[3] / 64));
+            preps.push_back({q[2], q[3], n_strips, 0, toff, koff});
+            toff += q[3] + SW_PAD;
             koff += n2;
         }
         const SweepPrep &pr = preps[(size_t)it->second];
@@ -1246,11 +1561,12 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
     unsigned long long *d_gkeys = (unsigned long long *)sfe_scratch(ctx, 24, sizeof(unsigned long long) * (size_t)std::max(koff, 1LL));
     float2 *d_qxy = (float2 *)sfe_scratch(ctx, 18, sizeof(float2) * (size_t)qoff);
     int4 *d_qst = (int4 *)sfe_scratch(ctx, 19, sizeof(int4) * (size_t)qoff);
-    int *d_qwl = (int *)sfe_scratch(ctx, 21, sizeof(int) * 3 * (size_t)qoff);
-    int4 *d_qlong = (int4 *)sfe_scratch(ctx, 23, sizeof(int4) * 2 * (size_t)qoff);
+    int *d_qwl = (int *)sfe_scratch(ctx, 21, sizeof(int) * 5 * (size_t)qoff);
+    float2 *d_qssrc = (float2 *)sfe_scratch(ctx, 30, sizeof(float2) * (size_t)qoff);
+    StripTab *d_tab = (StripTab *)sfe_scratch(ctx, 23, sizeof(StripTab) * (size_t)n_prep);
     float *d_nn_d2 = (float *)sfe_scratch(ctx, 5, sizeof(float) * (size_t)qoff);
     int *d_nn_pos = (int *)sfe_scratch(ctx, 6, sizeof(int) * (size_t)qoff);
-    if (!d_preps || !d_jobs || !d_stgt || !d_perm || (p->minimizer == 1 && !d_snrm) || !d_mean || !d_gkeys || !d_qxy || !d_qst || !d_qwl || !d_qlong ||
+    if (!d_preps || !d_jobs || !d_stgt || !d_perm || (p->minimizer == 1 && !d_snrm) || !d_mean || !d_gkeys || !d_qxy || !d_qst || !d_qwl || !d_qssrc || !d_tab ||
         !d_nn_d2 || !d_nn_pos)
         return SFE_ERR_HIP;
     SFE_HIP(ctx, hipMemcpyAsync(d_preps, preps.data(), sizeof(SweepPrep) * (size_t)n_prep, hipMemcpyHostToDevice,
@@ -1267,12 +1583,14 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
     SFE_HIP(ctx, hipFuncSetAttribute((const void *)icp_sweep_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)sizeof(PrepShared)));
     hipLaunchKernelGGL(icp_sweep_prep_kernel, dim3(n_prep), dim3(ICP_THREADS), sizeof(PrepShared), ctx->stream, *p,
-                       d_preps, (const float2 *)d_tgt, d_stgt, d_perm, d_snrm, d_mean, d_gkeys);
+                       d_preps, (const float2 *)d_tgt, d_stgt, d_perm, d_snrm, d_mean, d_gkeys, d_tab);
     SFE_LAUNCH_CHECK(ctx);
     static const bool debug = getenv("SFE_ICP_DEBUG") != nullptr;
     const int sw_budget = getenv("SFE_SW_BUDGET") ? atoi(getenv("SFE_SW_BUDGET")) : SW_BUDGET;
     const int sw_budget_a = getenv("SFE_SW_BUDGET_A") ? atoi(getenv("SFE_SW_BUDGET_A")) : SW_BUDGET_A;
-    const int sw_cache = getenv("SFE_SW_CACHE") ? atoi(getenv("SFE_SW_CACHE")) : 1; // 0: A/B without the witness / clearance cache
+    // bit 0: witness / clearance cache (0: A/B without it); bits 8..15: walk trips per second-pass round
+    const int sw_cache = ((getenv("SFE_SW_CACHE") ? atoi(getenv("SFE_SW_CACHE")) : 1) & 1) |
+                         (std::max(1, std::min(255, getenv("SFE_SW_RTRIPS") ? atoi(getenv("SFE_SW_RTRIPS")) : SW_ROUND_TRIPS)) << 8);
     int *d_dbg = nullptr;
     if (debug) {
         d_dbg = (int *)sfe_scratch(ctx, 22, sizeof(int) * 8);
@@ -1283,34 +1601,40 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
     long long *d_prof = ctx->icp_prof ? (long long *)sfe_scratch(ctx, 20, sizeof(long long) * 80) : nullptr;
     const size_t ctl_bytes = (sizeof(SweepShared) + 15) & ~(size_t)15;
     if (n_lds) {
-        const size_t smem = ctl_bytes + sizeof(float2) * (SW_TCAP + 4);
+        const size_t smem = ctl_bytes + sizeof(float2) * (SW_TCAP + SW_PAD);
         // up to one job per CU the 128-VGPR build wins (no spills, measured +8 %); beyond that two
         // 64-VGPR workgroups per CU overlap each other's serial phases (measured +14 % at 512 jobs)
         if (n_lds <= ctx->n_cu) {
             SFE_HIP(ctx, hipFuncSetAttribute((const void *)icp_sweep_kernel<4, true>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             hipLaunchKernelGGL((icp_sweep_kernel<4, true>), dim3(n_lds), dim3(ICP_THREADS), smem, ctx->stream, *p, d_jobs,
-                               d_ids, (const float2 *)d_src, d_guess9, d_stgt, d_perm, d_snrm, d_mean, d_qxy, d_qst, d_qwl,
-                               d_qlong, d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof, d_dbg, sw_budget, sw_budget_a, sw_cache);
+                               d_ids, (const float2 *)d_src, d_guess9, d_stgt, d_perm, d_snrm, d_mean, d_tab, d_qxy, d_qst, d_qwl,
+                               d_qssrc, d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof, d_dbg, sw_budget, sw_budget_a, sw_cache);
         } else {
             SFE_HIP(ctx, hipFuncSetAttribute((const void *)icp_sweep_kernel<8, true>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             hipLaunchKernelGGL((icp_sweep_kernel<8, true>), dim3(n_lds), dim3(ICP_THREADS), smem, ctx->stream, *p, d_jobs,
-                               d_ids, (const float2 *)d_src, d_guess9, d_stgt, d_perm, d_snrm, d_mean, d_qxy, d_qst, d_qwl,
-                               d_qlong, d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof, d_dbg, sw_budget, sw_budget_a, sw_cache);
+                               d_ids, (const float2 *)d_src, d_guess9, d_stgt, d_perm, d_snrm, d_mean, d_tab, d_qxy, d_qst, d_qwl,
+                               d_qssrc, d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof, d_dbg, sw_budget, sw_budget_a, sw_cache);
         }
         SFE_LAUNCH_CHECK(ctx);
     }
     if (n_glb) {
+        // the target stays in HBM / L2; the LDS behind the control block only serves the query sort
+        const size_t smem_g = ctl_bytes + sizeof(unsigned long long) * SW_TCAP;
+        SFE_HIP(ctx, hipFuncSetAttribute((const void *)icp_sweep_kernel<4, false>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_g));
+        SFE_HIP(ctx, hipFuncSetAttribute((const void *)icp_sweep_kernel<8, false>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_g));
         if (n_glb <= ctx->n_cu)
-            hipLaunchKernelGGL((icp_sweep_kernel<4, false>), dim3(n_glb), dim3(ICP_THREADS), ctl_bytes, ctx->stream, *p,
-                               d_jobs, d_ids + n_lds, (const float2 *)d_src, d_guess9, d_stgt, d_perm, d_snrm, d_mean,
-                               d_qxy, d_qst, d_qwl, d_qlong, d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof, d_dbg,
+            hipLaunchKernelGGL((icp_sweep_kernel<4, false>), dim3(n_glb), dim3(ICP_THREADS), smem_g, ctx->stream, *p,
+                               d_jobs, d_ids + n_lds, (const float2 *)d_src, d_guess9, d_stgt, d_perm, d_snrm, d_mean, d_tab,
+                               d_qxy, d_qst, d_qwl, d_qssrc, d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof, d_dbg,
                                sw_budget, sw_budget_a, sw_cache);
         else
-            hipLaunchKernelGGL((icp_sweep_kernel<8, false>), dim3(n_glb), dim3(ICP_THREADS), ctl_bytes, ctx->stream, *p,
-                               d_jobs, d_ids + n_lds, (const float2 *)d_src, d_guess9, d_stgt, d_perm, d_snrm, d_mean,
-                               d_qxy, d_qst, d_qwl, d_qlong, d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof, d_dbg,
+            hipLaunchKernelGGL((icp_sweep_kernel<8, false>), dim3(n_glb), dim3(ICP_THREADS), smem_g, ctx->stream, *p,
+                               d_jobs, d_ids + n_lds, (const float2 *)d_src, d_guess9, d_stgt, d_perm, d_snrm, d_mean, d_tab,
+                               d_qxy, d_qst, d_qwl, d_qssrc, d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof, d_dbg,
                                sw_budget, sw_budget_a, sw_cache);
         SFE_LAUNCH_CHECK(ctx);
     }

@@ -39,10 +39,13 @@ for mode, p in (("p2plane30", icp_config.shipped_params(minimizer=1, use_diff_ch
 combos = [(8, 24), (6, 24), (10, 24), (12, 24), (8, 16), (8, 32), (12, 32), (16, 32)]
 if len(sys.argv) > 1:  # e.g. "4,24 6,24 8,40"
     combos = [tuple(int(v) for v in c.split(",")) for c in " ".join(sys.argv[1:]).split()]
-for refill, budget in combos:
+for combo in combos:
+    refill, budget = combo[:2]
+    rtrips = combo[2] if len(combo) > 2 else 4
     os.environ["SFE_SW_BUDGET_A"] = str(refill)
     os.environ["SFE_SW_BUDGET"] = str(budget)
-    line = "budget A %2d B %2d:" % (refill, budget)
+    os.environ["SFE_SW_RTRIPS"] = str(rtrips)
+    line = "budget A %2d B %3d R %d:" % (refill, budget, rtrips)
     for mode, kb in kbs.items():
         ms = timed(kb.run_icp, 3)
         cyc = (ctypes.c_longlong * 80)()

@@ -54,13 +54,17 @@ def main():
                 kb.run_icp()
                 ctx.sync()
                 ctx._check(ctx.lib.sfe_icp_get_profile(ctx.handle, 0, cyc))
-                names = ["setup", "xform+bsearch", "-", "quantile", "reduce", "solve", "tier1", "tier2", "census",
-                         "#rounds", "#long", "#walks"]
+                names = ["setup", "first pass", "-", "quantile", "reduce", "solve", "later passes", "tier2", "census",
+                         "#rounds", "#long", "#second-pass"]
                 it = int(kb.results()["iters"][0])
                 print("   workgroup 0, %d iterations: " % it +
                       ", ".join("%s %d" % (n, c) for n, c in zip(names, list(cyc)[:12]) if n != "-"))
                 print("   tier 2: %d trips over %d walks; wave 0 of workgroup 0: fetch %d, walk %d, finish %d cycles"
                       % (cyc[12], cyc[10], cyc[13], cyc[14], cyc[15]))
+                if it <= 10:
+                    print("   first iteration by round (queries, second pass, long, kcycles since start): " + " ".join(
+                        "%d/%d/%d/%d" % (cyc[16 + 24 + 4 * r], cyc[16 + 25 + 4 * r], cyc[16 + 26 + 4 * r], cyc[16 + 27 + 4 * r] // 1000)
+                        for r in range(8)))
                 import struct
                 print("   per iteration (kcycles search, cap C, n_exact): " + " ".join(
                     "%d/%.3g/%d" % (cyc[16 + 2 * i] // 1000, struct.unpack("f", struct.pack("I", (cyc[17 + 2 * i] >> 32) & 0xFFFFFFFF))[0],
