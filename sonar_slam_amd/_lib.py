@@ -11,7 +11,8 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsonarfe.so")
+# SONARFE_LIB: load another build of the same library (kernel A/B runs inside one process pool / one GPU call)
+LIB_PATH = os.environ.get("SONARFE_LIB") or os.path.join(_HERE, "libsonarfe.so")
 
 SFE_ERR_CAP = -4
 
