@@ -634,6 +634,7 @@ struct SweepShared {
 #define SW_NQ 8         // results fetched per lane and batch in the census / quantile / reduction loops
 #define SW_BUDGET_A 6   // first pass (own strip): walk trips (4 candidates each) before a query is handed on
 #define SW_BUDGET 256   // second pass (all strips): trips + strips before a query is handed to the cooperative tier
+#define SW_CAP_MARGIN 15 // percent
 #define SW_ROUND_TRIPS 4 // second pass: walk trips between two chances to move on to the next strip
 #define SW_NONE (-1)
 // an unfinished / suspended (inexact) query is stored as pos = -2 - bpos (<= -2; bpos = 0: nothing met
@@ -841,6 +842,8 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
     SW_PROF(0);
 
     const int sw_rtrips = (sw_cache >> 8) & 255;
+    const bool sw_jump = (sw_cache & 2) != 0;
+    const float sw_margin = 1.0f + 0.01f * (float)((sw_cache >> 16) & 255);
     int wd_outer = 0;
     bool use_cache = false; // from the second iteration on: Q.pos / Q.st hold the previous iteration's results
     while (true) {
@@ -855,6 +858,89 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
         // suspended ones with a 4x larger cap. ----
         if (prof != nullptr && tid == 0)
             S.prof_b0 = clock64();
+        // exact order statistic by radix select (4 passes of 8 bits over the distances' bit patterns): the k_sel-th
+        // smallest (0-based) d2 among the exact matches, or among all finite ones (exact + inexact: an inexact
+        // query holds an upper bound of its neighbour's distance)
+        auto select_kth = [&](unsigned k_sel, bool all_finite) -> float {
+        if (tid == 0) {
+            S.sel_k = k_sel;
+            S.sel_prefix = 0;
+        }
+        __syncthreads();
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            if (tid < 256)
+                S.hist[tid] = 0;
+            __syncthreads();
+            const unsigned prefix = S.sel_prefix;
+            const unsigned himask = (shift == 24) ? 0u : (0xFFFFFFFFu << (shift + 8));
+            auto tally = [&](int pz, float dz) { // called wave-uniformly
+                unsigned bin = 0xFFFFFFFFu;      // no contribution
+                if (all_finite ? (pz != SW_NONE) : (pz >= 0)) {
+                    const unsigned u = __float_as_uint(dz); // d >= 0: bit pattern order == value order
+                    if ((u & himask) == prefix)
+                        bin = (u >> shift) & 255u;
+                }
+                if (shift == 24) {
+                    // the exponent byte is the same for nearly every point: aggregate per wave
+                    // instead of serialising 64 LDS atomics on one address
+                    unsigned long long todo = __ballot(bin != 0xFFFFFFFFu);
+                    int wd4 = 0;
+                    while (todo) {
+                        SW_WATCH(wd4, 64, 4)
+                        const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+                        const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)bin, leader);
+                        const unsigned long long same = __ballot(bin == b);
+                        if (lane == leader)
+                            atomicAdd(&S.hist[b], (unsigned)__popcll(same));
+                        todo &= ~same;
+                    }
+                } else if (bin != 0xFFFFFFFFu) {
+                    atomicAdd(&S.hist[bin], 1u);
+                }
+            };
+            for (int base = 0; base < ns; base += SW_NQ * ICP_THREADS) {
+                int pz[SW_NQ];
+                float dz[SW_NQ];
+#pragma unroll
+                for (int k = 0; k < SW_NQ; ++k) {
+                    const int i = base + k * ICP_THREADS + tid;
+                    pz[k] = i < ns ? Q.pos[i] : SW_NONE;
+                    dz[k] = i < ns ? Q.d2[i] : INFINITY;
+                }
+#pragma unroll
+                for (int k = 0; k < SW_NQ; ++k)
+                    tally(pz[k], dz[k]);
+            }
+            __syncthreads();
+            if (tid < 64) { // one wave: rank-in-histogram by shuffles instead of a 256-step serial walk
+                const unsigned k = S.sel_k;
+                const unsigned h0 = S.hist[4 * lane], h1 = S.hist[4 * lane + 1], h2 = S.hist[4 * lane + 2],
+                               h3 = S.hist[4 * lane + 3];
+                const unsigned tot = h0 + h1 + h2 + h3;
+                const unsigned incl = wave_inclusive_scan(tot);
+                const unsigned excl = incl - tot;
+                if (k >= excl && k < incl) { // exactly one lane
+                    unsigned r = k - excl, b = 4 * lane;
+                    if (r >= h0) {
+                        r -= h0;
+                        ++b;
+                        if (r >= h1) {
+                            r -= h1;
+                            ++b;
+                            if (r >= h2) {
+                                r -= h2;
+                                ++b;
+                            }
+                        }
+                    }
+                    S.sel_k = r;
+                    S.sel_prefix = prefix | (b << shift);
+                }
+            }
+            __syncthreads();
+        }
+        return sw_uniform(__uint_as_float(S.sel_prefix));
+        };
         float C = Cnext;
         unsigned nfin = 0, nexact = 0, ksel = 0;
         bool limit_inf = false;
@@ -1306,7 +1392,15 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                 }
                 if (done)
                     break;
-                C = sw_uniform((round >= 12) ? Cmax : fminf(fmaxf(4.0f * C, Cinit), Cmax));
+                if (P.use_trimmed_filter && sw_jump) {
+                    // Every finite query holds an upper bound U of its neighbour's distance (exact ones the distance
+                    // itself).  The k-th smallest U is >= the k-th smallest distance, so with C = that value the next
+                    // round is the last one: at least k+1 queries have their neighbour within C.
+                    const float uk = select_kth(ksel, true);
+                    C = sw_uniform(fminf(fmaxf(uk, C), Cmax));
+                } else {
+                    C = sw_uniform((round >= 12) ? Cmax : fminf(fmaxf(4.0f * C, Cinit), Cmax));
+                }
                 cur ^= 1;
                 nwork = nsusp;
             }
@@ -1326,90 +1420,15 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                 if (tid == 0)
                     S.flag_status = SFE_ICP_NO_OUTLIER;
             } else if (!limit_inf) {
-                if (tid == 0) {
-                    S.sel_k = ksel;
-                    S.sel_prefix = 0;
-                }
-                __syncthreads();
-                for (int shift = 24; shift >= 0; shift -= 8) {
-                    if (tid < 256)
-                        S.hist[tid] = 0;
-                    __syncthreads();
-                    const unsigned prefix = S.sel_prefix;
-                    const unsigned himask = (shift == 24) ? 0u : (0xFFFFFFFFu << (shift + 8));
-                    auto tally = [&](int pz, float dz) { // called wave-uniformly
-                        unsigned bin = 0xFFFFFFFFu;      // no contribution
-                        if (pz >= 0) {
-                            const unsigned u = __float_as_uint(dz); // d >= 0: bit pattern order == value order
-                            if ((u & himask) == prefix)
-                                bin = (u >> shift) & 255u;
-                        }
-                        if (shift == 24) {
-                            // the exponent byte is the same for nearly every point: aggregate per wave
-                            // instead of serialising 64 LDS atomics on one address
-                            unsigned long long todo = __ballot(bin != 0xFFFFFFFFu);
-                            int wd4 = 0;
-                            while (todo) {
-                                SW_WATCH(wd4, 64, 4)
-                                const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
-                                const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)bin, leader);
-                                const unsigned long long same = __ballot(bin == b);
-                                if (lane == leader)
-                                    atomicAdd(&S.hist[b], (unsigned)__popcll(same));
-                                todo &= ~same;
-                            }
-                        } else if (bin != 0xFFFFFFFFu) {
-                            atomicAdd(&S.hist[bin], 1u);
-                        }
-                    };
-                    for (int base = 0; base < ns; base += SW_NQ * ICP_THREADS) {
-                        int pz[SW_NQ];
-                        float dz[SW_NQ];
-#pragma unroll
-                        for (int k = 0; k < SW_NQ; ++k) {
-                            const int i = base + k * ICP_THREADS + tid;
-                            pz[k] = i < ns ? Q.pos[i] : SW_NONE;
-                            dz[k] = i < ns ? Q.d2[i] : INFINITY;
-                        }
-#pragma unroll
-                        for (int k = 0; k < SW_NQ; ++k)
-                            tally(pz[k], dz[k]);
-                    }
-                    __syncthreads();
-                    if (tid < 64) { // one wave: rank-in-histogram by shuffles instead of a 256-step serial walk
-                        const unsigned k = S.sel_k;
-                        const unsigned h0 = S.hist[4 * lane], h1 = S.hist[4 * lane + 1], h2 = S.hist[4 * lane + 2],
-                                       h3 = S.hist[4 * lane + 3];
-                        const unsigned tot = h0 + h1 + h2 + h3;
-                        const unsigned incl = wave_inclusive_scan(tot);
-                        const unsigned excl = incl - tot;
-                        if (k >= excl && k < incl) { // exactly one lane
-                            unsigned r = k - excl, b = 4 * lane;
-                            if (r >= h0) {
-                                r -= h0;
-                                ++b;
-                                if (r >= h1) {
-                                    r -= h1;
-                                    ++b;
-                                    if (r >= h2) {
-                                        r -= h2;
-                                        ++b;
-                                    }
-                                }
-                            }
-                            S.sel_k = r;
-                            S.sel_prefix = prefix | (b << shift);
-                        }
-                    }
-                    __syncthreads();
-                }
-                limit = sw_uniform(__uint_as_float(S.sel_prefix));
+                limit = select_kth(ksel, false);
             }
         }
         __syncthreads();
         if (fail)
             break;
-        Cnext = P.use_trimmed_filter ? ((limit < Cmax) ? fmaxf(limit, Cinit * 0.0625f) : Cmax) : Cmax;
+        // the next iteration's cap: this limit plus a margin (the clouds keep moving a little: without it about
+        // every fourth converged iteration finds one match too few inside the cap and has to search twice)
+        Cnext = P.use_trimmed_filter ? fminf(fmaxf(limit * sw_margin, Cinit * 0.0625f), Cmax) : Cmax;
         SW_PROF(3);
 
         // ---- D: error minimiser sums over the kept pairs, in two halves of five accumulators: ten fp64
@@ -1589,7 +1608,11 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
     const int sw_budget = getenv("SFE_SW_BUDGET") ? atoi(getenv("SFE_SW_BUDGET")) : SW_BUDGET;
     const int sw_budget_a = getenv("SFE_SW_BUDGET_A") ? atoi(getenv("SFE_SW_BUDGET_A")) : SW_BUDGET_A;
     // bit 0: witness / clearance cache (0: A/B without it); bits 8..15: walk trips per second-pass round
+    // bit 1: the cap of a repeated round comes from the queries' upper bounds (0: grows 4x)
     const int sw_cache = ((getenv("SFE_SW_CACHE") ? atoi(getenv("SFE_SW_CACHE")) : 1) & 1) |
+                         ((getenv("SFE_SW_JUMP") ? atoi(getenv("SFE_SW_JUMP")) : 1) ? 2 : 0) |
+                         // bits 16..23: margin (percent) of the next iteration's cap over this iteration's limit
+                         (std::max(0, std::min(255, getenv("SFE_SW_MARGIN") ? atoi(getenv("SFE_SW_MARGIN")) : SW_CAP_MARGIN)) << 16) |
                          (std::max(1, std::min(255, getenv("SFE_SW_RTRIPS") ? atoi(getenv("SFE_SW_RTRIPS")) : SW_ROUND_TRIPS)) << 8);
     int *d_dbg = nullptr;
     if (debug) {
