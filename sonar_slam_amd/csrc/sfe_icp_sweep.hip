@@ -1558,8 +1558,10 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
                 while (n2 < q[3])
                     n2 <<= 1;
             }
-            // ~64 points per strip on average, one strip (= a plain x sweep) for small clouds
-            const int n_strips = std::max(1, std::min(SW_NS_MAX, (int)q[3] / 64));
+            // ~96 points per strip on average (measured optimum 96-128 on 5000-point clouds: fewer queries need a
+            // second strip, a little more to walk in each), one strip (= a plain x sweep) for small clouds
+            static const int strip_pts = getenv("SFE_SW_STRIP_PTS") ? std::max(1, atoi(getenv("SFE_SW_STRIP_PTS"))) : 96;
+            const int n_strips = std::max(1, std::min(SW_NS_MAX, (int)q[3] / strip_pts));
             preps.push_back({q[2], q[3], n_strips, 0, toff, koff});
             toff += q[3] + SW_PAD;
             koff += n2;
