@@ -113,40 +113,51 @@ __device__ __forceinline__ unsigned long long cf_path_key(float2 p, const CfHead
 }
 
 // one workgroup per frame: keys, stable bitonic sort (keys in LDS, or in HBM scratch for frames beyond
-// CF_SORT_CAP points: config-B pings yield ~34k detections), leaves, medoids
-template <bool IN_LDS>
+// CF_SORT_CAP points: config-B pings yield ~34k detections), leaves, medoids.
+// K = sort key type.  The bitonic sort is bound by LDS bandwidth, and a sonar fan at 0.5 m resolution needs a
+// 7-level tree = 14 key bits: with K = uint32 (trees of <= 8 levels) the sort moves half the bytes and two
+// workgroups share a CU (64 KiB of keys each instead of one with 128 KiB).  A frame whose tree is deeper marks
+// itself CF_NEEDS_WIDE and is taken by the uint64 instantiation, which is launched behind it for those
+// frames only.
+#define CF_NEEDS_WIDE (-2)
+template <bool IN_LDS, typename K>
 __global__ __launch_bounds__(1024) void cf_downsample_kernel(const float2 *__restrict__ p32, long long cap,
                                                              CfHeader *__restrict__ hdrs, float2 *__restrict__ ds_out,
-                                                             int *__restrict__ seg_all,
-                                                             unsigned long long *__restrict__ gkeys_all, long long n2cap)
+                                                             int *__restrict__ seg_all, K *__restrict__ gkeys_all,
+                                                             long long n2cap, int only_marked)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long lds_keys[]; // n2 sort keys (IN_LDS)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[]; // n2 sort keys (IN_LDS)
     __shared__ int s_scan[1024];
-    unsigned long long *s_keys = IN_LDS ? lds_keys : gkeys_all + (size_t)blockIdx.x * n2cap;
+    K *s_keys = IN_LDS ? reinterpret_cast<K *>(lds_raw) : gkeys_all + (size_t)blockIdx.x * n2cap;
     const int f = blockIdx.x, tid = threadIdx.x;
     const CfHeader h = hdrs[f];
+    if (only_marked && h.n_seg != CF_NEEDS_WIDE)
+        return;
     const int n = h.n;
     const float2 *pts = p32 + (size_t)f * cap;
     float2 *out = ds_out + (size_t)f * cap;
     if (n == 0)
         return;
-    if (h.levels > 24) { // (key << 16 | index) holds 48 key bits: cells finer than extent / 2^24 are refused
+    constexpr int KEY_BITS = (int)sizeof(K) * 8 - 16;
+    if (2 * h.levels > KEY_BITS) {
+        // (key << 16 | index) holds KEY_BITS key bits: narrow keys hand the frame to the wide instantiation,
+        // which refuses cells finer than extent / 2^24
         if (tid == 0)
-            hdrs[f].n_seg = -1;
+            hdrs[f].n_seg = sizeof(K) == 4 ? CF_NEEDS_WIDE : -1;
         return;
     }
     unsigned n2 = 2;
     while (n2 < (unsigned)n)
         n2 <<= 1;
     for (unsigned i = tid; i < n2; i += 1024)
-        s_keys[i] = i < (unsigned)n ? ((cf_path_key(pts[i], h) << 16) | i) : ~0ull;
+        s_keys[i] = i < (unsigned)n ? (K)((cf_path_key(pts[i], h) << 16) | i) : (K)~(K)0;
     __syncthreads();
     for (unsigned k = 2; k <= n2; k <<= 1)
         for (unsigned j = k >> 1; j > 0; j >>= 1) {
             for (unsigned t = tid; t < n2 / 2; t += 1024) {
                 const unsigned i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
                 const unsigned l = i | j;
-                const unsigned long long a = s_keys[i], b = s_keys[l];
+                const K a = s_keys[i], b = s_keys[l];
                 if ((a > b) == ((i & k) == 0)) {
                     s_keys[i] = b;
                     s_keys[l] = a;
@@ -310,17 +321,21 @@ extern "C" int sfe_cloud_filter_batch_dev(sfe_ctx *ctx, const double *d_pts, con
         if (!d_seg)
             return SFE_ERR_HIP;
         if (cap <= CF_SORT_CAP) {
-            const size_t smem = 8 * n2;
-            SFE_HIP(ctx, hipFuncSetAttribute((const void *)cf_downsample_kernel<true>,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            hipLaunchKernelGGL(cf_downsample_kernel<true>, dim3(n_frames), dim3(1024), smem, ctx->stream, d_p32,
-                               (long long)cap, d_hdr, d_ds, d_seg, (unsigned long long *)nullptr, 0LL);
+            // narrow keys first (every frame of a sonar fan qualifies), then the wide ones for what is left
+            SFE_HIP(ctx, hipFuncSetAttribute((const void *)cf_downsample_kernel<true, unsigned>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * n2)));
+            hipLaunchKernelGGL((cf_downsample_kernel<true, unsigned>), dim3(n_frames), dim3(1024), 4 * n2, ctx->stream,
+                               d_p32, (long long)cap, d_hdr, d_ds, d_seg, (unsigned *)nullptr, 0LL, 0);
+            SFE_HIP(ctx, hipFuncSetAttribute((const void *)cf_downsample_kernel<true, unsigned long long>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(8 * n2)));
+            hipLaunchKernelGGL((cf_downsample_kernel<true, unsigned long long>), dim3(n_frames), dim3(1024), 8 * n2,
+                               ctx->stream, d_p32, (long long)cap, d_hdr, d_ds, d_seg, (unsigned long long *)nullptr, 0LL, 1);
         } else {
             unsigned long long *d_gk = (unsigned long long *)sfe_scratch(ctx, 29, 8 * n2 * (size_t)n_frames);
             if (!d_gk)
                 return SFE_ERR_HIP;
-            hipLaunchKernelGGL(cf_downsample_kernel<false>, dim3(n_frames), dim3(1024), 0, ctx->stream, d_p32,
-                               (long long)cap, d_hdr, d_ds, d_seg, d_gk, (long long)n2);
+            hipLaunchKernelGGL((cf_downsample_kernel<false, unsigned long long>), dim3(n_frames), dim3(1024), 0,
+                               ctx->stream, d_p32, (long long)cap, d_hdr, d_ds, d_seg, d_gk, (long long)n2, 0);
         }
         stage = d_ds;
     }
