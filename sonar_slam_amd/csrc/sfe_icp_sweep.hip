@@ -605,7 +605,7 @@ __device__ __forceinline__ long long sw_uniform_ll(long long v)
 struct SweepShared {
     double red[ICP_WAVES * 10 + 10];
     double acc[10];  // the reduced error-minimiser sums (read by the solving lane)
-    unsigned hist[256];
+    unsigned hist[256], hist0[256];
     unsigned sel_prefix, sel_k;
     int long_n, long_next, mid_n, wl_n[2];
     int flag_iterate, flag_status;
@@ -861,16 +861,22 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
         // exact order statistic by radix select (4 passes of 8 bits over the distances' bit patterns): the k_sel-th
         // smallest (0-based) d2 among the exact matches, or among all finite ones (exact + inexact: an inexact
         // query holds an upper bound of its neighbour's distance)
-        auto select_kth = [&](unsigned k_sel, bool all_finite) -> float {
+        // `top_tallied`: S.hist0 already holds the histogram of the top byte (the census of the final round
+        // counts it on the way), so the first of the four passes is skipped
+        auto select_kth = [&](unsigned k_sel, bool all_finite, bool top_tallied) -> float {
         if (tid == 0) {
             S.sel_k = k_sel;
             S.sel_prefix = 0;
         }
         __syncthreads();
         for (int shift = 24; shift >= 0; shift -= 8) {
+            const bool skip_tally = top_tallied && shift == 24;
+            unsigned *hist = skip_tally ? S.hist0 : S.hist;
+            if (!skip_tally) {
             if (tid < 256)
                 S.hist[tid] = 0;
             __syncthreads();
+            }
             const unsigned prefix = S.sel_prefix;
             const unsigned himask = (shift == 24) ? 0u : (0xFFFFFFFFu << (shift + 8));
             auto tally = [&](int pz, float dz) { // called wave-uniformly
@@ -898,6 +904,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                     atomicAdd(&S.hist[bin], 1u);
                 }
             };
+            if (!skip_tally) {
             for (int base = 0; base < ns; base += SW_NQ * ICP_THREADS) {
                 int pz[SW_NQ];
                 float dz[SW_NQ];
@@ -912,10 +919,11 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                     tally(pz[k], dz[k]);
             }
             __syncthreads();
+            }
             if (tid < 64) { // one wave: rank-in-histogram by shuffles instead of a 256-step serial walk
                 const unsigned k = S.sel_k;
-                const unsigned h0 = S.hist[4 * lane], h1 = S.hist[4 * lane + 1], h2 = S.hist[4 * lane + 2],
-                               h3 = S.hist[4 * lane + 3];
+                const unsigned h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2],
+                               h3 = hist[4 * lane + 3];
                 const unsigned tot = h0 + h1 + h2 + h3;
                 const unsigned incl = wave_inclusive_scan(tot);
                 const unsigned excl = incl - tot;
@@ -958,6 +966,8 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                     S.mid_n = 0;
                     S.wl_n[cur ^ 1] = 0;
                 }
+                if (tid < 256)
+                    S.hist0[tid] = 0; // filled by this round's census
                 __syncthreads();
                 const int *wl = Q.wl[cur];
                 int *wl_next = Q.wl[cur ^ 1];
@@ -1371,6 +1381,20 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                     for (int k = 0; k < SW_NQ; ++k) {
                         cnt[0] += (pz[k] != SW_NONE) ? 1.0 : 0.0;
                         cnt[1] += (pz[k] >= 0 && dz[k] <= C) ? 1.0 : 0.0;
+                        // first pass of the radix select over the exact matches, on the way (wave-aggregated: the
+                        // exponent byte is the same for nearly every point)
+                        const unsigned bin = (pz[k] >= 0) ? (__float_as_uint(dz[k]) >> 24) : 0xFFFFFFFFu;
+                        unsigned long long todo = __ballot(bin != 0xFFFFFFFFu);
+                        int wd6 = 0;
+                        while (todo) {
+                            SW_WATCH(wd6, 64, 6)
+                            const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+                            const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)bin, leader);
+                            const unsigned long long same = __ballot(bin == b);
+                            if (lane == leader)
+                                atomicAdd(&S.hist0[b], (unsigned)__popcll(same));
+                            todo &= ~same;
+                        }
                     }
                 }
                 block_sum<2>(cnt, S.red);
@@ -1396,7 +1420,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                     // Every finite query holds an upper bound U of its neighbour's distance (exact ones the distance
                     // itself).  The k-th smallest U is >= the k-th smallest distance, so with C = that value the next
                     // round is the last one: at least k+1 queries have their neighbour within C.
-                    const float uk = select_kth(ksel, true);
+                    const float uk = select_kth(ksel, true, false);
                     C = sw_uniform(fminf(fmaxf(uk, C), Cmax));
                 } else {
                     C = sw_uniform((round >= 12) ? Cmax : fminf(fmaxf(4.0f * C, Cinit), Cmax));
@@ -1420,7 +1444,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                 if (tid == 0)
                     S.flag_status = SFE_ICP_NO_OUTLIER;
             } else if (!limit_inf) {
-                limit = select_kth(ksel, false);
+                limit = select_kth(ksel, false, true);
             }
         }
         __syncthreads();
