@@ -107,7 +107,12 @@ def test_resident_cloud_filters_equal_the_per_cloud_api_and_the_oracle(ctx, ship
     kb.upload_frames(frames)
     kb.run_cfar()
     kb.run_extract()
-    for res, rad, mp in ((0.5, 1.0, 5), (0.0, 1.0, 5), (0.5, 1.0, 1), (0.25, 0.6, 3)):
+    # the last rows aim at the radius filter's cell path: radius far below / around / far above the octree's
+    # cell sizes (one cell level .. root cell narrower than the radius -> brute force), a tree deeper than the
+    # 8 levels of the narrow sort keys (wide keys, brute-force count), min_points that nothing / everything meets
+    for res, rad, mp in ((0.5, 1.0, 5), (0.0, 1.0, 5), (0.5, 1.0, 1), (0.25, 0.6, 3), (0.5, 0.05, 2), (0.5, 0.49, 2),
+                         (0.5, 3.7, 40), (0.5, 29.0, 300), (0.5, 500.0, 5), (0.05, 0.3, 3), (2.0, 2.0, 2),
+                         (0.5, 1.0, 100000)):
         kb.run_filter(res, rad, mp)
         ctx.sync()
         for j in range(len(frames)):
