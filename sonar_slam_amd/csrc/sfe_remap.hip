@@ -249,58 +249,78 @@ __global__ __launch_bounds__(256) void extract_scan_kernel(const unsigned long l
         frame_count[f] = s_part[255];
 }
 
-// pass 3: one wave per (row, frame): expand bitmap words in column order -> (row, col) and metres.  (Measured
-// alternatives, both slower: 8 rows per 512-thread workgroup +5 %; expansion fused into the per-frame scan
-// kernel, every thread streaming its own rows, +15 %.)
-__global__ __launch_bounds__(64) void extract_expand_kernel(const unsigned long long *__restrict__ bitmap,
-                                                            const int32_t *__restrict__ row_count,
-                                                            const int32_t *__restrict__ row_off,
-                                                            long long *__restrict__ rc_out,
-                                                            double *__restrict__ pts_out, long long cap,
-                                                            int crows, int ccols, int wpr, double width,
-                                                            double height)
+// pass 3: one lane per POINT: point t of a frame lies in the last row whose offset is <= t (binary search in
+// the row offsets; empty rows share their successor's offset, so the last such row is the occupied one) and is
+// the (t - offset)-th set bit of that row's words in column order (= np.nonzero order); then metres in fp64,
+// operation by operation.  (One wave per canvas row, a lane per bitmap word -- the first version -- kept 5 lanes
+// of 64 busy: a row holds ~10 detections.  Also measured and slower than that: 8 rows per 512-thread workgroup,
+// and the expansion fused into the per-frame scan kernel.)
+__global__ __launch_bounds__(256) void extract_expand_kernel(const unsigned long long *__restrict__ bitmap,
+                                                             const int32_t *__restrict__ row_off,
+                                                             const int32_t *__restrict__ frame_count,
+                                                             long long *__restrict__ rc_out,
+                                                             double *__restrict__ pts_out, long long cap,
+                                                             int crows, int ccols, int wpr, double width,
+                                                             double height)
 {
-    const int row = blockIdx.x, f = blockIdx.y;
-    const long long fr = (long long)f * crows + row;
-    if (row_count[fr] == 0)
+    extern __shared__ int32_t s_off[]; // the frame's row offsets: one coalesced fetch instead of a 10-step
+                                       // chain of dependent loads per point
+    const int f = blockIdx.y;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long n = min((long long)frame_count[f], cap);
+    if ((long long)blockIdx.x * 256 >= n)
+        return; // the whole workgroup is past the frame's last point
+    const int32_t *__restrict__ off = row_off + (long long)f * crows;
+    for (int i = threadIdx.x; i < crows; i += 256)
+        s_off[i] = off[i];
+    __syncthreads();
+    if (t >= n)
         return;
-    const unsigned long long *__restrict__ brow = bitmap + fr * wpr;
-    long long base = row_off[fr];
-    const int lane = threadIdx.x;
-    // feature_extraction.py:236-237 in float64, operation by operation
-    const double half_cols = ccols / 2.;
-    const double y = (-1 * ((double)row / (double)crows) * height) + height;
-    for (int w0 = 0; w0 < wpr; w0 += 64) {
-        const int w = w0 + lane;
-        unsigned long long word = (w < wpr) ? brow[w] : 0ull;
-        const int n = __popcll(word);
-        int incl = n; // inclusive wave scan of the per-word counts
-        for (int d = 1; d < 64; d <<= 1) {
-            const int v = __shfl_up(incl, d);
-            if (lane >= d)
-                incl += v;
-        }
-        long long o = base + incl - n;
-        while (word) {
-            const int b = __ffsll((long long)word) - 1;
-            word &= word - 1;
-            if (o < cap) {
-                const int col = w * 64 + b;
-                const long long dsto = ((long long)f * cap + o) * 2;
-                if (rc_out) {
-                    rc_out[dsto] = row;
-                    rc_out[dsto + 1] = col;
-                }
-                if (pts_out) {
-                    double x = (double)col - half_cols;
-                    x = (-1 * ((x / half_cols) * (width / 2.)));
-                    pts_out[dsto] = y;
-                    pts_out[dsto + 1] = x;
-                }
+    int lo = 0, hi = crows - 1; // largest row with off[row] <= t
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (s_off[mid] <= t)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    const int row = lo;
+    int k = (int)(t - s_off[row]);
+    const unsigned long long *__restrict__ brow = bitmap + ((long long)f * crows + row) * wpr;
+    int col = -1;
+    for (int w0 = 0; w0 < wpr && col < 0; w0 += 8) { // eight independent loads in flight, then the selection
+        unsigned long long wd[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            wd[u] = (w0 + u < wpr) ? brow[w0 + u] : 0ull;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = __popcll(wd[u]);
+            if (col < 0 && k < c) {
+                unsigned long long word = wd[u];
+                for (; k > 0; --k)
+                    word &= word - 1;
+                col = (w0 + u) * 64 + __ffsll((long long)word) - 1;
             }
-            ++o;
+            if (col < 0)
+                k -= c;
         }
-        base += __shfl(incl, 63);
+    }
+    if (col < 0)
+        return; // cannot happen: the offsets were counted from these very words
+    const long long dsto = ((long long)f * cap + t) * 2;
+    if (rc_out) {
+        rc_out[dsto] = row;
+        rc_out[dsto + 1] = col;
+    }
+    if (pts_out) {
+        // feature_extraction.py:236-237 in float64, operation by operation
+        const double half_cols = ccols / 2.;
+        const double y = (-1 * ((double)row / (double)crows) * height) + height;
+        double x = (double)col - half_cols;
+        x = (-1 * ((x / half_cols) * (width / 2.)));
+        pts_out[dsto] = y;
+        pts_out[dsto + 1] = x;
     }
 }
 
@@ -491,10 +511,12 @@ static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_f
                            scatter ? 1 : 0);
         hipLaunchKernelGGL(extract_scan_kernel, dim3(nf), dim3(256), 0, ctx->stream, d_bm, d_rcnt, d_roff,
                            d_counts + f0, crows, wpr);
-        hipLaunchKernelGGL(extract_expand_kernel, dim3(crows, nf), dim3(64), 0, ctx->stream, d_bm, d_rcnt, d_roff,
-                           d_rc ? d_rc + (size_t)f0 * cap * 2 : nullptr,
-                           d_pts ? d_pts + (size_t)f0 * cap * 2 : nullptr, cap, crows, g->cart_cols, wpr,
-                           g->width, g->height);
+        if (cap > 0)
+            hipLaunchKernelGGL(extract_expand_kernel, dim3((unsigned)((cap + 255) / 256), nf), dim3(256),
+                               sizeof(int32_t) * (size_t)crows, ctx->stream,
+                               d_bm, d_roff, d_counts + f0, d_rc ? d_rc + (size_t)f0 * cap * 2 : nullptr,
+                               d_pts ? d_pts + (size_t)f0 * cap * 2 : nullptr, cap, crows, g->cart_cols, wpr, g->width,
+                               g->height);
     }
     SFE_LAUNCH_CHECK(ctx);
     return 0;
