@@ -261,8 +261,10 @@ __global__ __launch_bounds__(1024) void cf_radius_filter_kernel(const float2 *__
                                                                 int32_t *__restrict__ out_counts, int do_filter,
                                                                 const unsigned *__restrict__ leaf_keys_all)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char cf_dyn[]; // fast path: points, then cell starts
-    __shared__ float2 s_p[2048];
+    // dynamic LDS: cell path = the cloud, then the cell starts; brute-force path = a tile of 2048 points (the
+    // launcher sizes it for whichever is larger, so two workgroups share a CU either way)
+    extern __shared__ __attribute__((aligned(16))) unsigned char cf_dyn[];
+    float2 *s_p = reinterpret_cast<float2 *>(cf_dyn);
     __shared__ int s_scan[1024];
     const int f = blockIdx.x, tid = threadIdx.x;
     const CfHeader h = hdrs[f];
@@ -449,7 +451,8 @@ extern "C" int sfe_cloud_filter_batch_dev(sfe_ctx *ctx, const double *d_pts, con
     const size_t cell_smem = sizeof(float2) * CF_CELL_PTS + sizeof(unsigned short) * ((1 << (2 * CF_CELL_LEVELS)) + 2);
     SFE_HIP(ctx, hipFuncSetAttribute((const void *)cf_radius_filter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)cell_smem));
-    hipLaunchKernelGGL(cf_radius_filter_kernel, dim3(n_frames), dim3(1024), d_lkeys ? cell_smem : 0, ctx->stream, stage,
+    hipLaunchKernelGGL(cf_radius_filter_kernel, dim3(n_frames), dim3(1024),
+                       d_lkeys ? cell_smem : sizeof(float2) * 2048, ctx->stream, stage,
                        (long long)cap, d_hdr, (float)(radius * radius), min_points, d_out, d_out_counts, do_filter ? 1 : 0,
                        (const unsigned *)d_lkeys);
     SFE_LAUNCH_CHECK(ctx);
