@@ -286,7 +286,7 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cfar_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_note": "bytes/launch = 2*FETCH_SIZE + WRITE_SIZE from profiles/cfar_pmc.json",
                          "bytes_per_launch": cfar_bytes, "ms_per_launch": ms_cfar, "frames_per_launch": nf},
-            # the ICP kernels prune the search (exact sorted-sweep NN), so pair evaluations are no longer
+            # the ICP kernels prune the search (exact strip-sweep NN), so pair evaluations are no longer
             # n_src*n_tgt per iteration: this is the brute-force-EQUIVALENT rate, not a utilisation
             "icp_kernel": {"kernel": "icp_sweep_kernel (+ icp_sweep_prep_kernel)", "bound": "valu/lds latency",
                            "ms_per_launch": ms_icp_b, "jobs_per_launch": args.batch,

@@ -178,16 +178,17 @@ int sfe_icp_compute_guesses(sfe_ctx *ctx, const sfe_icp_params *p, const float *
 int sfe_icp_compute_pairs(sfe_ctx *ctx, const sfe_icp_params *p, const float *src, const int32_t *src_off,
                           const float *tgt, const int32_t *tgt_off, const float *guesses9, int n_jobs,
                           float *T_out9, int32_t *status, int32_t *iters);
-/* A-B knob for the ICP kernels.  bit 2: 0 = sorted-sweep exact NN search (default; targets of up to
- * 8192 points, larger ones take the brute-force kernel), 1 = brute-force tile scan for everything.
+/* A-B knob for the ICP kernels.  bit 2: 0 = strip-sweep exact NN search (default; targets beyond 8192
+ * points are walked through L2 instead of LDS), 1 = brute-force tile scan for everything.
  * Brute-force only: bit 0: 0 = packed fp32 NN loop, 1 = scalar fp32; bit 1: 0 = 64-VGPR build,
  * 2 workgroups/CU, 1 = 128-VGPR build.  All variants return identical results. */
 int sfe_icp_set_tuning(sfe_ctx *ctx, int variant);
 /* debug: enable/disable per-phase cycle counters of the sweep kernel (workgroup 0) and read the
- * 80 values of the last launch (buffer of 80 long long), summed over iterations.  Cycles: [0] setup, [1] transform + binary
- * search, [3] trimmed quantile, [4] reduction, [5] solve, [6] lane-per-query walks, [7] cooperative
- * walks, [8] finite/exact census.  Counts: [9] search rounds, [10] walks handed to the cooperative
- * tier, [11] walks started or resumed. */
+ * 80 values of the last launch (buffer of 80 long long), summed over iterations.  Cycles: [0] setup incl. the
+ * query sort, [1] first search pass (own strip), [3] trimmed quantile, [4] reduction, [5] solve, [6] later
+ * search passes, [7] cooperative tier, [8] finite/exact census.  Counts: [9] search rounds, [10] queries
+ * handed to the cooperative tier, [11] queries handed to the second pass, [12] cooperative trips.
+ * [16 + 2i], [17 + 2i]: search cycles and (cap bits << 32 | exact matches) of iteration i < 32. */
 int sfe_icp_get_profile(sfe_ctx *ctx, int enable, long long *cycles16);
 /* independent jobs, device-resident: clouds concatenated, job j uses
  * src[src_off[j]..src_off[j+1]) and tgt[tgt_off[j]..tgt_off[j+1]) (offsets in points, host

@@ -659,7 +659,7 @@ static int icp_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_src,
         soff += q[1];
         noff += q[3];
     }
-    if (!(ctx->icp_variant & 4)) { // default: sorted-sweep search (sfe_icp_sweep.hip), same results
+    if (!(ctx->icp_variant & 4)) { // default: strip-sweep search (sfe_icp_sweep.hip), same results
         const int rc = sfe_icp_sweep_launch(ctx, p, d_src, d_tgt, jobs4, d_guess9, n_jobs, d_T9, d_status, d_iters);
         if (rc != 1)
             return rc;

@@ -1,5 +1,5 @@
 // Device helpers shared by the ICP kernels (sfe_icp.hip: brute-force tile scan, sfe_icp_sweep.hip:
-// sorted-sweep search).  Every float expression that decides a match or a weight is written with
+// strip-sweep search).  Every float expression that decides a match or a weight is written with
 // explicit IEEE roundings (no contraction) so both kernels and the oracle take the same decisions.
 #pragma once
 #include "sfe_internal.h"

@@ -582,10 +582,11 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_sweep_prep_kernel(sfe_icp_
 //   inexact : finite, C < d2_NN <= best            (suspended: best and its position are kept)
 // If the exact set holds more than k = floor(n_finite * ratio) values, the k-th smallest of them
 // IS the k-th smallest of all (everything else is > C), the limit is exact and so are all
-// weight-1 pairs.  Otherwise C grows 4x and the suspended queries search again (from scratch, but
+// weight-1 pairs.  Otherwise the suspended queries search again with C = the k-th smallest of the upper
+// bounds all finite queries hold (>= the k-th smallest distance: one repeat suffices), from scratch but
 // bounded by the best they already hold; a candidate is never mistaken for a tie with itself because
-// the position of the current best is excluded).  C starts from the previous iteration's limit, so far
-// outliers cost a handful of steps.  Decisions and results are identical to the exhaustive search.
+// the position of the current best is excluded.  C starts from the previous iteration's limit (+ a margin),
+// so far outliers cost a handful of steps.  Decisions and results are identical to the exhaustive search.
 //
 // wave-uniform float held in an SGPR instead of one VGPR per lane (the loop kernel runs at the
 // 64-VGPR budget: every uniform value kept out of the vector file is one spill less)
@@ -854,8 +855,8 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
             Ti[i] = sw_uniform(S.Ti[i]);
 
         // ---- A+B: cur = Ti * (T0 * src); exact NN for every pair that can matter.  Round 0 searches
-        // for every query (lane i handles queries i, i + 1024, ...), later rounds search again for the
-        // suspended ones with a 4x larger cap. ----
+        // for every query (lane i handles the queries i, i + 1024, ... of the spatial order), later rounds search again for the
+        // suspended ones with a larger cap. ----
         if (prof != nullptr && tid == 0)
             S.prof_b0 = clock64();
         // exact order statistic by radix select (4 passes of 8 bits over the distances' bit patterns): the k_sel-th

@@ -224,7 +224,7 @@ def _with_variant(ctx, variant, fn):
 
 @pytest.mark.parametrize("mz", [0, 1])
 def test_sweep_search_equals_brute_force_bit_for_bit(ctx, mz):
-    """The default sorted-sweep search and the brute-force tile scan (tuning bit 2) must take the
+    """The default strip-sweep search and the brute-force tile scan (tuning bit 2) must take the
     same decisions: identical transforms, iteration counts and statuses, also with duplicated
     target points (ties -> lowest original index) and with far outliers in the source."""
     src, tgt, guess, _ = synth.scan_pair(seed=21, n_src=4000, n_tgt=3500)
