@@ -634,7 +634,7 @@ struct SweepShared {
     }
 #define SW_NQ 8         // results fetched per lane and batch in the census / quantile / reduction loops
 #define SW_BUDGET_A 6   // first pass (own strip): walk trips (4 candidates each) before a query is handed on
-#define SW_BUDGET 256   // second pass (all strips): trips + strips before a query is handed to the cooperative tier
+#define SW_BUDGET 128   // second pass (all strips): trips + strips before a query is handed to the cooperative tier
 #define SW_CAP_MARGIN 15 // percent
 #define SW_ROUND_TRIPS 4 // second pass: walk trips between two chances to move on to the next strip
 #define SW_NONE (-1)
