@@ -612,7 +612,7 @@ int orc_icp(const orc_icp_params *P, const float *src, int ns, const float *tgt_
                 }
             } else
                 nn1(tgt, nt, cur[2 * i], cur[2 * i + 1], &id, &d);
-            if (id < 0 || !(d <= r2_match)) {
+            if (id < 0 || !(d <= r2_match) || d == INFINITY) { /* an infinite distance is no match, also with maxDist = inf */
                 id = -1;
                 d = INFINITY;
             } else

@@ -402,7 +402,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_job_kernel(sfe_icp_para
                             }
                         }
                     }
-                    if (id < 0 || !(d <= r2_match)) {
+                    if (id < 0 || !(d <= r2_match) || d == INFINITY) { // an infinite distance is no match, also for an unbounded matcher
                         id = -1;
                         d = INFINITY;
                     } else {

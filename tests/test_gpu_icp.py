@@ -386,6 +386,8 @@ def test_sweep_vs_brute_force_fuzz_many_iterations(ctx):
         k = ns // 4
         src[:k] = rng.uniform(-35, 35, (k, 2))                                   # outliers, some beyond everything
         src = src.astype(np.float32)
+        if case % 6 == 5:
+            tgt[int(rng.integers(0, nt)), int(rng.integers(0, 2))] = np.inf     # a point nothing can match
         p = IcpParams(matcher_max_dist=float(rng.choice([0.4, 1.0, 10.0, np.inf])),
                       use_max_dist_filter=int(rng.integers(0, 2)), max_dist_filter=float(rng.choice([0.3, 3.0])),
                       use_trimmed_filter=int(rng.integers(0, 4) > 0), trim_ratio=float(rng.choice([0.5, 0.8, 0.95])),
