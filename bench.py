@@ -42,6 +42,8 @@ def parse():
                     help="CPU-baseline keyframes per host core (0 = about 10 s of work per core)")
     ap.add_argument("--icp-mode", choices=["p2plane30", "reference"], default="p2plane30")
     ap.add_argument("--no-filters", action="store_true", help="leave pcl.downsample / remove_outlier out of the step")
+    ap.add_argument("--serial-prep", action="store_true",
+                    help="keep the ICP target preparation on the main stream (default: side stream, next to the front end)")
     return ap.parse_args()
 
 
@@ -198,6 +200,12 @@ def main():
     kb = KeyframeBatch(ctx, fe.geometry, det.params["SOCA"], "SOCA", 65, icp_p, args.batch)
     kb.upload_frames(frames)
     kb.upload_scan_pairs(srcs, tgts, guesses)
+    if not args.serial_prep:
+        # the scan pairs are resident and final: the preparation of the ICP targets (sort, strip table, normals)
+        # may run on the library's side stream, next to the front-end kernels of the same step (sonarfe.h,
+        # sfe_icp_set_tuning bit 3); the iteration kernel waits for both
+        ctx.sync()
+        ctx._check(ctx.lib.sfe_icp_set_tuning(ctx.handle, 8))
 
     def barrier():
         ctx.sync()
@@ -280,6 +288,7 @@ def main():
                                    % (args.batch, "" if args.no_filters else " -> downsample 0.5 -> remove_outlier 1.0/5",
                                       args.icp_mode),
                        "batch_per_gpu": args.batch, "icp_mode": args.icp_mode, "parallelism": "job farm x%d" % world,
+                       "icp_prep_stream": "main" if args.serial_prep else "side",
                        "icp_converged_jobs": ok, "mean_icp_iters": iters_total / float(args.batch),
                        "mean_points_per_frame": float(res["counts"].mean())},
             "roofline": {"kernel": "cfar_u8_ring<20,5,SOCA>", "bound": "hbm", "achieved": cfar_gbs,

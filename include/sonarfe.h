@@ -181,7 +181,11 @@ int sfe_icp_compute_pairs(sfe_ctx *ctx, const sfe_icp_params *p, const float *sr
 /* A-B knob for the ICP kernels.  bit 2: 0 = strip-sweep exact NN search (default; targets beyond 8192
  * points are walked through L2 instead of LDS), 1 = brute-force tile scan for everything.
  * Brute-force only: bit 0: 0 = packed fp32 NN loop, 1 = scalar fp32; bit 1: 0 = 64-VGPR build,
- * 2 workgroups/CU, 1 = 128-VGPR build.  All variants return identical results. */
+ * 2 workgroups/CU, 1 = 128-VGPR build.  bit 3 (strip sweep only): the clouds and guesses handed to the ICP
+ * entry points are final, i.e. no work enqueued earlier on this context still writes them; the preparation of
+ * the targets (sort, strip table, normals) then runs on a side stream next to that earlier work and only the
+ * iteration kernel waits for both.  Leave it clear when a preceding call on the context produces the clouds.
+ * All variants return identical results. */
 int sfe_icp_set_tuning(sfe_ctx *ctx, int variant);
 /* debug: enable/disable per-phase cycle counters of the sweep kernel (workgroup 0) and read the
  * 80 values of the last launch (buffer of 80 long long), summed over iterations.  Cycles: [0] setup incl. the

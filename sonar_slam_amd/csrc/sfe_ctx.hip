@@ -85,6 +85,9 @@ int sfe_ctx_create(int device, sfe_ctx **out)
     c->device = device;
     c->n_cu = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_prep, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_loop, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
         delete c;
         return sfe_set_err(nullptr, SFE_ERR_HIP, "stream/event creation failed on device %d", device);
@@ -99,11 +102,15 @@ void sfe_ctx_destroy(sfe_ctx *ctx)
         return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream2);
     for (auto &b : ctx->scratch)
         if (b.p)
             (void)hipFree(b.p);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
+    (void)hipEventDestroy(ctx->ev_prep);
+    (void)hipEventDestroy(ctx->ev_loop);
+    (void)hipStreamDestroy(ctx->stream2);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -699,7 +699,7 @@ int sfe_icp_set_tuning(sfe_ctx *ctx, int variant)
 {
     if (!ctx)
         return SFE_ERR_ARG;
-    SFE_ARG(ctx, variant >= 0 && variant <= 7);
+    SFE_ARG(ctx, variant >= 0 && variant <= 15);
     ctx->icp_variant = variant;
     return 0;
 }

@@ -1615,22 +1615,31 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
     if (!d_preps || !d_jobs || !d_stgt || !d_perm || (p->minimizer == 1 && !d_snrm) || !d_mean || !d_gkeys || !d_qxy || !d_qst || !d_qwl || !d_qssrc || !d_tab ||
         !d_nn_d2 || !d_nn_pos)
         return SFE_ERR_HIP;
-    SFE_HIP(ctx, hipMemcpyAsync(d_preps, preps.data(), sizeof(SweepPrep) * (size_t)n_prep, hipMemcpyHostToDevice,
-                                ctx->stream));
-    SFE_HIP(ctx, hipMemcpyAsync(d_jobs, jobs.data(), sizeof(SweepJob) * (size_t)n_jobs, hipMemcpyHostToDevice,
-                                ctx->stream));
+    // Tuning bit 3: the caller vouches that the clouds and guesses of this batch are final (nothing enqueued on
+    // ctx->stream still writes them).  The job tables and the prep kernel then go to the side stream and run next to
+    // whatever precedes this call on ctx->stream (a batch pipeline enqueues the front end of the same step there:
+    // latency-bound kernels that leave most of a CU idle, like the prep kernel); the loop kernel waits for them.
+    const bool side = (ctx->icp_variant & 8) != 0;
+    hipStream_t ps = side ? ctx->stream2 : ctx->stream;
+    if (side && ctx->icp_loop_pending) // the previous batch's loop kernel still reads the scratch the prep rewrites
+        SFE_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev_loop, 0));
+    SFE_HIP(ctx, hipMemcpyAsync(d_preps, preps.data(), sizeof(SweepPrep) * (size_t)n_prep, hipMemcpyHostToDevice, ps));
+    SFE_HIP(ctx, hipMemcpyAsync(d_jobs, jobs.data(), sizeof(SweepJob) * (size_t)n_jobs, hipMemcpyHostToDevice, ps));
     const int n_lds = (int)ids_lds.size(), n_glb = (int)ids_glb.size();
     ids_lds.insert(ids_lds.end(), ids_glb.begin(), ids_glb.end()); // [LDS-resident jobs | HBM-resident jobs]
-    SFE_HIP(ctx, hipMemcpyAsync(d_ids, ids_lds.data(), sizeof(int) * (size_t)n_jobs, hipMemcpyHostToDevice,
-                                ctx->stream));
+    SFE_HIP(ctx, hipMemcpyAsync(d_ids, ids_lds.data(), sizeof(int) * (size_t)n_jobs, hipMemcpyHostToDevice, ps));
     // the pageable host vectors must stay alive until the copies have been consumed
-    SFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SFE_HIP(ctx, hipStreamSynchronize(ps));
 
     SFE_HIP(ctx, hipFuncSetAttribute((const void *)icp_sweep_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)sizeof(PrepShared)));
-    hipLaunchKernelGGL(icp_sweep_prep_kernel, dim3(n_prep), dim3(ICP_THREADS), sizeof(PrepShared), ctx->stream, *p,
+    hipLaunchKernelGGL(icp_sweep_prep_kernel, dim3(n_prep), dim3(ICP_THREADS), sizeof(PrepShared), ps, *p,
                        d_preps, (const float2 *)d_tgt, d_stgt, d_perm, d_snrm, d_mean, d_gkeys, d_tab);
     SFE_LAUNCH_CHECK(ctx);
+    if (side) {
+        SFE_HIP(ctx, hipEventRecord(ctx->ev_prep, ps));
+        SFE_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prep, 0));
+    }
     static const bool debug = getenv("SFE_ICP_DEBUG") != nullptr;
     const int sw_budget = getenv("SFE_SW_BUDGET") ? atoi(getenv("SFE_SW_BUDGET")) : SW_BUDGET;
     const int sw_budget_a = getenv("SFE_SW_BUDGET_A") ? atoi(getenv("SFE_SW_BUDGET_A")) : SW_BUDGET_A;
@@ -1687,6 +1696,10 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
                                d_qxy, d_qst, d_qwl, d_qssrc, d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof, d_dbg,
                                sw_budget, sw_budget_a, sw_cache);
         SFE_LAUNCH_CHECK(ctx);
+    }
+    if (side) {
+        SFE_HIP(ctx, hipEventRecord(ctx->ev_loop, ctx->stream));
+        ctx->icp_loop_pending = true;
     }
     if (debug) {
         int h[8];

@@ -15,6 +15,12 @@ struct sfe_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // side stream of the ICP launcher (icp_variant bit 3): the prep kernel of a batch whose inputs are final runs
+    // here, next to whatever precedes the ICP call on `stream`; ev_prep orders the loop kernel behind it, ev_loop
+    // keeps the next batch's prep off the scratch the loop kernel still reads
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_prep = nullptr, ev_loop = nullptr;
+    bool icp_loop_pending = false;
     std::string err;
     struct Buf {
         void *p = nullptr;

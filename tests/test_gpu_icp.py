@@ -398,6 +398,44 @@ def test_sweep_vs_brute_force_fuzz_many_iterations(ctx):
         assert same, (case, ns, nt, p.as_dict(), a[0], b[0], a[2], b[2])
 
 
+def test_side_stream_preparation_returns_the_same_results(ctx):
+    """sfe_icp_set_tuning bit 3: the targets' preparation runs on the library's side stream and only the
+    iteration kernel waits for it; launches issued back to back (the next preparation must not overwrite the
+    scratch the previous iteration kernel still reads) return exactly what the one-stream order returns"""
+    from sonar_slam_amd.CFAR import CFAR
+    from sonar_slam_amd.feature_extraction import FeatureExtraction, SonarPing, oculus_bearings
+    from sonar_slam_amd.pipeline import KeyframeBatch
+    fe = FeatureExtraction(ctx)
+    fe.Ntc, fe.Ngc, fe.Pfa, fe.rank, fe.alg, fe.threshold = 40, 10, 0.1, 10, "SOCA", 65
+    fe.configure()
+    fe.generate_map_xy(SonarPing(np.zeros((64, 64), np.uint8), oculus_bearings(64), 0.25))
+    p = icp_config.shipped_params(minimizer=1, use_diff_checker=0, max_iter=12)
+    batches = []
+    for b in range(3):                                        # three different batches of 24 scan pairs
+        pairs = [synth.scan_pair(seed=900 + 31 * b + i, n_src=1500 + 40 * i, n_tgt=1400 + 55 * i) for i in range(24)]
+        kb = KeyframeBatch(ctx, fe.geometry, CFAR(40, 10, 0.1, 10).params["SOCA"], "SOCA", 65, p, len(pairs))
+        kb.upload_scan_pairs([q[0] for q in pairs], [q[1] for q in pairs], [q[2] for q in pairs])
+        batches.append(kb)
+    want = []
+    for kb in batches:
+        kb.run_icp()
+        want.append(kb.results())
+    ctx._check(ctx.lib.sfe_icp_set_tuning(ctx.handle, 8))
+    try:
+        for _ in range(2):
+            for kb in batches:                                # no sync in between: the launches overlap on the device
+                kb.run_icp()
+        got = [kb.results() for kb in batches]
+    finally:
+        ctx._check(ctx.lib.sfe_icp_set_tuning(ctx.handle, 0))
+    for w, g in zip(want, got):
+        for k in ("T", "status", "iters"):
+            assert np.array_equal(w[k], g[k]), k
+        assert (g["status"] == 0).all()
+    for kb in batches:
+        kb.free()
+
+
 def test_compute_pairs_and_the_farm_equal_single_calls(ctx):
     """ICP.compute_pairs (many independent pairs per launch) and farm.IcpFarm (one worker process per
     device, chunks of pairs per launch) return what one ICP.compute per pair returns"""
