@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Sweep the walk kernel's debug knobs (env SFE_SW_PART / SFE_SW_BUDGET) on the bench scan pairs."""
+"""Sweep the search budgets of the ICP loop kernel (env SFE_SW_BUDGET_A / SFE_SW_BUDGET / SFE_SW_RTRIPS) on the bench
+scan pairs: `python tools/icp_knobs.py 6,128,4 6,256,4 ...` (first pass trips, second pass budget, trips per round)."""
 import ctypes
 import os
 import sys
