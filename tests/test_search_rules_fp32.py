@@ -1,0 +1,110 @@
+"""The three pruning rules of the strip-sweep ICP search (sonar_slam_amd/csrc/sfe_icp_sweep.hip), checked in
+float32 on the CPU with numpy doing exactly the kernel's arithmetic.  The GPU tests compare whole ICP runs with
+the brute-force kernel; these fuzz each rule on its own, on inputs built to sit on the decision boundaries:
+
+  d2(p, t) = fl(fl(dx*dx) + fl(dy*dy)),  dx = fl(px - tx), dy = fl(py - ty)          (dist2 of the kernels)
+
+  1. x sweep: once fl(dx*dx) > bound for a point of an x-sorted run, no point further out has d2 <= bound;
+  2. strips: if ylb = fl(smin - py) > 0 and fl(ylb*ylb) > bound, no point with y >= smin has d2 <= bound
+     (smin = smallest y in the strips above; likewise below with smax);
+  3. clearance: a query that stood at p0 with every target at d2 >= best0 > maxDist^2 and has moved to p with
+     fl(|p - p0| * 1.00001) < fl(fl(sqrt(best0) * 0.99999) - fl(maxDist * 1.00001)) still has no target within
+     maxDist: d2(p, t) > maxDist^2 for every t.
+"""
+import numpy as np
+
+F = np.float32
+
+
+def d2(px, py, tx, ty):
+    dx = F(px) - np.asarray(tx, F)
+    dy = F(py) - np.asarray(ty, F)
+    return (dx * dx).astype(F) + (dy * dy).astype(F)          # every product and sum rounded to float32
+
+
+def _clouds(rng, n, scale):
+    kind = rng.integers(0, 4)
+    if kind == 0:                                              # uniform
+        return rng.uniform(-scale, scale, (n, 2)).astype(F)
+    if kind == 1:                                              # on a coarse raster: many equal coordinates
+        return (np.round(rng.uniform(-scale, scale, (n, 2)) * 4) / 4).astype(F)
+    if kind == 2:                                              # huge offsets: few mantissa bits left for the detail
+        return (rng.uniform(-scale, scale, (n, 2)) + 4096.0).astype(F)
+    return (rng.normal(0, scale * 1e-3, (n, 2))).astype(F)    # tiny distances (products near the denormals)
+
+
+def test_x_sweep_stop_rule_never_cuts_off_a_candidate():
+    rng = np.random.default_rng(1)
+    for case in range(400):
+        t = _clouds(rng, int(rng.integers(2, 200)), 10.0)
+        t = t[np.argsort(t[:, 0], kind="stable")]
+        q = t[rng.integers(0, len(t))] + rng.normal(0, 0.3, 2).astype(F)
+        px, py = F(q[0]), F(q[1])
+        d = d2(px, py, t[:, 0], t[:, 1])
+        e = ((px - t[:, 0]) * (px - t[:, 0])).astype(F)
+        for bound in (d.min(), np.nextafter(d.min(), F(np.inf)), F(np.median(d)), F(0.0)):
+            lo = int(np.searchsorted(t[:, 0], px, "left"))     # first point with x >= px
+            # walk right: stop at the first point with e > bound; nothing beyond may have d2 <= bound
+            r = lo
+            while r < len(t) and e[r] <= bound:
+                r += 1
+            assert not (d[r:] <= bound).any()
+            l = lo - 1
+            while l >= 0 and e[l] <= bound:
+                l -= 1
+            assert not (d[:l + 1] <= bound).any()
+
+
+def test_strip_bound_never_prunes_a_candidate():
+    rng = np.random.default_rng(2)
+    for case in range(400):
+        t = _clouds(rng, int(rng.integers(2, 300)), 10.0)
+        q = t[rng.integers(0, len(t))] + rng.normal(0, 1.0, 2).astype(F)
+        px, py = F(q[0]), F(q[1])
+        d = d2(px, py, t[:, 0], t[:, 1])
+        ys = np.sort(t[:, 1])
+        for smin in (ys[len(ys) // 2], ys[-1], np.nextafter(py, F(np.inf)), py):
+            above = t[:, 1] >= smin
+            ylb = F(smin) - py
+            for bound in (d.min(), F(np.median(d)), F((ylb * ylb)), np.nextafter(F(ylb * ylb), F(-np.inf))):
+                if ylb > 0 and F(ylb * ylb) > bound:            # the kernel skips these strips
+                    assert not (d[above] <= bound).any()
+        for smax in (ys[len(ys) // 2], ys[0], np.nextafter(py, F(-np.inf))):
+            below = t[:, 1] <= smax
+            ylb = py - F(smax)
+            for bound in (d.min(), F(np.median(d)), F(ylb * ylb), np.nextafter(F(ylb * ylb), F(-np.inf))):
+                if ylb > 0 and F(ylb * ylb) > bound:
+                    assert not (d[below] <= bound).any()
+
+
+def test_clearance_rule_never_hides_a_target_within_maxdist():
+    rng = np.random.default_rng(3)
+    skipped = 0
+    for case in range(3000):
+        md = F(rng.choice([0.3, 1.0, 10.0, 37.5]))
+        r2m = F(md * md)
+        w2 = F(r2m * F(1.1025))
+        n = int(rng.integers(1, 60))
+        ang = rng.uniform(0, 2 * np.pi, n)
+        # targets just outside maxDist of the query's first position (some far away), optionally at a large offset
+        rad = np.where(rng.random(n) < 0.7, md * (1 + rng.uniform(1e-7, 0.06, n)), md * rng.uniform(1.05, 3.0, n))
+        off = F(rng.choice([0.0, 0.0, 300.0, 4096.0]))
+        p0 = (rng.normal(0, 1, 2) + off).astype(F)
+        t = (p0.astype(np.float64) + np.c_[rad * np.cos(ang), rad * np.sin(ang)]).astype(F)
+        dd = d2(p0[0], p0[1], t[:, 0], t[:, 1])
+        if not (dd > r2m).all():
+            continue                                           # not a `none` query at p0
+        best0 = F(min(dd.min(), w2))                           # what the search holds: min(nearest, window)
+        clearance = F(F(np.sqrt(best0)) * F(0.99999)) - F(md * F(1.00001))
+        # move towards the nearest target by a fraction of / about / more than the clearance
+        j = int(np.argmin(dd))
+        u = (t[j].astype(np.float64) - p0) / max(np.linalg.norm(t[j].astype(np.float64) - p0), 1e-30)
+        for frac in (0.0, 0.5, 0.99, 0.9999, 1.0, 1.0001, 1.5):
+            step = max(float(clearance), 0.0) * frac
+            p = (p0.astype(np.float64) + u * step + rng.normal(0, 1e-7, 2)).astype(F)
+            mx, my = F(p[0] - p0[0]), F(p[1] - p0[1])
+            mv = F(np.sqrt(F(F(mx * mx) + F(my * my))))
+            if F(mv * F(1.00001)) < clearance:                 # the kernel keeps the query `none` without a search
+                skipped += 1
+                assert (d2(p[0], p[1], t[:, 0], t[:, 1]) > r2m).all(), (case, frac, md, off)
+    assert skipped > 2000                                      # the rule does fire on these inputs
