@@ -304,6 +304,13 @@ def main():
                                    "TFLOP/s = 33 % of the 157.3 TFLOP/s fp32 vector peak (sfe_icp_set_tuning 4)"},
             "stage_ms_per_step": {"cfar": ms_cfar_b, "extract": ms_extract_b, "filters": ms_filter_b, "icp": ms_icp_b},
         }
+        try:  # committed SQ counter pass of the ICP loop kernel (rocprofv3 cannot run inside the timed process)
+            with open(os.path.join(ROOT, "profiles", "icp_sq.json")) as f:
+                sq = json.load(f)
+            out["icp_kernel"].update({"valu_active_frac": sq["valu_active_frac"], "wave_wait_frac": sq["wave_wait_frac"],
+                                      "counters_from": sq["source"].split(" ")[0]})
+        except (OSError, KeyError, ValueError):
+            pass
         if cpu is not None:
             out["cpu_baseline"] = cpu
     if dist is not None:
