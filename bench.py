@@ -42,6 +42,8 @@ def parse():
                     help="CPU-baseline keyframes per host core (0 = about 10 s of work per core)")
     ap.add_argument("--icp-mode", choices=["p2plane30", "reference"], default="p2plane30")
     ap.add_argument("--no-filters", action="store_true", help="leave pcl.downsample / remove_outlier out of the step")
+    ap.add_argument("--parity-jobs", type=int, default=8,
+                    help="keyframes of the timed batch re-computed by the oracle after the timed region (0 = skip)")
     ap.add_argument("--serial-prep", action="store_true",
                     help="keep the ICP target preparation on the main stream (default: side stream, next to the front end)")
     return ap.parse_args()
@@ -159,6 +161,57 @@ def cpu_baseline(frames, srcs, tgts, guesses, n_kf, det, fe, icp_mode, filters=T
                          1e3 * np.mean([o[1] for o in one]), 1e3 * np.mean([o[2] for o in one]), ref_note)}
 
 
+def pose_diff(Ta, Tb):
+    """max(|dx|, |dy|, |dtheta|) between two 3x3 Pose2 matrices: the north_star bar is 1e-4 m / 1e-4 rad"""
+    dth = np.arctan2(Ta[1, 0], Ta[0, 0]) - np.arctan2(Tb[1, 0], Tb[0, 0])
+    return float(max(abs(Ta[0, 2] - Tb[0, 2]), abs(Ta[1, 2] - Tb[1, 2]), abs(np.arctan2(np.sin(dth), np.cos(dth)))))
+
+
+def parity_check(kb, res, frames, srcs, tgts, guesses, det, fe, icp_mode, filters, k_jobs):
+    """Oracle sample of the TIMED batch (the outputs left in HBM by the last timed step): k_jobs keyframes spread
+    over the batch, each through the whole oracle chain -- CFAR mask, extracted points (order included), filtered
+    cloud: bit-exact; ICP pose: <= 1e-4 m / rad against the oracle in float (PointMatcher<float>) with its exact
+    kd-tree, and the same statuses / iteration counts as the oracle with fp64 sums.  Raises on any mismatch: a bench line
+    whose work is wrong must not be printed."""
+    import oracle
+    th, gh, tau = det.params["SOCA"]
+    n = len(frames)
+    picks = sorted(set(int(round(i * (n - 1) / max(1, k_jobs - 1))) for i in range(k_jobs)))
+    mk = dict(minimizer=1, use_diff_checker=0, max_iter=30) if icp_mode == "p2plane30" else {}
+    worst, worst64, bit_exact = 0.0, 0.0, 0
+    oracle.set_kdtree(1)
+    try:
+        for j in picks:
+            m = oracle.gate(frames[j], oracle.cfar(frames[j], "SOCA", th, gh, tau), 65)
+            if not np.array_equal(kb.mask(j), m):
+                raise AssertionError("parity: CFAR mask of timed frame %d differs from the oracle" % j)
+            rc = oracle.nonzero(oracle.remap_u8(m, fe.map_x, fe.map_y))
+            pts = oracle.px_to_m(rc, fe.rows, fe.cols, fe.width, fe.height)
+            if not np.array_equal(kb.points(j), pts):
+                raise AssertionError("parity: extracted points of timed frame %d differ from the oracle" % j)
+            if filters:
+                cl = oracle.remove_outlier(oracle.downsample(pts.astype(np.float32), 0.5), 1.0, 5)
+                if not np.array_equal(kb.cloud(j), cl):
+                    raise AssertionError("parity: filtered cloud of timed frame %d differs from the oracle" % j)
+            bit_exact += 1
+            st, To, it = oracle.icp(srcs[j], tgts[j], guesses[j], oracle.shipped_icp_params(precision=0, **mk))
+            st64, To64, it64 = oracle.icp(srcs[j], tgts[j], guesses[j], oracle.shipped_icp_params(precision=1, **mk))
+            if int(res["status"][j]) != st64 or int(res["iters"][j]) != it64:
+                raise AssertionError("parity: ICP job %d status/iterations (%d, %d) vs oracle (%d, %d)"
+                                     % (j, res["status"][j], res["iters"][j], st64, it64))
+            worst = max(worst, pose_diff(res["T"][j], To))
+            worst64 = max(worst64, pose_diff(res["T"][j], To64))
+    finally:
+        oracle.set_kdtree(0)
+    if not worst <= 1e-4:
+        raise AssertionError("parity: ICP pose differs from the oracle by %.3e (> 1e-4)" % worst)
+    return {"jobs": len(picks), "frames_bit_exact": bit_exact, "icp_max_pose_diff": worst,
+            "icp_max_pose_diff_vs_f64_sums": worst64, "icp_tolerance": 1e-4,
+            "checked": "CFAR mask, extracted points (np.nonzero order), %sICP pose/status/iterations of keyframes %s of "
+                       "the last timed step vs the CPU oracle (exact kd-tree)"
+                       % ("downsample+remove_outlier cloud, " if filters else "", picks)}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -228,6 +281,10 @@ def main():
         dt = float(t[0])
     res = kb.results()
     ok = int((res["status"] == 0).sum())
+    parity = None
+    if rank == 0 and args.parity_jobs > 0:   # the timed step's own outputs, before anything overwrites them
+        parity = parity_check(kb, res, frames, srcs, tgts, guesses, det, fe, args.icp_mode, not args.no_filters,
+                              args.parity_jobs)
 
     out = None
     if rank == 0:
@@ -290,7 +347,8 @@ def main():
                        "batch_per_gpu": args.batch, "icp_mode": args.icp_mode, "parallelism": "job farm x%d" % world,
                        "icp_prep_stream": "main" if args.serial_prep else "side",
                        "icp_converged_jobs": ok, "mean_icp_iters": iters_total / float(args.batch),
-                       "mean_points_per_frame": float(res["counts"].mean())},
+                       "mean_points_per_frame": float(res["counts"].mean()),
+                       "max_points_per_frame": int(res["counts"].max()), "points_capacity": kb.cap},
             "roofline": {"kernel": "cfar_u8_ring<20,5,SOCA>", "bound": "hbm", "achieved": cfar_gbs,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cfar_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_note": "bytes/launch = 2*FETCH_SIZE + WRITE_SIZE from profiles/cfar_pmc.json",
@@ -311,6 +369,8 @@ def main():
                                       "counters_from": sq["source"].split(" ")[0]})
         except (OSError, KeyError, ValueError):
             pass
+        if parity is not None:
+            out["parity_check"] = parity
         if cpu is not None:
             out["cpu_baseline"] = cpu
     if dist is not None:

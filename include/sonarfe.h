@@ -178,6 +178,13 @@ int sfe_icp_compute_guesses(sfe_ctx *ctx, const sfe_icp_params *p, const float *
 int sfe_icp_compute_pairs(sfe_ctx *ctx, const sfe_icp_params *p, const float *src, const int32_t *src_off,
                           const float *tgt, const int32_t *tgt_off, const float *guesses9, int n_jobs,
                           float *T_out9, int32_t *status, int32_t *iters);
+/* the same with an explicit job table, so that jobs may SHARE clouds (many guesses on one pair, one target matched
+ * against many sources: the loop of slam.py:346-358 and the job farm's chunks): src / tgt = all clouds back to
+ * back (n_src_pts / n_tgt_pts points in total), jobs4 = n_jobs x (src_start, n_src, tgt_start, n_tgt) in points.
+ * Jobs naming the same target slice share one target preparation (sort, strip table, normals). */
+int sfe_icp_compute_jobs(sfe_ctx *ctx, const sfe_icp_params *p, const float *src, int n_src_pts, const float *tgt,
+                         int n_tgt_pts, const int32_t *jobs4, const float *guesses9, int n_jobs, float *T_out9,
+                         int32_t *status, int32_t *iters);
 /* A-B knob for the ICP kernels.  bit 2: 0 = strip-sweep exact NN search (default; targets beyond 8192
  * points are walked through L2 instead of LDS), 1 = brute-force tile scan for everything.
  * Brute-force only: bit 0: 0 = packed fp32 NN loop, 1 = scalar fp32; bit 1: 0 = 64-VGPR build,

@@ -101,6 +101,8 @@ SIGNATURES = {
                                           _f32p, C.c_int, _f32p, _i32p, _i32p]),
     "sfe_icp_compute_pairs": (C.c_int, [_vp, C.POINTER(IcpParams), _f32p, _i32p, _f32p, _i32p, _f32p, C.c_int,
                                         _f32p, _i32p, _i32p]),
+    "sfe_icp_compute_jobs": (C.c_int, [_vp, C.POINTER(IcpParams), _f32p, C.c_int, _f32p, C.c_int, _i32p, _f32p, C.c_int,
+                                       _f32p, _i32p, _i32p]),
     "sfe_icp_set_tuning": (C.c_int, [_vp, C.c_int]),
     "sfe_icp_get_profile": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_longlong)]),
     "sfe_icp_batch_dev": (C.c_int, [_vp, C.POINTER(IcpParams), _vp, _i32p, _vp, _i32p, _vp, C.c_int,

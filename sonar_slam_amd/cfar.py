@@ -18,6 +18,7 @@ Extension (not in the reference): ``detect_gated`` fuses ``peaks &= img > thresh
 (feature_extraction.py:224) into the same kernel.
 """
 import ctypes as _C
+import math as _math
 import operator as _operator
 
 import numpy as _np
@@ -33,9 +34,20 @@ def _as_index(k):
         raise TypeError("cfar.os(): k must be an integer, got %r" % (k,))
 
 
-def _run(alg, img, train_hs, guard_hs, k, tau, want_thr, intensity_thr=-1, ctx=None):
+def _gate_u8(threshold):
+    """``img > threshold`` (feature_extraction.py:224) for uint8 pixels as the integer gate of
+    sfe_cfar_u8: x > t  <=>  x > floor(t) for integer x; a negative threshold gates nothing (-1 = off),
+    a threshold >= 255 gates everything."""
+    t = _math.floor(float(threshold))
+    return -1 if t < 0 else int(min(t, 255))
+
+
+def _run(alg, img, train_hs, guard_hs, k, tau, want_thr, gate=None, ctx=None):
+    """gate: None = plain cfar.*; else the intensity threshold of feature_extraction.py:224 as given
+    (compared as is against float images, floored for uint8 ones)."""
     ctx = ctx or _L.default_context()
     img = _np.asarray(img)
+    intensity_thr = -1 if gate is None else _gate_u8(gate)
     if img.ndim != 2:
         raise TypeError("cfar: expected a 2-D array, got shape %r" % (img.shape,))
     rows, cols = img.shape
@@ -53,8 +65,8 @@ def _run(alg, img, train_hs, guard_hs, k, tau, want_thr, intensity_thr=-1, ctx=N
             a = _np.ascontiguousarray(img, _np.float32)
             rc = ctx.lib.sfe_cfar_f32(ctx.handle, _L.ptr(a, _C.c_float), rows, cols, alg, train_hs,
                                       guard_hs, k, float(tau), _L.ptr(mask, _C.c_uint8), tp)
-            if intensity_thr >= 0:
-                mask &= (a > intensity_thr).astype(_np.uint8)
+            if gate is not None:
+                mask &= (a > gate).astype(_np.uint8)
         ctx._check(rc)
     return (mask, thr) if want_thr else mask
 
@@ -104,4 +116,4 @@ def detect_gated(img, alg, params, threshold, ctx=None):
     else:
         train_hs, guard_hs, tau = params
         k = 0
-    return _run(code, img, train_hs, guard_hs, k, tau, False, intensity_thr=int(threshold), ctx=ctx)
+    return _run(code, img, train_hs, guard_hs, k, tau, False, gate=threshold, ctx=ctx)

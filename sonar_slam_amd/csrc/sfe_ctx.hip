@@ -26,6 +26,8 @@ void *sfe_scratch(sfe_ctx *ctx, int slot, size_t bytes)
         return b.p;
     if (b.p) {
         (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->stream2)
+            (void)hipStreamSynchronize(ctx->stream2); // the ICP target preparation may run there
         (void)hipFree(b.p);
         b.p = nullptr;
         b.cap = 0;
@@ -38,6 +40,41 @@ void *sfe_scratch(sfe_ctx *ctx, int slot, size_t bytes)
     }
     b.cap = want;
     return b.p;
+}
+
+void *sfe_pinned_begin(sfe_ctx *ctx, size_t bytes)
+{
+    auto &b = ctx->pin[ctx->pin_next];
+    if (b.pending) {
+        if (hipEventSynchronize(b.ev) != hipSuccess) {
+            sfe_set_err(ctx, SFE_ERR_HIP, "hipEventSynchronize on a pinned staging block failed");
+            return nullptr;
+        }
+        b.pending = false;
+    }
+    if (bytes > b.cap || !b.p) {
+        if (b.p)
+            (void)hipHostFree(b.p);
+        b.p = nullptr;
+        b.cap = 0;
+        const size_t want = bytes + bytes / 4 + 4096;
+        if (hipHostMalloc(&b.p, want, hipHostMallocDefault) != hipSuccess) {
+            b.p = nullptr;
+            sfe_set_err(ctx, SFE_ERR_HIP, "hipHostMalloc(%zu) for the pinned staging block failed", want);
+            return nullptr;
+        }
+        b.cap = want;
+    }
+    return b.p;
+}
+
+int sfe_pinned_end(sfe_ctx *ctx, hipStream_t s)
+{
+    auto &b = ctx->pin[ctx->pin_next];
+    SFE_HIP(ctx, hipEventRecord(b.ev, s));
+    b.pending = true;
+    ctx->pin_next ^= 1;
+    return 0;
 }
 
 extern "C" {
@@ -88,6 +125,8 @@ int sfe_ctx_create(int device, sfe_ctx **out)
         hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_prep, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_loop, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->pin[0].ev, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->pin[1].ev, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
         delete c;
         return sfe_set_err(nullptr, SFE_ERR_HIP, "stream/event creation failed on device %d", device);
@@ -106,6 +145,12 @@ void sfe_ctx_destroy(sfe_ctx *ctx)
     for (auto &b : ctx->scratch)
         if (b.p)
             (void)hipFree(b.p);
+    for (auto &b : ctx->pin) {
+        if (b.p)
+            (void)hipHostFree(b.p);
+        if (b.ev)
+            (void)hipEventDestroy(b.ev);
+    }
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
     (void)hipEventDestroy(ctx->ev_prep);

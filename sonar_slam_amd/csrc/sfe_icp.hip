@@ -670,10 +670,15 @@ static int icp_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_src,
     float2 *d_nrm = p->minimizer == 1 ? (float2 *)sfe_scratch(ctx, 7, sizeof(float2) * (size_t)noff) : nullptr;
     if (!d_jobs || !d_nn_d2 || !d_nn_idx || (p->minimizer == 1 && !d_nrm))
         return SFE_ERR_HIP;
-    SFE_HIP(ctx, hipMemcpyAsync(d_jobs, jobs.data(), sizeof(IcpJob) * (size_t)n_jobs, hipMemcpyHostToDevice,
-                                ctx->stream));
-    // the pageable host vector must stay alive until the copy has been consumed
-    SFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    { // pinned staging: no stream synchronisation on an enqueue-only path
+        void *h = sfe_pinned_begin(ctx, sizeof(IcpJob) * (size_t)n_jobs);
+        if (!h)
+            return SFE_ERR_HIP;
+        memcpy(h, jobs.data(), sizeof(IcpJob) * (size_t)n_jobs);
+        SFE_HIP(ctx, hipMemcpyAsync(d_jobs, h, sizeof(IcpJob) * (size_t)n_jobs, hipMemcpyHostToDevice, ctx->stream));
+        if (int rc = sfe_pinned_end(ctx, ctx->stream))
+            return rc;
+    }
     // occupancy A/B: bit 1 of the tuning variant selects the 128-VGPR build (1 workgroup per CU)
     const int nnv = ctx->icp_variant & 1;
     if (!(ctx->icp_variant & 2)) { // default: 64-VGPR build, two workgroups per CU (measured 7 % faster)
@@ -786,6 +791,44 @@ int sfe_icp_compute_pairs(sfe_ctx *ctx, const sfe_icp_params *p, const float *sr
     SFE_HIP(ctx, hipMemcpyAsync(d_tgt, tgt, sizeof(float) * 2 * nt, hipMemcpyHostToDevice, ctx->stream));
     SFE_HIP(ctx, hipMemcpyAsync(d_g, guesses9, sizeof(float) * 9 * (size_t)n_jobs, hipMemcpyHostToDevice, ctx->stream));
     if (int rc = sfe_icp_batch_dev(ctx, p, d_src, src_off, d_tgt, tgt_off, d_g, n_jobs, d_T, d_st, d_st + n_jobs))
+        return rc;
+    SFE_HIP(ctx, hipMemcpyAsync(T_out9, d_T, sizeof(float) * 9 * (size_t)n_jobs, hipMemcpyDeviceToHost, ctx->stream));
+    SFE_HIP(ctx, hipMemcpyAsync(status, d_st, sizeof(int32_t) * (size_t)n_jobs, hipMemcpyDeviceToHost, ctx->stream));
+    if (iters)
+        SFE_HIP(ctx, hipMemcpyAsync(iters, d_st + n_jobs, sizeof(int32_t) * (size_t)n_jobs, hipMemcpyDeviceToHost,
+                                    ctx->stream));
+    SFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int sfe_icp_compute_jobs(sfe_ctx *ctx, const sfe_icp_params *p, const float *src, int n_src_pts, const float *tgt,
+                         int n_tgt_pts, const int32_t *jobs4, const float *guesses9, int n_jobs, float *T_out9,
+                         int32_t *status, int32_t *iters)
+{
+    if (int rc = sfe_use(ctx))
+        return rc;
+    SFE_ARG(ctx, n_jobs >= 0 && n_src_pts >= 0 && n_tgt_pts >= 0 &&
+                     (n_jobs == 0 || (src && tgt && jobs4 && guesses9 && T_out9 && status)));
+    if (n_jobs == 0)
+        return 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const int32_t *q = jobs4 + 4 * (size_t)j;
+        if (q[0] < 0 || q[1] < 0 || q[2] < 0 || q[3] < 0 || (long long)q[0] + q[1] > n_src_pts ||
+            (long long)q[2] + q[3] > n_tgt_pts)
+            return sfe_set_err(ctx, SFE_ERR_ARG, "ICP job %d (%d+%d, %d+%d) lies outside the clouds (%d, %d points)", j,
+                               q[0], q[1], q[2], q[3], n_src_pts, n_tgt_pts);
+    }
+    float *d_src = (float *)sfe_scratch(ctx, 0, sizeof(float) * 2 * (size_t)std::max(n_src_pts, 1));
+    float *d_tgt = (float *)sfe_scratch(ctx, 1, sizeof(float) * 2 * (size_t)std::max(n_tgt_pts, 1));
+    float *d_g = (float *)sfe_scratch(ctx, 2, sizeof(float) * 9 * (size_t)n_jobs);
+    float *d_T = (float *)sfe_scratch(ctx, 3, sizeof(float) * 9 * (size_t)n_jobs);
+    int32_t *d_st = (int32_t *)sfe_scratch(ctx, 8, sizeof(int32_t) * 2 * (size_t)n_jobs);
+    if (!d_src || !d_tgt || !d_g || !d_T || !d_st)
+        return SFE_ERR_HIP;
+    SFE_HIP(ctx, hipMemcpyAsync(d_src, src, sizeof(float) * 2 * (size_t)n_src_pts, hipMemcpyHostToDevice, ctx->stream));
+    SFE_HIP(ctx, hipMemcpyAsync(d_tgt, tgt, sizeof(float) * 2 * (size_t)n_tgt_pts, hipMemcpyHostToDevice, ctx->stream));
+    SFE_HIP(ctx, hipMemcpyAsync(d_g, guesses9, sizeof(float) * 9 * (size_t)n_jobs, hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = icp_launch(ctx, p, d_src, d_tgt, jobs4, d_g, n_jobs, d_T, d_st, d_st + n_jobs))
         return rc;
     SFE_HIP(ctx, hipMemcpyAsync(T_out9, d_T, sizeof(float) * 9 * (size_t)n_jobs, hipMemcpyDeviceToHost, ctx->stream));
     SFE_HIP(ctx, hipMemcpyAsync(status, d_st, sizeof(int32_t) * (size_t)n_jobs, hipMemcpyDeviceToHost, ctx->stream));

@@ -39,6 +39,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <type_traits>
 #include <utility>
@@ -1597,13 +1598,16 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
         (q[3] <= SW_TCAP ? ids_lds : ids_glb).push_back(j);
     }
     const int n_prep = (int)preps.size();
-    SweepPrep *d_preps = (SweepPrep *)sfe_scratch(ctx, 12, sizeof(SweepPrep) * (size_t)n_prep);
-    SweepJob *d_jobs = (SweepJob *)sfe_scratch(ctx, 13, sizeof(SweepJob) * (size_t)n_jobs);
+    const int n_lds = (int)ids_lds.size(), n_glb = (int)ids_glb.size();
+    // the three tables travel as ONE block: [preps | jobs | job ids: LDS-resident jobs, then HBM-resident jobs]
+    const size_t o_jobs = (sizeof(SweepPrep) * (size_t)n_prep + 15) & ~(size_t)15;
+    const size_t o_ids = (o_jobs + sizeof(SweepJob) * (size_t)n_jobs + 15) & ~(size_t)15;
+    const size_t tab_bytes = o_ids + sizeof(int) * (size_t)n_jobs;
+    char *d_tables = (char *)sfe_scratch(ctx, 12, tab_bytes);
     float2 *d_stgt = (float2 *)sfe_scratch(ctx, 14, sizeof(float2) * (size_t)toff);
     int *d_perm = (int *)sfe_scratch(ctx, 15, sizeof(int) * (size_t)toff);
     float2 *d_snrm = p->minimizer == 1 ? (float2 *)sfe_scratch(ctx, 16, sizeof(float2) * (size_t)toff) : nullptr;
-    float *d_mean = (float *)sfe_scratch(ctx, 17, sizeof(float) * 2 * (size_t)n_prep + sizeof(int) * (size_t)n_jobs);
-    int *d_ids = d_mean ? (int *)(d_mean + 2 * (size_t)n_prep) : nullptr;
+    float *d_mean = (float *)sfe_scratch(ctx, 17, sizeof(float) * 2 * (size_t)n_prep);
     unsigned long long *d_gkeys = (unsigned long long *)sfe_scratch(ctx, 24, sizeof(unsigned long long) * (size_t)std::max(koff, 1LL));
     float2 *d_qxy = (float2 *)sfe_scratch(ctx, 18, sizeof(float2) * (size_t)qoff);
     int4 *d_qst = (int4 *)sfe_scratch(ctx, 19, sizeof(int4) * (size_t)qoff);
@@ -1612,9 +1616,12 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
     StripTab *d_tab = (StripTab *)sfe_scratch(ctx, 23, sizeof(StripTab) * (size_t)n_prep);
     float *d_nn_d2 = (float *)sfe_scratch(ctx, 5, sizeof(float) * (size_t)qoff);
     int *d_nn_pos = (int *)sfe_scratch(ctx, 6, sizeof(int) * (size_t)qoff);
-    if (!d_preps || !d_jobs || !d_stgt || !d_perm || (p->minimizer == 1 && !d_snrm) || !d_mean || !d_gkeys || !d_qxy || !d_qst || !d_qwl || !d_qssrc || !d_tab ||
+    if (!d_tables || !d_stgt || !d_perm || (p->minimizer == 1 && !d_snrm) || !d_mean || !d_gkeys || !d_qxy || !d_qst || !d_qwl || !d_qssrc || !d_tab ||
         !d_nn_d2 || !d_nn_pos)
         return SFE_ERR_HIP;
+    SweepPrep *d_preps = (SweepPrep *)d_tables;
+    SweepJob *d_jobs = (SweepJob *)(d_tables + o_jobs);
+    int *d_ids = (int *)(d_tables + o_ids);
     // Tuning bit 3: the caller vouches that the clouds and guesses of this batch are final (nothing enqueued on
     // ctx->stream still writes them).  The job tables and the prep kernel then go to the side stream and run next to
     // whatever precedes this call on ctx->stream (a batch pipeline enqueues the front end of the same step there:
@@ -1623,13 +1630,19 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
     hipStream_t ps = side ? ctx->stream2 : ctx->stream;
     if (side && ctx->icp_loop_pending) // the previous batch's loop kernel still reads the scratch the prep rewrites
         SFE_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev_loop, 0));
-    SFE_HIP(ctx, hipMemcpyAsync(d_preps, preps.data(), sizeof(SweepPrep) * (size_t)n_prep, hipMemcpyHostToDevice, ps));
-    SFE_HIP(ctx, hipMemcpyAsync(d_jobs, jobs.data(), sizeof(SweepJob) * (size_t)n_jobs, hipMemcpyHostToDevice, ps));
-    const int n_lds = (int)ids_lds.size(), n_glb = (int)ids_glb.size();
-    ids_lds.insert(ids_lds.end(), ids_glb.begin(), ids_glb.end()); // [LDS-resident jobs | HBM-resident jobs]
-    SFE_HIP(ctx, hipMemcpyAsync(d_ids, ids_lds.data(), sizeof(int) * (size_t)n_jobs, hipMemcpyHostToDevice, ps));
-    // the pageable host vectors must stay alive until the copies have been consumed
-    SFE_HIP(ctx, hipStreamSynchronize(ps));
+    { // pinned staging (no stream synchronisation: this entry point only enqueues)
+        char *h = (char *)sfe_pinned_begin(ctx, tab_bytes);
+        if (!h)
+            return SFE_ERR_HIP;
+        memcpy(h, preps.data(), sizeof(SweepPrep) * (size_t)n_prep);
+        memcpy(h + o_jobs, jobs.data(), sizeof(SweepJob) * (size_t)n_jobs);
+        memcpy(h + o_ids, ids_lds.data(), sizeof(int) * (size_t)n_lds);
+        if (n_glb)
+            memcpy(h + o_ids + sizeof(int) * (size_t)n_lds, ids_glb.data(), sizeof(int) * (size_t)n_glb);
+        SFE_HIP(ctx, hipMemcpyAsync(d_tables, h, tab_bytes, hipMemcpyHostToDevice, ps));
+        if (int rc = sfe_pinned_end(ctx, ps))
+            return rc;
+    }
 
     SFE_HIP(ctx, hipFuncSetAttribute((const void *)icp_sweep_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)sizeof(PrepShared)));

@@ -26,6 +26,16 @@ struct sfe_ctx {
         void *p = nullptr;
         size_t cap = 0;
     } scratch[SFE_NSCRATCH];
+    // pinned host staging for the small tables a launch hands to the device (job records, offsets): two blocks
+    // used alternately, each guarded by the event recorded behind its last copy, so that enqueue-only (_dev)
+    // entry points never synchronise a stream to keep a pageable vector alive
+    struct Pin {
+        void *p = nullptr;
+        size_t cap = 0;
+        hipEvent_t ev = nullptr;
+        bool pending = false;
+    } pin[2];
+    int pin_next = 0;
     int cfar_tile_rows = 0;
     int cfar_variant = 0;
     int icp_variant = 0;
@@ -53,6 +63,11 @@ struct sfe_geom {
 
 int sfe_set_err(sfe_ctx *ctx, int code, const char *fmt, ...);
 void *sfe_scratch(sfe_ctx *ctx, int slot, size_t bytes);  // grow-only device scratch; nullptr on failure
+// Pinned staging: sfe_pinned_begin hands out a host block of >= bytes (waiting, if need be, for the copy that last
+// read it -- two launches ago); the caller fills it, enqueues its hipMemcpyAsync calls on `s` and then calls
+// sfe_pinned_end(ctx, s) so the block is not reused before those copies have run.  nullptr on failure.
+void *sfe_pinned_begin(sfe_ctx *ctx, size_t bytes);
+int sfe_pinned_end(sfe_ctx *ctx, hipStream_t s);
 
 #define SFE_HIP(ctx, call)                                                                       \
     do {                                                                                         \

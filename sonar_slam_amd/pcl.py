@@ -188,6 +188,31 @@ class ICP(object):
         msgs = [_L.ICP_STATUS_MESSAGES.get(int(s), "ICP failure %d" % s) for s in st]
         return msgs, T, it
 
+    def compute_jobs(self, src_all, tgt_all, jobs4, guesses9, out=None):
+        """Scan matches named by a job table over two cloud pools (extension; what a farm worker runs per
+        chunk): src_all / tgt_all = clouds back to back (N x 2 float32), jobs4 = n x (src_start, n_src,
+        tgt_start, n_tgt) in points, guesses9 = n x 9.  Jobs may share clouds; jobs naming the same target slice
+        share its preparation.  -> (status int32 [n], T [n x 3 x 3] float32, iterations int32 [n]); the three
+        arrays may be handed in preallocated (``out=(status, T, iters)``, e.g. views of shared memory)."""
+        ctx = self._ctx or _L.default_context()
+        src = _cloud(src_all, "ICP.compute_jobs(src_all)")
+        tgt = _cloud(tgt_all, "ICP.compute_jobs(tgt_all)")
+        jobs4 = _np.ascontiguousarray(jobs4, _np.int32).reshape(-1, 4)
+        n = len(jobs4)
+        g = _np.ascontiguousarray(guesses9, _np.float32).reshape(n, 9)
+        if out is None:
+            st, T, it = _np.zeros(n, _np.int32), _np.zeros((n, 3, 3), _np.float32), _np.zeros(n, _np.int32)
+        else:
+            st, T, it = out
+        if n and ((jobs4[:, 1] <= 0).any() or (jobs4[:, 3] <= 0).any()):
+            raise RuntimeError("ICP.compute_jobs: empty point cloud (libpointmatcher would throw)")
+        with ctx.lock:
+            ctx._check(ctx.lib.sfe_icp_compute_jobs(
+                ctx.handle, _C.byref(self.params), _L.ptr(src, _C.c_float), len(src), _L.ptr(tgt, _C.c_float), len(tgt),
+                _L.ptr(jobs4, _C.c_int32), _L.ptr(g, _C.c_float), n, _L.ptr(T, _C.c_float), _L.ptr(st, _C.c_int32),
+                _L.ptr(it, _C.c_int32)))
+        return st, T, it
+
     def getCovariance(self):
         """errorMinimizer->getCovariance() (pcl.cpp:213).  libpointmatcher's base ErrorMinimizer
         returns a zero dim x dim matrix unless the point-to-plane minimiser estimated one; no

@@ -11,6 +11,7 @@ import ctypes as _C
 import numpy as np
 
 from . import _lib as _L
+from .cfar import _gate_u8
 
 
 class KeyframeBatch(object):
@@ -23,7 +24,7 @@ class KeyframeBatch(object):
         else:
             self.train_hs, self.guard_hs, self.tau = cfar_params
             self.k = 0
-        self.intensity_thr = int(intensity_thr)
+        self.intensity_thr = _gate_u8(intensity_thr)   # img > thr on uint8 pixels (feature_extraction.py:224)
         self.icp_params = icp_params
         self.n = int(n_jobs)
         self.rows, self.cols = geometry.polar_rows, geometry.polar_cols
@@ -88,8 +89,22 @@ class KeyframeBatch(object):
 
     def cloud(self, j):
         """the filtered float32 feature cloud of frame j (after run_filter)"""
+        self._check_frame(j)
         n = int(self.d_cloud_cnt.download(np.int32, 1, offset=4 * j)[0])
-        return self.d_cloud.download(np.float32, 2 * max(n, 0), offset=j * self.cap * 8).reshape(-1, 2)
+        if n < 0:
+            raise _L.SonarFEError("frame %d: the octree of pcl.downsample is deeper than 24 levels "
+                                  "(sfe_cloud_filter_batch_dev reports -1); use the per-cloud pcl.downsample" % j)
+        return self.d_cloud.download(np.float32, 2 * n, offset=j * self.cap * 8).reshape(-1, 2)
+
+    def _check_frame(self, j):
+        """The resident path stores only the first `cap` points of a frame (sonarfe.h,
+        sfe_extract_points_batch_dev): a frame above the cap is an error here, never a silently
+        truncated cloud (the per-cloud API, Geometry.extract, retries with a larger buffer instead)."""
+        n = int(self.d_cnt.download(np.int32, 1, offset=4 * j)[0])
+        if n > self.cap:
+            raise _L.SonarFEError("frame %d has %d points, more than the batch capacity %d: construct the "
+                                  "KeyframeBatch with max_points >= %d" % (j, n, self.cap, n))
+        return n
 
     def run_icp(self):
         c = self.ctx
@@ -109,18 +124,30 @@ class KeyframeBatch(object):
         self.run_icp()
 
     def results(self):
+        """Per-job outputs.  Raises if any frame overflowed the point capacity (its cloud, and everything
+        computed from it, would be truncated) or could not be filtered."""
         self.ctx.sync()
+        counts = self.d_cnt.download(np.int32, self.n)
+        if counts.size and int(counts.max()) > self.cap:
+            f = int(counts.argmax())
+            raise _L.SonarFEError("frame %d has %d points, more than the batch capacity %d: construct the "
+                                  "KeyframeBatch with max_points >= %d" % (f, counts[f], self.cap, counts[f]))
+        if self.d_cloud_cnt is not None:
+            cc = self.d_cloud_cnt.download(np.int32, self.n)
+            if (cc < 0).any():
+                raise _L.SonarFEError("frame %d: the octree of pcl.downsample is deeper than 24 levels"
+                                      % int(np.argmin(cc)))
         return {
-            "counts": self.d_cnt.download(np.int32, self.n),
+            "counts": counts,
+            "cloud_counts": cc if self.d_cloud_cnt is not None else None,
             "T": self.d_T.download(np.float32, self.n * 9).reshape(self.n, 3, 3),
             "status": self.d_status.download(np.int32, self.n),
             "iters": self.d_iters.download(np.int32, self.n),
         }
 
     def points(self, j):
-        n = int(self.d_cnt.download(np.int32, 1, offset=4 * j)[0])
-        m = min(n, self.cap)
-        return self.d_pts.download(np.float64, 2 * m, offset=j * self.cap * 16).reshape(m, 2)
+        n = self._check_frame(j)
+        return self.d_pts.download(np.float64, 2 * n, offset=j * self.cap * 16).reshape(n, 2)
 
     def mask(self, j):
         sz = self.rows * self.cols

@@ -35,3 +35,53 @@ def test_cpu_baseline_leg_runs_and_reports_the_contract_fields():
     assert set(out) >= {"value", "unit", "cores", "kind", "sample"}
     assert out["kind"] == "port" and out["unit"] == "keyframes/s" and out["value"] > 0
     assert out["cores"] == bench.usable_cores()
+
+
+class _OracleBackedBatch(object):
+    """stands in for KeyframeBatch in the parity_check test: hands back what a correct device would hold"""
+
+    def __init__(self, frames, det, fe):
+        import oracle
+        th, gh, tau = det.params["SOCA"]
+        self.cap = 16384
+        self.m, self.p, self.c = [], [], []
+        for f in frames:
+            m = oracle.gate(f, oracle.cfar(f, "SOCA", th, gh, tau), 65)
+            pts = oracle.px_to_m(oracle.nonzero(oracle.remap_u8(m, fe.map_x, fe.map_y)), fe.rows, fe.cols, fe.width,
+                                 fe.height)
+            self.m.append(m)
+            self.p.append(pts)
+            self.c.append(oracle.remove_outlier(oracle.downsample(pts.astype(np.float32), 0.5), 1.0, 5))
+
+    def mask(self, j):
+        return self.m[j]
+
+    def points(self, j):
+        return self.p[j]
+
+    def cloud(self, j):
+        return self.c[j]
+
+
+def test_parity_check_accepts_correct_outputs_and_raises_on_wrong_ones():
+    import pytest
+
+    import oracle
+    det = CFAR(40, 10, 0.1, 10)
+    frames, srcs, tgts, guesses = bench.make_inputs(0, 2)
+    srcs, tgts = [s[:600] for s in srcs], [t[:600] for t in tgts]
+    res_, height_, rows_, width_, cols_, mx, my = build_maps(oculus_bearings(bench.COLS), 30.0 / bench.ROWS, bench.ROWS)
+    fe = SimpleNamespace(map_x=mx, map_y=my, rows=rows_, cols=cols_, width=width_, height=height_)
+    kb = _OracleBackedBatch(frames, det, fe)
+    out = [oracle.icp(s, t, g, oracle.shipped_icp_params(precision=1)) for s, t, g in zip(srcs, tgts, guesses)]
+    res = {"status": np.array([o[0] for o in out]), "T": np.stack([o[1] for o in out]),
+           "iters": np.array([o[2] for o in out])}
+    pc = bench.parity_check(kb, res, frames, srcs, tgts, guesses, det, fe, "reference", True, 2)
+    assert pc["jobs"] == 2 and pc["frames_bit_exact"] == 2 and pc["icp_max_pose_diff"] <= 1e-4
+    bad = dict(res, T=res["T"].copy())
+    bad["T"][1, 0, 2] += 1e-3
+    with pytest.raises(AssertionError):
+        bench.parity_check(kb, bad, frames, srcs, tgts, guesses, det, fe, "reference", True, 2)
+    kb.p[0] = kb.p[0][::-1].copy()          # right points, wrong order
+    with pytest.raises(AssertionError):
+        bench.parity_check(kb, res, frames, srcs, tgts, guesses, det, fe, "reference", True, 2)

@@ -135,3 +135,59 @@ def test_two_rank_gloo_farm():
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
         assert "FARM_OK" in o, o
+
+
+def test_farm_packs_shared_clouds_once():
+    from sonar_slam_amd import farm
+    rng = np.random.default_rng(0)
+    a, b, c = (rng.normal(size=(n, 2)).astype(np.float32) for n in (5, 7, 3))
+    g = np.eye(3, dtype=np.float32)
+    jobs = [(a, b, [g, g, g]), (c, b, [g]), (a, c, [])]
+    sp, tp, ns, nt, rows, gs = farm.pack_jobs(jobs)
+    assert [len(x) for x in sp] == [5, 3] and [len(x) for x in tp] == [7, 3] and (ns, nt) == (8, 10)
+    assert rows == [(0, 5, 0, 7)] * 3 + [(5, 3, 0, 7)] and len(gs) == 4
+    lay = farm._layout(ns, nt, len(rows))
+    assert all(lay[k] % 64 == 0 for k in ("src", "tgt", "jobs4", "guess", "T", "status", "iters"))
+    with pytest.raises(RuntimeError):
+        farm.pack_jobs([(np.zeros((0, 2), np.float32), b, [g])])
+    with pytest.raises(TypeError):
+        farm.pack_jobs([(a, b, [np.eye(4)])])
+
+
+def test_persistent_two_worker_farm_over_shared_memory():
+    """world size 2 on the CPU: two persistent worker processes, jobs through shared memory, two consecutive
+    batches on the same workers (the second one larger: the block grows), results in job order and equal to
+    the oracle called directly; a failing worker surfaces as an exception in the parent."""
+    import oracle
+    from sonar_slam_amd import farm, icp_config, synth
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    p = icp_config.shipped_params()
+    pairs = [synth.scan_pair(seed=s, n_src=150 + 10 * s, n_tgt=140) for s in range(3)]
+    rng = np.random.default_rng(1)
+
+    def batch(n):
+        jobs = []
+        for j in range(n):
+            s, t, g, _ = pairs[j % 3]
+            jobs.append((s, t, [g @ synth.pose_matrix(*rng.normal(0, [0.05, 0.05, 0.005])).astype(np.float32)
+                                for _ in range(1 + j % 2)]))
+        return jobs
+    with farm.IcpFarm(p, devices=[0, 1], chunk=4, _backend="farm_backend:oracle_compute") as f:
+        pids = None
+        for n in (5, 9):
+            jobs = batch(n)
+            out = f.run(jobs)
+            assert len(out) == n
+            for (s, t, gs), (msgs, T, it) in zip(jobs, out):
+                assert len(msgs) == len(gs) == len(T) == len(it)
+                for g, m, Tj, i in zip(gs, msgs, T, it):
+                    st, To, ito = oracle.icp(s, t, g, oracle.IcpParams(precision=1, **p.as_dict()))
+                    assert m == oracle.ICP_STATUS_MESSAGES[st] and i == ito and np.array_equal(Tj, To)
+            now = [w.proc.pid for w in f._workers]
+            assert pids is None or pids == now          # the same processes served both batches
+            pids = now
+            assert len(set(w.name for w in f._workers)) == 2
+    assert f._workers == []
+    with farm.IcpFarm(p, devices=[0], _backend="farm_backend:failing_compute") as f:
+        with pytest.raises(RuntimeError, match="boom"):
+            f.run(batch(2))

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--points", type=int, default=5000)
     ap.add_argument("--mode", choices=["p2plane30", "reference"], default="p2plane30")
     ap.add_argument("--devices", type=int, default=0, help="0 = all visible")
+    ap.add_argument("--repeats", type=int, default=3, help="batches sent to the same (persistent) workers")
     a = ap.parse_args()
     p = (icp_config.shipped_params(minimizer=1, use_diff_checker=0, max_iter=30) if a.mode == "p2plane30"
          else icp_config.shipped_params())
@@ -31,13 +32,19 @@ def main():
         s, t, g, _ = pairs[j % a.distinct]
         jobs.append((s, t, [g @ synth.pose_matrix(*rng.normal(0, [0.05, 0.05, 0.005])).astype(np.float32)]))
     n_dev = a.devices or _lib.device_count()
-    farm = IcpFarm(p, devices=list(range(n_dev)))
-    t0 = time.perf_counter()
-    out = farm.run(jobs)
-    dt = time.perf_counter() - t0
+    with IcpFarm(p, devices=list(range(n_dev))) as farm:
+        t0 = time.perf_counter()
+        farm.start()                       # worker processes + their sfe_ctx: paid once per farm, not per batch
+        t_start = time.perf_counter() - t0
+        times = []
+        for rep in range(a.repeats):
+            t0 = time.perf_counter()
+            out = farm.run(jobs)
+            times.append(time.perf_counter() - t0)
     ok = sum(m[0] == "success" for m, _, _ in out)
-    print("%d jobs (%dx%d points, %s) on %d device(s): %.2f s wall incl. worker start-up and host copies -> %.0f jobs/s, %d converged"
-          % (a.jobs, a.points, a.points, a.mode, n_dev, dt, a.jobs / dt, ok))
+    print("%d jobs (%dx%d points, %s) on %d device(s): worker start-up %.2f s once; batches %s s wall incl. shared-memory "
+          "packing and host<->device copies -> %.0f jobs/s (best), %d converged"
+          % (a.jobs, a.points, a.points, a.mode, n_dev, t_start, ["%.3f" % t for t in times], a.jobs / min(times), ok))
 
 
 if __name__ == "__main__":

@@ -1,0 +1,172 @@
+#!/usr/bin/env python
+"""Soak: the HIP ICP path (strip sweep, default) against the CPU ORACLE on thousands of random scan matches --
+bench-like pairs with the shipped chains, and small random problems with random chain parameters including the
+degenerate classes of tests/test_gpu_icp.py::test_sweep_vs_brute_force_fuzz (points on a raster, exact duplicates,
+sources beyond maxDist, NaN / inf coordinates, 1-point clouds).
+
+Checked per scan match, against the oracle with fp64 sums (same discrete decisions by construction): status equal,
+iteration count equal, pose within 1e-6 (point-to-point) / 1e-4 (point-to-plane: cos/sin of the step and the
+Cholesky solve round differently); against the oracle in float (PointMatcher<float>): pose within 1e-4 -- reported
+for the bench-like class only (on degenerate inputs float sums flip discrete decisions, in libpointmatcher too).
+
+The oracle runs on the host cores (worker pool forked before the first HIP call).  Prints a JSON summary; exit
+code 1 on any mismatch.  Test infrastructure: imports oracle/ as the checker, never as the product."""
+import argparse
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import oracle  # noqa: E402
+from sonar_slam_amd import _lib, pcl, synth  # noqa: E402
+
+FIELDS = ["matcher_max_dist", "use_max_dist_filter", "max_dist_filter", "use_trimmed_filter", "trim_ratio", "minimizer",
+          "max_iter", "use_diff_checker", "min_diff_rot", "min_diff_trans", "smooth_len", "normals_knn"]
+
+
+def pose_diff(Ta, Tb):
+    a, b = synth.pose_of(Ta), synth.pose_of(Tb)
+    return max(abs(a[0] - b[0]), abs(a[1] - b[1]), abs(np.arctan2(np.sin(a[2] - b[2]), np.cos(a[2] - b[2]))))
+
+
+def shipped(minimizer):
+    p = dict(matcher_max_dist=10.0, use_max_dist_filter=1, max_dist_filter=3.0, use_trimmed_filter=1, trim_ratio=0.8,
+             minimizer=minimizer, max_iter=40, use_diff_checker=1, min_diff_rot=0.01, min_diff_trans=0.1, smooth_len=4,
+             normals_knn=10)
+    if minimizer == 1:
+        p.update(max_iter=30, use_diff_checker=0)
+    return p
+
+
+def make_problems(seed, n_big, n_small):
+    rng = np.random.default_rng(seed)
+    probs = []
+    for i in range(n_big):
+        n = int(rng.choice([500, 1200, 2500, 5000]))
+        s, t, g, _ = synth.scan_pair(seed=int(rng.integers(0, 1 << 30)), n_src=n, n_tgt=int(n * rng.uniform(0.8, 1.3)))
+        probs.append(("bench", s, t, g, shipped(i % 2)))
+    for case in range(n_small):
+        ns, nt = int(rng.integers(1, 400)), int(rng.integers(1, 400))
+        if case % 7 == 0:
+            ns, nt = int(rng.integers(1, 6)), int(rng.integers(1, 6))
+        tgt = rng.uniform(-8, 8, (nt, 2)).astype(np.float32)
+        if case % 3 == 0:
+            tgt[:, 0] = np.round(tgt[:, 0])
+        if case % 5 == 0 and nt > 4:
+            tgt[nt // 2:] = tgt[:nt - nt // 2]
+        th = rng.uniform(-0.2, 0.2)
+        R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+        src = (tgt[rng.integers(0, nt, ns)] @ R.T + rng.normal(0, 0.05, (ns, 2)) + rng.uniform(-0.5, 0.5, 2)).astype(np.float32)
+        if case % 4 == 0:
+            src[rng.integers(0, ns)] += 100.0
+        if case % 11 == 0:
+            src[rng.integers(0, ns), 0] = np.nan
+        if case % 13 == 0:
+            tgt[rng.integers(0, nt), 1] = np.inf
+        p = dict(matcher_max_dist=float(rng.choice([0.5, 3.0, 10.0])), use_max_dist_filter=int(rng.integers(0, 2)),
+                 max_dist_filter=float(rng.choice([0.3, 3.0, 20.0])), use_trimmed_filter=int(rng.integers(0, 2)),
+                 trim_ratio=float(rng.choice([0.3, 0.8, 1.0])), minimizer=int(rng.integers(0, 2)),
+                 max_iter=int(rng.integers(1, 15)), use_diff_checker=int(rng.integers(0, 2)), min_diff_rot=0.001,
+                 min_diff_trans=0.01, smooth_len=int(rng.integers(1, 4)), normals_knn=int(rng.integers(2, 17)))
+        g = synth.pose_matrix(*rng.normal(0, [0.3, 0.3, 0.05])).astype(np.float32)
+        probs.append(("small", src, tgt, g, p))
+    return probs
+
+
+_P = []
+
+
+def _oracle_one(i):
+    kind, s, t, g, p = _P[i]
+    oracle.set_kdtree(1 if kind == "bench" else 0)
+    d = oracle.icp(s, t, g, oracle.IcpParams(precision=1, **p))
+    f = oracle.icp(s, t, g, oracle.IcpParams(precision=0, **p))
+    return i, d, f
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--big", type=int, default=800)
+    ap.add_argument("--small", type=int, default=1600)
+    ap.add_argument("--seed", type=int, default=20260926)
+    ap.add_argument("--workers", type=int, default=0)
+    a = ap.parse_args()
+    t0 = time.time()
+    _P.extend(make_problems(a.seed, a.big, a.small))
+    n = len(_P)
+    workers = a.workers or min(64, len(os.sched_getaffinity(0)))
+    pool = mp.get_context("fork").Pool(workers)          # before any HIP call
+    pending = pool.map_async(_oracle_one, range(n), chunksize=4)
+
+    ctx = _lib.default_context()
+    got = [None] * n
+    # group by chain parameters: one launch per group
+    groups = {}
+    for i, (kind, s, t, g, p) in enumerate(_P):
+        groups.setdefault(tuple(p[k] for k in FIELDS), []).append(i)
+    for key, idx in groups.items():
+        icp = pcl.ICP(ctx)
+        icp.setParams(_lib.IcpParams(**dict(zip(FIELDS, key))))
+        for c0 in range(0, len(idx), 256):
+            part = idx[c0:c0 + 256]
+            msgs, T, it = icp.compute_pairs([_P[i][1] for i in part], [_P[i][2] for i in part], [_P[i][3] for i in part])
+            for i, m, Tj, itj in zip(part, msgs, T, it):
+                got[i] = (m, Tj, int(itj))
+    t_gpu = time.time() - t0
+    res = pending.get()
+    pool.close()
+    out = {"scan_matches": n, "bench_like": a.big, "small_random": a.small, "seed": a.seed, "status_mismatch": 0,
+           "iteration_mismatch": 0, "pose_mismatch_f64": 0, "pose_mismatch_float_bench": 0, "max_pose_diff_f64_p2p": 0.0,
+           "max_pose_diff_f64_p2plane": 0.0, "max_pose_diff_float_bench": 0.0, "failures_agreed": 0, "successes": 0,
+           "float_oracle_status_differs_small": 0}
+    bad = []
+    for i, (st_d, T_d, it_d), (st_f, T_f, it_f) in res:
+        kind, s, t, g, p = _P[i]
+        m, T, it = got[i]
+        if m != oracle.ICP_STATUS_MESSAGES[st_d]:
+            out["status_mismatch"] += 1
+            bad.append((i, "status", m, st_d))
+            continue
+        if st_d != 0:
+            out["failures_agreed"] += 1
+            if not np.array_equal(T, g):
+                out["pose_mismatch_f64"] += 1
+                bad.append((i, "guess not returned"))
+            continue
+        out["successes"] += 1
+        if it != it_d:
+            out["iteration_mismatch"] += 1
+            bad.append((i, "iters", it, it_d))
+        d = pose_diff(T, T_d)
+        key = "max_pose_diff_f64_p2plane" if p["minimizer"] else "max_pose_diff_f64_p2p"
+        if not d <= (1e-4 if p["minimizer"] else 1e-6):
+            out["pose_mismatch_f64"] += 1
+            bad.append((i, "pose", d))
+        else:
+            out[key] = max(out[key], float(d))
+        if kind == "bench":
+            df = pose_diff(T, T_f) if st_f == 0 else np.inf
+            out["max_pose_diff_float_bench"] = max(out["max_pose_diff_float_bench"], float(df))
+            if not df <= 1e-4:
+                out["pose_mismatch_float_bench"] += 1
+                bad.append((i, "pose vs float oracle", float(df)))
+        elif st_f != st_d:
+            out["float_oracle_status_differs_small"] += 1
+    out["seconds"] = round(time.time() - t0, 1)
+    out["gpu_seconds_incl_setup"] = round(t_gpu, 1)
+    out["oracle_workers"] = workers
+    out["device"] = ctx.name()
+    for b in bad[:40]:
+        kind, s, t, g, p = _P[b[0]]
+        print("MISMATCH", b, kind, len(s), len(t), p, file=sys.stderr, flush=True)
+    print(json.dumps(out))
+    sys.exit(1 if (out["status_mismatch"] or out["iteration_mismatch"] or out["pose_mismatch_f64"]
+                   or out["pose_mismatch_float_bench"]) else 0)
+
+
+if __name__ == "__main__":
+    main()
