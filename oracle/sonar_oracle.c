@@ -440,6 +440,7 @@ typedef struct {
 #define ORC_ICP_NAN_ROT 3    /* "abs rotation norm not a number"                           */
 #define ORC_ICP_NAN_TRANS 4  /* "abs translation norm not a number"                        */
 #define ORC_ICP_SINGULAR 5   /* p2plane normal system not positive definite                */
+#define ORC_PIVOT_RTOL 1e-10 /* Cholesky pivot / diagonal entry below which the system counts as singular */
 
 static void mat3_mul_f(const float *a, const float *b, float *c)
 {
@@ -762,12 +763,18 @@ int orc_icp(const orc_icp_params *P, const float *src, int ns, const float *tgt_
                 break;
             }
             /* Cholesky A = L L^T, A = [[A0,A1,A2],[A1,A3,A4],[A2,A4,A5]] */
+            /* A pivot that has lost ten digits against its diagonal entry is a rank-deficient system (all normals
+             * parallel, a two-point target, ...): in exact arithmetic that pivot is zero, in floating point its
+             * sign is summation-order noise.  A relative test decides such systems the same way in every
+             * implementation (the kernels use the same expression). */
             double l00 = sqrt(A[0]);
             double l10 = A[1] / l00, l20 = A[2] / l00;
-            double l11 = sqrt(A[3] - l10 * l10);
+            double p11 = A[3] - l10 * l10;
+            double l11 = sqrt(p11);
             double l21 = (A[4] - l20 * l10) / l11;
-            double l22 = sqrt(A[5] - l20 * l20 - l21 * l21);
-            if (!(l00 > 0) || !(l11 > 0) || !(l22 > 0)) {
+            double p22 = A[5] - l20 * l20 - l21 * l21;
+            double l22 = sqrt(p22);
+            if (!(l00 > 0) || !(p11 > ORC_PIVOT_RTOL * A[3]) || !(p22 > ORC_PIVOT_RTOL * A[5])) {
                 status = ORC_ICP_SINGULAR;
                 break;
             }

@@ -11,6 +11,7 @@
 #define ICP_CH 16     // target points per chunk of the two-level arg-min
 #define ICP_KMAX 16   // max neighbours for the PCA normals
 #define ICP_MAX_HIST 64 // transformation history kept for the differential checker
+#define ICP_PIVOT_RTOL 1e-10 // Cholesky pivot / diagonal entry below which the point-to-plane system counts as singular
 
 struct IcpJob {
     int src_start, n_src, tgt_start, n_tgt;
@@ -181,12 +182,17 @@ __device__ __forceinline__ void icp_solve_and_check(const sfe_icp_params &P, con
         Ts[4] = (float)c;
         Ts[5] = (float)ty;
     } else {
+        // a pivot that has lost ten digits against its diagonal entry = rank-deficient system (in exact arithmetic the
+        // pivot is zero, in floating point its sign is summation-order noise): decided by a relative test, the same
+        // expression as the oracle's, so that every implementation reports such systems the same way
         const double l00 = sqrt(acc[1]);
         const double l10 = acc[2] / l00, l20 = acc[3] / l00;
-        const double l11 = sqrt(acc[4] - l10 * l10);
+        const double p11 = acc[4] - l10 * l10;
+        const double l11 = sqrt(p11);
         const double l21 = (acc[5] - l20 * l10) / l11;
-        const double l22 = sqrt(acc[6] - l20 * l20 - l21 * l21);
-        if (!(l00 > 0) || !(l11 > 0) || !(l22 > 0)) {
+        const double p22 = acc[6] - l20 * l20 - l21 * l21;
+        const double l22 = sqrt(p22);
+        if (!(l00 > 0) || !(p11 > ICP_PIVOT_RTOL * acc[4]) || !(p22 > ICP_PIVOT_RTOL * acc[6])) {
             status = SFE_ICP_SINGULAR;
         } else {
             const double y0 = acc[7] / l00;

@@ -7,8 +7,11 @@ as its brute-force scan, tests/test_oracle_pipeline.py; 0.3 s per 20k x 20k x 30
               (persistent worker, shared-memory job blocks), every one against the oracle
   configs[1]  bench.py end to end with its own parity sample, and the 2-rank launch on one device
 
-Tolerances as in test_gpu_icp.py: 1e-4 m / rad against the oracle in float (PointMatcher<float>), identical status
-and iteration counts (and 1e-6) against the oracle with fp64 sums (same discrete decisions)."""
+Tolerances.  Against the oracle with fp64 sums (same discrete decisions): identical status and iteration counts, pose
+within 1e-6 (point-to-point) / 1e-4 (point-to-plane).  Against the oracle in float (PointMatcher<float>): 1e-4 m / rad
+at 5 000 points; at 20 000 points the float oracle's OWN sums are the error (sequential float accumulation of 16 000
+products: it sits 3e-4 from its fp64 version), so there the statement is that the HIP result is no farther from the
+float oracle than the fp64 oracle is (+ 1e-6), and that spread is bounded at 1e-3."""
 import json
 import os
 import subprocess
@@ -51,11 +54,12 @@ def test_config4_hires_many_to_one_30_guesses_30_iterations_vs_oracle(ctx, kdtre
     for g, m, Tg, i in zip(guesses, msgs, T, it):
         st_d, T_d, it_d = oracle.icp(src, tgt, g, oracle.shipped_icp_params(precision=1, **over))
         st_f, T_f, it_f = oracle.icp(src, tgt, g, oracle.shipped_icp_params(precision=0, **over))
-        assert m == oracle.ICP_STATUS_MESSAGES[st_d] and i == it_d == 30
+        assert m == oracle.ICP_STATUS_MESSAGES[st_d] and i == it_d == 30 and st_f == 0
         worst_d = max(worst_d, _pose_diff(Tg, T_d))
         worst_f = max(worst_f, _pose_diff(Tg, T_f))
+        assert _pose_diff(Tg, T_f) <= _pose_diff(T_d, T_f) + 1e-6      # the float oracle's own accumulation noise
     assert worst_d < (1e-6 if minimizer == 0 else 1e-4), worst_d
-    assert worst_f < 1e-4, worst_f
+    assert worst_f < 1e-3, worst_f
     assert min(_pose_diff(Tg, truth) for Tg in T) < 0.02
 
 

@@ -32,7 +32,8 @@ def main():
         s, t, g, _ = pairs[j % a.distinct]
         jobs.append((s, t, [g @ synth.pose_matrix(*rng.normal(0, [0.05, 0.05, 0.005])).astype(np.float32)]))
     n_dev = a.devices or _lib.device_count()
-    with IcpFarm(p, devices=list(range(n_dev))) as farm:
+    farm = IcpFarm(p, devices=list(range(n_dev)))
+    try:
         t0 = time.perf_counter()
         farm.start()                       # worker processes + their sfe_ctx: paid once per farm, not per batch
         t_start = time.perf_counter() - t0
@@ -41,6 +42,8 @@ def main():
             t0 = time.perf_counter()
             out = farm.run(jobs)
             times.append(time.perf_counter() - t0)
+    finally:
+        farm.close()
     ok = sum(m[0] == "success" for m, _, _ in out)
     print("%d jobs (%dx%d points, %s) on %d device(s): worker start-up %.2f s once; batches %s s wall incl. shared-memory "
           "packing and host<->device copies -> %.0f jobs/s (best), %d converged"
