@@ -34,6 +34,7 @@ class KeyframeBatch(object):
         self.d_mask = ctx.alloc(fb)
         self.d_pts = ctx.alloc(self.n * self.cap * 16)
         self.d_cnt = ctx.alloc(self.n * 4)
+        self.d_cnt.zero()                           # no extraction run yet = no points (results() checks them)
         self.d_cloud = self.d_cloud_cnt = None      # filtered float32 feature clouds (run_filter)
         self.d_src = self.d_tgt = self.d_guess = None
         self.d_T = ctx.alloc(self.n * 36)
