@@ -609,6 +609,7 @@ struct SweepShared {
     double acc[10];  // the reduced error-minimiser sums (read by the solving lane)
     unsigned hist[256], hist0[256];
     unsigned sel_prefix, sel_k;
+    unsigned n_none, n_exact; // census of the iteration, tallied where a query is settled
     int long_n, long_next, mid_n, wl_n[2];
     int flag_iterate, flag_status;
     float Ti[9];
@@ -646,8 +647,8 @@ struct SweepShared {
 #define SW_TIED 0x40000000u     // own strip finished / a tie with the current best was seen there
 #define SW_QMASK 0x3FFFFFFFu
 
-struct SweepQ { // per-job views of the per-query scratch
-    float2 *xy;   // transformed query
+struct SweepQ { // per-job views of the per-query scratch (the transformed query itself is never stored: whoever needs
+                // it again recomputes it from the source point, two affine maps with wave-uniform coefficients)
     int4 *st;     // clearance record of a `none` query: (px, py, clearance) as float bits
     float *d2;    // best so far / final d2
     int *pos;     // >= 0 sorted position - 1 of the NN, SW_NONE, <= -2 inexact (SW_INEXACT_OF)
@@ -699,7 +700,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
     sfe_icp_params P, const SweepJob *__restrict__ jobs, const int *__restrict__ job_ids, const float2 *__restrict__ src_all,
     const float *__restrict__ guess_all, const float2 *__restrict__ stgt_all, const int *__restrict__ perm_all,
     const float2 *__restrict__ snrm_all, const float *__restrict__ mean_all, const StripTab *__restrict__ tab_all,
-    float2 *__restrict__ q_xy_all, int4 *__restrict__ q_st_all, int *__restrict__ q_wl_all, float2 *__restrict__ q_ssrc_all,
+    int4 *__restrict__ q_st_all, int *__restrict__ q_wl_all, float2 *__restrict__ q_ssrc_all,
     float *__restrict__ nn_d2_all,
     int *__restrict__ nn_pos_all, float *__restrict__ T_out, int *__restrict__ status_out,
     int *__restrict__ iters_out, long long *prof, int *dbg, int sw_budget, int sw_budget_a, int sw_cache)
@@ -723,7 +724,6 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
     const float2 *__restrict__ T = LDS_TGT ? (const float2 *)lds_tgt : stgt; // sorted target incl. sentinels
     const float2 *__restrict__ snrm = snrm_all ? snrm_all + J.tgt_off : nullptr;
     SweepQ Q;
-    Q.xy = q_xy_all + J.q_off;
     Q.st = q_st_all + J.q_off;
     Q.d2 = nn_d2_all + J.q_off;
     Q.pos = nn_pos_all + J.q_off;
@@ -847,6 +847,12 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
     const bool sw_jump = (sw_cache & 2) != 0;
     const float sw_margin = 1.0f + 0.01f * (float)((sw_cache >> 16) & 255);
     int wd_outer = 0;
+    // cur = Ti * (T0 * src): the same two roundings wherever a query is (re)computed
+    auto xform = [&](const float (&Ti)[9], float2 sp) {
+        const float rx = affine1(T0[0], T0[1], T0[2], sp.x, sp.y);
+        const float ry = affine1(T0[3], T0[4], T0[5], sp.x, sp.y);
+        return make_float2(affine1(Ti[0], Ti[1], Ti[2], rx, ry), affine1(Ti[3], Ti[4], Ti[5], rx, ry));
+    };
     bool use_cache = false; // from the second iteration on: Q.pos / Q.st hold the previous iteration's results
     while (true) {
         SW_WATCH(wd_outer, P.max_iter + 2, 0)
@@ -954,6 +960,38 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
         float C = Cnext;
         unsigned nfin = 0, nexact = 0, ksel = 0;
         bool limit_inf = false;
+        // The census of the iteration -- queries without a match, true neighbours within the cap, and the histogram
+        // of the top byte of their distances (= the first pass of the radix select) -- is tallied where a query is
+        // settled: `none` and `exact` are final for the iteration, so every query is counted once, in whatever round
+        // and tier it ends.
+        if (tid < 256)
+            S.hist0[tid] = 0;
+        if (tid == 0) {
+            S.n_none = 0;
+            S.n_exact = 0;
+        }
+        auto tally_settled = [&](bool is_none, bool is_exact, float best) { // called wave-uniformly
+            const unsigned long long mn = __ballot(is_none), me = __ballot(is_exact);
+            if (lane == 0) {
+                if (mn)
+                    atomicAdd(&S.n_none, (unsigned)__popcll(mn));
+                if (me)
+                    atomicAdd(&S.n_exact, (unsigned)__popcll(me));
+            }
+            // wave-aggregated: the exponent byte is the same for nearly every point
+            const unsigned bin = is_exact ? (__float_as_uint(best) >> 24) : 0xFFFFFFFFu;
+            unsigned long long todo = me;
+            int wd6 = 0;
+            while (todo) {
+                SW_WATCH(wd6, 64, 6)
+                const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+                const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)bin, leader);
+                const unsigned long long same = __ballot(bin == b);
+                if (lane == leader)
+                    atomicAdd(&S.hist0[b], (unsigned)__popcll(same));
+                todo &= ~same;
+            }
+        };
         {
             int nwork = ns, cur = 0;
             for (int round = 0;; ++round) {
@@ -968,8 +1006,6 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                     S.mid_n = 0;
                     S.wl_n[cur ^ 1] = 0;
                 }
-                if (tid < 256)
-                    S.hist0[tid] = 0; // filled by this round's census
                 __syncthreads();
                 const int *wl = Q.wl[cur];
                 int *wl_next = Q.wl[cur ^ 1];
@@ -1005,18 +1041,15 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                     if (valid) {
                         if (fresh) {
                             q = q_cur;
-                            const float2 sp = sp_cur;
-                            const float rx = affine1(T0[0], T0[1], T0[2], sp.x, sp.y);
-                            const float ry = affine1(T0[3], T0[4], T0[5], sp.x, sp.y);
-                            px = affine1(Ti[0], Ti[1], Ti[2], rx, ry);
-                            py = affine1(Ti[3], Ti[4], Ti[5], rx, ry);
-                            Q.xy[q] = make_float2(px, py);
+                            const float2 p = xform(Ti, sp_cur);
+                            px = p.x;
+                            py = p.y;
                         } else {
                             const unsigned e = (unsigned)list[slot];
                             q = (int)(e & SW_QMASK);
                             own_done = (e & SW_OWN_DONE) != 0;
                             tied = (e & SW_TIED) != 0;
-                            const float2 p = Q.xy[q];
+                            const float2 p = xform(Ti, src[q]);
                             px = p.x;
                             py = p.y;
                             bpos = -2 - Q.pos[q];
@@ -1152,6 +1185,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                         Q.d2[q] = best;
                         Q.pos[q] = SW_INEXACT_OF(bpos);
                     }
+                    tally_settled(is_none, is_exact, best);
                     { // wave-aggregated appends
                         const unsigned long long ms = __ballot(is_susp), ml = __ballot(is_long);
                         const unsigned long long below = (1ull << lane) - 1ull;
@@ -1213,7 +1247,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                     float bn = 0;
                     auto fetch = [&](int sl) {
                         qn = (int)((unsigned)Q.lng[sl] & SW_QMASK);
-                        pn = Q.xy[qn];
+                        pn = src[qn];
                         bn = Q.d2[qn];
                         posn = Q.pos[qn];
                     };
@@ -1226,7 +1260,8 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                         if (prof != nullptr && tid == 0)
                             tp0 = clock64();
                         const int q = __builtin_amdgcn_readfirstlane(qn);
-                        const float px = sw_uniform(pn.x), py = sw_uniform(pn.y);
+                        const float2 pq = xform(Ti, make_float2(sw_uniform(pn.x), sw_uniform(pn.y)));
+                        const float px = sw_uniform(pq.x), py = sw_uniform(pq.y);
                         float best = sw_uniform(bn);
                         int bpos = -2 - __builtin_amdgcn_readfirstlane(posn);
                         bool tied = false;
@@ -1344,11 +1379,14 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                                 Q.pos[q] = SW_NONE;
                                 Q.st[q] = make_int4(__float_as_int(px), __float_as_int(py),
                                                     __float_as_int(f_add(f_mul(sqrtf(best), 0.99999f), -md_hi)), 0);
+                                atomicAdd(&S.n_none, 1u);
                             } else if (best <= C) {
                                 if (tied)
                                     bpos = sweep_resolve_tie(T, tab, Q, px, py, best);
                                 Q.d2[q] = best;
                                 Q.pos[q] = bpos - 1;
+                                atomicAdd(&S.n_exact, 1u);
+                                atomicAdd(&S.hist0[__float_as_uint(best) >> 24], 1u);
                             } else {
                                 Q.d2[q] = best;
                                 Q.pos[q] = SW_INEXACT_OF(bpos);
@@ -1368,40 +1406,9 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                     S.prof_it[26 + 4 * round] = nlong;
                     S.prof_it[27 + 4 * round] = t_ - S.prof_b0;
                 }
-                // -- census: finite matches, and true neighbours within the cap --
-                double cnt[2] = {0, 0};
-                for (int base = 0; base < ns; base += SW_NQ * ICP_THREADS) { // SW_NQ loads in flight, not a chain
-                    int pz[SW_NQ];
-                    float dz[SW_NQ];
-#pragma unroll
-                    for (int k = 0; k < SW_NQ; ++k) {
-                        const int i = base + k * ICP_THREADS + tid;
-                        pz[k] = i < ns ? Q.pos[i] : SW_NONE;
-                        dz[k] = i < ns ? Q.d2[i] : INFINITY;
-                    }
-#pragma unroll
-                    for (int k = 0; k < SW_NQ; ++k) {
-                        cnt[0] += (pz[k] != SW_NONE) ? 1.0 : 0.0;
-                        cnt[1] += (pz[k] >= 0 && dz[k] <= C) ? 1.0 : 0.0;
-                        // first pass of the radix select over the exact matches, on the way (wave-aggregated: the
-                        // exponent byte is the same for nearly every point)
-                        const unsigned bin = (pz[k] >= 0) ? (__float_as_uint(dz[k]) >> 24) : 0xFFFFFFFFu;
-                        unsigned long long todo = __ballot(bin != 0xFFFFFFFFu);
-                        int wd6 = 0;
-                        while (todo) {
-                            SW_WATCH(wd6, 64, 6)
-                            const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
-                            const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)bin, leader);
-                            const unsigned long long same = __ballot(bin == b);
-                            if (lane == leader)
-                                atomicAdd(&S.hist0[b], (unsigned)__popcll(same));
-                            todo &= ~same;
-                        }
-                    }
-                }
-                block_sum<2>(cnt, S.red);
-                nfin = (unsigned)cnt[0];
-                nexact = (unsigned)cnt[1];
+                // -- census (tallied on the way, see tally_settled) --
+                nfin = (unsigned)ns - S.n_none;
+                nexact = S.n_exact;
                 SW_PROF(8);
                 const int nsusp = S.wl_n[cur ^ 1];
                 bool done;
@@ -1469,7 +1476,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                                 (!P.use_trimmed_filter || d <= limit);
                 if (!ok)
                     continue;
-                const float2 p = Q.xy[i];
+                const float2 p = xform(Ti, src[i]);
                 const double px = p.x, py = p.y;
                 const float2 q = T[id + 1];
                 const double qx = q.x, qy = q.y;
@@ -1609,14 +1616,13 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
     float2 *d_snrm = p->minimizer == 1 ? (float2 *)sfe_scratch(ctx, 16, sizeof(float2) * (size_t)toff) : nullptr;
     float *d_mean = (float *)sfe_scratch(ctx, 17, sizeof(float) * 2 * (size_t)n_prep);
     unsigned long long *d_gkeys = (unsigned long long *)sfe_scratch(ctx, 24, sizeof(unsigned long long) * (size_t)std::max(koff, 1LL));
-    float2 *d_qxy = (float2 *)sfe_scratch(ctx, 18, sizeof(float2) * (size_t)qoff);
     int4 *d_qst = (int4 *)sfe_scratch(ctx, 19, sizeof(int4) * (size_t)qoff);
     int *d_qwl = (int *)sfe_scratch(ctx, 21, sizeof(int) * 5 * (size_t)qoff);
     float2 *d_qssrc = (float2 *)sfe_scratch(ctx, 30, sizeof(float2) * (size_t)qoff);
     StripTab *d_tab = (StripTab *)sfe_scratch(ctx, 23, sizeof(StripTab) * (size_t)n_prep);
     float *d_nn_d2 = (float *)sfe_scratch(ctx, 5, sizeof(float) * (size_t)qoff);
     int *d_nn_pos = (int *)sfe_scratch(ctx, 6, sizeof(int) * (size_t)qoff);
-    if (!d_tables || !d_stgt || !d_perm || (p->minimizer == 1 && !d_snrm) || !d_mean || !d_gkeys || !d_qxy || !d_qst || !d_qwl || !d_qssrc || !d_tab ||
+    if (!d_tables || !d_stgt || !d_perm || (p->minimizer == 1 && !d_snrm) || !d_mean || !d_gkeys || !d_qst || !d_qwl || !d_qssrc || !d_tab ||
         !d_nn_d2 || !d_nn_pos)
         return SFE_ERR_HIP;
     SweepPrep *d_preps = (SweepPrep *)d_tables;
@@ -1680,13 +1686,13 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
             SFE_HIP(ctx, hipFuncSetAttribute((const void *)icp_sweep_kernel<4, true>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             hipLaunchKernelGGL((icp_sweep_kernel<4, true>), dim3(n_lds), dim3(ICP_THREADS), smem, ctx->stream, *p, d_jobs,
-                               d_ids, (const float2 *)d_src, d_guess9, d_stgt, d_perm, d_snrm, d_mean, d_tab, d_qxy, d_qst, d_qwl,
+                               d_ids, (const float2 *)d_src, d_guess9, d_stgt, d_perm, d_snrm, d_mean, d_tab, d_qst, d_qwl,
                                d_qssrc, d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof, d_dbg, sw_budget, sw_budget_a, sw_cache);
         } else {
             SFE_HIP(ctx, hipFuncSetAttribute((const void *)icp_sweep_kernel<8, true>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             hipLaunchKernelGGL((icp_sweep_kernel<8, true>), dim3(n_lds), dim3(ICP_THREADS), smem, ctx->stream, *p, d_jobs,
-                               d_ids, (const float2 *)d_src, d_guess9, d_stgt, d_perm, d_snrm, d_mean, d_tab, d_qxy, d_qst, d_qwl,
+                               d_ids, (const float2 *)d_src, d_guess9, d_stgt, d_perm, d_snrm, d_mean, d_tab, d_qst, d_qwl,
                                d_qssrc, d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof, d_dbg, sw_budget, sw_budget_a, sw_cache);
         }
         SFE_LAUNCH_CHECK(ctx);
@@ -1701,12 +1707,12 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
         if (n_glb <= ctx->n_cu)
             hipLaunchKernelGGL((icp_sweep_kernel<4, false>), dim3(n_glb), dim3(ICP_THREADS), smem_g, ctx->stream, *p,
                                d_jobs, d_ids + n_lds, (const float2 *)d_src, d_guess9, d_stgt, d_perm, d_snrm, d_mean, d_tab,
-                               d_qxy, d_qst, d_qwl, d_qssrc, d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof, d_dbg,
+                               d_qst, d_qwl, d_qssrc, d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof, d_dbg,
                                sw_budget, sw_budget_a, sw_cache);
         else
             hipLaunchKernelGGL((icp_sweep_kernel<8, false>), dim3(n_glb), dim3(ICP_THREADS), smem_g, ctx->stream, *p,
                                d_jobs, d_ids + n_lds, (const float2 *)d_src, d_guess9, d_stgt, d_perm, d_snrm, d_mean, d_tab,
-                               d_qxy, d_qst, d_qwl, d_qssrc, d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof, d_dbg,
+                               d_qst, d_qwl, d_qssrc, d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof, d_dbg,
                                sw_budget, sw_budget_a, sw_cache);
         SFE_LAUNCH_CHECK(ctx);
     }
