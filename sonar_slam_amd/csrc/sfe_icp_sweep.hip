@@ -694,8 +694,13 @@ __device__ __forceinline__ int sweep_resolve_tie(const float2 *__restrict__ T, c
 }
 
 // LDS_TGT: sorted target resident in LDS (n_tgt <= SW_TCAP) or read from its HBM scratch slice (it
-// stays in L2: <= 160 KB for a 20k-point cloud, shared by all guesses of a many-to-one batch)
-template <int MINW, bool LDS_TGT>
+// stays in L2: <= 160 KB for a 20k-point cloud, shared by all guesses of a many-to-one batch).
+// LDS_Q: the per-query results (d2 as float, position as int16) live in LDS behind the target instead of HBM
+// scratch: with two jobs per CU the scratch of the 64 jobs an XCD runs at a time (~20 MB) does not fit its 4 MB
+// L2, so every phase that streams over the results (radix select, error-minimiser sums, the witness lookup of
+// the next iteration) otherwise waits for Infinity-Cache / HBM latencies.  Chosen by the launcher when
+// control block + 8 (n_tgt + pad) + 6 n_src bytes fit the workgroup's LDS share (5000 x 5000: 76 KB of 80).
+template <int MINW, bool LDS_TGT, bool LDS_Q>
 __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
     sfe_icp_params P, const SweepJob *__restrict__ jobs, const int *__restrict__ job_ids, const float2 *__restrict__ src_all,
     const float *__restrict__ guess_all, const float2 *__restrict__ stgt_all, const int *__restrict__ perm_all,
@@ -703,8 +708,9 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
     int4 *__restrict__ q_st_all, int *__restrict__ q_wl_all, float2 *__restrict__ q_ssrc_all,
     float *__restrict__ nn_d2_all,
     int *__restrict__ nn_pos_all, float *__restrict__ T_out, int *__restrict__ status_out,
-    int *__restrict__ iters_out, long long *prof, int *dbg, int sw_budget, int sw_budget_a, int sw_cache)
+    int *__restrict__ iters_out, long long *prof, int *dbg, int sw_budget, int sw_budget_a, int sw_cache, int t_cap, int q_cap, int sort_chunk)
 {
+    static_assert(LDS_TGT || !LDS_Q, "LDS_Q needs the LDS-resident target layout");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     SweepShared &S = *reinterpret_cast<SweepShared *>(smem_raw);
 
@@ -727,6 +733,30 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
     Q.st = q_st_all + J.q_off;
     Q.d2 = nn_d2_all + J.q_off;
     Q.pos = nn_pos_all + J.q_off;
+    // LDS_Q: [target: t_cap float2][d2: q_cap float][pos: q_cap int16] behind the control block
+    float *l_d2 = reinterpret_cast<float *>(lds_tgt + t_cap);
+    short *l_pos = reinterpret_cast<short *>(l_d2 + q_cap);
+    auto Pz = [&](int i) -> int { // position record of query i: >= 0 exact, SW_NONE, <= -2 inexact
+        if constexpr (LDS_Q)
+            return (int)l_pos[i];
+        else
+            return Q.pos[i];
+    };
+    auto Dz = [&](int i) -> float {
+        if constexpr (LDS_Q)
+            return l_d2[i];
+        else
+            return Q.d2[i];
+    };
+    auto setQ = [&](int i, float d, int pz) {
+        if constexpr (LDS_Q) {
+            l_d2[i] = d;
+            l_pos[i] = (short)pz;
+        } else {
+            Q.d2[i] = d;
+            Q.pos[i] = pz;
+        }
+    };
     Q.wl[0] = q_wl_all + 5 * J.q_off;
     Q.wl[1] = Q.wl[0] + ns;
     Q.mid = Q.wl[1] + ns;
@@ -773,8 +803,8 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
     // original order.  Sorted once per job, in the LDS that will hold the target (chunks of 8192). ----
     {
         unsigned long long *skeys = reinterpret_cast<unsigned long long *>(lds_tgt);
-        for (int c0 = 0; c0 < ns; c0 += SW_TCAP) {
-            const int n = min(SW_TCAP, ns - c0);
+        for (int c0 = 0; c0 < ns; c0 += sort_chunk) { // sort_chunk = the power of two of keys this LDS region holds
+            const int n = min(sort_chunk, ns - c0);
             unsigned n2 = 2;
             while (n2 < (unsigned)n)
                 n2 <<= 1;
@@ -919,8 +949,8 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
 #pragma unroll
                 for (int k = 0; k < SW_NQ; ++k) {
                     const int i = base + k * ICP_THREADS + tid;
-                    pz[k] = i < ns ? Q.pos[i] : SW_NONE;
-                    dz[k] = i < ns ? Q.d2[i] : INFINITY;
+                    pz[k] = i < ns ? Pz(i) : SW_NONE;
+                    dz[k] = i < ns ? Dz(i) : INFINITY;
                 }
 #pragma unroll
                 for (int k = 0; k < SW_NQ; ++k)
@@ -1030,7 +1060,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                     const int q_cur = q_next;
                     int prev = 0;
                     if (fresh && use_cache && valid)
-                        prev = Q.pos[q_cur]; // last iteration's result of this query (used after the transform)
+                        prev = Pz(q_cur); // last iteration's result of this query (used after the transform)
                     if (fresh && slot + ICP_THREADS < n) {
                         sp_next = Q.ssrc[slot + ICP_THREADS];
                         q_next = Q.order[slot + ICP_THREADS];
@@ -1052,8 +1082,8 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                             const float2 p = xform(Ti, src[q]);
                             px = p.x;
                             py = p.y;
-                            bpos = -2 - Q.pos[q];
-                            best = Q.d2[q];
+                            bpos = -2 - Pz(q);
+                            best = Dz(q);
                         }
                     }
                     // What the previous iteration knew about this query (the cloud moves little between
@@ -1169,8 +1199,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                     const bool is_exact = settled && found && best <= C;
                     const bool is_susp = settled && found && !(best <= C);
                     if (is_none) {
-                        Q.d2[q] = INFINITY;
-                        Q.pos[q] = SW_NONE;
+                        setQ(q, INFINITY, SW_NONE);
                         if (!skip) // a full search: every target is at least sqrt(best) away from (px, py)
                             Q.st[q] = make_int4(__float_as_int(px), __float_as_int(py),
                                                 __float_as_int(f_add(f_mul(sqrtf(best), 0.99999f), -md_hi)), 0);
@@ -1178,13 +1207,10 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                     if (is_exact) {
                         if (tied)
                             bpos = sweep_resolve_tie(T, tab, Q, px, py, best);
-                        Q.d2[q] = best;
-                        Q.pos[q] = bpos - 1;
+                        setQ(q, best, bpos - 1);
                     }
-                    if (is_susp || is_long) {
-                        Q.d2[q] = best;
-                        Q.pos[q] = SW_INEXACT_OF(bpos);
-                    }
+                    if (is_susp || is_long)
+                        setQ(q, best, SW_INEXACT_OF(bpos));
                     tally_settled(is_none, is_exact, best);
                     { // wave-aggregated appends
                         const unsigned long long ms = __ballot(is_susp), ml = __ballot(is_long);
@@ -1248,8 +1274,8 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                     auto fetch = [&](int sl) {
                         qn = (int)((unsigned)Q.lng[sl] & SW_QMASK);
                         pn = src[qn];
-                        bn = Q.d2[qn];
-                        posn = Q.pos[qn];
+                        bn = Dz(qn);
+                        posn = Pz(qn);
                     };
                     if (slot < nlong)
                         fetch(slot);
@@ -1375,21 +1401,18 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                         }
                         if (lane == 0) {
                             if (!(best < r2m_up)) {
-                                Q.d2[q] = INFINITY;
-                                Q.pos[q] = SW_NONE;
+                                setQ(q, INFINITY, SW_NONE);
                                 Q.st[q] = make_int4(__float_as_int(px), __float_as_int(py),
                                                     __float_as_int(f_add(f_mul(sqrtf(best), 0.99999f), -md_hi)), 0);
                                 atomicAdd(&S.n_none, 1u);
                             } else if (best <= C) {
                                 if (tied)
                                     bpos = sweep_resolve_tie(T, tab, Q, px, py, best);
-                                Q.d2[q] = best;
-                                Q.pos[q] = bpos - 1;
+                                setQ(q, best, bpos - 1);
                                 atomicAdd(&S.n_exact, 1u);
                                 atomicAdd(&S.hist0[__float_as_uint(best) >> 24], 1u);
                             } else {
-                                Q.d2[q] = best;
-                                Q.pos[q] = SW_INEXACT_OF(bpos);
+                                setQ(q, best, SW_INEXACT_OF(bpos));
                                 wl_next[atomicAdd(&S.wl_n[cur ^ 1], 1)] = q;
                             }
                         }
@@ -1470,8 +1493,8 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
             constexpr int LO = decltype(lo_tag)::value;
             double a5[5] = {0, 0, 0, 0, 0};
             for (int i = tid; i < ns; i += ICP_THREADS) {
-                const int id = Q.pos[i];
-                const float d = Q.d2[i];
+                const int id = Pz(i);
+                const float d = Dz(i);
                 const bool ok = id >= 0 && (!P.use_max_dist_filter || d <= r2_filter) &&
                                 (!P.use_trimmed_filter || d <= limit);
                 if (!ok)
@@ -1576,9 +1599,17 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
 {
     std::vector<SweepPrep> preps;
     std::vector<SweepJob> jobs((size_t)n_jobs);
-    std::vector<int> ids_lds, ids_glb; // jobs whose target fits LDS / is read from HBM scratch
+    // three kinds of jobs, one launch each: target AND per-query results in LDS / target in LDS / target in HBM scratch
+    std::vector<int> ids_q, ids_lds, ids_glb;
     std::map<std::pair<int, int>, int> seen; // many guesses on one pair share one prep
     long long toff = 0, qoff = 0, koff = 0;
+    const size_t ctl_bytes = (sizeof(SweepShared) + 15) & ~(size_t)15;
+    // LDS share of a workgroup: two workgroups per CU when the batch has more jobs than CUs, else the whole CU
+    static const int force_wide = getenv("SFE_SW_WIDE") ? atoi(getenv("SFE_SW_WIDE")) : -1; // A/B: 1 = one 128-VGPR workgroup per CU
+    const bool wide = force_wide >= 0 ? force_wide != 0 : n_jobs <= ctx->n_cu;
+    const size_t lds_share = (wide ? 160 : 80) * (size_t)1024;
+    static const bool no_ldsq = getenv("SFE_SW_NO_LDSQ") != nullptr; // A/B
+    int q_tmax = 0, q_smax = 0;
     for (int j = 0; j < n_jobs; ++j) {
         const int32_t *q = jobs4 + 4 * (size_t)j;
         const auto key = std::make_pair((int)q[2], (int)q[3]);
@@ -1602,11 +1633,26 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
         const SweepPrep &pr = preps[(size_t)it->second];
         jobs[(size_t)j] = {q[0], q[1], q[3], it->second, pr.off, qoff};
         qoff += q[1];
-        (q[3] <= SW_TCAP ? ids_lds : ids_glb).push_back(j);
+        const bool fits_q = !no_ldsq && q[3] <= SW_TCAP &&
+                            ctl_bytes + 8 * (size_t)(q[3] + SW_PAD) + 6 * (size_t)q[1] + 16 <= lds_share;
+        if (fits_q) {
+            ids_q.push_back(j);
+            q_tmax = std::max(q_tmax, (int)q[3]);
+            q_smax = std::max(q_smax, (int)q[1]);
+        } else {
+            (q[3] <= SW_TCAP ? ids_lds : ids_glb).push_back(j);
+        }
+    }
+    // the LDS_Q launch is sized by the largest target and the largest source among its jobs
+    int t_cap = q_tmax + SW_PAD, q_cap = (q_smax + 3) & ~3;
+    if (!ids_q.empty() && ctl_bytes + 8 * (size_t)t_cap + 6 * (size_t)q_cap > lds_share) {
+        ids_lds.insert(ids_lds.end(), ids_q.begin(), ids_q.end()); // odd mix of shapes: keep the results in HBM
+        std::sort(ids_lds.begin(), ids_lds.end());
+        ids_q.clear();
     }
     const int n_prep = (int)preps.size();
-    const int n_lds = (int)ids_lds.size(), n_glb = (int)ids_glb.size();
-    // the three tables travel as ONE block: [preps | jobs | job ids: LDS-resident jobs, then HBM-resident jobs]
+    const int n_q = (int)ids_q.size(), n_lds = (int)ids_lds.size(), n_glb = (int)ids_glb.size();
+    // the three tables travel as ONE block: [preps | jobs | job ids: LDS_Q jobs, LDS-resident targets, HBM-resident targets]
     const size_t o_jobs = (sizeof(SweepPrep) * (size_t)n_prep + 15) & ~(size_t)15;
     const size_t o_ids = (o_jobs + sizeof(SweepJob) * (size_t)n_jobs + 15) & ~(size_t)15;
     const size_t tab_bytes = o_ids + sizeof(int) * (size_t)n_jobs;
@@ -1642,9 +1688,12 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
             return SFE_ERR_HIP;
         memcpy(h, preps.data(), sizeof(SweepPrep) * (size_t)n_prep);
         memcpy(h + o_jobs, jobs.data(), sizeof(SweepJob) * (size_t)n_jobs);
-        memcpy(h + o_ids, ids_lds.data(), sizeof(int) * (size_t)n_lds);
+        if (n_q)
+            memcpy(h + o_ids, ids_q.data(), sizeof(int) * (size_t)n_q);
+        if (n_lds)
+            memcpy(h + o_ids + sizeof(int) * (size_t)n_q, ids_lds.data(), sizeof(int) * (size_t)n_lds);
         if (n_glb)
-            memcpy(h + o_ids + sizeof(int) * (size_t)n_lds, ids_glb.data(), sizeof(int) * (size_t)n_glb);
+            memcpy(h + o_ids + sizeof(int) * (size_t)(n_q + n_lds), ids_glb.data(), sizeof(int) * (size_t)n_glb);
         SFE_HIP(ctx, hipMemcpyAsync(d_tables, h, tab_bytes, hipMemcpyHostToDevice, ps));
         if (int rc = sfe_pinned_end(ctx, ps))
             return rc;
@@ -1677,45 +1726,46 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
         SFE_HIP(ctx, hipMemsetAsync(d_dbg, 0, sizeof(int) * 8, ctx->stream));
     }
     long long *d_prof = ctx->icp_prof ? (long long *)sfe_scratch(ctx, 20, sizeof(long long) * 80) : nullptr;
-    const size_t ctl_bytes = (sizeof(SweepShared) + 15) & ~(size_t)15;
+    // one launch per kind; up to one job per CU the 128-VGPR build wins (no spills, measured +8 %), beyond that two
+    // 64-VGPR workgroups per CU overlap each other's serial phases (measured +14 % at 512 jobs)
+    auto pow2_floor = [](size_t v) {
+        size_t p = 1;
+        while (2 * p <= v)
+            p *= 2;
+        return (int)p;
+    };
+#define SW_LAUNCH(KERNEL, N, IDS, SMEM, TCAP, QCAP)                                                                    \
+    do {                                                                                                               \
+        SFE_HIP(ctx, hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SMEM))); \
+        hipLaunchKernelGGL(KERNEL, dim3(N), dim3(ICP_THREADS), (SMEM), ctx->stream, *p, d_jobs, (IDS),                 \
+                           (const float2 *)d_src, d_guess9, d_stgt, d_perm, d_snrm, d_mean, d_tab, d_qst, d_qwl, d_qssrc, \
+                           d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof, d_dbg, sw_budget, sw_budget_a, sw_cache, \
+                           (TCAP), (QCAP), pow2_floor(((SMEM)-ctl_bytes) / 8));                                        \
+        SFE_LAUNCH_CHECK(ctx);                                                                                         \
+    } while (0)
+    if (n_q) {
+        const size_t smem = ctl_bytes + 8 * (size_t)t_cap + 6 * (size_t)q_cap;
+        if (wide)
+            SW_LAUNCH((icp_sweep_kernel<4, true, true>), n_q, d_ids, smem, t_cap, q_cap);
+        else
+            SW_LAUNCH((icp_sweep_kernel<8, true, true>), n_q, d_ids, smem, t_cap, q_cap);
+    }
     if (n_lds) {
         const size_t smem = ctl_bytes + sizeof(float2) * (SW_TCAP + SW_PAD);
-        // up to one job per CU the 128-VGPR build wins (no spills, measured +8 %); beyond that two
-        // 64-VGPR workgroups per CU overlap each other's serial phases (measured +14 % at 512 jobs)
-        if (n_lds <= ctx->n_cu) {
-            SFE_HIP(ctx, hipFuncSetAttribute((const void *)icp_sweep_kernel<4, true>,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            hipLaunchKernelGGL((icp_sweep_kernel<4, true>), dim3(n_lds), dim3(ICP_THREADS), smem, ctx->stream, *p, d_jobs,
-                               d_ids, (const float2 *)d_src, d_guess9, d_stgt, d_perm, d_snrm, d_mean, d_tab, d_qst, d_qwl,
-                               d_qssrc, d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof, d_dbg, sw_budget, sw_budget_a, sw_cache);
-        } else {
-            SFE_HIP(ctx, hipFuncSetAttribute((const void *)icp_sweep_kernel<8, true>,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            hipLaunchKernelGGL((icp_sweep_kernel<8, true>), dim3(n_lds), dim3(ICP_THREADS), smem, ctx->stream, *p, d_jobs,
-                               d_ids, (const float2 *)d_src, d_guess9, d_stgt, d_perm, d_snrm, d_mean, d_tab, d_qst, d_qwl,
-                               d_qssrc, d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof, d_dbg, sw_budget, sw_budget_a, sw_cache);
-        }
-        SFE_LAUNCH_CHECK(ctx);
+        if (wide)
+            SW_LAUNCH((icp_sweep_kernel<4, true, false>), n_lds, d_ids + n_q, smem, SW_TCAP + SW_PAD, 0);
+        else
+            SW_LAUNCH((icp_sweep_kernel<8, true, false>), n_lds, d_ids + n_q, smem, SW_TCAP + SW_PAD, 0);
     }
     if (n_glb) {
         // the target stays in HBM / L2; the LDS behind the control block only serves the query sort
         const size_t smem_g = ctl_bytes + sizeof(unsigned long long) * SW_TCAP;
-        SFE_HIP(ctx, hipFuncSetAttribute((const void *)icp_sweep_kernel<4, false>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_g));
-        SFE_HIP(ctx, hipFuncSetAttribute((const void *)icp_sweep_kernel<8, false>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_g));
-        if (n_glb <= ctx->n_cu)
-            hipLaunchKernelGGL((icp_sweep_kernel<4, false>), dim3(n_glb), dim3(ICP_THREADS), smem_g, ctx->stream, *p,
-                               d_jobs, d_ids + n_lds, (const float2 *)d_src, d_guess9, d_stgt, d_perm, d_snrm, d_mean, d_tab,
-                               d_qst, d_qwl, d_qssrc, d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof, d_dbg,
-                               sw_budget, sw_budget_a, sw_cache);
+        if (wide)
+            SW_LAUNCH((icp_sweep_kernel<4, false, false>), n_glb, d_ids + n_q + n_lds, smem_g, SW_TCAP, 0);
         else
-            hipLaunchKernelGGL((icp_sweep_kernel<8, false>), dim3(n_glb), dim3(ICP_THREADS), smem_g, ctx->stream, *p,
-                               d_jobs, d_ids + n_lds, (const float2 *)d_src, d_guess9, d_stgt, d_perm, d_snrm, d_mean, d_tab,
-                               d_qst, d_qwl, d_qssrc, d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof, d_dbg,
-                               sw_budget, sw_budget_a, sw_cache);
-        SFE_LAUNCH_CHECK(ctx);
+            SW_LAUNCH((icp_sweep_kernel<8, false, false>), n_glb, d_ids + n_q + n_lds, smem_g, SW_TCAP, 0);
     }
+#undef SW_LAUNCH
     if (side) {
         SFE_HIP(ctx, hipEventRecord(ctx->ev_loop, ctx->stream));
         ctx->icp_loop_pending = true;
