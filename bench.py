@@ -161,6 +161,42 @@ def cpu_baseline(frames, srcs, tgts, guesses, n_kf, det, fe, icp_mode, filters=T
                          1e3 * np.mean([o[1] for o in one]), 1e3 * np.mean([o[2] for o in one]), ref_note)}
 
 
+VALU_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: fp32 vector peak
+LDS_PEAK_GBS = 256 * 256 * 2.4     # 256 B/clk/CU (ds_read_b64, MI355X_MICROARCH.md LDS table) x 256 CUs x 2.4 GHz
+
+
+def icp_utilisation(ctx, kb, ms_launch, iters_total, n_jobs):
+    """Counted work of the ICP loop kernel (one profiled launch of the same batch: candidate distance evaluations of the
+    lane-per-query tiers, the cooperative tier and the witnesses, lower-bound probes) against the fp32 vector peak and the
+    LDS peak, next to what an exhaustive search of the same jobs would have evaluated."""
+    import ctypes
+    prof = (ctypes.c_longlong * 96)()
+    ctx._check(ctx.lib.sfe_icp_get_profile(ctx.handle, 1, prof))
+    kb.run_icp()
+    ctx.sync()
+    ctx._check(ctx.lib.sfe_icp_get_profile(ctx.handle, 0, prof))
+    evals = int(prof[80]) + int(prof[81]) + int(prof[82])
+    probes = int(prof[83])
+    iters_counted = int(prof[84])
+    flop = 8.0 * evals                                   # SURVEY 8d: 8 flop per pair evaluation
+    sec = ms_launch * 1e-3
+    out = {"kernel": "icp_sweep_kernel (+ icp_sweep_prep_kernel)", "bound": "valu/salu issue + lds/barrier latency",
+           "ms_per_launch": ms_launch, "jobs_per_launch": n_jobs,
+           "pair_evals_per_launch": evals, "lower_bound_probes_per_launch": probes,
+           "pair_evals_per_query_and_iteration": evals / max(1.0, float(iters_counted) * N_PTS),
+           "valu_frac": flop / sec / 1e12 / VALU_PEAK_TFLOPS,
+           "valu_note": "8 flop x counted pair evaluations / launch time / 157.3 TFLOP/s fp32 vector peak: the search "
+                        "evaluates ~0.1 % of the n_src x n_tgt pairs, the rest of the kernel is control flow, "
+                        "selection and fp64 sums",
+           "lds_frac": 8.0 * (evals + probes) / sec / 1e9 / LDS_PEAK_GBS,
+           "lds_note": "8 B per candidate / probe read from LDS / launch time / 157 TB/s (256 B/clk/CU x 256 CUs x 2.4 GHz)",
+           "exhaustive_pairs_per_launch": float(N_PTS) * N_PTS * iters_total,
+           "pruning_factor": float(N_PTS) * N_PTS * iters_total / max(1, evals)}
+    if iters_counted != iters_total:
+        out["note"] = "profiled launch ran %d iterations, timed launch %d" % (iters_counted, iters_total)
+    return out
+
+
 def pose_diff(Ta, Tb):
     """max(|dx|, |dy|, |dtheta|) between two 3x3 Pose2 matrices: the north_star bar is 1e-4 m / 1e-4 rad"""
     dth = np.arctan2(Ta[1, 0], Ta[0, 0]) - np.arctan2(Tb[1, 0], Tb[0, 0])
@@ -301,10 +337,7 @@ def main():
         ms_filter_b = 0.0 if args.no_filters else timed(kb.run_filter, 5)
         ms_icp_b = timed(kb.run_icp, 2)
         iters_total = int(res["iters"].sum())
-        icp_flops = 8.0 * N_PTS * N_PTS * iters_total      # 8 flop per pair evaluation
-        if args.icp_mode == "p2plane30":
-            icp_flops += 8.0 * N_PTS * N_PTS * args.batch   # the k-NN pass of the PCA normals
-        icp_tflops = icp_flops / (ms_icp_b * 1e-3) / 1e12
+        icp_kernel = icp_utilisation(ctx, kb, ms_icp_b, iters_total, args.batch)
 
         # CFAR roofline leg: a batch larger than the 256 MiB Infinity Cache, one kernel per launch
         nf = args.cfar_frames
@@ -353,13 +386,9 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cfar_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_note": "bytes/launch = 2*FETCH_SIZE + WRITE_SIZE from profiles/cfar_pmc.json",
                          "bytes_per_launch": cfar_bytes, "ms_per_launch": ms_cfar, "frames_per_launch": nf},
-            # the ICP kernels prune the search (exact strip-sweep NN), so pair evaluations are no longer
-            # n_src*n_tgt per iteration: this is the brute-force-EQUIVALENT rate, not a utilisation
-            "icp_kernel": {"kernel": "icp_sweep_kernel (+ icp_sweep_prep_kernel)", "bound": "valu/lds latency",
-                           "ms_per_launch": ms_icp_b, "jobs_per_launch": args.batch,
-                           "brute_force_equivalent_tflops": icp_tflops,
-                           "note": "8 flop x n_src x n_tgt x iterations / time; brute force itself reaches 51 "
-                                   "TFLOP/s = 33 % of the 157.3 TFLOP/s fp32 vector peak (sfe_icp_set_tuning 4)"},
+            # the ICP kernels prune the search (exact strip-sweep NN): the work below is COUNTED by the kernel in a
+            # separate profiled launch of the same batch (sfe_icp_get_profile), not derived from n_src * n_tgt
+            "icp_kernel": icp_kernel,
             "stage_ms_per_step": {"cfar": ms_cfar_b, "extract": ms_extract_b, "filters": ms_filter_b, "icp": ms_icp_b},
         }
         try:  # committed SQ counter pass of the ICP loop kernel (rocprofv3 cannot run inside the timed process)

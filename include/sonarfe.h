@@ -194,8 +194,11 @@ int sfe_icp_compute_jobs(sfe_ctx *ctx, const sfe_icp_params *p, const float *src
  * iteration kernel waits for both.  Leave it clear when a preceding call on the context produces the clouds.
  * All variants return identical results. */
 int sfe_icp_set_tuning(sfe_ctx *ctx, int variant);
-/* debug: enable/disable per-phase cycle counters of the sweep kernel (workgroup 0) and read the
- * 80 values of the last launch (buffer of 80 long long), summed over iterations.  Cycles: [0] setup incl. the
+/* profile mode of the strip-sweep ICP kernel: enable/disable, and read the 96 values of the last profiled launch
+ * (buffer of 96 long long; batches of more jobs than CUs with LDS-resident targets only).  [80..84] are counted
+ * over the WHOLE launch: [80] candidate distance evaluations by the lane-per-query tiers, [81] by the cooperative
+ * tier, [82] witness evaluations, [83] lower-bound probes, [84] ICP iterations run (all jobs).  The rest are
+ * per-phase cycle counters of workgroup 0, summed over iterations.  Cycles: [0] setup incl. the
  * query sort, [1] first search pass (own strip), [3] trimmed quantile, [4] reduction, [5] solve, [6] later
  * search passes, [7] cooperative tier, [8] finite/exact census.  Counts: [9] search rounds, [10] queries
  * handed to the cooperative tier, [11] queries handed to the second pass, [12] cooperative trips.

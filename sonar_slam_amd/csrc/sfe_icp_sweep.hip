@@ -620,7 +620,7 @@ struct SweepShared {
 
 #define SW_PROF(k)                                                                               \
     do {                                                                                         \
-        if (prof != nullptr && threadIdx.x == 0) {                                               \
+        if (PROF && threadIdx.x == 0) {                                               \
             const long long t_ = clock64();                                                      \
             S.prof[k] += t_ - S.prof_t;                                                          \
             S.prof_t = t_;                                                                       \
@@ -700,7 +700,9 @@ __device__ __forceinline__ int sweep_resolve_tie(const float2 *__restrict__ T, c
 // L2, so every phase that streams over the results (radix select, error-minimiser sums, the witness lookup of
 // the next iteration) otherwise waits for Infinity-Cache / HBM latencies.  Chosen by the launcher when
 // control block + 8 (n_tgt + pad) + 6 n_src bytes fit the workgroup's LDS share (5000 x 5000: 76 KB of 80).
-template <int MINW, bool LDS_TGT, bool LDS_Q>
+// PROF: per-phase cycle counters of workgroup 0 and launch-wide counts of the work done (candidate evaluations,
+// lower-bound probes); instantiated for the two-jobs-per-CU builds with an LDS-resident target only.
+template <int MINW, bool LDS_TGT, bool LDS_Q, bool PROF>
 __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
     sfe_icp_params P, const SweepJob *__restrict__ jobs, const int *__restrict__ job_ids, const float2 *__restrict__ src_all,
     const float *__restrict__ guess_all, const float2 *__restrict__ stgt_all, const int *__restrict__ perm_all,
@@ -768,11 +770,14 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
     const int tid = threadIdx.x, lane = threadIdx.x & 63;
     const float mx = sw_uniform(mean_all[2 * J.prep]), my = sw_uniform(mean_all[2 * J.prep + 1]);
 
-    if (prof != nullptr && tid == 0) {
+    if (PROF && tid == 0) {
         for (int i = 0; i < 16; ++i)
             S.prof[i] = 0;
         S.prof_t = clock64();
     }
+    // wave-uniform work counters (PROF only): candidate distance evaluations of the lane-per-query tiers, of the
+    // cooperative tier, witness evaluations, lower-bound probes
+    unsigned long long c_eval = 0, c_coop = 0, c_wit = 0, c_lb = 0;
     { // strip table -> LDS
         const int *tsrc = reinterpret_cast<const int *>(tab_all + J.prep);
         int *tdst = reinterpret_cast<int *>(&S.tab);
@@ -894,7 +899,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
         // ---- A+B: cur = Ti * (T0 * src); exact NN for every pair that can matter.  Round 0 searches
         // for every query (lane i handles the queries i, i + 1024, ... of the spatial order), later rounds search again for the
         // suspended ones with a larger cap. ----
-        if (prof != nullptr && tid == 0)
+        if (PROF && tid == 0)
             S.prof_b0 = clock64();
         // exact order statistic by radix select (4 passes of 8 bits over the distances' bit patterns): the k_sel-th
         // smallest (0-based) d2 among the exact matches, or among all finite ones (exact + inexact: an inexact
@@ -1097,6 +1102,8 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                     bool skip = false;
                     if (fresh && use_cache && valid) {
                         const int w = prev >= 0 ? prev + 1 : (prev <= -3 ? -2 - prev : 0);
+                        if (PROF)
+                            c_wit += (unsigned long long)__popcll(__ballot(w != 0));
                         if (w) {
                             const float2 t = T[w];
                             const float dxw = f_add(px, -t.x), dyw = f_add(py, -t.y);
@@ -1148,6 +1155,13 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                         ++used;
                         const bool start = fin && s >= 0;
                         if (__ballot(start)) {
+                            if (PROF) { // ceil(log2(strip population + 1)) probes per starting lane
+                                const int len_ = start ? tab.sbeg[s + 1] - 1 - tab.sbeg[s] : 0;
+                                int steps_ = len_ > 0 ? 32 - __clz(len_) : 0;
+                                for (int o_ = 32; o_ > 0; o_ >>= 1)
+                                    steps_ += __shfl_xor(steps_, o_);
+                                c_lb += (unsigned long long)__builtin_amdgcn_readfirstlane(steps_);
+                            }
                             const int lo = strip_lower_bound(T, start ? tab.sbeg[s] : 0, start ? tab.sbeg[s + 1] - 1 : 0, px);
                             if (start) {
                                 iR = lo;
@@ -1157,6 +1171,8 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                         }
                         for (int trip = 0; trip < rtrips && __ballot(!fin); ++trip) {
                             ++used;
+                            if (PROF)
+                                c_eval += 4ull * (unsigned long long)__popcll(__ballot(!fin)); // 2 sub-steps x 2 cursors
                             if (!fin) {
 #pragma unroll
                                 for (int s2 = 0; s2 < 2; ++s2) {
@@ -1242,7 +1258,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                     walk_pass(wl, nwork, true, sw_budget_a, false);
                     __syncthreads();
                     SW_PROF(1);
-                    if (prof != nullptr && tid == 0)
+                    if (PROF && tid == 0)
                         S.prof[11] += S.mid_n;
                     walk_pass(Q.mid, S.mid_n, false, sw_budget, true);
                 } else {
@@ -1251,7 +1267,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                 __syncthreads();
                 SW_PROF(6);
                 const int nlong = S.long_n;
-                if (prof != nullptr && tid == 0) {
+                if (PROF && tid == 0) {
                     S.prof[9] += 1;
                     S.prof[10] += nlong;
                 }
@@ -1283,7 +1299,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                     while (slot < nlong) {
                         SW_WATCH(wd2, ns + 2, 5)
                         long long tp0 = 0;
-                        if (prof != nullptr && tid == 0)
+                        if (PROF && tid == 0)
                             tp0 = clock64();
                         const int q = __builtin_amdgcn_readfirstlane(qn);
                         const float2 pq = xform(Ti, make_float2(sw_uniform(pn.x), sw_uniform(pn.y)));
@@ -1294,7 +1310,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                         slot = next_slot();
                         if (slot < nlong) // prefetch the next query
                             fetch(slot);
-                        if (prof != nullptr && tid == 0) {
+                        if (PROF && tid == 0) {
                             const long long t_ = clock64();
                             S.prof[13] += t_ - tp0;
                             tp0 = t_;
@@ -1388,13 +1404,15 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                                 iR += nR;
                                 doneL |= nL < 32 * U;
                                 doneR |= nR < 32 * U;
-                                if (prof != nullptr && lane == 0)
+                                if (PROF && lane == 0)
                                     atomicAdd((unsigned long long *)&S.prof[12], 1ull);
+                                if (PROF)
+                                    c_coop += 64ull * U;
                                 if (doneL && doneR)
                                     break;
                             }
                         }
-                        if (prof != nullptr && tid == 0) {
+                        if (PROF && tid == 0) {
                             const long long t_ = clock64();
                             S.prof[14] += t_ - tp0;
                             tp0 = t_;
@@ -1416,13 +1434,13 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                                 wl_next[atomicAdd(&S.wl_n[cur ^ 1], 1)] = q;
                             }
                         }
-                        if (prof != nullptr && tid == 0)
+                        if (PROF && tid == 0)
                             S.prof[15] += clock64() - tp0;
                     }
                 }
                 __syncthreads();
                 SW_PROF(7);
-                if (prof != nullptr && tid == 0 && chk.iters == 0 && round < 8) { // first iteration, round by round
+                if (PROF && tid == 0 && chk.iters == 0 && round < 8) { // first iteration, round by round
                     const long long t_ = clock64();
                     S.prof_it[24 + 4 * round] = nwork;
                     S.prof_it[25 + 4 * round] = (round == 0) ? S.mid_n : 0;
@@ -1462,7 +1480,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
             }
         }
         SW_PROF(2);
-        if (prof != nullptr && tid == 0 && chk.iters < 32) {
+        if (PROF && tid == 0 && chk.iters < 32) {
             S.prof_it[2 * chk.iters] = clock64() - S.prof_b0;
             S.prof_it[2 * chk.iters + 1] = ((long long)__float_as_uint(C) << 32) | nexact;
         }
@@ -1580,12 +1598,21 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
         }
         status_out[jb] = status;
         iters_out[jb] = chk.iters;
-        if (prof != nullptr && jb == 0) {
+        if (PROF && jb == 0) {
             for (int i = 0; i < 16; ++i)
                 prof[i] = S.prof[i];
             for (int i = 0; i < 64; ++i)
                 prof[16 + i] = S.prof_it[i];
         }
+    }
+    if (PROF && lane == 0) { // launch-wide work counts: [80] lane-tier evaluations, [81] cooperative tier, [82] witnesses,
+                             // [83] lower-bound probes, [84] iterations run
+        atomicAdd((unsigned long long *)&prof[80], c_eval);
+        atomicAdd((unsigned long long *)&prof[81], c_coop);
+        atomicAdd((unsigned long long *)&prof[82], c_wit);
+        atomicAdd((unsigned long long *)&prof[83], c_lb);
+        if (tid == 0)
+            atomicAdd((unsigned long long *)&prof[84], (unsigned long long)chk.iters);
     }
 }
 
@@ -1725,7 +1752,11 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
             return SFE_ERR_HIP;
         SFE_HIP(ctx, hipMemsetAsync(d_dbg, 0, sizeof(int) * 8, ctx->stream));
     }
-    long long *d_prof = ctx->icp_prof ? (long long *)sfe_scratch(ctx, 20, sizeof(long long) * 80) : nullptr;
+    long long *d_prof = ctx->icp_prof ? (long long *)sfe_scratch(ctx, 20, sizeof(long long) * SFE_ICP_PROF_N) : nullptr;
+    if (ctx->icp_prof && !d_prof)
+        return SFE_ERR_HIP;
+    if (d_prof)
+        SFE_HIP(ctx, hipMemsetAsync(d_prof, 0, sizeof(long long) * SFE_ICP_PROF_N, ctx->stream));
     // one launch per kind; up to one job per CU the 128-VGPR build wins (no spills, measured +8 %), beyond that two
     // 64-VGPR workgroups per CU overlap each other's serial phases (measured +14 % at 512 jobs)
     auto pow2_floor = [](size_t v) {
@@ -1746,24 +1777,28 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
     if (n_q) {
         const size_t smem = ctl_bytes + 8 * (size_t)t_cap + 6 * (size_t)q_cap;
         if (wide)
-            SW_LAUNCH((icp_sweep_kernel<4, true, true>), n_q, d_ids, smem, t_cap, q_cap);
+            SW_LAUNCH((icp_sweep_kernel<4, true, true, false>), n_q, d_ids, smem, t_cap, q_cap);
+        else if (d_prof)
+            SW_LAUNCH((icp_sweep_kernel<8, true, true, true>), n_q, d_ids, smem, t_cap, q_cap);
         else
-            SW_LAUNCH((icp_sweep_kernel<8, true, true>), n_q, d_ids, smem, t_cap, q_cap);
+            SW_LAUNCH((icp_sweep_kernel<8, true, true, false>), n_q, d_ids, smem, t_cap, q_cap);
     }
     if (n_lds) {
         const size_t smem = ctl_bytes + sizeof(float2) * (SW_TCAP + SW_PAD);
         if (wide)
-            SW_LAUNCH((icp_sweep_kernel<4, true, false>), n_lds, d_ids + n_q, smem, SW_TCAP + SW_PAD, 0);
+            SW_LAUNCH((icp_sweep_kernel<4, true, false, false>), n_lds, d_ids + n_q, smem, SW_TCAP + SW_PAD, 0);
+        else if (d_prof)
+            SW_LAUNCH((icp_sweep_kernel<8, true, false, true>), n_lds, d_ids + n_q, smem, SW_TCAP + SW_PAD, 0);
         else
-            SW_LAUNCH((icp_sweep_kernel<8, true, false>), n_lds, d_ids + n_q, smem, SW_TCAP + SW_PAD, 0);
+            SW_LAUNCH((icp_sweep_kernel<8, true, false, false>), n_lds, d_ids + n_q, smem, SW_TCAP + SW_PAD, 0);
     }
     if (n_glb) {
         // the target stays in HBM / L2; the LDS behind the control block only serves the query sort
         const size_t smem_g = ctl_bytes + sizeof(unsigned long long) * SW_TCAP;
         if (wide)
-            SW_LAUNCH((icp_sweep_kernel<4, false, false>), n_glb, d_ids + n_q + n_lds, smem_g, SW_TCAP, 0);
+            SW_LAUNCH((icp_sweep_kernel<4, false, false, false>), n_glb, d_ids + n_q + n_lds, smem_g, SW_TCAP, 0);
         else
-            SW_LAUNCH((icp_sweep_kernel<8, false, false>), n_glb, d_ids + n_q + n_lds, smem_g, SW_TCAP, 0);
+            SW_LAUNCH((icp_sweep_kernel<8, false, false, false>), n_glb, d_ids + n_q + n_lds, smem_g, SW_TCAP, 0);
     }
 #undef SW_LAUNCH
     if (side) {
@@ -1779,7 +1814,7 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
                 fprintf(stderr, "sfe_icp_sweep: watchdog %d tripped (workgroup %d)\n", i, h[i] - 1);
     }
     if (d_prof) {
-        SFE_HIP(ctx, hipMemcpyAsync(ctx->icp_prof_host, d_prof, sizeof(long long) * 80, hipMemcpyDeviceToHost,
+        SFE_HIP(ctx, hipMemcpyAsync(ctx->icp_prof_host, d_prof, sizeof(long long) * SFE_ICP_PROF_N, hipMemcpyDeviceToHost,
                                     ctx->stream));
         SFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
@@ -1791,7 +1826,7 @@ extern "C" int sfe_icp_get_profile(sfe_ctx *ctx, int enable, long long *cycles16
     if (!ctx)
         return SFE_ERR_ARG;
     if (cycles16)
-        for (int i = 0; i < 80; ++i)
+        for (int i = 0; i < SFE_ICP_PROF_N; ++i)
             cycles16[i] = ctx->icp_prof_host[i];
     ctx->icp_prof = enable;
     return 0;

@@ -10,6 +10,7 @@
 #include "../../include/sonarfe.h"
 
 #define SFE_NSCRATCH 32
+#define SFE_ICP_PROF_N 96 // values sfe_icp_get_profile hands back
 
 struct sfe_ctx {
     int device = -1;
@@ -41,7 +42,7 @@ struct sfe_ctx {
     int icp_variant = 0;
     int extract_variant = 0;     // 0 = inverse-map scatter for binary masks (default), 1 = dense pass only (A/B)
     int icp_prof = 0;            // debug: per-phase cycle counts of workgroup 0 of the sweep kernel
-    long long icp_prof_host[80] = {0};
+    long long icp_prof_host[SFE_ICP_PROF_N] = {0};
     int n_cu = 256;
 };
 

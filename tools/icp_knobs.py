@@ -49,7 +49,7 @@ for combo in combos:
     line = "budget A %2d B %3d R %d:" % (refill, budget, rtrips)
     for mode, kb in kbs.items():
         ms = timed(kb.run_icp, 3)
-        cyc = (ctypes.c_longlong * 80)()
+        cyc = (ctypes.c_longlong * 96)()
         ctx._check(ctx.lib.sfe_icp_get_profile(ctx.handle, 1, cyc))
         kb.run_icp()
         ctx.sync()

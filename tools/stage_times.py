@@ -49,7 +49,7 @@ def main():
             print("icp %-9s variant %d %8.3f ms / %d jobs" % (mode, v, timed(kb.run_icp, 3), a.batch))
             if not (v & 4):
                 import ctypes
-                cyc = (ctypes.c_longlong * 80)()
+                cyc = (ctypes.c_longlong * 96)()
                 ctx._check(ctx.lib.sfe_icp_get_profile(ctx.handle, 1, cyc))
                 kb.run_icp()
                 ctx.sync()
@@ -59,6 +59,10 @@ def main():
                 it = int(kb.results()["iters"][0])
                 print("   workgroup 0, %d iterations: " % it +
                       ", ".join("%s %d" % (n, c) for n, c in zip(names, list(cyc)[:12]) if n != "-"))
+                print("   whole launch: %d lane-tier + %d cooperative + %d witness evaluations, %d lower-bound probes, %d "
+                      "iterations -> %.1f evaluations per query and iteration"
+                      % (cyc[80], cyc[81], cyc[82], cyc[83], cyc[84],
+                         (cyc[80] + cyc[81] + cyc[82]) / max(1.0, cyc[84] * float(bench.N_PTS))))
                 print("   tier 2: %d trips over %d walks; wave 0 of workgroup 0: fetch %d, walk %d, finish %d cycles"
                       % (cyc[12], cyc[10], cyc[13], cyc[14], cyc[15]))
                 if it <= 10:
