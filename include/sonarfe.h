@@ -119,6 +119,8 @@ int sfe_geom_create(sfe_ctx *ctx, const float *map_x, const float *map_y, int ca
 void sfe_geom_destroy(sfe_geom *g);
 /* cv2.remap(src, map_x, map_y, cv2.INTER_LINEAR) for a uint8 image (BORDER_CONSTANT 0) */
 int sfe_remap_u8(sfe_ctx *ctx, sfe_geom *g, const uint8_t *src, uint8_t *dst);
+/* the same on device pointers (enqueue only): d_src polar_rows x polar_cols, d_dst cart_rows x cart_cols */
+int sfe_remap_u8_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_src, uint8_t *d_dst);
 /*
  * remap(mask) -> np.nonzero -> px->m in one call (feature_extraction.py:231-238).
  * mask: polar_rows x polar_cols uint8 0/1 (host).  Outputs (host, nullable):
@@ -221,6 +223,23 @@ int sfe_icp_batch_dev(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_src,
 int sfe_cloud_filter_batch_dev(sfe_ctx *ctx, const double *d_pts, const int32_t *d_counts, int n_frames,
                                int64_t cap, float resolution, double radius, int min_points,
                                float *d_out, int32_t *d_out_counts);
+
+/*
+ * ONE ping through the whole of FeatureExtraction.callback (feature_extraction.py:223-249) in one call, for the live
+ * node (one ping per callback: latency, not throughput): img (host, polar_rows x polar_cols uint8) goes up once through
+ * pinned staging; CFAR + gate (alg / train_hs / guard_hs / k / tau / intensity_thr as for sfe_cfar_u8), remap +
+ * nonzero + px->m, pcl.downsample(resolution) and pcl.remove_outlier(radius, min_points) run back to back on the
+ * stream (resolution <= 0 / min_points <= 1 skip a filter like :241 / :245); the float32 cloud comes down once:
+ * one stream synchronisation per ping.  cloud_out: host [cap x 2] float32 (y_forward, x_lateral), *n_out points;
+ * *n_raw_out (nullable) = points before the filters.  vis_out (nullable, host cart_rows x cart_cols) additionally
+ * receives cv2.remap(img) for the visualisation (:226).  Returns SFE_ERR_CAP when more than cap points were extracted
+ * (*n_raw_out says how many: retry with a larger cap; cap <= 65536); *n_out = -1 when the cloud's octree is deeper
+ * than the resident filter's 24 levels (take the per-cloud entry points).  Results are bit-identical to the chain of
+ * sfe_cfar_u8 -> sfe_extract_points -> sfe_downsample -> sfe_remove_outlier.
+ */
+int sfe_feature_extract_ping(sfe_ctx *ctx, sfe_geom *g, const uint8_t *img, int alg, int train_hs, int guard_hs,
+                             int k, double tau, int intensity_thr, float resolution, double radius, int min_points,
+                             int64_t cap, float *cloud_out, int32_t *n_out, int32_t *n_raw_out, uint8_t *vis_out);
 
 /* ---- global-initialisation matching cost: slam.py:461-570 ---------------- */
 /*

@@ -151,6 +151,9 @@ void sfe_ctx_destroy(sfe_ctx *ctx)
         if (b.ev)
             (void)hipEventDestroy(b.ev);
     }
+    for (auto &b : ctx->pin_io)
+        if (b.p)
+            (void)hipHostFree(b.p);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
     (void)hipEventDestroy(ctx->ev_prep);

@@ -739,17 +739,24 @@ int sfe_icp_compute_guesses(sfe_ctx *ctx, const sfe_icp_params *p, const float *
         return 0;
     if (n_src == 0 || n_tgt == 0)
         return sfe_set_err(ctx, SFE_ERR_ARG, "ICP needs non-empty clouds (n_src=%d, n_tgt=%d)", n_src, n_tgt);
-    float *d_src = (float *)sfe_scratch(ctx, 0, sizeof(float) * 2 * (size_t)n_src);
-    float *d_tgt = (float *)sfe_scratch(ctx, 1, sizeof(float) * 2 * (size_t)n_tgt);
-    float *d_g = (float *)sfe_scratch(ctx, 2, sizeof(float) * 9 * (size_t)n_guesses);
-    float *d_T = (float *)sfe_scratch(ctx, 3, sizeof(float) * 9 * (size_t)n_guesses);
-    int32_t *d_st = (int32_t *)sfe_scratch(ctx, 8, sizeof(int32_t) * 2 * (size_t)n_guesses);
-    if (!d_src || !d_tgt || !d_g || !d_T || !d_st)
+    // one pinned block up ([source | target | guesses]), one down ([T | status | iterations]): the live node calls this
+    // once per scan match with clouds of 10^2..10^3 points, where the copies and their latencies are the cost
+    const size_t b_src = sizeof(float) * 2 * (size_t)n_src, b_tgt = sizeof(float) * 2 * (size_t)n_tgt;
+    const size_t b_g = sizeof(float) * 9 * (size_t)n_guesses, b_in = b_src + b_tgt + b_g;
+    const size_t b_out = (sizeof(float) * 9 + 2 * sizeof(int32_t)) * (size_t)n_guesses;
+    char *d_in = (char *)sfe_scratch(ctx, 0, b_in);
+    char *d_out = (char *)sfe_scratch(ctx, 3, b_out);
+    char *h_in = (char *)sfe_pinned_io(ctx, 2, b_in);
+    char *h_out = (char *)sfe_pinned_io(ctx, 3, b_out);
+    if (!d_in || !d_out || !h_in || !h_out)
         return SFE_ERR_HIP;
-    SFE_HIP(ctx, hipMemcpyAsync(d_src, src, sizeof(float) * 2 * (size_t)n_src, hipMemcpyHostToDevice, ctx->stream));
-    SFE_HIP(ctx, hipMemcpyAsync(d_tgt, tgt, sizeof(float) * 2 * (size_t)n_tgt, hipMemcpyHostToDevice, ctx->stream));
-    SFE_HIP(ctx, hipMemcpyAsync(d_g, guesses9, sizeof(float) * 9 * (size_t)n_guesses, hipMemcpyHostToDevice,
-                                ctx->stream));
+    memcpy(h_in, src, b_src);
+    memcpy(h_in + b_src, tgt, b_tgt);
+    memcpy(h_in + b_src + b_tgt, guesses9, b_g);
+    SFE_HIP(ctx, hipMemcpyAsync(d_in, h_in, b_in, hipMemcpyHostToDevice, ctx->stream));
+    float *d_src = (float *)d_in, *d_tgt = (float *)(d_in + b_src), *d_g = (float *)(d_in + b_src + b_tgt);
+    float *d_T = (float *)d_out;
+    int32_t *d_st = (int32_t *)(d_out + sizeof(float) * 9 * (size_t)n_guesses);
     std::vector<int32_t> jobs4(4 * (size_t)n_guesses);
     for (int j = 0; j < n_guesses; ++j) {
         jobs4[4 * j] = 0;
@@ -759,14 +766,12 @@ int sfe_icp_compute_guesses(sfe_ctx *ctx, const sfe_icp_params *p, const float *
     }
     if (int rc = icp_launch(ctx, p, d_src, d_tgt, jobs4.data(), d_g, n_guesses, d_T, d_st, d_st + n_guesses))
         return rc;
-    SFE_HIP(ctx, hipMemcpyAsync(T_out9, d_T, sizeof(float) * 9 * (size_t)n_guesses, hipMemcpyDeviceToHost,
-                                ctx->stream));
-    SFE_HIP(ctx, hipMemcpyAsync(status, d_st, sizeof(int32_t) * (size_t)n_guesses, hipMemcpyDeviceToHost,
-                                ctx->stream));
-    if (iters)
-        SFE_HIP(ctx, hipMemcpyAsync(iters, d_st + n_guesses, sizeof(int32_t) * (size_t)n_guesses,
-                                    hipMemcpyDeviceToHost, ctx->stream));
+    SFE_HIP(ctx, hipMemcpyAsync(h_out, d_out, b_out, hipMemcpyDeviceToHost, ctx->stream));
     SFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(T_out9, h_out, sizeof(float) * 9 * (size_t)n_guesses);
+    memcpy(status, h_out + sizeof(float) * 9 * (size_t)n_guesses, sizeof(int32_t) * (size_t)n_guesses);
+    if (iters)
+        memcpy(iters, h_out + (sizeof(float) * 9 + sizeof(int32_t)) * (size_t)n_guesses, sizeof(int32_t) * (size_t)n_guesses);
     return 0;
 }
 

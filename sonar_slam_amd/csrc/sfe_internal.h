@@ -9,7 +9,7 @@
 
 #include "../../include/sonarfe.h"
 
-#define SFE_NSCRATCH 32
+#define SFE_NSCRATCH 48
 #define SFE_ICP_PROF_N 96 // values sfe_icp_get_profile hands back
 
 struct sfe_ctx {
@@ -37,6 +37,7 @@ struct sfe_ctx {
         bool pending = false;
     } pin[2];
     int pin_next = 0;
+    Pin pin_io[4]; // grow-only pinned buffers of the synchronous single-item entry points (no events: the call syncs)
     int cfar_tile_rows = 0;
     int cfar_variant = 0;
     int icp_variant = 0;
@@ -69,6 +70,8 @@ void *sfe_scratch(sfe_ctx *ctx, int slot, size_t bytes);  // grow-only device sc
 // sfe_pinned_end(ctx, s) so the block is not reused before those copies have run.  nullptr on failure.
 void *sfe_pinned_begin(sfe_ctx *ctx, size_t bytes);
 int sfe_pinned_end(sfe_ctx *ctx, hipStream_t s);
+// grow-only pinned buffer `slot` (0..3) of >= bytes for entry points that end with a stream synchronisation
+void *sfe_pinned_io(sfe_ctx *ctx, int slot, size_t bytes);
 
 #define SFE_HIP(ctx, call)                                                                       \
     do {                                                                                         \

@@ -1,0 +1,91 @@
+// One sonar ping through the whole of FeatureExtraction.callback in ONE call:
+//   bruce_slam/src/bruce_slam/feature_extraction.py:223-224  CFAR.detect + intensity gate
+//   :226                                                      cv2.remap(img) for the visualisation (optional)
+//   :231-238                                                  cv2.remap(peaks) -> np.nonzero -> pixel -> metres
+//   :241-249                                                  pcl.downsample, pcl.remove_outlier
+// The live ROS node handles one ping per callback, so what counts is latency, not throughput: the per-stage
+// host entry points (sfe_cfar_u8, sfe_extract_points, sfe_downsample, sfe_remove_outlier) each pay a pageable
+// host->device copy, a device->host copy and a stream synchronisation.  Here the ping goes up once through pinned
+// staging, the stages run back to back on the context's stream (the same kernels as the batched resident path, batch
+// of one), and the final float32 cloud comes down once: one synchronisation per ping.
+#include "sfe_internal.h"
+
+#include <algorithm>
+#include <cstring>
+
+// grow-only pinned host buffers for the synchronous single-item entry points (their call ends with a stream
+// synchronisation, so a buffer is free again when the call returns)
+static void *pinned_io(sfe_ctx *ctx, int slot, size_t bytes)
+{
+    auto &b = ctx->pin_io[slot];
+    if (bytes <= b.cap && b.p)
+        return b.p;
+    if (b.p)
+        (void)hipHostFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    if (hipHostMalloc(&b.p, want, hipHostMallocDefault) != hipSuccess) {
+        b.p = nullptr;
+        sfe_set_err(ctx, SFE_ERR_HIP, "hipHostMalloc(%zu) for pinned staging failed", want);
+        return nullptr;
+    }
+    b.cap = want;
+    return b.p;
+}
+
+void *sfe_pinned_io(sfe_ctx *ctx, int slot, size_t bytes) { return pinned_io(ctx, slot, bytes); }
+
+extern "C" int sfe_feature_extract_ping(sfe_ctx *ctx, sfe_geom *g, const uint8_t *img, int alg, int train_hs,
+                                        int guard_hs, int k, double tau, int intensity_thr, float resolution,
+                                        double radius, int min_points, int64_t cap, float *cloud_out, int32_t *n_out,
+                                        int32_t *n_raw_out, uint8_t *vis_out)
+{
+    if (int rc = sfe_use(ctx))
+        return rc;
+    SFE_ARG(ctx, g && img && cloud_out && n_out && g->ctx == ctx && cap > 0 && cap <= 65536);
+    const size_t np = (size_t)g->polar_rows * g->polar_cols, nc = (size_t)g->cart_rows * g->cart_cols;
+    uint8_t *d_img = (uint8_t *)sfe_scratch(ctx, 32, np);
+    uint8_t *d_mask = (uint8_t *)sfe_scratch(ctx, 33, np);
+    double *d_pts = (double *)sfe_scratch(ctx, 34, (size_t)cap * 16);
+    // [0] raw point count, [1] filtered count, then the filtered float32 cloud: one block, one copy back
+    int32_t *d_res = (int32_t *)sfe_scratch(ctx, 35, 16 + (size_t)cap * 8);
+    uint8_t *d_vis = vis_out ? (uint8_t *)sfe_scratch(ctx, 36, nc) : nullptr;
+    uint8_t *h_img = (uint8_t *)pinned_io(ctx, 0, np);
+    char *h_res = (char *)pinned_io(ctx, 1, 16 + (size_t)cap * 8 + (vis_out ? nc : 0));
+    if (!d_img || !d_mask || !d_pts || !d_res || (vis_out && !d_vis) || !h_img || !h_res)
+        return SFE_ERR_HIP;
+    memcpy(h_img, img, np);
+    SFE_HIP(ctx, hipMemcpyAsync(d_img, h_img, np, hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = sfe_cfar_u8_batch_dev(ctx, d_img, 1, g->polar_rows, g->polar_cols, alg, train_hs, guard_hs, k, tau,
+                                       intensity_thr, d_mask, nullptr))
+        return rc;
+    if (vis_out)
+        if (int rc = sfe_remap_u8_dev(ctx, g, d_img, d_vis))
+            return rc;
+    if (int rc = sfe_extract_points_batch_dev(ctx, g, d_mask, 1, cap, d_pts, d_res))
+        return rc;
+    float *d_cloud = reinterpret_cast<float *>(d_res + 4);
+    if (int rc = sfe_cloud_filter_batch_dev(ctx, d_pts, d_res, 1, cap, resolution, radius, min_points, d_cloud, d_res + 1))
+        return rc;
+    SFE_HIP(ctx, hipMemcpyAsync(h_res, d_res, 16 + (size_t)cap * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (vis_out)
+        SFE_HIP(ctx, hipMemcpyAsync(h_res + 16 + (size_t)cap * 8, d_vis, nc, hipMemcpyDeviceToHost, ctx->stream));
+    SFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int32_t n_raw = reinterpret_cast<int32_t *>(h_res)[0], n = reinterpret_cast<int32_t *>(h_res)[1];
+    if (n_raw_out)
+        *n_raw_out = n_raw;
+    if (vis_out)
+        memcpy(vis_out, h_res + 16 + (size_t)cap * 8, nc);
+    if (n_raw > cap) {
+        *n_out = 0;
+        return sfe_set_err(ctx, SFE_ERR_CAP, "feature_extract_ping: %d points exceed capacity %lld", n_raw, (long long)cap);
+    }
+    if (n < 0) { // octree deeper than 24 levels (sfe_cloud_filter_batch_dev): the caller takes the per-cloud path
+        *n_out = -1;
+        return 0;
+    }
+    *n_out = n;
+    memcpy(cloud_out, h_res + 16, (size_t)n * 8);
+    return 0;
+}

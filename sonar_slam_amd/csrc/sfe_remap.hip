@@ -717,6 +717,18 @@ int sfe_remap_u8(sfe_ctx *ctx, sfe_geom *g, const uint8_t *src, uint8_t *dst)
     return 0;
 }
 
+int sfe_remap_u8_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_src, uint8_t *d_dst)
+{
+    if (int rc = sfe_use(ctx))
+        return rc;
+    SFE_ARG(ctx, g && d_src && d_dst && g->ctx == ctx);
+    const size_t nc = (size_t)g->cart_rows * g->cart_cols;
+    hipLaunchKernelGGL(remap_u8_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, ctx->stream, d_src,
+                       (const uint32_t *)g->d_code, d_dst, g->polar_rows, g->polar_cols, g->rcp, (long long)nc, 1);
+    SFE_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
 int sfe_extract_points_batch_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_frames, int64_t cap,
                                  double *d_pts, int32_t *d_counts)
 {

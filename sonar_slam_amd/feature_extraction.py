@@ -97,6 +97,42 @@ class Geometry(object):
             self.ctx._check(ret)
             return rc[:n.value].copy(), pts[:n.value].copy()
 
+    def feature_extract(self, img, alg, cfar_params, threshold, resolution, radius, min_points, want_vis=False,
+                        cap=16384):
+        """One ping through CFAR + gate -> remap + nonzero + px->m -> pcl.downsample -> pcl.remove_outlier in ONE
+        library call (sfe_feature_extract_ping: one pinned upload, one download, one synchronisation).
+        -> (cloud float32 [N x 2], vis image or None), or None when the cloud's octree is too deep for the
+        resident filter (the caller then takes the per-stage entry points).  Bit-identical to the per-stage chain."""
+        from .cfar import _gate_u8
+        img = np.ascontiguousarray(img, np.uint8)
+        if img.shape != (self.polar_rows, self.polar_cols):
+            raise ValueError("feature_extract: image shape %r does not match the geometry" % (img.shape,))
+        code = _L.ALG[alg]
+        if code == 3:
+            train_hs, guard_hs, k, tau = cfar_params
+        else:
+            (train_hs, guard_hs, tau), k = cfar_params, 0
+        vis = np.zeros((self.cart_rows, self.cart_cols), np.uint8) if want_vis else None
+        cap = int(cap)
+        while True:
+            cloud = np.zeros((cap, 2), np.float32)
+            n, n_raw = _C.c_int32(0), _C.c_int32(0)
+            with self.ctx.lock:
+                ret = self.ctx.lib.sfe_feature_extract_ping(
+                    self.ctx.handle, self.handle, _L.ptr(img, _C.c_uint8), code, int(train_hs), int(guard_hs), int(k),
+                    float(tau), _gate_u8(threshold), float(resolution), float(radius), int(min_points), cap,
+                    _L.ptr(cloud, _C.c_float), _C.byref(n), _C.byref(n_raw),
+                    _L.ptr(vis, _C.c_uint8) if want_vis else None)
+            if ret == _L.SFE_ERR_CAP and n_raw.value > cap and n_raw.value <= 65536:
+                cap = int(n_raw.value)
+                continue
+            if ret == _L.SFE_ERR_CAP:
+                return None                     # more points than the resident filter holds: per-stage path
+            self.ctx._check(ret)
+            if n.value < 0:
+                return None
+            return cloud[:n.value].copy(), vis
+
     def close(self):
         if self.handle is not None:
             self.ctx.lib.sfe_geom_destroy(self.handle)
@@ -155,6 +191,7 @@ class FeatureExtraction(object):
         self.geometry = None
         self.feature_img = None
         self.make_vis_image = False
+        self.fused = True          # callback() = one sfe_feature_extract_ping call (False: the per-stage calls)
 
     # ---- configuration: the rosparam keys of init_node (feature_extraction.py:83-110) ----
     def load_yaml(self, path):
@@ -213,6 +250,16 @@ class FeatureExtraction(object):
             return np.array([[np.nan, np.nan]])
         img = ping.image
         self.generate_map_xy(ping)
+        if self.fused and np.asarray(img).dtype == np.uint8:
+            # the live path: the whole chain below in one library call (bit-identical to it)
+            out = self.geometry.feature_extract(img, self.alg, self.detector.params[self.alg], self.threshold,
+                                                self.resolution, self.outlier_filter_radius,
+                                                self.outlier_filter_min_points, want_vis=self.make_vis_image)
+            if out is not None:
+                points, vis = out
+                if self.make_vis_image:
+                    self.feature_img = vis
+                return points
         peaks = self.detect(img)
         if self.make_vis_image:
             self.feature_img = self.geometry.remap(img)  # :226 (colour map is applied by the node)

@@ -181,3 +181,48 @@ def test_inverse_map_extraction_equals_dense_pass_and_oracle(ctx, density):
         assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
         rc = oracle.nonzero(oracle.remap_u8(mask, fe.map_x, fe.map_y))
         assert np.array_equal(out[0][0], rc)
+
+
+def test_fused_ping_call_equals_the_per_stage_chain_and_the_oracle(ctx, shipped_cfar):
+    """sfe_feature_extract_ping (one upload, one download, one synchronisation per ping: what
+    FeatureExtraction.callback calls) against the per-stage entry points and the oracle chain, on several frames,
+    all four CFAR variants, with and without the visualisation image and the filters, and with a too-small
+    capacity (retry path)."""
+    from sonar_slam_amd.CFAR import CFAR
+    from sonar_slam_amd.feature_extraction import FeatureExtraction, SonarPing, oculus_bearings
+    det = CFAR(40, 10, 0.1, 10)
+    for seed, (rows, cols), alg, res, mp in ((5, (1024, 512), "SOCA", 0.5, 5), (6, (512, 256), "CA", 0.5, 5),
+                                             (7, (512, 256), "GOCA", 0.0, 5), (8, (300, 256), "OS", 0.3, 1),
+                                             (9, (1024, 512), "SOCA", 0.5, 5)):
+        img = synth.sonar_frame(seed=seed, rows=rows, cols=cols)
+        ping = SonarPing(img, oculus_bearings(cols), 30.0 / rows, ping_id=0)
+        out = {}
+        for fused in (True, False):
+            fe = FeatureExtraction(ctx)
+            fe.Ntc, fe.Ngc, fe.Pfa, fe.rank, fe.alg, fe.threshold, fe.skip = 40, 10, 0.1, 10, alg, 65, 1
+            fe.resolution, fe.outlier_filter_min_points = res, mp
+            fe.configure()
+            fe.fused = fused
+            fe.make_vis_image = seed % 2 == 1
+            out[fused] = (fe.callback(ping), fe.feature_img)
+        a, b = out[True], out[False]
+        assert a[0].dtype == np.float32 or len(a[0]) == 0
+        assert np.array_equal(np.asarray(a[0], np.float32), np.asarray(b[0], np.float32)), (seed, alg)
+        assert (a[1] is None) == (b[1] is None) and (a[1] is None or np.array_equal(a[1], b[1]))
+        prm = det.params[alg]
+        m = oracle.gate(img, oracle.cfar(img, alg, prm[0], prm[1], prm[-1], k=prm[2] if alg == "OS" else 0), 65)
+        p = oracle.px_to_m(oracle.nonzero(oracle.remap_u8(m, fe.map_x, fe.map_y)), fe.rows, fe.cols, fe.width, fe.height)
+        p = p.astype(np.float32)
+        if len(p) and res > 0:
+            p = oracle.downsample(p, res)
+        if mp > 1 and len(p):
+            p = oracle.remove_outlier(p, 1.0, mp)
+        assert np.array_equal(np.asarray(a[0], np.float32), p), (seed, alg)
+        if a[1] is not None:
+            assert np.array_equal(a[1], oracle.remap_u8(img, fe.map_x, fe.map_y))
+    # capacity retry: a first call with room for 64 points only
+    got = fe.geometry.feature_extract(img, "SOCA", det.params["SOCA"], 65, 0.5, 1.0, 5, cap=64)
+    assert got is not None and np.array_equal(got[0], np.asarray(out[True][0], np.float32))
+    # an all-dark ping: no detections, empty cloud
+    dark = SonarPing(np.zeros((1024, 512), np.uint8), oculus_bearings(512), 30.0 / 1024, ping_id=0)
+    assert fe.callback(dark).shape == (0, 2)
