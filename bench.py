@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-filters", action="store_true", help="leave pcl.downsample / remove_outlier out of the step")
     ap.add_argument("--parity-jobs", type=int, default=8,
                     help="keyframes of the timed batch re-computed by the oracle after the timed region (0 = skip)")
+    ap.add_argument("--no-latency", action="store_true", help="skip the live single-ping / single-scan-match latency leg")
     ap.add_argument("--serial-prep", action="store_true",
                     help="keep the ICP target preparation on the main stream (default: side stream, next to the front end)")
     return ap.parse_args()
@@ -398,6 +399,17 @@ def main():
                                       "counters_from": sq["source"].split(" ")[0]})
         except (OSError, KeyError, ValueError):
             pass
+        if not args.no_latency:
+            # the live single-item path of the ROS nodes (one ping / one scan match per call, host wall clock incl.
+            # PCIe copies and the one synchronisation); the oracle's per-ping / per-match milliseconds are in
+            # cpu_baseline.sample
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import live_latency
+            kb.free()
+            out["live_latency"] = live_latency.measure(ctx)
+            out["live_latency"]["note"] = ("median host wall time per call: FeatureExtraction.callback on a 1024x512 ping "
+                                           "(fused = sfe_feature_extract_ping, per_stage = the four per-stage calls), "
+                                           "pcl.ICP.compute (shipped chain) on n x n points")
         if parity is not None:
             out["parity_check"] = parity
         if cpu is not None:
