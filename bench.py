@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--no-filters", action="store_true", help="leave pcl.downsample / remove_outlier out of the step")
     ap.add_argument("--parity-jobs", type=int, default=8,
                     help="keyframes of the timed batch re-computed by the oracle after the timed region (0 = skip)")
+    ap.add_argument("--no-farm", action="store_true", help="skip the BASELINE configs[3] leg (job farm on this device)")
+    ap.add_argument("--farm-jobs", type=int, default=10000)
     ap.add_argument("--no-latency", action="store_true", help="skip the live single-ping / single-scan-match latency leg")
     ap.add_argument("--serial-prep", action="store_true",
                     help="keep the ICP target preparation on the main stream (default: side stream, next to the front end)")
@@ -198,6 +200,33 @@ def icp_utilisation(ctx, kb, ms_launch, iters_total, n_jobs):
     return out
 
 
+def farm_leg(icp_p, srcs, tgts, guesses, n_jobs):
+    """BASELINE configs[3] at N = 1: n_jobs independent 5000 x 5000 scan matches through farm.IcpFarm (one persistent
+    worker process per device -- here this rank's device only --, jobs over shared memory, 1024 per launch), host wall
+    clock per batch incl. packing, host<->device copies and unpacking; every job has its own guess."""
+    from sonar_slam_amd import synth
+    from sonar_slam_amd.farm import IcpFarm
+    rng = np.random.default_rng(0)
+    nd = len(srcs)
+    jobs = [(srcs[j % nd], tgts[j % nd], [np.asarray(guesses[j % nd], np.float64)
+                                           @ synth.pose_matrix(*rng.normal(0, [0.05, 0.05, 0.005]))])
+            for j in range(n_jobs)]
+    jobs = [(s, t, [g[0].astype(np.float32)]) for s, t, g in jobs]
+    dev = int(os.environ.get("SONARFE_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    with IcpFarm(icp_p, devices=[dev]) as farm:
+        farm.run(jobs[:64])                                   # worker start-up, scratch growth
+        times = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            out = farm.run(jobs)
+            times.append(time.perf_counter() - t0)
+    ok = sum(m[0] == "success" for m, _, _ in out)
+    return {"jobs": n_jobs, "distinct_pairs": nd, "devices": 1, "seconds_per_batch": min(times),
+            "jobs_per_s": n_jobs / min(times), "converged": ok,
+            "note": "farm.IcpFarm on this device: persistent worker, shared-memory job blocks; 8-GPU scaling = one such "
+                    "worker per device, job j -> device j mod G, no collective (not measurable on a 1-GPU box)"}
+
+
 def pose_diff(Ta, Tb):
     """max(|dx|, |dy|, |dtheta|) between two 3x3 Pose2 matrices: the north_star bar is 1e-4 m / 1e-4 rad"""
     dth = np.arctan2(Ta[1, 0], Ta[0, 0]) - np.arctan2(Tb[1, 0], Tb[0, 0])
@@ -336,6 +365,7 @@ def main():
         ms_cfar_b = timed(kb.run_cfar, 5)
         ms_extract_b = timed(kb.run_extract, 5)
         ms_filter_b = 0.0 if args.no_filters else timed(kb.run_filter, 5)
+        extract_bytes = float(args.batch) * ROWS * COLS + 16.0 * float(res["counts"].sum())
         ms_icp_b = timed(kb.run_icp, 2)
         iters_total = int(res["iters"].sum())
         icp_kernel = icp_utilisation(ctx, kb, ms_icp_b, iters_total, args.batch)
@@ -391,6 +421,14 @@ def main():
             # separate profiled launch of the same batch (sfe_icp_get_profile), not derived from n_src * n_tgt
             "icp_kernel": icp_kernel,
             "stage_ms_per_step": {"cfar": ms_cfar_b, "extract": ms_extract_b, "filters": ms_filter_b, "icp": ms_icp_b},
+            # SURVEY 8d, on-the-fly form: R*B bytes of mask in + 16 B per extracted point out
+            "roofline_extract": {"kernel": "mask_pack + extract_scatter + extract_scan + extract_expand", "bound": "hbm",
+                                 "achieved": extract_bytes / (ms_extract_b * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": extract_bytes / (ms_extract_b * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "bytes_per_launch": extract_bytes, "ms_per_launch": ms_extract_b,
+                                 "note": "algorithmic bytes = R*B mask bytes + 16 B per point per frame; the kernels are "
+                                         "bound by gathers into the inverse remap tables (29 MB, scattered 4-byte reads), not "
+                                         "by streaming"},
         }
         try:  # committed SQ counter pass of the ICP loop kernel (rocprofv3 cannot run inside the timed process)
             with open(os.path.join(ROOT, "profiles", "icp_sq.json")) as f:
@@ -410,6 +448,8 @@ def main():
             out["live_latency"]["note"] = ("median host wall time per call: FeatureExtraction.callback on a 1024x512 ping "
                                            "(fused = sfe_feature_extract_ping, per_stage = the four per-stage calls), "
                                            "pcl.ICP.compute (shipped chain) on n x n points")
+        if not args.no_farm:
+            out["configs3_farm"] = farm_leg(icp_p, srcs, tgts, guesses, args.farm_jobs)
         if parity is not None:
             out["parity_check"] = parity
         if cpu is not None:

@@ -15,7 +15,9 @@
 #include "sfe_internal.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <algorithm>
 
 #define SFE_CODE_NONE 0xFFFFFFFFu
 
@@ -120,12 +122,16 @@ __global__ __launch_bounds__(256) void extract_bits_kernel(const uint8_t *__rest
                                                            unsigned long long *__restrict__ bitmap, int prows,
                                                            int pcols, unsigned rcp, int crows, int ccols, int wpr,
                                                            int word_groups, int tiles_per_frame,
-                                                           long long words_per_frame, int only_general)
+                                                           long long words_per_frame, int only_general, int n_frames)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_bits[];
-    const int f = blockIdx.x / tiles_per_frame, tile = blockIdx.x % tiles_per_frame;
-    if (only_general && nonbinary[f] == 0) // binary frames were done by extract_scatter_kernel
-        return;
+    // grid = tiles x (frames or fewer): a workgroup takes its tile of frames f0, f0 + stride, ...  When the binary
+    // frames were done by extract_scatter_kernel (only_general) the launcher keeps the grid small -- a sonar batch
+    // normally has no other frame, and 100 000 workgroups that only find that out cost 30 us per launch.
+    const int tile = blockIdx.x % tiles_per_frame;
+    for (int f = blockIdx.x / tiles_per_frame; f < n_frames; f += gridDim.x / tiles_per_frame) {
+    if (only_general && nonbinary[f] == 0) // binary frames were done by extract_scatter_kernel (block-uniform)
+        continue;
     const int w = (tile % word_groups) * 4 + (threadIdx.x >> 6); // wave-uniform
     const int r0 = (tile / word_groups) * EXTRACT_RG, r1 = min(r0 + EXTRACT_RG, crows);
     const int c = w * 64 + (threadIdx.x & 63);
@@ -157,10 +163,8 @@ __global__ __launch_bounds__(256) void extract_bits_kernel(const uint8_t *__rest
         }
     }
     __syncthreads();
-    if (w >= wpr)
-        return;
     const uint8_t *__restrict__ msrc = mask + (long long)f * prows * pcols;
-    for (int rb = r0; rb < r1; rb += EXTRACT_U) {
+    for (int rb = r0; rb < r1 && w < wpr; rb += EXTRACT_U) {
         uint32_t cd[EXTRACT_U];
 #pragma unroll
         for (int i = 0; i < EXTRACT_U; ++i) {
@@ -209,44 +213,64 @@ __global__ __launch_bounds__(256) void extract_bits_kernel(const uint8_t *__rest
                 bitmap[((long long)f * crows + row) * wpr + w] = word;
         }
     }
+    __syncthreads(); // the staged rows are replaced by the next frame's
+    }
 }
 
-// pass 2: one workgroup per frame: row counts from the bitmap, exclusive scan -> row offsets + total
-__global__ __launch_bounds__(256) void extract_scan_kernel(const unsigned long long *__restrict__ bitmap,
-                                                           int32_t *__restrict__ row_count,
-                                                           int32_t *__restrict__ row_off,
-                                                           int32_t *__restrict__ frame_count, int crows, int wpr)
+// pass 2: one workgroup per frame: row counts from the bitmap, exclusive scan -> row offsets + total.  The bitmap is
+// read as one flat stream (lane t takes words t, t + 1024, ...: coalesced); the few non-empty words add their
+// popcount to their row's LDS counter.
+#define SCAN_THREADS 1024
+__global__ __launch_bounds__(SCAN_THREADS) void extract_scan_kernel(const unsigned long long *__restrict__ bitmap,
+                                                                    int32_t *__restrict__ row_count,
+                                                                    int32_t *__restrict__ row_off,
+                                                                    int32_t *__restrict__ frame_count, int crows, int wpr)
 {
-    const int f = blockIdx.x;
+    extern __shared__ int s_cnt[]; // crows row counts, then SCAN_THREADS partial sums
+    int *s_part = s_cnt + crows;
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const unsigned long long *__restrict__ bm = bitmap + (long long)f * crows * wpr;
+    for (int i = tid; i < crows; i += SCAN_THREADS)
+        s_cnt[i] = 0;
+    __syncthreads();
+    const int nw = crows * wpr;
+    for (int i0 = tid; i0 < nw; i0 += 8 * SCAN_THREADS) { // eight loads in flight per lane
+        unsigned long long wd[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * SCAN_THREADS;
+            wd[u] = i < nw ? bm[i] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (wd[u])
+                atomicAdd(&s_cnt[(i0 + u * SCAN_THREADS) / wpr], __popcll(wd[u]));
+    }
+    __syncthreads();
     int32_t *__restrict__ cnt = row_count + (long long)f * crows;
     int32_t *__restrict__ off = row_off + (long long)f * crows;
-    __shared__ int s_part[256];
-    const int per = (crows + 255) / 256;
-    const int b = threadIdx.x * per, e = min(b + per, crows);
+    const int per = (crows + SCAN_THREADS - 1) / SCAN_THREADS;
+    const int b = tid * per, e = min(b + per, crows);
     int s = 0;
     for (int i = b; i < e; ++i) {
-        const unsigned long long *__restrict__ brow = bitmap + ((long long)f * crows + i) * wpr;
-        int c = 0;
-        for (int w = 0; w < wpr; ++w)
-            c += __popcll(brow[w]);
-        cnt[i] = c;
-        s += c;
+        cnt[i] = s_cnt[i];
+        s += s_cnt[i];
     }
-    s_part[threadIdx.x] = s;
+    s_part[tid] = s;
     __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) { // Hillis-Steele inclusive scan
-        const int v = (threadIdx.x >= d) ? s_part[threadIdx.x - d] : 0;
+    for (int d = 1; d < SCAN_THREADS; d <<= 1) { // Hillis-Steele inclusive scan
+        const int v = (tid >= d) ? s_part[tid - d] : 0;
         __syncthreads();
-        s_part[threadIdx.x] += v;
+        s_part[tid] += v;
         __syncthreads();
     }
-    int run = (threadIdx.x == 0) ? 0 : s_part[threadIdx.x - 1];
+    int run = (tid == 0) ? 0 : s_part[tid - 1];
     for (int i = b; i < e; ++i) {
         off[i] = run;
-        run += cnt[i];
+        run += s_cnt[i];
     }
-    if (threadIdx.x == 255)
-        frame_count[f] = s_part[255];
+    if (tid == SCAN_THREADS - 1)
+        frame_count[f] = s_part[SCAN_THREADS - 1];
 }
 
 // pass 3: one lane per POINT: point t of a frame lies in the last row whose offset is <= t (binary search in
@@ -331,7 +355,7 @@ __global__ __launch_bounds__(256) void extract_expand_kernel(const unsigned long
 // (a canvas pixel reached through two of its taps is evaluated twice, idempotent).  40x less work
 // than the dense pass on sonar frames; the bitmap must be zero beforehand.  One workgroup = one frame
 // x SC_ROWS polar rows, which it stages (+1 halo row each side) as bits in LDS.
-#define SC_ROWS 16
+#define SC_ROWS 64 // (16 measured 2 % slower: four times the workgroups, each with a handful of set pixels)
 #define SC_LIST 256 // set pixels a wave collects before it expands them
 #define SC_U 4      // candidates per lane whose dependent loads (inverse map -> code) overlap
 __global__ __launch_bounds__(256) void extract_scatter_kernel(const uint32_t *__restrict__ bits,
@@ -341,9 +365,9 @@ __global__ __launch_bounds__(256) void extract_scatter_kernel(const uint32_t *__
                                                               const uint32_t *__restrict__ inv_ent,
                                                               unsigned long long *__restrict__ bitmap, int prows,
                                                               int pcols, unsigned rcp, int crows, int ccols, int wpr,
-                                                              long long words_per_frame)
+                                                              long long words_per_frame, int sc_rows)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_rows[]; // (SC_ROWS + 2) x pw words, then per-wave lists
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_rows[]; // (sc_rows + 2) x pw words, then per-wave lists
     // Workgroups are dealt to the 8 XCDs round robin in launch order (x fastest).  Row block -> XCD is
     // arranged so that XCD k works on ONE contiguous eighth of the polar rows of every frame: its slice of the
     // inverse map and of the code table (a ring of the canvas, ~3 MB of the 27 MB) then stays in that XCD's
@@ -351,12 +375,12 @@ __global__ __launch_bounds__(256) void extract_scatter_kernel(const uint32_t *__
     int rb = blockIdx.x;
     if ((gridDim.x & 7) == 0)
         rb = (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
-    const int f = blockIdx.y, y0 = rb * SC_ROWS;
+    const int f = blockIdx.y, y0 = rb * sc_rows;
     if (nonbinary[f] != 0)
         return;
     const int pw = pcols >> 5;
     const uint32_t *__restrict__ src = bits + (long long)f * words_per_frame;
-    for (int i = threadIdx.x; i < (SC_ROWS + 2) * pw; i += 256) {
+    for (int i = threadIdx.x; i < (sc_rows + 2) * pw; i += 256) {
         const int r = y0 - 1 + i / pw;
         s_rows[i] = (r >= 0 && r < prows) ? src[(long long)r * pw + (i % pw)] : 0u; // rows outside the image: no taps
     }
@@ -372,7 +396,7 @@ __global__ __launch_bounds__(256) void extract_scatter_kernel(const uint32_t *__
     //   3. load-balanced expansion: lane k takes candidate k of the concatenated ranges (binary search in
     //      the prefix), so the dependent loads inv_ent -> code run 64 wide instead of as a per-lane chain.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t *s_list = s_rows + (SC_ROWS + 2) * pw + wave * (SC_LIST + 128); // set pixels collected by this wave
+    uint32_t *s_list = s_rows + (sc_rows + 2) * pw + wave * (SC_LIST + 128); // set pixels collected by this wave
     uint32_t *s_off = s_list + SC_LIST, *s_excl = s_off + 64;                // per pass: range start, exclusive prefix
     int nset = 0;
     auto flush = [&]() { // expand the collected set pixels (wave-uniform)
@@ -446,13 +470,36 @@ __global__ __launch_bounds__(256) void extract_scatter_kernel(const uint32_t *__
         }
         nset = 0;
     };
-    for (int c0 = wave * 64; c0 < SC_ROWS * pw; c0 += 4 * 64) {
+    for (int c0 = wave * 64; c0 < sc_rows * pw; c0 += 4 * 64) {
         const int wi = c0 + lane;
         const int r = y0 + wi / pw, w = wi % pw;
-        const uint32_t word = (wi < SC_ROWS * pw && r < prows) ? s_rows[(r - (y0 - 1)) * pw + w] : 0u;
-        if (!__ballot(word != 0))
+        uint32_t word = (wi < sc_rows * pw && r < prows) ? s_rows[(r - (y0 - 1)) * pw + w] : 0u;
+        const int pc = __popc(word);
+        if (!__ballot(pc != 0))
             continue;
-        for (int bb = 0; bb < 32; ++bb) {
+        // every lane appends the set bits of its own word behind those of the lanes before it (wave prefix sum of
+        // the popcounts): a handful of steps for a sparse mask, where one ballot per bit position costs 32
+        int incl = pc;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int v = __shfl_up(incl, d);
+            if (lane >= d)
+                incl += v;
+        }
+        const int total = __shfl(incl, 63);
+        if (total <= SC_LIST) {
+            if (nset + total > SC_LIST)
+                flush();
+            int pos = nset + incl - pc;
+            while (word) {
+                const int bb = __ffs((int)word) - 1;
+                s_list[pos++] = (uint32_t)(r * pcols + w * 32 + bb);
+                word &= word - 1u;
+            }
+            nset += total;
+            continue;
+        }
+        for (int bb = 0; bb < 32; ++bb) { // a dense stretch of the mask: bit position by bit position, <= 64 at a time
             const bool set = (word >> bb) & 1u;
             const unsigned long long m = __ballot(set);
             if (!m)
@@ -472,7 +519,7 @@ static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_f
                        long long *d_rc, double *d_pts, int32_t *d_counts)
 {
     const int crows = g->cart_rows, wpr = g->words_per_row;
-    const int chunk = 256; // frames per pass: bounds the bitmap scratch
+    static const int chunk = getenv("SFE_EXTRACT_CHUNK") ? std::max(1, atoi(getenv("SFE_EXTRACT_CHUNK"))) : 1024; // frames per pass: bounds the bitmap scratch (0.25 MB per frame), fewer passes = fewer launches
     const size_t bm_bytes = (size_t)chunk * crows * wpr * sizeof(unsigned long long);
     unsigned long long *d_bm = (unsigned long long *)sfe_scratch(ctx, 4, bm_bytes);
     int32_t *d_rcnt = (int32_t *)sfe_scratch(ctx, 5, (size_t)chunk * crows * 4);
@@ -500,17 +547,18 @@ static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_f
             // sparse binary masks: inverse map (binary frames), dense pass only for frames with other values
             SFE_HIP(ctx, hipMemsetAsync(d_bm, 0, (size_t)nf * crows * wpr * sizeof(unsigned long long), ctx->stream));
             const int pw = g->polar_cols >> 5;
-            hipLaunchKernelGGL(extract_scatter_kernel, dim3((unsigned)((g->polar_rows + SC_ROWS - 1) / SC_ROWS), nf),
-                               dim3(256), ((size_t)(SC_ROWS + 2) * pw + 4 * (SC_LIST + 128)) * 4, ctx->stream, d_bits, d_nonbin,
+            static const int sc_rows = getenv("SFE_SC_ROWS") ? std::max(1, atoi(getenv("SFE_SC_ROWS"))) : SC_ROWS;
+            hipLaunchKernelGGL(extract_scatter_kernel, dim3((unsigned)((g->polar_rows + sc_rows - 1) / sc_rows), nf),
+                               dim3(256), ((size_t)(sc_rows + 2) * pw + 4 * (SC_LIST + 128)) * 4, ctx->stream, d_bits, d_nonbin,
                                (const uint32_t *)g->d_code, g->d_inv_off, g->d_inv_ent, d_bm, g->polar_rows,
-                               g->polar_cols, g->rcp, crows, g->cart_cols, wpr, wpf);
+                               g->polar_cols, g->rcp, crows, g->cart_cols, wpr, wpf, sc_rows);
         }
-        hipLaunchKernelGGL(extract_bits_kernel, dim3((unsigned)(nf * tiles)), dim3(256), g->lds_bytes, ctx->stream, m,
-                           d_bits, d_nonbin, (const uint32_t *)g->d_code, g->d_span, g->d_tile_rows, d_bm,
-                           g->polar_rows, g->polar_cols, g->rcp, crows, g->cart_cols, wpr, word_groups, tiles, wpf,
-                           scatter ? 1 : 0);
-        hipLaunchKernelGGL(extract_scan_kernel, dim3(nf), dim3(256), 0, ctx->stream, d_bm, d_rcnt, d_roff,
-                           d_counts + f0, crows, wpr);
+        hipLaunchKernelGGL(extract_bits_kernel, dim3((unsigned)((scatter ? std::min(nf, 8) : nf) * tiles)), dim3(256),
+                           g->lds_bytes, ctx->stream, m, d_bits, d_nonbin, (const uint32_t *)g->d_code, g->d_span,
+                           g->d_tile_rows, d_bm, g->polar_rows, g->polar_cols, g->rcp, crows, g->cart_cols, wpr, word_groups,
+                           tiles, wpf, scatter ? 1 : 0, nf);
+        hipLaunchKernelGGL(extract_scan_kernel, dim3(nf), dim3(SCAN_THREADS), sizeof(int) * ((size_t)crows + SCAN_THREADS),
+                           ctx->stream, d_bm, d_rcnt, d_roff, d_counts + f0, crows, wpr);
         if (cap > 0)
             hipLaunchKernelGGL(extract_expand_kernel, dim3((unsigned)((cap + 255) / 256), nf), dim3(256),
                                sizeof(int32_t) * (size_t)crows, ctx->stream,
