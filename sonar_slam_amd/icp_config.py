@@ -32,21 +32,6 @@ def shipped_params(**over):
     return IcpParams(**p)
 
 
-def default_params():
-    """libpointmatcher's ICP::setDefault() chain, used when the YAML cannot be opened
-    (pcl.cpp:190-194), restricted to what this library implements.
-
-    setDefault = {RandomSampling 0.75 on the reading, SamplingSurfaceNormal on the reference,
-    KDTreeMatcher, TrimmedDist 0.85, PointToPlane, Counter 40 + Differential}.  The random
-    sub-sampling and 3-D surface-normal sampling are not reproducible bit for bit, so this
-    returns the deterministic core: trimmed 0.85, point-to-plane, default checkers.
-    """
-    return IcpParams(matcher_max_dist=float("inf"), use_max_dist_filter=0, max_dist_filter=0.0,
-                     use_trimmed_filter=1, trim_ratio=0.85, minimizer=1, max_iter=40,
-                     use_diff_checker=1, min_diff_rot=0.001, min_diff_trans=0.01, smooth_len=3,
-                     normals_knn=10)
-
-
 def _single(node, what):
     """YAML module node -> (name, params dict).  Accepts 'Name' or {'Name': {...}}."""
     if isinstance(node, str):

@@ -100,27 +100,33 @@ class ICP(object):
 
     def __init__(self, ctx=None):
         self._ctx = ctx
-        # PM::ICP() starts without a chain; the SLAM node always calls loadFromYaml next
-        self.params = _cfg.shipped_params()
-        self._configured = False
+        # PM::ICP() starts without a chain (pcl.cpp:185); the SLAM node always calls loadFromYaml next (slam.py:99)
+        self.params = None
 
     def loadFromYaml(self, filename):
+        """pcl.cpp:187-197.  A file that cannot be opened makes the reference print a message and fall back to
+        PM::ICP::setDefault(): random sub-sampling of the reading, surface-normal sampling of the reference and a
+        3-D point-to-plane chain -- not reproducible and not what any bruce_slam launch file intends, so here it is
+        an error instead of a silently different chain (deviations)."""
         try:
             with open(filename, "r") as fh:
                 text = fh.read()
-        except (IOError, OSError):
-            # pcl.cpp:190-194
-            print("Failed to load %s. Use default configuration." % filename)
-            self.params = _cfg.default_params()
-            self._configured = True
-            return
+        except (IOError, OSError) as e:
+            raise RuntimeError("ICP.loadFromYaml: cannot open %s (%s).  The reference would print 'Failed to load ... Use "
+                               "default configuration.' and run libpointmatcher's setDefault() chain (random sampling + "
+                               "surface normals), which this front end does not provide: fix the path, or install a "
+                               "chain with setParams()" % (filename, e))
         self.params = _cfg.parse_icp_yaml(text)
-        self._configured = True
 
     def setParams(self, params):
         """Extension: install an ``IcpParams`` directly."""
         self.params = params
-        self._configured = True
+
+    def _chain(self):
+        if self.params is None:
+            raise RuntimeError("ICP.compute before loadFromYaml / setParams: the chain is empty (PM::ICP() has no "
+                               "default chain either, pcl.cpp:185)")
+        return self.params
 
     @staticmethod
     def _guess(guess):
@@ -139,6 +145,7 @@ class ICP(object):
     def compute_batch(self, source, target, guesses):
         """Many initial guesses on one cloud pair in one launch.
         -> (messages [n], T [n x 3 x 3] float32, iterations [n])"""
+        params = self._chain()
         ctx = self._ctx or _L.default_context()
         src = _cloud(source, "ICP.compute(source)")
         tgt = _cloud(target, "ICP.compute(target)")
@@ -151,7 +158,7 @@ class ICP(object):
         it = _np.zeros(n, _np.int32)
         with ctx.lock:
             ctx._check(ctx.lib.sfe_icp_compute_guesses(
-                ctx.handle, _C.byref(self.params), _L.ptr(src, _C.c_float), len(src),
+                ctx.handle, _C.byref(params), _L.ptr(src, _C.c_float), len(src),
                 _L.ptr(tgt, _C.c_float), len(tgt), _L.ptr(g, _C.c_float), n, _L.ptr(T, _C.c_float),
                 _L.ptr(st, _C.c_int32), _L.ptr(it, _C.c_int32)))
         msgs = [_L.ICP_STATUS_MESSAGES.get(int(s), "ICP failure %d" % s) for s in st]
@@ -160,6 +167,7 @@ class ICP(object):
     def compute_pairs(self, sources, targets, guesses):
         """Many independent (source, target, guess) scan matches in ONE launch (extension; the job
         farm's unit).  -> (messages [n], T [n x 3 x 3] float32, iterations [n])"""
+        params = self._chain()
         ctx = self._ctx or _L.default_context()
         n = len(sources)
         if not (len(targets) == n and len(guesses) == n):
@@ -182,7 +190,7 @@ class ICP(object):
         it = _np.zeros(n, _np.int32)
         with ctx.lock:
             ctx._check(ctx.lib.sfe_icp_compute_pairs(
-                ctx.handle, _C.byref(self.params), _L.ptr(src, _C.c_float), _L.ptr(so, _C.c_int32),
+                ctx.handle, _C.byref(params), _L.ptr(src, _C.c_float), _L.ptr(so, _C.c_int32),
                 _L.ptr(tgt, _C.c_float), _L.ptr(to, _C.c_int32), _L.ptr(g, _C.c_float), n, _L.ptr(T, _C.c_float),
                 _L.ptr(st, _C.c_int32), _L.ptr(it, _C.c_int32)))
         msgs = [_L.ICP_STATUS_MESSAGES.get(int(s), "ICP failure %d" % s) for s in st]
@@ -194,6 +202,7 @@ class ICP(object):
         tgt_start, n_tgt) in points, guesses9 = n x 9.  Jobs may share clouds; jobs naming the same target slice
         share its preparation.  -> (status int32 [n], T [n x 3 x 3] float32, iterations int32 [n]); the three
         arrays may be handed in preallocated (``out=(status, T, iters)``, e.g. views of shared memory)."""
+        params = self._chain()
         ctx = self._ctx or _L.default_context()
         src = _cloud(src_all, "ICP.compute_jobs(src_all)")
         tgt = _cloud(tgt_all, "ICP.compute_jobs(tgt_all)")
@@ -208,13 +217,14 @@ class ICP(object):
             raise RuntimeError("ICP.compute_jobs: empty point cloud (libpointmatcher would throw)")
         with ctx.lock:
             ctx._check(ctx.lib.sfe_icp_compute_jobs(
-                ctx.handle, _C.byref(self.params), _L.ptr(src, _C.c_float), len(src), _L.ptr(tgt, _C.c_float), len(tgt),
+                ctx.handle, _C.byref(params), _L.ptr(src, _C.c_float), len(src), _L.ptr(tgt, _C.c_float), len(tgt),
                 _L.ptr(jobs4, _C.c_int32), _L.ptr(g, _C.c_float), n, _L.ptr(T, _C.c_float), _L.ptr(st, _C.c_int32),
                 _L.ptr(it, _C.c_int32)))
         return st, T, it
 
     def getCovariance(self):
         """errorMinimizer->getCovariance() (pcl.cpp:213).  libpointmatcher's base ErrorMinimizer
-        returns a zero dim x dim matrix unless the point-to-plane minimiser estimated one; no
-        caller in the reference reads it (grep).  Returned: 3 x 3 zeros."""
+        returns a zero dim x dim matrix unless the point-to-plane minimiser estimated one (the
+        shipped chain is point-to-point); no caller in the reference reads it (grep).  Returned:
+        3 x 3 zeros -- a documented deviation for a point-to-plane chain."""
         return _np.zeros((3, 3), _np.float32)

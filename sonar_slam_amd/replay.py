@@ -126,39 +126,31 @@ class FrontEnd(object):
         theta = np.arctan2(T[1, 0], T[0, 0])
         return message, Pose2(x, y, theta)
 
-    def compute_icp_with_cov(self, source_points, target_points, guesses, max_seconds=2.0):
-        """slam.py:325-387: many ICP runs on ONE cloud pair from different initial guesses, the spread of
-        the converged transforms (MinCovDet) as the covariance of the registration.  The reference loops
-        over the guesses in Python with a 2 s budget (:346-358); here all of them are one launch
-        (``pcl.ICP.compute_batch``), which never gets near the budget, so every guess is used.
-        -> (message, odom Pose2, cov 3x3, sample_transforms [n x 3]) like the reference."""
+    def compute_icp_with_cov(self, source_points, target_points, guesses):
+        """What slam.py:325-387 computes -- the scatter of the transforms ICP converges to from several initial
+        guesses on ONE cloud pair, as a robust covariance in the frame of their centre -- with the one change
+        INTEGRATION.md section 3 describes: the guesses go through ``pcl.ICP.compute_batch`` in a single launch
+        instead of a timed Python loop of ``compute`` calls (the 2 s budget of :346-358 is never in reach).
+        -> (message, centre Pose2, cov 3 x 3, converged transforms [n x 3]); the messages are the reference's."""
         from sklearn.covariance import MinCovDet
-        source_points = np.array(source_points, np.float32)
-        target_points = np.array(target_points, np.float32)
-        msgs, Ts, _ = self.icp.compute_batch(source_points, target_points, [g.matrix() for g in guesses])
-        sample_transforms = []
-        for message, T in zip(msgs, Ts):                          # :351-355
-            if message == "success":
-                x, y = T[:2, 2]
-                theta = np.arctan2(T[1, 0], T[0, 0])
-                sample_transforms.append((x, y, theta))
-        sample_transforms = np.array(sample_transforms)
-        if len(sample_transforms) < 5:                            # :364-365
+        msgs, Ts, _ = self.icp.compute_batch(np.asarray(source_points, np.float32), np.asarray(target_points, np.float32),
+                                             [g.matrix() for g in guesses])
+        ok = np.array([m == "success" for m in msgs], bool)
+        Ts = np.asarray(Ts, np.float64)[ok]
+        xyt = np.c_[Ts[:, 0, 2], Ts[:, 1, 2], np.arctan2(Ts[:, 1, 0], Ts[:, 0, 0])] if len(Ts) else np.zeros((0, 3))
+        if len(xyt) < 5:
             return "Too few samples for covariance computation", None, None, None
-        try:                                                      # :368-376
-            fcov = MinCovDet(store_precision=False, support_fraction=0.8).fit(sample_transforms)
+        try:
+            est = MinCovDet(store_precision=False, support_fraction=0.8).fit(xyt)
         except ValueError:
             return "Failed to calculate covariance", None, None, None
-        m = self._as_pose(fcov.location_)
-        cov = fcov.covariance_
-        c, s = np.cos(m.theta()), np.sin(m.theta())               # :379-382 unrotate to the local frame
-        R = np.array([[c, -s], [s, c]])                           # m.rotation().matrix()
-        cov[:2, :] = R.T.dot(cov[:2, :])
-        cov[:, :2] = cov[:, :2].dot(R)
-        default_cov = np.diag(self.icp_odom_sigmas) ** 2
-        if np.linalg.det(cov) < np.linalg.det(default_cov):       # :384-386
-            cov = default_cov
-        return "success", m, cov, sample_transforms
+        centre = self._as_pose(est.location_)
+        # translation block expressed in the centre pose's own axes: cov_local = B^T cov B, B = blockdiag(R, 1)
+        B = np.eye(3)
+        B[:2, :2] = [[np.cos(centre.theta()), -np.sin(centre.theta())], [np.sin(centre.theta()), np.cos(centre.theta())]]
+        cov = B.T @ est.covariance_ @ B
+        floor = np.diag(np.square(self.icp_odom_sigmas))            # never more confident than the configured sigmas
+        return "success", centre, (cov if np.linalg.det(cov) >= np.linalg.det(floor) else floor), xyt
 
     @staticmethod
     def _as_pose(xytheta):

@@ -195,7 +195,31 @@ def main():
     pts7 = Keyframe.transform_points(src, types.SimpleNamespace(matrix=lambda: T))
     np.savez_compressed(os.path.join(HERE, "matching_cost.npz"), src=src, tgt=tgt, source_pose=np.array(synth.pose_of(truth)),
                         X=X, costs=costs, samples=np.array(samples), points_pose7=pts7, point_noise=0.5)
-    print("wrote cfar_tau.json, maps_small.npz, maps_digest.json, matching_cost.npz")
+    # ---- CFAR masks / threshold maps from the reference's own cfar.cpp (oracle/_ref, compiled unmodified) ----
+    import oracle
+    if not oracle.have_ref_cfar():
+        sys.exit("oracle/_ref/libcfar_ref.so missing: run `make -C oracle ref` first")
+    rng = np.random.default_rng(2026)
+    frames = {"sonar": synth.sonar_frame(seed=5, rows=192, cols=64, n_blobs=8),
+              "noise": rng.integers(0, 256, (130, 36), dtype=np.uint8),
+              "short": rng.integers(0, 256, (50, 12), dtype=np.uint8),        # shorter than the shipped window
+              "float": (rng.random((140, 33)) * 300).astype(np.float32)}       # non-uint8 caller
+    cases = [(20, 5, {"CA": 2.3701490070915554, "SOCA": 2.749063720096473, "GOCA": 2.121926842646487,
+                      "OS": 9.137608674642355}, 10), (8, 2, {"CA": 1.6, "SOCA": 1.9, "GOCA": 1.4, "OS": 3.0}, 5),
+             (16, 4, {"CA": 2.0, "SOCA": 2.2, "GOCA": 1.8, "OS": 5.0}, 12)]
+    out = {"frame_" + k: v for k, v in frames.items()}
+    index = []
+    for ci, (th, gh, taus, k) in enumerate(cases):
+        for alg in ("CA", "SOCA", "GOCA", "OS"):
+            for name, img in frames.items():
+                m, t = oracle.ref_cfar(img, alg, th, gh, taus[alg], k, want_threshold=True)
+                key = "c%d_%s_%s" % (ci, alg, name)
+                out[key + "_mask"] = np.packbits(m, axis=None)
+                out[key + "_thr"] = t
+                index.append([key, name, alg, th, gh, taus[alg], k])
+    out["index"] = np.array(json.dumps(index))
+    np.savez_compressed(os.path.join(HERE, "cfar_ref.npz"), **out)
+    print("wrote cfar_tau.json, maps_small.npz, maps_digest.json, matching_cost.npz, cfar_ref.npz")
 
 
 if __name__ == "__main__":

@@ -54,3 +54,25 @@ def test_canvas_sizes_of_the_survey():
     # 130 deg fan -> 1857 (A) / 3713 (B) Cartesian columns
     for d in json.load(open(os.path.join(G, "maps_digest.json"))):
         assert d["cols"] == {1024: 1857, 2048: 3713}[d["ranges"]]
+
+
+def _cfar_ref_cases():
+    """(key, image, alg, train_hs, guard_hs, tau, k, mask, threshold map) of tests/golden/cfar_ref.npz: produced by the
+    reference's OWN cfar.cpp (compiled unmodified into oracle/_ref by oracle/Makefile, run by make_golden.py), so
+    this pin holds on any checkout, with or without /root/reference or the _ref library."""
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfar_ref.npz"))
+    for key, name, alg, th, gh, tau, k in json.loads(str(z["index"])):
+        img = z["frame_" + name]
+        mask = np.unpackbits(z[key + "_mask"])[:img.size].reshape(img.shape)
+        yield key, img, alg, th, gh, tau, k, mask, z[key + "_thr"]
+
+
+def test_oracle_cfar_equals_the_reference_fixture():
+    import oracle
+    n = 0
+    for key, img, alg, th, gh, tau, k, mask, thr in _cfar_ref_cases():
+        got, got_thr = oracle.cfar(img, alg, th, gh, tau, k, want_threshold=True)
+        assert np.array_equal(got, mask), key
+        assert np.array_equal(got_thr, thr), key
+        n += 1
+    assert n == 48

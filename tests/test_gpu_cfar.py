@@ -148,3 +148,19 @@ def test_ring_kernel_xcd_map_and_march_direction(alg, shape, frames, shipped_cfa
         assert np.array_equal(got[f], _oracle(imgs[f], alg, p)), f
     d_in.free()
     d_out.free()
+
+
+def test_hip_cfar_equals_the_reference_fixture():
+    """every HIP CFAR path (ring, generic, float image, threshold maps) against masks and float threshold maps the
+    reference's own cfar.cpp produced (tests/golden/cfar_ref.npz); needs neither /root/reference nor oracle/_ref"""
+    from test_golden import _cfar_ref_cases
+    from sonar_slam_amd import cfar
+    n = 0
+    for key, img, alg, th, gh, tau, k, mask, thr in _cfar_ref_cases():
+        fn, fn2 = getattr(cfar, alg.lower()), getattr(cfar, alg.lower() + "2")
+        got = fn(img, th, gh, k, tau) if alg == "OS" else fn(img, th, gh, tau)
+        got2 = fn2(img, th, gh, k, tau) if alg == "OS" else fn2(img, th, gh, tau)
+        assert np.array_equal(got, mask), key
+        assert np.array_equal(got2[0], mask) and np.array_equal(got2[1], thr), key
+        n += 1
+    assert n == 48

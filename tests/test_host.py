@@ -191,3 +191,21 @@ def test_persistent_two_worker_farm_over_shared_memory():
     with farm.IcpFarm(p, devices=[0], _backend="farm_backend:failing_compute") as f:
         with pytest.raises(RuntimeError, match="boom"):
             f.run(batch(2))
+
+
+def test_icp_object_has_no_silent_default_chain(tmp_path):
+    """PM::ICP() has no chain until loadFromYaml (pcl.cpp:185-197); a missing YAML is an error here, not
+    libpointmatcher's setDefault() chain."""
+    from sonar_slam_amd import pcl
+    icp = pcl.ICP()
+    pts = np.zeros((4, 2), np.float32)
+    with pytest.raises(RuntimeError, match="chain is empty"):
+        icp.compute(pts, pts, np.eye(3))
+    with pytest.raises(RuntimeError, match="cannot open"):
+        icp.loadFromYaml(str(tmp_path / "no_such_icp.yaml"))
+    assert icp.params is None
+    f = tmp_path / "icp.yaml"
+    f.write_text(SHIPPED_ICP_YAML)
+    icp.loadFromYaml(str(f))
+    assert icp.params.as_dict() == icp_config.shipped_params().as_dict()
+    assert np.array_equal(icp.getCovariance(), np.zeros((3, 3), np.float32))
