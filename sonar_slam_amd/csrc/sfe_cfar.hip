@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
@@ -193,6 +194,324 @@ __global__ __launch_bounds__(256, 3) void cfar_u8_ring(const uint8_t *__restrict
             // the ring needs); the D-deep prefetch FIFO already hides the load latency
             __builtin_amdgcn_sched_barrier(0);
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sliding-sum kernel: ANY window (train_hs, guard_hs at run time), CA / SOCA / GOCA, optionally the float
+// threshold map of the *2 variants (cfar.cpp:98-192).  Same work decomposition and the same exact decision
+// table as the ring kernel -- one lane owns 4 adjacent beams, marches down the range axis, a wave reads 256
+// contiguous bytes per row -- but the window is kept as two running sums per beam (packed u16 pairs, exact
+// mod 2^16 for sums <= 65535) that slide by one row per step:
+//     lead += x[r-G] - x[r-T-G],   lag += x[r+T+G+1] - x[r+G+1]
+// so a step costs five dword loads per lane: the new row r+T+G+1 from HBM, the four others are rows this
+// wave read a few steps ago (L1 / L2 hits: the window of a 256-beam strip is 2(T+G) x 256 B).  No register
+// ring, hence no compile-time window: this is what every feature.yaml window other than the shipped
+// (Ntc 40, Ngc 10) runs on, at ~2x the instructions per pixel of the ring kernel.
+// THR: thr[r][c] = (float)(tau * s / T) looked up in a table over the integer sums s (built on the host
+// with the reference's double expression, like the decision table) and stored as one float4 per lane.
+// ---------------------------------------------------------------------------------------------
+template <int ALG, bool THR>
+__global__ __launch_bounds__(256) void cfar_u8_slide(const uint8_t *__restrict__ img, uint8_t *__restrict__ mask,
+                                                     float *__restrict__ thr, const float *__restrict__ thr_tab,
+                                                     int rows, int cols, int n_frames, int T, int G, int tile_rows,
+                                                     int tiles_per_frame, int chunks_per_row, CfarLut lut)
+{
+    __shared__ uint16_t s_lut[256];
+    s_lut[threadIdx.x] = lut.v[threadIdx.x];
+    __syncthreads();
+    const int H = T + G;
+    const int lane = threadIdx.x & 63;
+    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // frame f -> XCD f % 8, its workgroups consecutive in that XCD's dispatch order (as the ring kernel)
+    const int wpf = tiles_per_frame * chunks_per_row;
+    const int bpf = (wpf + 3) >> 2;
+    const int xcd = blockIdx.x & 7, kb = blockIdx.x >> 3;
+    const int fg = kb / bpf;
+    const long long f = (long long)fg * 8 + xcd;
+    const int wvf = (kb - fg * bpf) * 4 + wave_in_block;
+    if (f >= n_frames || wvf >= wpf)
+        return;
+    const int chunk = wvf % chunks_per_row;
+    const int t = wvf / chunks_per_row;
+    const int lpr = cols >> 2;                                  // 4-beam lanes per row
+    const int cx0 = lpr >= 64 ? min(chunk * 64, lpr - 64) : 0;  // last chunk shifted left (outputs recomputed identically)
+    if (cx0 + lane >= lpr)
+        return;                                                 // images narrower than 256 beams: the spare lanes idle
+    const uint32_t voff = (uint32_t)(cx0 + lane) * 4u;
+    const int r0 = t * tile_rows, r1 = min(r0 + tile_rows, rows);
+    const size_t frame_bytes = (size_t)rows * cols;
+    const sfe_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(img + (size_t)f * frame_bytes),
+                                                             0, (int)frame_bytes, 0x00020000);
+    const sfe_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(mask + (size_t)f * frame_bytes, 0,
+                                                             (int)frame_bytes, 0x00020000);
+    // rows outside the image are clamped: they only enter windows of border rows, whose output is forced to 0
+    auto ld = [&](int i) -> uint32_t {
+        const int ic = min(max(i, 0), rows - 1);
+        return __builtin_amdgcn_raw_buffer_load_b32(src, voff, ic * cols, 0);
+    };
+    uint32_t leadL = 0, leadH = 0, lagL = 0, lagH = 0;
+    for (int i = 0; i < T; i += 2) { // the windows of the tile's first row (two rows of each window per trip)
+        const uint32_t a0 = ld(r0 - H + i), b0 = ld(r0 + G + 1 + i);
+        const uint32_t a1 = i + 1 < T ? ld(r0 - H + i + 1) : 0u, b1 = i + 1 < T ? ld(r0 + G + 2 + i) : 0u;
+        leadL = pk_add(pk_add(leadL, unpack_lo(a0)), unpack_lo(a1));
+        leadH = pk_add(pk_add(leadH, unpack_hi(a0)), unpack_hi(a1));
+        lagL = pk_add(pk_add(lagL, unpack_lo(b0)), unpack_lo(b1));
+        lagH = pk_add(pk_add(lagH, unpack_hi(b0)), unpack_hi(b1));
+    }
+    uint32_t x = ld(r0), a = ld(r0 - G), b = ld(r0 - H), c = ld(r0 + H + 1), d = ld(r0 + G + 1);
+    for (int r = r0; r < r1; ++r) {
+        // the next row's five loads go out before this row is evaluated
+        const uint32_t xn = ld(r + 1), an = ld(r + 1 - G), bn = ld(r + 1 - H), cn = ld(r + H + 2), dn = ld(r + G + 2);
+        uint32_t sL, sH;
+        if (ALG == SFE_CFAR_SOCA) {
+            sL = pk_min(leadL, lagL);
+            sH = pk_min(leadH, lagH);
+        } else if (ALG == SFE_CFAR_GOCA) {
+            sL = pk_max(leadL, lagL);
+            sH = pk_max(leadH, lagH);
+        } else {
+            sL = pk_add(leadL, lagL);
+            sH = pk_add(leadH, lagH);
+        }
+        const uint32_t l0 = s_lut[x & 0xffu], l1 = s_lut[(x >> 8) & 0xffu];
+        const uint32_t l2 = s_lut[(x >> 16) & 0xffu], l3 = s_lut[x >> 24];
+        // s < lut[x] per beam (sums and table entries reach 65535 here: compare, do not subtract)
+        const uint32_t s0 = sL & 0xffffu, s1 = sL >> 16, s2 = sH & 0xffffu, s3 = sH >> 16;
+        uint32_t o = (s0 < l0 ? 1u : 0u) | (s1 < l1 ? 0x100u : 0u) | (s2 < l2 ? 0x10000u : 0u) | (s3 < l3 ? 0x1000000u : 0u);
+        const bool inside = r >= H && r < rows - H; // cfar.cpp:16,36
+        o = inside ? o : 0u;
+        __builtin_amdgcn_raw_buffer_store_b32(o, dst, voff, r * cols, 0);
+        if (THR) {
+            float4 tv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (inside)
+                tv = make_float4(thr_tab[s0], thr_tab[s1], thr_tab[s2], thr_tab[s3]);
+            *reinterpret_cast<float4 *>(thr + (size_t)f * frame_bytes + (size_t)r * cols + voff) = tv;
+        }
+        leadL = pk_sub(pk_add(leadL, unpack_lo(a)), unpack_lo(b));
+        leadH = pk_sub(pk_add(leadH, unpack_hi(a)), unpack_hi(b));
+        lagL = pk_sub(pk_add(lagL, unpack_lo(c)), unpack_lo(d));
+        lagH = pk_sub(pk_add(lagH, unpack_hi(c)), unpack_hi(d));
+        x = xn;
+        a = an;
+        b = bn;
+        c = cn;
+        d = dn;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same sliding sums with the window rows staged in LDS: each wave keeps the last R = 2(T+G)+2 rows of its
+// 256-beam strip in a private LDS ring (ring[row mod R][lane], one dword per lane and row: conflict-free), so a
+// step is ONE global load (the new row, prefetched D rows ahead into registers) + one ds_write + four ds_reads for
+// the cells that enter / leave the two sums.  The plain sliding-sum kernel above re-reads those four rows through
+// the caches, and with a few thousand waves in flight their windows (R x 256 B each) overflow the 4 MB L2 of an
+// XCD: it then moves ~5 B per pixel over the fabric instead of 1 (measured 2.6 TB/s algorithmic; this one keeps
+// the traffic of the register-ring kernel for any run-time window).  LDS: R KiB per 4-wave workgroup.
+// ---------------------------------------------------------------------------------------------
+#define SLIDE_D 4 // rows in flight per lane
+template <int ALG, bool THR>
+__global__ __launch_bounds__(256) void cfar_u8_slide_lds(const uint8_t *__restrict__ img, uint8_t *__restrict__ mask,
+                                                         float *__restrict__ thr, const float *__restrict__ thr_tab,
+                                                         int rows, int cols, int n_frames, int T, int G, int tile_rows,
+                                                         int tiles_per_frame, int chunks_per_row, CfarLut lut)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_ring_all[]; // [4 waves][R][64]
+    __shared__ uint16_t s_lut[256];
+    s_lut[threadIdx.x] = lut.v[threadIdx.x];
+    __syncthreads();
+    const int H = T + G, R = 2 * H + 2;
+    const int lane = threadIdx.x & 63;
+    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wpf = tiles_per_frame * chunks_per_row;
+    const int bpf = (wpf + 3) >> 2;
+    const int xcd = blockIdx.x & 7, kb = blockIdx.x >> 3;
+    const int fg = kb / bpf;
+    const long long f = (long long)fg * 8 + xcd;
+    const int wvf = (kb - fg * bpf) * 4 + wave_in_block;
+    if (f >= n_frames || wvf >= wpf)
+        return;
+    const int chunk = wvf % chunks_per_row;
+    const int t = wvf / chunks_per_row;
+    const int lpr = cols >> 2;
+    const int cx0 = lpr >= 64 ? min(chunk * 64, lpr - 64) : 0;
+    if (cx0 + lane >= lpr)
+        return;
+    const uint32_t voff = (uint32_t)(cx0 + lane) * 4u;
+    const int r0 = t * tile_rows, r1 = min(r0 + tile_rows, rows);
+    const size_t frame_bytes = (size_t)rows * cols;
+    const sfe_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(img + (size_t)f * frame_bytes),
+                                                             0, (int)frame_bytes, 0x00020000);
+    const sfe_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(mask + (size_t)f * frame_bytes, 0,
+                                                             (int)frame_bytes, 0x00020000);
+    auto ld = [&](int i) -> uint32_t { // clamped: rows outside the image only enter windows of border rows
+        const int ic = min(max(i, 0), rows - 1);
+        return __builtin_amdgcn_raw_buffer_load_b32(src, voff, ic * cols, 0);
+    };
+    uint32_t *ring = s_ring_all + (size_t)wave_in_block * R * 64 + lane; // row slot s lives at ring[s * 64]
+    // fill: rows r0-H .. r0+H+1 -> slots 0 .. R-1; the two sums of row r0 on the way
+    uint32_t leadL = 0, leadH = 0, lagL = 0, lagH = 0;
+    for (int m0 = 0; m0 < R; m0 += SLIDE_D) {
+        uint32_t v[SLIDE_D];
+#pragma unroll
+        for (int u = 0; u < SLIDE_D; ++u)
+            v[u] = ld(r0 - H + m0 + u);
+#pragma unroll
+        for (int u = 0; u < SLIDE_D; ++u) {
+            const int m = m0 + u;
+            if (m < R) {
+                ring[m * 64] = v[u];
+                if (m < T) {
+                    leadL = pk_add(leadL, unpack_lo(v[u]));
+                    leadH = pk_add(leadH, unpack_hi(v[u]));
+                }
+                if (m > H + G && m <= 2 * H) {
+                    lagL = pk_add(lagL, unpack_lo(v[u]));
+                    lagH = pk_add(lagH, unpack_hi(v[u]));
+                }
+            }
+        }
+    }
+    uint32_t pre[SLIDE_D]; // rows r+H+2 .. of the steps to come
+#pragma unroll
+    for (int u = 0; u < SLIDE_D; ++u)
+        pre[u] = ld(r0 + H + 2 + u);
+    // slots of the five rows a step touches (wave-uniform counters, wrapped at R)
+    int sb = 0, sx = H, sa = H - G, sd = H + G + 1, sc = 2 * H + 1;
+    auto wrap = [&](int &v) { v = (v + 1 == R) ? 0 : v + 1; };
+    for (int rb = r0; rb < r1; rb += SLIDE_D) {
+#pragma unroll
+        for (int u = 0; u < SLIDE_D; ++u) {
+            const int r = rb + u;
+            if (r < r1) { // wave-uniform
+                const uint32_t x = ring[sx * 64], a = ring[sa * 64], b = ring[sb * 64], c = ring[sc * 64], d = ring[sd * 64];
+                ring[sb * 64] = pre[u]; // row r+H+2 takes the slot of row r-H (read above)
+                pre[u] = ld(r + H + 2 + SLIDE_D);
+                uint32_t sL, sH;
+                if (ALG == SFE_CFAR_SOCA) {
+                    sL = pk_min(leadL, lagL);
+                    sH = pk_min(leadH, lagH);
+                } else if (ALG == SFE_CFAR_GOCA) {
+                    sL = pk_max(leadL, lagL);
+                    sH = pk_max(leadH, lagH);
+                } else {
+                    sL = pk_add(leadL, lagL);
+                    sH = pk_add(leadH, lagH);
+                }
+                const uint32_t l0 = s_lut[x & 0xffu], l1 = s_lut[(x >> 8) & 0xffu];
+                const uint32_t l2 = s_lut[(x >> 16) & 0xffu], l3 = s_lut[x >> 24];
+                const uint32_t s0 = sL & 0xffffu, s1 = sL >> 16, s2 = sH & 0xffffu, s3 = sH >> 16;
+                uint32_t o = (s0 < l0 ? 1u : 0u) | (s1 < l1 ? 0x100u : 0u) | (s2 < l2 ? 0x10000u : 0u) |
+                             (s3 < l3 ? 0x1000000u : 0u);
+                const bool inside = r >= H && r < rows - H; // cfar.cpp:16,36
+                o = inside ? o : 0u;
+                __builtin_amdgcn_raw_buffer_store_b32(o, dst, voff, r * cols, 0);
+                if (THR) {
+                    float4 tv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (inside)
+                        tv = make_float4(thr_tab[s0], thr_tab[s1], thr_tab[s2], thr_tab[s3]);
+                    *reinterpret_cast<float4 *>(thr + (size_t)f * frame_bytes + (size_t)r * cols + voff) = tv;
+                }
+                leadL = pk_sub(pk_add(leadL, unpack_lo(a)), unpack_lo(b));
+                leadH = pk_sub(pk_add(leadH, unpack_hi(a)), unpack_hi(b));
+                lagL = pk_sub(pk_add(lagL, unpack_lo(c)), unpack_lo(d));
+                lagH = pk_sub(pk_add(lagH, unpack_hi(c)), unpack_hi(d));
+                wrap(sb);
+                wrap(sx);
+                wrap(sa);
+                wrap(sd);
+                wrap(sc);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// OS-CFAR (cfar.cpp:76-96, 170-192) for uint8 images: sliding 256-bin histogram + rank walk.
+// The order statistic of the 2T training cells is the smallest value v with #{cells <= v} >= k + 1.  One lane owns
+// one beam and marches down the range axis; its window's histogram (256 uint8 counts, 2T <= 255) lives in LDS,
+// value-major (hist[v][lane]).  Moving one row down replaces two cells (one leaves / one enters each half-window):
+// four read-modify-writes, then the lane walks v up or down until
+//     below <= k < below + hist[v],        below = #{cells < v}
+// holds again -- a step or two, because 2 of the 2T cells changed.  The reference gathers the 2T cells and runs
+// nth_element for every pixel; the generic kernel counted ranks in O((2T)^2).  Decision and threshold are table
+// look-ups over the 256 possible values of v, built on the host with the reference's double expression.
+// ---------------------------------------------------------------------------------------------
+struct CfarOsTab {
+    uint16_t min_x[256]; // pixel fires iff x >= min_x[v]  (256 = never); the intensity gate is folded in
+    float thr[256];      // (float)(tau * v)
+};
+
+__global__ __launch_bounds__(64) void cfar_u8_os(const uint8_t *__restrict__ img, uint8_t *__restrict__ mask,
+                                                 float *__restrict__ thr, int rows, int cols, int n_frames, int T, int G,
+                                                 int k, int tile_rows, int tiles_per_frame, int chunks_per_row,
+                                                 CfarOsTab tab)
+{
+    __shared__ uint8_t s_hist[256 * 64];
+    __shared__ uint16_t s_minx[256];
+    __shared__ float s_thr[256];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 256; i += 64) {
+        s_minx[i] = tab.min_x[i];
+        s_thr[i] = tab.thr[i];
+    }
+    for (int i = lane; i < 256 * 64 / 4; i += 64)
+        reinterpret_cast<uint32_t *>(s_hist)[i] = 0u;
+    __syncthreads();
+    const int H = T + G;
+    const int wpf = tiles_per_frame * chunks_per_row;
+    const long long f = blockIdx.x / wpf;
+    const int wvf = blockIdx.x % wpf;
+    const int chunk = wvf % chunks_per_row, t = wvf / chunks_per_row;
+    const int c = chunk * 64 + lane;
+    if (f >= n_frames || c >= cols)
+        return; // (no barrier below)
+    const int r0 = t * tile_rows, r1 = min(r0 + tile_rows, rows);
+    const uint8_t *__restrict__ in = img + (size_t)f * rows * cols + c;
+    uint8_t *__restrict__ mo = mask + (size_t)f * rows * cols + c;
+    float *__restrict__ to = thr ? thr + (size_t)f * rows * cols + c : nullptr;
+    auto ld = [&](int i) -> int { return in[(size_t)min(max(i, 0), rows - 1) * cols]; }; // clamped: border rows only
+    uint8_t *h = s_hist + lane;                                                            // h[v * 64]
+    for (int i = 0; i < T; ++i) {
+        h[ld(r0 - H + i) * 64] += 1;
+        h[ld(r0 + G + 1 + i) * 64] += 1;
+    }
+    int v = 0, below = 0;
+    // per row: the pixel, and the four cells that change when the windows move on; fetched one row ahead (the rank
+    // walk below does not depend on them, so their latency hides behind it)
+    int xn = ld(r0), aln = ld(r0 - G), rln = ld(r0 - H), agn = ld(r0 + H + 1), rgn = ld(r0 + G + 1);
+    for (int r = r0; r < r1; ++r) {
+        const int x = xn, add_lead = aln, rem_lead = rln, add_lag = agn, rem_lag = rgn;
+        xn = ld(r + 1);
+        aln = ld(r + 1 - G);
+        rln = ld(r + 1 - H);
+        agn = ld(r + H + 2);
+        rgn = ld(r + G + 2);
+        while (below > k) { // restore below <= k < below + hist[v]
+            --v;
+            below -= h[v * 64];
+        }
+        int hv = h[v * 64];
+        while (below + hv <= k) {
+            below += hv;
+            ++v;
+            hv = h[v * 64];
+        }
+        const bool inside = r >= H && r < rows - H; // cfar.cpp:82
+        mo[(size_t)r * cols] = (inside && x >= (int)s_minx[v]) ? 1 : 0;
+        if (to)
+            to[(size_t)r * cols] = inside ? s_thr[v] : 0.0f;
+        // four bins change; read them together and write each one's final count (bins named twice get the same
+        // value from both writes)
+        {
+            const int c0 = h[rem_lead * 64], c1 = h[add_lead * 64], c2 = h[rem_lag * 64], c3 = h[add_lag * 64];
+            auto net = [&](int val) { return (val == add_lead) + (val == add_lag) - (val == rem_lead) - (val == rem_lag); };
+            h[rem_lead * 64] = (uint8_t)(c0 + net(rem_lead));
+            h[add_lead * 64] = (uint8_t)(c1 + net(add_lead));
+            h[rem_lag * 64] = (uint8_t)(c2 + net(rem_lag));
+            h[add_lag * 64] = (uint8_t)(c3 + net(add_lag));
+        }
+        below += (add_lead < v) - (rem_lead < v) + (add_lag < v) - (rem_lag < v);
     }
 }
 
@@ -393,6 +712,30 @@ static void launch_ring(sfe_ctx *ctx, int alg, const uint8_t *d_img, uint8_t *d_
 // 2 groups keep that speed and most of the 2*(T+G) halo rows a tile re-reads are L2 hits.
 static int default_groups(const sfe_ctx *, int rows, int, int, int R) { return rows >= 2 * R ? 2 : 1; }
 
+static int launch_os_hist(sfe_ctx *ctx, const uint8_t *d_img, int n_frames, int rows, int cols, int T, int G, int k,
+                          double tau, int intensity_thr, uint8_t *d_mask, float *d_thr)
+{
+    CfarOsTab tab;
+    for (int v = 0; v < 256; ++v) {
+        const double t = tau * (double)(float)v; // cfar.cpp:92 / :186
+        tab.thr[v] = (float)t;
+        int mx = 256;
+        for (int x = 255; x >= 0; --x) // (double)x > t is monotone in x
+            if ((double)(float)x > t && !(intensity_thr >= 0 && x <= intensity_thr))
+                mx = x;
+            else
+                break;
+        tab.min_x[v] = (uint16_t)mx;
+    }
+    const int tile_rows = std::min(rows, std::max(256, 8 * T));
+    const int tiles = (rows + tile_rows - 1) / tile_rows;
+    const int chunks = (cols + 63) / 64;
+    const long long blocks = (long long)n_frames * tiles * chunks;
+    hipLaunchKernelGGL(cfar_u8_os, dim3((unsigned)blocks), dim3(64), 0, ctx->stream, d_img, d_mask, d_thr, rows, cols,
+                       n_frames, T, G, k, tile_rows, tiles, chunks, tab);
+    return 0;
+}
+
 static int cfar_u8_dev(sfe_ctx *ctx, const uint8_t *d_img, int n_frames, int rows, int cols, int alg,
                        int T, int G, int k, double tau, int intensity_thr, uint8_t *d_mask, float *d_thr)
 {
@@ -405,21 +748,112 @@ static int cfar_u8_dev(sfe_ctx *ctx, const uint8_t *d_img, int n_frames, int row
     if (n_frames == 0 || rows == 0 || cols == 0)
         return 0;
     CfarLut lut;
-    bool ring = (alg != SFE_CFAR_OS) && !d_thr && (cols % 4 == 0) && cols >= 256 && rows >= 52 && (size_t)rows * cols < (1u << 30) &&
+    // register-ring kernel: instantiated for the shipped window (Ntc 40, Ngc 10 -> 20, 5) and for the other windows
+    // the reference's feature.yaml comments and tests go through: (32, 8), (20, 4), (16, 2)
+    const bool ring_window = (T == 20 && G == 5) || (T == 16 && G == 4) || (T == 10 && G == 2) || (T == 8 && G == 1);
+    const int ringR = 2 * (T + G) + 2;
+    bool ring = (alg != SFE_CFAR_OS) && !d_thr && (cols % 4 == 0) && cols >= 256 && rows >= ringR && (size_t)rows * cols < (1u << 30) &&
                 ctx->cfar_variant != 1 &&
                 ((reinterpret_cast<uintptr_t>(d_img) | reinterpret_cast<uintptr_t>(d_mask)) % 4 == 0) &&
-                (T == 20 && G == 5) && build_lut(alg, T, tau, intensity_thr, &lut);
+                ring_window && build_lut(alg, T, tau, intensity_thr, &lut);
     if (ctx->cfar_variant >= 2 && !ring)
         return sfe_set_err(ctx, SFE_ERR_ARG, "ring CFAR kernel forced but not applicable to this call");
+    // every other window / the threshold maps: sliding-sum kernel (run-time window), then the OS histogram kernel;
+    // what is left (odd widths, unaligned buffers, windows beyond the 16-bit sums) takes the generic kernel
+    const bool aligned = (cols % 4 == 0) && (size_t)rows * cols < (1u << 30) &&
+                         ((reinterpret_cast<uintptr_t>(d_img) | reinterpret_cast<uintptr_t>(d_mask)) % 4 == 0) &&
+                         (!d_thr || reinterpret_cast<uintptr_t>(d_thr) % 16 == 0);
+    const bool slide = !ring && alg != SFE_CFAR_OS && aligned && ctx->cfar_variant != 1 &&
+                       build_lut(alg, T, tau, intensity_thr, &lut);
+    const bool os_hist = !ring && alg == SFE_CFAR_OS && ctx->cfar_variant != 1 && 2 * T <= 255 &&
+                         (size_t)rows * cols < (1u << 30);
     if (ring) {
-        constexpr int R = 2 * (20 + 5) + 2;
+        const int R = ringR;
         int groups = ctx->cfar_tile_rows > 0 ? std::max(1, std::min(ctx->cfar_tile_rows / R, rows / R))
-                                             : default_groups(ctx, rows, cols, n_frames, R);
+                                             : std::max(1, std::min(104 / R, rows / R)); // ~104-row tiles (see default_groups)
+        if (T == 20)
+            groups = ctx->cfar_tile_rows > 0 ? groups : default_groups(ctx, rows, cols, n_frames, R);
         const int tiles = (rows + groups * R - 1) / (groups * R);
-        if (ctx->cfar_variant == 3)
+        if (T == 20 && ctx->cfar_variant == 3)
             launch_ring<20, 5, 13>(ctx, alg, d_img, d_mask, rows, cols, n_frames, groups, tiles, lut);
-        else
+        else if (T == 20)
             launch_ring<20, 5, 4>(ctx, alg, d_img, d_mask, rows, cols, n_frames, groups, tiles, lut);
+        else if (T == 16)
+            launch_ring<16, 4, 6>(ctx, alg, d_img, d_mask, rows, cols, n_frames, groups, tiles, lut);
+        else if (T == 10)
+            launch_ring<10, 2, 13>(ctx, alg, d_img, d_mask, rows, cols, n_frames, groups, tiles, lut);
+        else
+            launch_ring<8, 1, 5>(ctx, alg, d_img, d_mask, rows, cols, n_frames, groups, tiles, lut);
+    } else if (slide) {
+        const float *d_tab = nullptr;
+        if (d_thr) { // thr = (float)(tau * s / T) per integer window sum s, with the reference's double expression
+            const int smax = (alg == SFE_CFAR_CA) ? 255 * 2 * T : 255 * T;
+            float *tab = (float *)sfe_scratch(ctx, 37, sizeof(float) * (size_t)(smax + 1));
+            if (!tab)
+                return SFE_ERR_HIP;
+            if (!(ctx->thr_tab_alg == alg && ctx->thr_tab_T == T && ctx->thr_tab_tau == tau && ctx->thr_tab_ptr == tab)) {
+                float *h = (float *)sfe_pinned_begin(ctx, sizeof(float) * (size_t)(smax + 1));
+                if (!h)
+                    return SFE_ERR_HIP;
+                for (int sv = 0; sv <= smax; ++sv) {
+                    const float sf = (float)sv;
+                    h[sv] = (float)((alg == SFE_CFAR_CA) ? tau * (double)sf / (2.0 * T) : tau * (double)sf / T);
+                }
+                SFE_HIP(ctx, hipMemcpyAsync(tab, h, sizeof(float) * (size_t)(smax + 1), hipMemcpyHostToDevice, ctx->stream));
+                if (int rc = sfe_pinned_end(ctx, ctx->stream))
+                    return rc;
+                ctx->thr_tab_alg = alg;
+                ctx->thr_tab_T = T;
+                ctx->thr_tab_tau = tau;
+                ctx->thr_tab_ptr = tab;
+            }
+            d_tab = tab;
+        }
+        // long tiles: a tile starts with 2T loads per lane to build its first windows
+        const int tile_rows = std::min(rows, std::max(128, 8 * T));
+        const int tiles = (rows + tile_rows - 1) / tile_rows;
+        const int chunks = std::max(1, ((cols >> 2) + 63) / 64);
+        const long long bpf = ((long long)tiles * chunks + 3) / 4;
+        const unsigned blocks = (unsigned)((((long long)n_frames + 7) / 8) * 8 * bpf);
+        // window rows staged in LDS (R KiB per workgroup) unless the window is too tall for it
+        const int R = 2 * (T + G) + 2;
+        const size_t ring_bytes = (size_t)R * 1024;
+        static const bool no_lds = getenv("SFE_CFAR_NO_LDS_RING") != nullptr; // A/B
+        // beyond two workgroups per CU (R > 80 rows = 80 KiB) the ring starves the CU of waves and re-reading the four
+        // rows through the caches is faster (measured (80, 20): 15 % of HBM with the LDS ring, 25 % without)
+        const bool lds_ring = ring_bytes <= 80 * 1024 && !no_lds;
+#define SLIDE_LAUNCH(A, THRB)                                                                                          \
+    do {                                                                                                               \
+        if (lds_ring) {                                                                                                \
+            SFE_HIP(ctx, hipFuncSetAttribute((const void *)cfar_u8_slide_lds<A, THRB>,                                 \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_bytes));            \
+            hipLaunchKernelGGL((cfar_u8_slide_lds<A, THRB>), dim3(blocks), dim3(256), ring_bytes, ctx->stream, d_img,  \
+                               d_mask, d_thr, d_tab, rows, cols, n_frames, T, G, tile_rows, tiles, chunks, lut);       \
+        } else {                                                                                                       \
+            hipLaunchKernelGGL((cfar_u8_slide<A, THRB>), dim3(blocks), dim3(256), 0, ctx->stream, d_img, d_mask,       \
+                               d_thr, d_tab, rows, cols, n_frames, T, G, tile_rows, tiles, chunks, lut);               \
+        }                                                                                                              \
+    } while (0)
+        if (alg == SFE_CFAR_SOCA) {
+            if (d_thr)
+                SLIDE_LAUNCH(SFE_CFAR_SOCA, true);
+            else
+                SLIDE_LAUNCH(SFE_CFAR_SOCA, false);
+        } else if (alg == SFE_CFAR_GOCA) {
+            if (d_thr)
+                SLIDE_LAUNCH(SFE_CFAR_GOCA, true);
+            else
+                SLIDE_LAUNCH(SFE_CFAR_GOCA, false);
+        } else {
+            if (d_thr)
+                SLIDE_LAUNCH(SFE_CFAR_CA, true);
+            else
+                SLIDE_LAUNCH(SFE_CFAR_CA, false);
+        }
+#undef SLIDE_LAUNCH
+    } else if (os_hist) {
+        if (int rc = launch_os_hist(ctx, d_img, n_frames, rows, cols, T, G, k, tau, intensity_thr, d_mask, d_thr))
+            return rc;
     } else {
         const int tr = std::min(rows, 64);
         const int tiles = (rows + tr - 1) / tr;

@@ -38,6 +38,10 @@ struct sfe_ctx {
     } pin[2];
     int pin_next = 0;
     Pin pin_io[4]; // grow-only pinned buffers of the synchronous single-item entry points (no events: the call syncs)
+    // float threshold table of the sliding-sum CFAR kernel currently on the device (scratch slot 37)
+    int thr_tab_alg = -1, thr_tab_T = -1;
+    double thr_tab_tau = 0.0;
+    const void *thr_tab_ptr = nullptr;
     int cfar_tile_rows = 0;
     int cfar_variant = 0;
     int icp_variant = 0;
