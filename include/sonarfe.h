@@ -158,6 +158,16 @@ typedef struct sfe_icp_params {
  * d2 float [n_in] squared distance (inf = none).  Ties -> lowest reference index. */
 int sfe_match(sfe_ctx *ctx, const float *ref, int n_ref, const float *in, int n_in, float max_dist,
               int32_t *ids, float *d2);
+/* the same for knn >= 1 neighbours (pcl.cpp:161-174 hands knn to KDTreeMatcher): ids / d2 are [knn x n_in] row-major
+ * (the IntMatrix / Matrix pybind returns), row j = the (j+1)-th nearest reference point in ascending (d2, index)
+ * order; -1 / inf where fewer than j+1 reference points lie within max_dist. */
+int sfe_match_knn(sfe_ctx *ctx, const float *ref, int n_ref, const float *in, int n_in, int knn, float max_dist,
+                  int32_t *ids, float *d2);
+/* The densities pcl.density_filter computes (pcl.cpp:76-126: libpointmatcher SurfaceNormalDataPointsFilter{knn,
+ * keepDensities}): per point the knn nearest points incl. itself, density = knn / ((4/3) pi r^3), r = the largest
+ * distance of a neighbour from the neighbours' mean.  knn > n is an error (libnabo refuses it).  The second stage of
+ * the reference's function (MaxDensityDataPointsFilter: sequential, std::rand) stays on the host, see pcl.py. */
+int sfe_knn_density(sfe_ctx *ctx, const float *pts, int n, int knn, float *dens_out);
 /* pcl.remove_outlier(points, radius, min_points) (pcl.cpp:54-74): order preserved */
 int sfe_remove_outlier(sfe_ctx *ctx, const float *pts, int n, double radius, int min_points,
                        float *out, int *n_out);

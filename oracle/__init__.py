@@ -87,6 +87,9 @@ def lib():
         L.orc_nonzero.restype = C.c_int64
         L.orc_px_to_m.argtypes = [i64p, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_double, f64p]
         L.orc_match.argtypes = [f32p, C.c_int, f32p, C.c_int, C.c_float, i32p, f32p]
+        L.orc_match_knn.argtypes = [f32p, C.c_int, f32p, C.c_int, C.c_int, C.c_float, i32p, f32p]
+        L.orc_knn_density.argtypes = [f32p, C.c_int, C.c_int, f32p]
+        L.orc_knn_density.restype = C.c_int
         L.orc_normals2d.argtypes = [f32p, C.c_int, C.c_int, f32p]
         L.orc_icp.argtypes = [C.POINTER(IcpParams), f32p, C.c_int, f32p, C.c_int, f32p, f32p,
                               C.POINTER(C.c_int)]
@@ -172,6 +175,26 @@ def match(ref, pts, max_dist):
     lib().orc_match(_p(ref, C.c_float), len(ref), _p(pts, C.c_float), len(pts), float(max_dist),
                     _p(ids, C.c_int32), _p(d2, C.c_float))
     return ids[None, :], d2[None, :]
+
+
+def match_knn(ref, pts, knn, max_dist):
+    """pcl.match(ref, in, knn, max_dist) (pcl.cpp:161-174) -> (ids [knn x N] int32, d2 [knn x N] f32), ascending."""
+    ref = np.ascontiguousarray(ref, np.float32).reshape(-1, 2)
+    pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+    ids = np.zeros((knn, len(pts)), np.int32)
+    d2 = np.zeros((knn, len(pts)), np.float32)
+    lib().orc_match_knn(_p(ref, C.c_float), len(ref), _p(pts, C.c_float), len(pts), int(knn), float(max_dist),
+                        _p(ids, C.c_int32), _p(d2, C.c_float))
+    return ids, d2
+
+
+def knn_density(pts, knn):
+    """densities of SurfaceNormalDataPointsFilter{knn, keepDensities} (pcl.cpp:81-88)"""
+    pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+    out = np.zeros(len(pts), np.float32)
+    if lib().orc_knn_density(_p(pts, C.c_float), len(pts), int(knn), _p(out, C.c_float)):
+        raise RuntimeError("Requesting more points than available in cloud")
+    return out
 
 
 def normals2d(tgt, k):

@@ -414,6 +414,92 @@ void orc_match(const float *ref, int nref, const float *in, int nin, float max_d
     kd_free(tree);
 }
 
+/* pcl.match with knn >= 1 (pcl.cpp:161-174; libpointmatcher KDTreeMatcher on libnabo's linear-heap tree: the knn
+ * nearest, ascending; -1 / inf beyond maxDist).  Brute force: all distances, the knn smallest by (d2, index). */
+typedef struct {
+    float d;
+    int id;
+} orc_knn_ent;
+static int orc_knn_cmp(const void *a, const void *b)
+{
+    const orc_knn_ent *x = (const orc_knn_ent *)a, *y = (const orc_knn_ent *)b;
+    if (x->d < y->d)
+        return -1;
+    if (x->d > y->d)
+        return 1;
+    return (x->id > y->id) - (x->id < y->id);
+}
+void orc_match_knn(const float *ref, int nref, const float *in, int nin, int knn, float max_dist, int32_t *ids, float *d2)
+{
+    const float r2 = max_dist * max_dist;
+    orc_knn_ent *e = (orc_knn_ent *)malloc(sizeof(orc_knn_ent) * (size_t)(nref > 0 ? nref : 1));
+    for (int i = 0; i < nin; ++i) {
+        int m = 0;
+        for (int j = 0; j < nref; ++j) {
+            volatile float dx = in[2 * i] - ref[2 * j], dy = in[2 * i + 1] - ref[2 * j + 1];
+            volatile float a = dx * dx, b = dy * dy;
+            const float d = a + b;
+            if (d == d) { /* a NaN distance is never a match */
+                e[m].d = d;
+                e[m].id = j;
+                ++m;
+            }
+        }
+        qsort(e, (size_t)m, sizeof(orc_knn_ent), orc_knn_cmp);
+        for (int j = 0; j < knn; ++j) {
+            const int ok = j < m && e[j].d <= r2;
+            ids[(size_t)j * nin + i] = ok ? e[j].id : -1;
+            d2[(size_t)j * nin + i] = ok ? e[j].d : INFINITY;
+        }
+    }
+    free(e);
+}
+
+/* The densities of pcl.density_filter's first stage (pcl.cpp:81-88): libpointmatcher SurfaceNormalDataPointsFilter
+ * {knn, keepNormals 0, keepDensities 1}: for every point its knn nearest points incl. itself, NN = neighbours - their
+ * mean (float), density = knn / volume, volume = (float)((4/3) pi pow(max ||NN_j||, 3)) (the pow / product in double).
+ * Returns -1 when knn exceeds the cloud (libnabo throws).  PARITY UNPINNED like every libpointmatcher stage: Eigen's
+ * vectorised rowwise().sum() may round the mean differently from this sequential float sum. */
+int orc_knn_density(const float *pts, int n, int knn, float *dens)
+{
+    if (knn > n)
+        return -1;
+    int32_t *ids = (int32_t *)malloc(sizeof(int32_t) * (size_t)n * knn);
+    float *d2 = (float *)malloc(sizeof(float) * (size_t)n * knn);
+    orc_match_knn(pts, n, pts, n, knn, INFINITY, ids, d2);
+    for (int i = 0; i < n; ++i) {
+        volatile float sx = 0.0f, sy = 0.0f;
+        int real = 0;
+        for (int j = 0; j < knn; ++j) {
+            const int id = ids[(size_t)j * n + i];
+            if (id >= 0) {
+                sx = sx + pts[2 * id];
+                sy = sy + pts[2 * id + 1];
+                ++real;
+            }
+        }
+        const float mx = sx / (float)real, my = sy / (float)real;
+        float rmax = 0.0f;
+        for (int j = 0; j < knn; ++j) {
+            const int id = ids[(size_t)j * n + i];
+            if (id >= 0) {
+                volatile float dx = pts[2 * id] - mx, dy = pts[2 * id + 1] - my;
+                volatile float a = dx * dx, b = dy * dy;
+                volatile float q = a + b;
+                const float r = sqrtf(q);
+                if (r > rmax)
+                    rmax = r;
+            }
+        }
+        const double r = (double)rmax;
+        const float volume = (float)((4. / 3.) * 3.14159265358979323846 * (r * r * r));
+        dens[i] = (float)real / volume;
+    }
+    free(ids);
+    free(d2);
+    return 0;
+}
+
 /* ------------------------------------------------------------------------- */
 /* ICP: pcl.cpp:198-212 -> libpointmatcher PM::ICP::operator() configured by   */
 /* config/icp.yaml:1-31.  See DESIGN.md for the restated chain.               */

@@ -95,6 +95,8 @@ SIGNATURES = {
     "sfe_extract_set_tuning": (C.c_int, [_vp, C.c_int]),
     "sfe_extract_points_batch_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int64, _vp, _vp]),
     "sfe_match": (C.c_int, [_vp, _f32p, C.c_int, _f32p, C.c_int, C.c_float, _i32p, _f32p]),
+    "sfe_match_knn": (C.c_int, [_vp, _f32p, C.c_int, _f32p, C.c_int, C.c_int, C.c_float, _i32p, _f32p]),
+    "sfe_knn_density": (C.c_int, [_vp, _f32p, C.c_int, C.c_int, _f32p]),
     "sfe_remove_outlier": (C.c_int, [_vp, _f32p, C.c_int, C.c_double, C.c_int, _f32p,
                                      C.POINTER(C.c_int)]),
     "sfe_downsample": (C.c_int, [_vp, _f32p, C.c_int, C.c_float, _f32p, _i32p, C.POINTER(C.c_int)]),

@@ -599,6 +599,90 @@ __global__ __launch_bounds__(256) void match_kernel(const float2 *__restrict__ r
     }
 }
 
+// pcl.match with knn > 1 (pcl.cpp:161-174 takes knn): the knn nearest reference points of every query in ascending
+// (d2, index) order, -1 / inf where fewer than knn lie within the radius.  One lane per query; neighbour j is the
+// lexicographic minimum of (d2, index) above neighbour j-1: knn passes over the reference (tiled through LDS) --
+// exact for any knn without a per-lane list; knn is small (1 in the SLAM node).
+__global__ __launch_bounds__(256) void match_knn_kernel(const float2 *__restrict__ ref, int nref,
+                                                        const float2 *__restrict__ in, int nin, int knn, float r2,
+                                                        int *__restrict__ ids, float *__restrict__ d2)
+{
+    __shared__ float2 s_ref[2048];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float px = 0, py = 0;
+    if (i < nin) {
+        const float2 p = in[i];
+        px = p.x;
+        py = p.y;
+    }
+    float prev_d = -1.0f; // every distance is >= 0
+    int prev_i = -1;
+    for (int jn = 0; jn < knn; ++jn) {
+        float best = INFINITY;
+        int bi = -1;
+        for (int tb = 0; tb < nref; tb += 2048) {
+            const int tn = min(2048, nref - tb);
+            __syncthreads();
+            for (int j = threadIdx.x; j < tn; j += 256)
+                s_ref[j] = ref[tb + j];
+            __syncthreads();
+            for (int j = 0; j < tn; ++j) {
+                const float2 t = s_ref[j];
+                const float dx = f_add(px, -t.x), dy = f_add(py, -t.y);
+                const float d = f_add(f_mul(dx, dx), f_mul(dy, dy));
+                const bool after = d > prev_d || (d == prev_d && tb + j > prev_i); // NaN: never
+                if (after && d < best) { // ascending index: the first point attaining the minimum wins
+                    best = d;
+                    bi = tb + j;
+                }
+            }
+        }
+        if (bi < 0 || !(best <= r2)) { // nothing left within the radius: this and all further neighbours are missing
+            bi = -1;
+            best = INFINITY;
+        }
+        if (i < nin) {
+            ids[(size_t)jn * nin + i] = bi;
+            d2[(size_t)jn * nin + i] = best;
+        }
+        prev_d = bi < 0 ? INFINITY : best;
+        prev_i = bi;
+    }
+}
+
+// Densities of libpointmatcher's SurfaceNormalDataPointsFilter{keepDensities} (pcl.cpp:81-88): per point, the knn
+// nearest points incl. itself (ids from match_knn_kernel), their float mean, r = the largest distance of a
+// neighbour from that mean, density = knn / ((4/3) pi r^3) with the volume computed in double and rounded to float.
+__global__ __launch_bounds__(256) void knn_density_kernel(const float2 *__restrict__ pts, int n, int knn,
+                                                          const int *__restrict__ ids, float *__restrict__ dens)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n)
+        return;
+    float sx = 0.0f, sy = 0.0f;
+    int real = 0;
+    for (int j = 0; j < knn; ++j) {
+        const int id = ids[(size_t)j * n + i];
+        if (id >= 0) {
+            sx = f_add(sx, pts[id].x);
+            sy = f_add(sy, pts[id].y);
+            ++real;
+        }
+    }
+    const float mx = __fdiv_rn(sx, (float)real), my = __fdiv_rn(sy, (float)real);
+    float rmax = 0.0f;
+    for (int j = 0; j < knn; ++j) {
+        const int id = ids[(size_t)j * n + i];
+        if (id >= 0) {
+            const float dx = f_add(pts[id].x, -mx), dy = f_add(pts[id].y, -my);
+            rmax = fmaxf(rmax, sqrtf(f_add(f_mul(dx, dx), f_mul(dy, dy))));
+        }
+    }
+    const double r = (double)rmax;
+    const float volume = (float)((4. / 3.) * 3.14159265358979323846 * (r * r * r));
+    dens[i] = __fdiv_rn((float)real, volume);
+}
+
 // pcl.remove_outlier: count points within radius (incl. self); keep iff count > min_points
 __global__ __launch_bounds__(256) void radius_count_kernel(const float2 *__restrict__ pts, int n, float r2,
                                                            int min_points, int *__restrict__ keep)
@@ -878,6 +962,58 @@ int sfe_match(sfe_ctx *ctx, const float *ref, int n_ref, const float *in, int n_
     SFE_LAUNCH_CHECK(ctx);
     SFE_HIP(ctx, hipMemcpyAsync(ids, d_ids, sizeof(int) * (size_t)n_in, hipMemcpyDeviceToHost, ctx->stream));
     SFE_HIP(ctx, hipMemcpyAsync(d2, d_d2, sizeof(float) * (size_t)n_in, hipMemcpyDeviceToHost, ctx->stream));
+    SFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int sfe_match_knn(sfe_ctx *ctx, const float *ref, int n_ref, const float *in, int n_in, int knn, float max_dist,
+                  int32_t *ids, float *d2)
+{
+    if (int rc = sfe_use(ctx))
+        return rc;
+    SFE_ARG(ctx, n_ref >= 0 && n_in >= 0 && knn >= 1 && (n_in == 0 || (in && ids && d2)) && (n_ref == 0 || ref));
+    if (n_in == 0)
+        return 0;
+    float *d_ref = (float *)sfe_scratch(ctx, 0, sizeof(float) * 2 * (size_t)std::max(n_ref, 1));
+    float *d_in = (float *)sfe_scratch(ctx, 1, sizeof(float) * 2 * (size_t)n_in);
+    int *d_ids = (int *)sfe_scratch(ctx, 2, sizeof(int) * (size_t)n_in * knn);
+    float *d_d2 = (float *)sfe_scratch(ctx, 3, sizeof(float) * (size_t)n_in * knn);
+    if (!d_ref || !d_in || !d_ids || !d_d2)
+        return SFE_ERR_HIP;
+    if (n_ref)
+        SFE_HIP(ctx, hipMemcpyAsync(d_ref, ref, sizeof(float) * 2 * (size_t)n_ref, hipMemcpyHostToDevice, ctx->stream));
+    SFE_HIP(ctx, hipMemcpyAsync(d_in, in, sizeof(float) * 2 * (size_t)n_in, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(match_knn_kernel, dim3((n_in + 255) / 256), dim3(256), 0, ctx->stream, (const float2 *)d_ref, n_ref,
+                       (const float2 *)d_in, n_in, knn, max_dist * max_dist, d_ids, d_d2);
+    SFE_LAUNCH_CHECK(ctx);
+    SFE_HIP(ctx, hipMemcpyAsync(ids, d_ids, sizeof(int) * (size_t)n_in * knn, hipMemcpyDeviceToHost, ctx->stream));
+    SFE_HIP(ctx, hipMemcpyAsync(d2, d_d2, sizeof(float) * (size_t)n_in * knn, hipMemcpyDeviceToHost, ctx->stream));
+    SFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int sfe_knn_density(sfe_ctx *ctx, const float *pts, int n, int knn, float *dens_out)
+{
+    if (int rc = sfe_use(ctx))
+        return rc;
+    SFE_ARG(ctx, n >= 0 && knn >= 1 && (n == 0 || (pts && dens_out)));
+    if (n == 0)
+        return 0;
+    if (knn > n) // libnabo: "Requesting more points than available in cloud"
+        return sfe_set_err(ctx, SFE_ERR_ARG, "knn density: %d neighbours requested from a cloud of %d points", knn, n);
+    float *d_pts = (float *)sfe_scratch(ctx, 0, sizeof(float) * 2 * (size_t)n);
+    int *d_ids = (int *)sfe_scratch(ctx, 2, sizeof(int) * (size_t)n * knn);
+    float *d_d2 = (float *)sfe_scratch(ctx, 3, sizeof(float) * (size_t)n * knn);
+    float *d_dens = (float *)sfe_scratch(ctx, 1, sizeof(float) * (size_t)n);
+    if (!d_pts || !d_ids || !d_d2 || !d_dens)
+        return SFE_ERR_HIP;
+    SFE_HIP(ctx, hipMemcpyAsync(d_pts, pts, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(match_knn_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const float2 *)d_pts, n,
+                       (const float2 *)d_pts, n, knn, INFINITY, d_ids, d_d2);
+    hipLaunchKernelGGL(knn_density_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const float2 *)d_pts, n, knn,
+                       d_ids, d_dens);
+    SFE_LAUNCH_CHECK(ctx);
+    SFE_HIP(ctx, hipMemcpyAsync(dens_out, d_dens, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     SFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }

@@ -8,7 +8,8 @@ Same names and call signatures as ``PYBIND11_MODULE(pcl, m)``
     class ICP: loadFromYaml(path), compute(source, target, guess) -> (message, T),
                getCovariance()                                                      pcl.cpp:184-213
     downsample(points[, descriptors], resolution) -> points'[, descriptors']       pcl.cpp:128-159
-    density_filter: not built (no caller in the reference)
+    density_filter(points[, descriptors], knn, min_density, max_density)           pcl.cpp:76-126 (raises like
+                   the reference does; knn_density / max_density_filter are the working pieces)
 
 Extension (not in the reference): ``ICP.compute_batch(source, target, guesses)`` runs the
 many-guesses-one-pair loop of SLAM.compute_icp_with_cov (slam.py:346-358) in one launch.
@@ -33,21 +34,28 @@ def _cloud(a, name):
 
 
 def match(ref, pts, knn, max_dist, ctx=None):
-    """KDTreeMatcher replacement (pcl.cpp:161-174): exact NN, squared distances, -1 / inf beyond
-    max_dist, ties resolved to the lowest reference index."""
-    if int(knn) != 1:
-        raise NotImplementedError("pcl.match: only knn=1 is used by the SLAM path (slam.py:418)")
+    """KDTreeMatcher replacement (pcl.cpp:161-174): the knn exact nearest reference points of every query in
+    ascending (d2, index) order, squared distances, -1 / inf beyond max_dist.
+    -> (ids int32 [knn x N], dists float32 [knn x N]) like the pybind IntMatrix / Matrix pair."""
+    knn = int(knn)
+    if knn < 1:
+        raise RuntimeError("pcl.match: knn must be >= 1, got %d" % knn)
     ctx = ctx or _L.default_context()
     ref = _cloud(ref, "match(ref)")
     pts = _cloud(pts, "match(in)")
-    ids = _np.full(len(pts), -1, _np.int32)
-    d2 = _np.full(len(pts), _np.inf, _np.float32)
+    ids = _np.full((knn, len(pts)), -1, _np.int32)
+    d2 = _np.full((knn, len(pts)), _np.inf, _np.float32)
     if len(pts):
         with ctx.lock:
-            ctx._check(ctx.lib.sfe_match(ctx.handle, _L.ptr(ref, _C.c_float), len(ref),
-                                         _L.ptr(pts, _C.c_float), len(pts), float(max_dist),
-                                         _L.ptr(ids, _C.c_int32), _L.ptr(d2, _C.c_float)))
-    return ids[None, :], d2[None, :]
+            if knn == 1:    # the SLAM node's only use (slam.py:418): one pass over the reference
+                ctx._check(ctx.lib.sfe_match(ctx.handle, _L.ptr(ref, _C.c_float), len(ref),
+                                             _L.ptr(pts, _C.c_float), len(pts), float(max_dist),
+                                             _L.ptr(ids, _C.c_int32), _L.ptr(d2, _C.c_float)))
+            else:
+                ctx._check(ctx.lib.sfe_match_knn(ctx.handle, _L.ptr(ref, _C.c_float), len(ref),
+                                                 _L.ptr(pts, _C.c_float), len(pts), knn, float(max_dist),
+                                                 _L.ptr(ids, _C.c_int32), _L.ptr(d2, _C.c_float)))
+    return ids, d2
 
 
 def remove_outlier(points, radius, min_points, ctx=None):
@@ -90,9 +98,114 @@ def downsample(points, *args, **kw):
     return out if desc is None else (out, desc[idx[:n.value]].copy())
 
 
-def density_filter(*args):
-    raise NotImplementedError(
-        "pcl.density_filter (pcl.cpp:76-126) has no caller in the reference and is not built")
+class _GlibcRand(object):
+    """glibc's rand() (TYPE_3 additive feedback generator, r[i] = r[i-3] + r[i-31]), which is what the std::rand()
+    of libpointmatcher's MaxDensityDataPointsFilter resolves to on the reference's platform (Ubuntu / ROS noetic).
+    Process-wide state like the C library's: seeded with 1 until somebody calls srand."""
+    RAND_MAX = 2147483647
+
+    def __init__(self, seed=1):
+        self.srand(seed)
+
+    def srand(self, seed):
+        seed = int(seed) & 0xFFFFFFFF or 1
+        r = [0] * 34
+        r[0] = seed
+        for i in range(1, 31):
+            hi, lo = divmod(r[i - 1], 127773)                 # 16807 * x mod (2^31 - 1), Schrage
+            w = 16807 * lo - 2836 * hi
+            r[i] = w + 2147483647 if w < 0 else w
+        for i in range(31, 34):
+            r[i] = r[i - 31]
+        self._r = r
+        for _ in range(310):
+            self._step()
+
+    def _step(self):
+        r = self._r
+        o = (r[-31] + r[-3]) & 0xFFFFFFFF
+        r.append(o)
+        del r[0]
+        return o
+
+    def rand(self):
+        return self._step() >> 1
+
+
+_rand = _GlibcRand(1)
+
+
+def srand(seed):
+    """std::srand for the random thinning of max_density_filter (extension: the reference never seeds)."""
+    _rand.srand(seed)
+
+
+def knn_density(points, knn, ctx=None):
+    """The ``densities`` descriptor pcl.density_filter computes first (pcl.cpp:81-88): libpointmatcher
+    SurfaceNormalDataPointsFilter{knn, keepDensities}: knn / ((4/3) pi r^3), r = the largest distance of one of the
+    point's knn nearest points (itself included) from their mean.  -> float32 [N]"""
+    ctx = ctx or _L.default_context()
+    pts = _cloud(points, "knn_density(points)")
+    knn = int(knn)
+    if knn < 1:
+        raise RuntimeError("knn_density: knn must be >= 1")
+    if knn > len(pts):
+        raise RuntimeError("Requesting more points than available in cloud")   # libnabo
+    dens = _np.zeros(len(pts), _np.float32)
+    if len(pts):
+        with ctx.lock:
+            ctx._check(ctx.lib.sfe_knn_density(ctx.handle, _L.ptr(pts, _C.c_float), len(pts), knn,
+                                               _L.ptr(dens, _C.c_float)))
+    return dens
+
+
+def max_density_filter(points, *args, **kw):
+    """What the body of the reference's ``density_filter`` does once its stray ``minDensity`` parameter is taken out
+    (pcl.cpp:76-126): densities from the knn nearest neighbours (``knn_density``), then libpointmatcher's
+    MaxDensityDataPointsFilter: a point with density <= max_density stays; a denser one stays with probability
+    max_density / density (scaled by 1 - nbSaturated / nbPoints -- an integer division, i.e. 1 unless every point is
+    saturated -- for the points at the maximum density), drawn with std::rand() in input order.
+    ``max_density_filter(points, knn, max_density)`` -> points', or with descriptors
+    ``max_density_filter(points, descriptors, knn, max_density)`` -> (points', descriptors').  Extension."""
+    ctx = kw.pop("ctx", None)
+    if len(args) == 2:
+        desc, (knn, max_density) = None, args
+    elif len(args) == 3:
+        desc, knn, max_density = _np.ascontiguousarray(args[0], _np.float32), args[1], args[2]
+    else:
+        raise TypeError("max_density_filter(points, [descriptors,] knn, max_density)")
+    pts = _cloud(points, "max_density_filter(points)")
+    if len(pts) == 0:
+        return pts if desc is None else (pts, desc)
+    dens = knn_density(pts, knn, ctx=ctx)
+    max_density = _np.float32(max_density)
+    last = dens.max()
+    n_sat = int((dens == last).sum())
+    keep = _np.ones(len(pts), bool)
+    for i in _np.nonzero(dens > max_density)[0]:        # input order; only the dense points draw a number
+        r = _np.float32(_rand.rand()) / _np.float32(_GlibcRand.RAND_MAX)
+        accept = _np.float32(max_density / dens[i])
+        if dens[i] == last:
+            accept = _np.float32(accept * _np.float32(1 - n_sat // len(pts)))
+        keep[i] = r < accept
+    return pts[keep].copy() if desc is None else (pts[keep].copy(), desc[keep].copy())
+
+
+def density_filter(points, *args):
+    """``pcl.density_filter(points[, descriptors], knn, min_density, max_density)`` (pcl.cpp:76-126, both overloads).
+    The reference hands libpointmatcher's MaxDensityDataPointsFilter a ``minDensity`` parameter that filter does not
+    have (pcl.cpp:90-92, 115-117); its registrar rejects parameters a module never reads, so on a non-empty cloud the
+    reference call ends in ``InvalidParameter`` -- a RuntimeError in Python -- which is presumably why its only call
+    site is commented out (feature_extraction.py:246).  This drop-in behaves the same: empty clouds come back
+    unchanged (:78-79, :103-104), anything else raises with libpointmatcher's message.  ``max_density_filter`` is the
+    working form."""
+    if len(args) not in (3, 4):
+        raise TypeError("density_filter(points, knn, min_density, max_density) or "
+                        "density_filter(points, descriptors, knn, min_density, max_density)")
+    pts = _np.asarray(points)
+    if pts.ndim == 2 and pts.shape[0] == 0:
+        return pts if len(args) == 3 else (pts, _np.asarray(args[0]))
+    raise RuntimeError("Parameter minDensity for module MaxDensityDataPointsFilter was set but is not used")
 
 
 class ICP(object):

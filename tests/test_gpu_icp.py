@@ -453,3 +453,50 @@ def test_compute_pairs_and_the_farm_equal_single_calls(ctx):
     for (s, t, gs), (m, Tf, itf) in zip(jobs, out):
         mb, Tb, itb = icp.compute_batch(s, t, gs)
         assert m == mb and np.array_equal(Tf, Tb) and np.array_equal(itf, itb)
+
+
+def test_match_knn_bit_exact():
+    """pcl.match with knn > 1 (pcl.cpp:161-174): the knn nearest in ascending (d2, index) order, -1 / inf where
+    fewer lie within max_dist; against the oracle, with duplicated reference points and knn > n_ref"""
+    rng = np.random.default_rng(3)
+    ref = rng.uniform(-10, 10, (2500, 2)).astype(np.float32)
+    ref[100:140] = ref[:40]                                  # exact duplicates: ties by index
+    q = rng.uniform(-11, 11, (1700, 2)).astype(np.float32)
+    for knn, md in ((2, 0.6), (5, 3.0), (9, 100.0)):
+        ids, d2 = pcl.match(ref, q, knn, md)
+        oi, od = oracle.match_knn(ref, q, knn, md)
+        assert ids.shape == (knn, 1700) and ids.dtype == np.int32 and d2.dtype == np.float32
+        assert np.array_equal(ids, oi) and np.array_equal(d2, od)
+        assert np.array_equal(ids[0], pcl.match(ref, q, 1, md)[0][0])
+    small = ref[:3]
+    ids, d2 = pcl.match(small, q[:10], 5, 100.0)
+    assert (ids[3:] == -1).all() and np.isinf(d2[3:]).all() and (ids[:3] >= 0).all()
+    assert np.array_equal(ids, oracle.match_knn(small, q[:10], 5, 100.0)[0])
+
+
+def test_knn_density_and_max_density_filter():
+    """the two stages of the reference's density_filter body (pcl.cpp:81-97): densities against the oracle (bit
+    exact), the std::rand thinning against a plain restatement of MaxDensityDataPointsFilter on those densities"""
+    rng = np.random.default_rng(8)
+    pts = np.r_[rng.normal(0, 0.3, (600, 2)), rng.uniform(-15, 15, (500, 2))].astype(np.float32)
+    for knn in (3, 10):
+        dens = pcl.knn_density(pts, knn)
+        assert np.array_equal(dens, oracle.knn_density(pts, knn))
+    with pytest.raises(RuntimeError, match="more points than available"):
+        pcl.knn_density(pts[:4], 5)
+    dens = oracle.knn_density(pts, 10)
+    md = np.float32(np.median(dens))
+    g = pcl._GlibcRand(1)
+    keep = []
+    for d in dens:
+        if d > md:
+            r = np.float32(g.rand()) / np.float32(2147483647)
+            keep.append(bool(r < np.float32(md / d)))      # 1 - nbSaturated / nbPoints == 1 (integer division)
+        else:
+            keep.append(True)
+    pcl.srand(1)
+    out = pcl.max_density_filter(pts, 10, md)
+    assert np.array_equal(out, pts[np.array(keep)]) and 600 < len(out) < len(pts)
+    pcl.srand(1)
+    out2, desc2 = pcl.max_density_filter(pts, np.arange(len(pts), dtype=np.float32)[:, None], 10, md)
+    assert np.array_equal(out2, out) and np.array_equal(desc2[:, 0].astype(int), np.nonzero(keep)[0])

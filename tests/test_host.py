@@ -209,3 +209,22 @@ def test_icp_object_has_no_silent_default_chain(tmp_path):
     icp.loadFromYaml(str(f))
     assert icp.params.as_dict() == icp_config.shipped_params().as_dict()
     assert np.array_equal(icp.getCovariance(), np.zeros((3, 3), np.float32))
+
+
+def test_glibc_rand_restatement_and_density_filter_surface():
+    """std::rand of the reference's platform: the first outputs after srand(1) / srand(42) are glibc's; and
+    pcl.density_filter behaves like the reference call (empty cloud returned, otherwise libpointmatcher's
+    'was set but is not used' InvalidParameter for the minDensity it hands to MaxDensityDataPointsFilter)."""
+    from sonar_slam_amd import pcl
+    g = pcl._GlibcRand(1)
+    assert [g.rand() for _ in range(5)] == [1804289383, 846930886, 1681692777, 1714636915, 1957747793]
+    g.srand(42)
+    assert g.rand() == 71876166
+    empty = np.zeros((0, 2), np.float32)
+    assert pcl.density_filter(empty, 10, 0.0, 100.0).shape == (0, 2)
+    e2, d2 = pcl.density_filter(empty, np.zeros((0, 1), np.float32), 10, 0.0, 100.0)
+    assert e2.shape == (0, 2) and d2.shape == (0, 1)
+    with pytest.raises(RuntimeError, match="minDensity"):
+        pcl.density_filter(np.ones((5, 2), np.float32), 3, 0.0, 100.0)
+    with pytest.raises(TypeError):
+        pcl.density_filter(np.ones((5, 2), np.float32), 3)
