@@ -34,7 +34,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=512, help="keyframes per step per GPU")
+    ap.add_argument("--batch", type=int, default=2048,
+                    help="keyframes per step per GPU (512 = one scan match per workgroup slot of the 256 CUs: every job's "
+                         "tail is exposed; with a few times more the dispatcher refills slots as jobs finish, -15 %% per job)")
     ap.add_argument("--cfar-frames", type=int, default=1024, help="frames per launch for the CFAR roofline leg")
     ap.add_argument("--cfar-launches", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -421,6 +423,9 @@ def main():
             # separate profiled launch of the same batch (sfe_icp_get_profile), not derived from n_src * n_tgt
             "icp_kernel": icp_kernel,
             "stage_ms_per_step": {"cfar": ms_cfar_b, "extract": ms_extract_b, "filters": ms_filter_b, "icp": ms_icp_b},
+            "stage_ms_per_512_keyframes": {k: v * 512.0 / args.batch for k, v in
+                                           (("cfar", ms_cfar_b), ("extract", ms_extract_b), ("filters", ms_filter_b),
+                                            ("icp", ms_icp_b))},
             # SURVEY 8d, on-the-fly form: R*B bytes of mask in + 16 B per extracted point out
             "roofline_extract": {"kernel": "mask_pack + extract_scatter + extract_scan + extract_expand", "bound": "hbm",
                                  "achieved": extract_bytes / (ms_extract_b * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
