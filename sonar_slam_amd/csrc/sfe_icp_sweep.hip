@@ -47,6 +47,7 @@
 #define SW_TCAP 8192   // target points resident in LDS
 #define SW_NS_MAX 64   // strips per target
 #define SW_PAD (SW_NS_MAX + 4) // sentinels: one in front, one behind every strip, two spare behind the last
+#define SW_GRID_MAX 8192 // cells of a target's witness grid (built in the prep kernel's LDS: 8 B per cell)
 
 // Strip table of one target (built by the prep kernel, read by every job on that target).
 // Sorted-cloud layout (float2 positions): [0] NaN, then for every strip s its points ascending in x
@@ -58,7 +59,11 @@ struct StripTab {
     int ns, len;
     float ylo, inv_g;         // strip(y) = clamp(int((y - ylo) * inv_g), 0, ns - 1)
     float ext_x;              // x extent of the finite points (initial cap of the search)
-    int pad_[3];
+    // witness grid (iteration 0): cell (ix, iy) = clamp(int((x - gx0) * ginv)), clamp(int((y - gy0) * ginv));
+    // grid[iy * gnx + ix] = sorted position of the target point nearest to the cell's centre (0: none)
+    float gx0, gy0, ginv;
+    int gnx, gny;
+    int pad_[2];
     int sbeg[SW_NS_MAX + 1];
     float smin[SW_NS_MAX];    // smallest y of any point in strips >= s (+inf if none)
     float smax[SW_NS_MAX];    // largest y of any point in strips <= s (-inf if none)
@@ -335,6 +340,89 @@ __device__ __forceinline__ void sweep_knn_normals(const sfe_icp_params &P, const
     }
 }
 
+// Witness grid of one target (for the first iteration of every job on it, which has no previous neighbours to start
+// from): per cell the sorted position of a target point near the cell's centre -- any real point is a valid upper bound
+// of a query's neighbour distance; a near one is a good bound.  Built without searching: every point claims its own
+// cell (the point nearest to the centre wins: atomicMin on the distance bits, then the winner writes its position), then
+// a few dilation sweeps hand witnesses to the empty cells around occupied ones (a cell takes, among its 8 neighbours'
+// witnesses, the one nearest to its own centre; in place, so a sweep carries them further than one cell).  Cells
+// that stay empty are far from every structure: queries there start the first iteration without a witness, as before.
+// (A per-cell nearest-neighbour search was tried first: the empty two thirds of a sonar fan's bounding box have their
+// nearest point metres away, and those searches cost 2 ms per 512 targets.)
+#define SW_GRID_SWEEPS 6
+__device__ __forceinline__ void sweep_grid_witness(const StripTab &tab, const float2 *__restrict__ s_tgt,
+                                                   int *__restrict__ grid_out, int *grid, unsigned *gdist)
+{ // grid / gdist: LDS (SW_GRID_MAX entries each); grid_out: the target's slice of the HBM scratch
+    const int gnx = tab.gnx, gny = tab.gny, ncell = gnx * gny, len = tab.len;
+    const float cs = tab.ginv > 0.0f ? 1.0f / tab.ginv : 0.0f;
+    auto cell_of = [&](float2 q) {
+        float gxv = f_mul(f_add(q.x, -tab.gx0), tab.ginv), gyv = f_mul(f_add(q.y, -tab.gy0), tab.ginv);
+        gxv = fminf(fmaxf(gxv, 0.0f), (float)(gnx - 1));
+        gyv = fminf(fmaxf(gyv, 0.0f), (float)(gny - 1));
+        return (int)gyv * gnx + (int)gxv;
+    };
+    auto centre_of = [&](int c) {
+        const int iy = c / gnx, ix = c - iy * gnx;
+        return make_float2(tab.gx0 + ((float)ix + 0.5f) * cs, tab.gy0 + ((float)iy + 0.5f) * cs);
+    };
+    for (int c = threadIdx.x; c < ncell; c += ICP_THREADS) {
+        grid[c] = 0;
+        gdist[c] = 0x7F800000u;
+    }
+    __syncthreads();
+    for (int p = threadIdx.x + 1; p < len; p += ICP_THREADS) {
+        const float2 q = s_tgt[p];
+        if (!(fabsf(q.x) < INFINITY && fabsf(q.y) < INFINITY))
+            continue; // sentinels, non-finite points
+        const int c = cell_of(q);
+        const float2 m = centre_of(c);
+        atomicMin(&gdist[c], __float_as_uint(dist2(m.x, m.y, q.x, q.y))); // d >= 0: bit order = value order
+    }
+    __syncthreads();
+    for (int p = threadIdx.x + 1; p < len; p += ICP_THREADS) {
+        const float2 q = s_tgt[p];
+        if (!(fabsf(q.x) < INFINITY && fabsf(q.y) < INFINITY))
+            continue;
+        const int c = cell_of(q);
+        const float2 m = centre_of(c);
+        if (gdist[c] == __float_as_uint(dist2(m.x, m.y, q.x, q.y)))
+            grid[c] = p; // equal distances: any of them
+    }
+    __syncthreads();
+    for (int it = 0; it < SW_GRID_SWEEPS; ++it) {
+        for (int c = threadIdx.x; c < ncell; c += ICP_THREADS) {
+            if (grid[c] != 0)
+                continue;
+            const int iy = c / gnx, ix = c - iy * gnx;
+            const float2 m = centre_of(c);
+            float best = INFINITY;
+            int bp = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int dx = (k < 3) ? k - 1 : (k == 3 ? -1 : (k == 4 ? 1 : k - 6));
+                const int dy = (k < 3) ? -1 : (k < 5 ? 0 : 1);
+                const int jx = ix + dx, jy = iy + dy;
+                if (jx < 0 || jx >= gnx || jy < 0 || jy >= gny)
+                    continue;
+                const int w = grid[jy * gnx + jx];
+                if (w != 0) {
+                    const float2 t = s_tgt[w];
+                    const float d = dist2(m.x, m.y, t.x, t.y);
+                    if (d < best) {
+                        best = d;
+                        bp = w;
+                    }
+                }
+            }
+            if (bp != 0)
+                grid[c] = bp;
+        }
+        __syncthreads();
+    }
+    for (int c = threadIdx.x; c < ncell; c += ICP_THREADS)
+        grid_out[c] = grid[c];
+}
+
 // bitonic sort of n2 (power of two) 64-bit keys in HBM scratch by one workgroup (targets that do
 // not fit LDS; once per target, the keys stay in L2)
 __device__ __forceinline__ void bitonic_sort_global(unsigned long long *keys, unsigned n2)
@@ -370,10 +458,12 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_sweep_prep_kernel(sfe_icp_
                                                                         float2 *__restrict__ snrm_all,
                                                                         float *__restrict__ mean_all,
                                                                         unsigned long long *__restrict__ gkeys_all,
-                                                                        StripTab *__restrict__ tab_all)
+                                                                        StripTab *__restrict__ tab_all,
+                                                                        int *__restrict__ grid_all)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     PrepShared &S = *reinterpret_cast<PrepShared *>(smem_raw);
+    int *s_grid = reinterpret_cast<int *>(smem_raw + ((sizeof(PrepShared) + 15) & ~(size_t)15)); // witness grid + distances
     const SweepPrep J = preps[blockIdx.x];
     const int nt = J.n_tgt, ns = J.ns, tid = threadIdx.x, lane = threadIdx.x & 63;
     const float2 *__restrict__ tgt = tgt_all + J.tgt_start;
@@ -442,6 +532,29 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_sweep_prep_kernel(sfe_icp_
             const float inv = (y1 > y0) ? (float)ns / f_add(y1, -y0) : 0.0f;
             S.tab.inv_g = (inv < INFINITY) ? inv : 0.0f;
             S.tab.ext_x = (x1 >= x0) ? f_add(x1, -x0) : 0.0f;
+            // witness grid over the bounding box: about one cell per target point, at most SW_GRID_MAX cells
+            const float ex = (x1 >= x0) ? f_add(x1, -x0) : 0.0f, ey = (y1 >= y0) ? f_add(y1, -y0) : 0.0f;
+            float cs = sqrtf(fmaxf(ex, 1e-30f) * fmaxf(ey, 1e-30f) / (float)max(nt, 1));
+            cs = fmaxf(cs, sqrtf(fmaxf(ex, 1e-30f) * fmaxf(ey, 1e-30f) / (float)(SW_GRID_MAX / 2)));
+            if (!(cs > 0.0f) || !(cs < INFINITY))
+                cs = 1.0f;
+            int gnx = (int)fminf(ex / cs, 4096.0f) + 1, gny = (int)fminf(ey / cs, 4096.0f) + 1;
+            while ((long long)gnx * gny > SW_GRID_MAX) { // a very elongated box
+                if (gnx >= gny)
+                    gnx = (gnx + 1) / 2;
+                else
+                    gny = (gny + 1) / 2;
+            }
+            S.tab.gx0 = (x1 >= x0) ? x0 : 0.0f;
+            S.tab.gy0 = (y1 >= y0) ? y0 : 0.0f;
+            S.tab.gnx = gnx;
+            S.tab.gny = gny;
+            // one cell size for both axes, large enough that gnx x gny cells cover the box
+            const float csx = ex / (float)gnx, csy = ey / (float)gny;
+            const float csz = fmaxf(fmaxf(csx, csy), 1e-30f);
+            S.tab.ginv = 1.0f / csz;
+            if (!(S.tab.ginv < INFINITY))
+                S.tab.ginv = 0.0f;
         }
         __syncthreads();
     }
@@ -549,6 +662,8 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_sweep_prep_kernel(sfe_icp_
             else
                 sweep_knn_normals<ICP_KMAX>(P, S.tab, s_tgt, perm, nrm, nt);
         }
+        if (grid_all)
+            sweep_grid_witness(S.tab, s_tgt, grid_all + (size_t)blockIdx.x * SW_GRID_MAX, s_grid, reinterpret_cast<unsigned *>(s_grid + SW_GRID_MAX));
     } else {
         bitonic_sort_global(keys, n2);
         for (int r = tid; r < nt; r += ICP_THREADS) {
@@ -568,6 +683,8 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_sweep_prep_kernel(sfe_icp_
             else
                 sweep_knn_normals<ICP_KMAX>(P, S.tab, stgt, perm, nrm, nt);
         }
+        if (grid_all)
+            sweep_grid_witness(S.tab, stgt, grid_all + (size_t)blockIdx.x * SW_GRID_MAX, s_grid, reinterpret_cast<unsigned *>(s_grid + SW_GRID_MAX));
     }
 }
 
@@ -610,6 +727,7 @@ struct SweepShared {
     unsigned hist[256], hist0[256];
     unsigned sel_prefix, sel_k;
     unsigned n_none, n_exact; // census of the iteration, tallied where a query is settled
+    int grid_skips;           // first iteration: queries that took a grid witness instead of searching in round 0
     int long_n, long_next, mid_n, wl_n[2];
     int flag_iterate, flag_status;
     float Ti[9];
@@ -707,7 +825,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
     sfe_icp_params P, const SweepJob *__restrict__ jobs, const int *__restrict__ job_ids, const float2 *__restrict__ src_all,
     const float *__restrict__ guess_all, const float2 *__restrict__ stgt_all, const int *__restrict__ perm_all,
     const float2 *__restrict__ snrm_all, const float *__restrict__ mean_all, const StripTab *__restrict__ tab_all,
-    int4 *__restrict__ q_st_all, int *__restrict__ q_wl_all, float2 *__restrict__ q_ssrc_all,
+    const int *__restrict__ grid_all, int4 *__restrict__ q_st_all, int *__restrict__ q_wl_all, float2 *__restrict__ q_ssrc_all,
     float *__restrict__ nn_d2_all,
     int *__restrict__ nn_pos_all, float *__restrict__ T_out, int *__restrict__ status_out,
     int *__restrict__ iters_out, long long *prof, int *dbg, int sw_budget, int sw_budget_a, int sw_cache, int t_cap, int q_cap, int sort_chunk)
@@ -766,6 +884,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
     Q.order = Q.lng + ns;
     Q.ssrc = q_ssrc_all + J.q_off;
     Q.perm = perm_all + J.tgt_off;
+    const int *__restrict__ grid = (grid_all != nullptr && (sw_cache & 4) != 0) ? grid_all + (size_t)J.prep * SW_GRID_MAX : nullptr;
     const float *guess = guess_all + 9 * (size_t)jb;
     const int tid = threadIdx.x, lane = threadIdx.x & 63;
     const float mx = sw_uniform(mean_all[2 * J.prep]), my = sw_uniform(mean_all[2 * J.prep + 1]);
@@ -1004,6 +1123,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
         if (tid == 0) {
             S.n_none = 0;
             S.n_exact = 0;
+            S.grid_skips = 0;
         }
         auto tally_settled = [&](bool is_none, bool is_exact, float best) { // called wave-uniformly
             const unsigned long long mn = __ballot(is_none), me = __ballot(is_exact);
@@ -1099,7 +1219,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                     // A `none` query stays none as long as it has moved less than its recorded clearance:
                     // |p - t| >= |p0 - t| - |p - p0| > maxDist for every target t (1e-5 relative slop on
                     // each term, two orders above the rounding of the fp32 distances involved).
-                    bool skip = false;
+                    bool skip = false, grid_hit = false;
                     if (fresh && use_cache && valid) {
                         const int w = prev >= 0 ? prev + 1 : (prev <= -3 ? -2 - prev : 0);
                         if (PROF)
@@ -1118,11 +1238,35 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                             const float mv = sqrtf(f_add(f_mul(mx0, mx0), f_mul(my0, my0)));
                             skip = f_mul(mv, 1.00001f) < __int_as_float(r.z); // NaN -> search
                         }
+                    } else if (fresh && valid && grid != nullptr) {
+                        // first iteration: no previous neighbour yet -- the target point nearest to the centre of the
+                        // query's grid cell (prep kernel) is the witness: a real target within half a cell diagonal
+                        // of the best one, instead of whatever the own strip's x-walk happens to meet first
+                        float gxv = f_mul(f_add(px, -tab.gx0), tab.ginv), gyv = f_mul(f_add(py, -tab.gy0), tab.ginv);
+                        gxv = fminf(fmaxf(gxv, 0.0f), (float)(tab.gnx - 1)); // NaN -> 0
+                        gyv = fminf(fmaxf(gyv, 0.0f), (float)(tab.gny - 1));
+                        const int w = grid[(int)gyv * tab.gnx + (int)gxv];
+                        if (PROF)
+                            c_wit += (unsigned long long)__popcll(__ballot(w != 0));
+                        if (w) {
+                            const float2 t = T[w];
+                            const float dxw = f_add(px, -t.x), dyw = f_add(py, -t.y);
+                            const float dw = f_add(f_mul(dxw, dxw), f_mul(dyw, dyw));
+                            if (dw < best) {
+                                best = dw;
+                                bpos = w;
+                                // With a trimmed-distance filter the cap of this round is a placeholder (a few point
+                                // spacings): hardly anything would be settled within it, so the query goes straight to the
+                                // round whose cap comes from the witnesses.  Only while C < Cmax: at Cmax there is no
+                                // further round, every query must be searched now.
+                                grid_hit = P.use_trimmed_filter && C < Cmax && dw < r2m_up && (sw_cache & 8) != 0; // (a witness just beyond maxDist settles nothing)
+                            }
+                        }
                     }
                     const int so = strip_of(py, ylo, inv_g, nst);
                     int s_up = own_done ? so + 1 : so, s_dn = so - 1;
                     // a query with a NaN coordinate has no neighbour (every d2 is NaN): nothing to visit
-                    bool lane_done = !valid || skip || !(px == px && py == py);
+                    bool lane_done = !valid || skip || grid_hit || !(px == px && py == py);
                     bool pending = false; // holds a strip it could not start or finish within the budget
                     bool own_fin = own_done;
                     int used = 0;
@@ -1212,8 +1356,9 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                     const bool settled = valid && !is_long;
                     const bool found = best < r2m_up; // <=> some target with d2 <= maxDist^2 was met (best starts at W2 >= r2m_up)
                     const bool is_none = settled && !found;
-                    const bool is_exact = settled && found && best <= C;
-                    const bool is_susp = settled && found && !(best <= C);
+                    // (a grid-witnessed query of the first iteration has not searched anything yet: never exact)
+                    const bool is_exact = settled && found && best <= C && !grid_hit;
+                    const bool is_susp = settled && found && (!(best <= C) || grid_hit);
                     if (is_none) {
                         setQ(q, INFINITY, SW_NONE);
                         if (!skip) // a full search: every target is at least sqrt(best) away from (px, py)
@@ -1228,6 +1373,8 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                     if (is_susp || is_long)
                         setQ(q, best, SW_INEXACT_OF(bpos));
                     tally_settled(is_none, is_exact, best);
+                    if (__ballot(grid_hit) && lane == 0)
+                        S.grid_skips = 1;
                     { // wave-aggregated appends
                         const unsigned long long ms = __ballot(is_susp), ml = __ballot(is_long);
                         const unsigned long long below = (1ull << lane) - 1ull;
@@ -1459,6 +1606,11 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                 } else {
                     done = nsusp == 0;
                 }
+                // queries that took a grid witness instead of searching are suspended WITHOUT the guarantee "neighbour
+                // beyond the cap" the other suspended ones carry: the round that searches them must follow, whatever
+                // the census says (they exist only in round 0 of the first iteration, and only while C < Cmax)
+                if (round == 0 && S.grid_skips != 0 && nsusp != 0)
+                    done = false;
                 if (!done && (C >= Cmax || nsusp == 0)) {
                     // the k-th finite distance exceeds MaxDist^2 (or every neighbour is already known)
                     limit_inf = C >= Cmax && nsusp != 0;
@@ -1693,9 +1845,10 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
     int *d_qwl = (int *)sfe_scratch(ctx, 21, sizeof(int) * 5 * (size_t)qoff);
     float2 *d_qssrc = (float2 *)sfe_scratch(ctx, 30, sizeof(float2) * (size_t)qoff);
     StripTab *d_tab = (StripTab *)sfe_scratch(ctx, 23, sizeof(StripTab) * (size_t)n_prep);
+    int *d_grid = (int *)sfe_scratch(ctx, 38, sizeof(int) * (size_t)SW_GRID_MAX * (size_t)n_prep);
     float *d_nn_d2 = (float *)sfe_scratch(ctx, 5, sizeof(float) * (size_t)qoff);
     int *d_nn_pos = (int *)sfe_scratch(ctx, 6, sizeof(int) * (size_t)qoff);
-    if (!d_tables || !d_stgt || !d_perm || (p->minimizer == 1 && !d_snrm) || !d_mean || !d_gkeys || !d_qst || !d_qwl || !d_qssrc || !d_tab ||
+    if (!d_tables || !d_stgt || !d_perm || (p->minimizer == 1 && !d_snrm) || !d_mean || !d_gkeys || !d_qst || !d_qwl || !d_qssrc || !d_tab || !d_grid ||
         !d_nn_d2 || !d_nn_pos)
         return SFE_ERR_HIP;
     SweepPrep *d_preps = (SweepPrep *)d_tables;
@@ -1726,10 +1879,11 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
             return rc;
     }
 
+    const size_t prep_smem = ((sizeof(PrepShared) + 15) & ~(size_t)15) + 8 * (size_t)SW_GRID_MAX;
     SFE_HIP(ctx, hipFuncSetAttribute((const void *)icp_sweep_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)sizeof(PrepShared)));
-    hipLaunchKernelGGL(icp_sweep_prep_kernel, dim3(n_prep), dim3(ICP_THREADS), sizeof(PrepShared), ps, *p,
-                       d_preps, (const float2 *)d_tgt, d_stgt, d_perm, d_snrm, d_mean, d_gkeys, d_tab);
+                                     (int)prep_smem));
+    hipLaunchKernelGGL(icp_sweep_prep_kernel, dim3(n_prep), dim3(ICP_THREADS), prep_smem, ps, *p,
+                       d_preps, (const float2 *)d_tgt, d_stgt, d_perm, d_snrm, d_mean, d_gkeys, d_tab, d_grid);
     SFE_LAUNCH_CHECK(ctx);
     if (side) {
         SFE_HIP(ctx, hipEventRecord(ctx->ev_prep, ps));
@@ -1740,7 +1894,11 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
     const int sw_budget_a = getenv("SFE_SW_BUDGET_A") ? atoi(getenv("SFE_SW_BUDGET_A")) : SW_BUDGET_A;
     // bit 0: witness / clearance cache (0: A/B without it); bits 8..15: walk trips per second-pass round
     // bit 1: the cap of a repeated round comes from the queries' upper bounds (0: grows 4x)
+    // bit 2: grid witnesses in the first iteration (0: A/B without them)
     const int sw_cache = ((getenv("SFE_SW_CACHE") ? atoi(getenv("SFE_SW_CACHE")) : 1) & 1) |
+                         ((getenv("SFE_SW_GRID") ? atoi(getenv("SFE_SW_GRID")) : 1) ? 4 : 0) |
+                         ((getenv("SFE_SW_GRID_SKIP") ? atoi(getenv("SFE_SW_GRID_SKIP")) : 1) ? 8 : 0) | // bit 3: witnessed queries skip round 0
+
                          ((getenv("SFE_SW_JUMP") ? atoi(getenv("SFE_SW_JUMP")) : 1) ? 2 : 0) |
                          // bits 16..23: margin (percent) of the next iteration's cap over this iteration's limit
                          (std::max(0, std::min(255, getenv("SFE_SW_MARGIN") ? atoi(getenv("SFE_SW_MARGIN")) : SW_CAP_MARGIN)) << 16) |
@@ -1769,7 +1927,7 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
     do {                                                                                                               \
         SFE_HIP(ctx, hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SMEM))); \
         hipLaunchKernelGGL(KERNEL, dim3(N), dim3(ICP_THREADS), (SMEM), ctx->stream, *p, d_jobs, (IDS),                 \
-                           (const float2 *)d_src, d_guess9, d_stgt, d_perm, d_snrm, d_mean, d_tab, d_qst, d_qwl, d_qssrc, \
+                           (const float2 *)d_src, d_guess9, d_stgt, d_perm, d_snrm, d_mean, d_tab, d_grid, d_qst, d_qwl, d_qssrc, \
                            d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof, d_dbg, sw_budget, sw_budget_a, sw_cache, \
                            (TCAP), (QCAP), pow2_floor(((SMEM)-ctl_bytes) / 8));                                        \
         SFE_LAUNCH_CHECK(ctx);                                                                                         \
