@@ -34,9 +34,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=2048,
+    ap.add_argument("--batch", type=int, default=4096,
                     help="keyframes per step per GPU (512 = one scan match per workgroup slot of the 256 CUs: every job's "
-                         "tail is exposed; with a few times more the dispatcher refills slots as jobs finish, -15 %% per job)")
+                         "tail is exposed; with several times more the dispatcher refills slots as jobs finish: -15 %% per job at 2048, "
+                         "-19 %% at 4096)")
     ap.add_argument("--cfar-frames", type=int, default=1024, help="frames per launch for the CFAR roofline leg")
     ap.add_argument("--cfar-launches", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -209,7 +210,7 @@ def farm_leg(icp_p, srcs, tgts, guesses, n_jobs):
     from sonar_slam_amd import synth
     from sonar_slam_amd.farm import IcpFarm
     rng = np.random.default_rng(0)
-    nd = len(srcs)
+    nd = min(len(srcs), 512)
     jobs = [(srcs[j % nd], tgts[j % nd], [np.asarray(guesses[j % nd], np.float64)
                                            @ synth.pose_matrix(*rng.normal(0, [0.05, 0.05, 0.005]))])
             for j in range(n_jobs)]

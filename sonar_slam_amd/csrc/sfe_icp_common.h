@@ -4,7 +4,9 @@
 #pragma once
 #include "sfe_internal.h"
 
+#ifndef ICP_THREADS
 #define ICP_THREADS 1024
+#endif
 #define ICP_WAVES (ICP_THREADS / 64)
 #define ICP_TCAP 8192 // target points resident in LDS (64 KiB as float2)
 #define ICP_PB 8      // max source points per lane per pass over the target
