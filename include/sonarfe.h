@@ -27,6 +27,12 @@
  *     SFE_ICP_*; the reference turns these into (what(), guess)); < 0 = hard error
  *     (bad argument, HIP failure) with text in sfe_last_error().  There is no CPU
  *     fallback anywhere: without a gfx950 device every compute entry point fails.
+ *   - A/B knobs read from the environment (measurement only: every setting returns identical results):
+ *     SFE_SW_STRIP_PTS, SFE_SW_BUDGET, SFE_SW_BUDGET_A, SFE_SW_RTRIPS, SFE_SW_MARGIN, SFE_SW_JUMP, SFE_SW_CACHE,
+ *     SFE_SW_GRID, SFE_SW_GRID_SKIP, SFE_SW_NO_LDSQ, SFE_SW_WIDE (strip-sweep ICP: strip population, search budgets,
+ *     cap margin, cap jump, iteration cache, first-iteration grid witnesses, results in LDS, one workgroup per CU),
+ *     SFE_SC_ROWS, SFE_EXTRACT_CHUNK (extraction: polar rows per scatter workgroup, frames per pass),
+ *     SFE_CFAR_NO_LDS_RING (sliding-sum CFAR without the LDS ring), SFE_ICP_DEBUG (watchdog report).
  *   - one sfe_ctx = one device + one HIP stream + its scratch; a ctx is not
  *     re-entrant (the reference's pybind calls hold the GIL and its ICP object is
  *     stateful, SURVEY 8b "Threading"); use one ctx per worker thread/process.
