@@ -16,6 +16,7 @@
 // sort of sfe_downsample.hip.
 #include "sfe_internal.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 
@@ -228,6 +229,245 @@ __global__ __launch_bounds__(1024) void cf_downsample_kernel(const float2 *__res
     }
 }
 
+// exclusive prefix sum of one int per thread over the 1024-thread workgroup (wave scan by shuffles, then the 16 wave
+// totals by the first wave): two barriers instead of the twenty of a Hillis-Steele scan through LDS.  s_tmp: >= 17 ints.
+__device__ __forceinline__ int cf_block_excl_scan(int v, int *s_tmp, int *total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d);
+        if (lane >= d)
+            incl += t;
+    }
+    __syncthreads(); // s_tmp may still be read from a previous call
+    if (lane == 63)
+        s_tmp[wave] = incl;
+    __syncthreads();
+    if (wave == 0) {
+        const int w = lane < 16 ? s_tmp[lane] : 0;
+        int wi = w;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            const int t = __shfl_up(wi, d);
+            if (lane >= d)
+                wi += t;
+        }
+        if (lane < 16)
+            s_tmp[lane] = wi - w;
+        if (lane == 15)
+            s_tmp[16] = wi;
+    }
+    __syncthreads();
+    *total = s_tmp[16];
+    return incl - v + s_tmp[wave];
+}
+
+// The same downsample for trees of <= 8 levels (16 path-key bits: every sonar fan at the shipped 0.5 m), with the stable
+// sort done as an LSD radix sort of the point INDICES in LDS instead of a bitonic sort of (key << 16 | index): the
+// bitonic network is 105 stages with a workgroup barrier each for 16384 slots; this is two passes of 8 key bits with
+// three barriers each.  A pass: every wave owns a contiguous range of the current order and goes through it 64
+// indices at a time; the lanes holding the same digit find each other with 8 ballots (match mask), so the wave's digit
+// counts and, in the second sweep, every index's rank inside its digit come out of popcounts in lane order -- stable
+// by construction (waves in range order, groups in order, lanes in order) without an atomic.  Between the sweeps one
+// scan over (digit, wave) turns the counts into output offsets.  The path key of a point is
+// computed once and kept in LDS next to the two uint16 index buffers; afterwards the same LDS (128 KiB for 16384
+// points: one frame per CU) holds the frame's points in sorted order for the per-leaf loops.  Leaves, medoids and outputs are exactly those of
+// cf_downsample_kernel.
+#define CF_RDX_BITS 8
+#define CF_RDX_DIGITS (1 << CF_RDX_BITS)
+__global__ __launch_bounds__(1024) void cf_downsample_radix_kernel(const float2 *__restrict__ p32, long long cap,
+                                                                   CfHeader *__restrict__ hdrs, float2 *__restrict__ ds_out,
+                                                                   int *__restrict__ seg_all, int n2cap,
+                                                                   unsigned *__restrict__ leaf_keys_all,
+                                                                   float2 *__restrict__ spts_all, int lds_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[]; // ids[2][n2cap], key[n2cap], cnt[16][256]: u16
+    __shared__ int s_scan[1024];
+    const int f = blockIdx.x, tid = threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const CfHeader h = hdrs[f];
+    const int n = h.n;
+    const float2 *pts = p32 + (size_t)f * cap;
+    float2 *out = ds_out + (size_t)f * cap;
+    if (n == 0)
+        return;
+    if (2 * h.levels > 16) { // deeper tree: the 64-bit bitonic instantiation launched behind takes the frame
+        if (tid == 0)
+            hdrs[f].n_seg = CF_NEEDS_WIDE;
+        return;
+    }
+    unsigned short *idA = reinterpret_cast<unsigned short *>(lds_raw);
+    unsigned short *idB = idA + n2cap;
+    unsigned short *skey = idB + n2cap; // path key of point i (<= 16 bits), computed once: the sort only moves indices
+    unsigned short *cnt = skey + n2cap; // [wave][digit]
+    for (int i = tid; i < n; i += 1024) {
+        idA[i] = (unsigned short)i;
+        skey[i] = (unsigned short)cf_path_key(pts[i], h);
+    }
+    // a wave's range of the current order: whole groups of 64
+    const int groups = (n + 63) >> 6, gpw = (groups + 15) >> 4;
+    const int g0 = min(wave * gpw, groups), g1 = min(g0 + gpw, groups);
+    const int passes = (2 * h.levels + CF_RDX_BITS - 1) / CF_RDX_BITS;
+    for (int pass = 0; pass < passes; ++pass) {
+        const int shift = CF_RDX_BITS * pass;
+        volatile unsigned short *wc = cnt + wave * CF_RDX_DIGITS; // (lanes read what another lane of the wave wrote)
+        for (int d = lane; d < CF_RDX_DIGITS; d += 64)
+            wc[d] = 0;
+        __syncthreads(); // idA complete (first pass: the identity; later: the previous scatter)
+        // lanes of the same digit: `same`; `valid` lanes only
+        auto match = [&](bool valid, unsigned d) {
+            unsigned long long same = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < CF_RDX_BITS; ++b) {
+                const bool bit = (d >> b) & 1u;
+                const unsigned long long bb = __ballot(bit);
+                same &= bit ? bb : ~bb;
+            }
+            return same;
+        };
+        for (int g = g0; g < g1; ++g) { // sweep 1: digit counts of this wave's range
+            const int pos = g * 64 + lane;
+            const bool valid = pos < n;
+            const unsigned d = valid ? ((unsigned)skey[idA[pos]] >> shift) & (CF_RDX_DIGITS - 1) : 0u;
+            const unsigned long long same = match(valid, d);
+            if (valid && lane == __ffsll((long long)same) - 1)
+                wc[d] += (unsigned short)__popcll(same); // one lane per digit, this wave's own row: no atomic
+        }
+        __syncthreads();
+        { // exclusive scan over (digit major, wave minor): thread t owns digits/waves L = 4t .. 4t+3
+            int v[4], s = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int L = 4 * tid + k, d = L >> 4, w = L & 15;
+                v[k] = cnt[w * CF_RDX_DIGITS + d];
+                s += v[k];
+            }
+            int tot_;
+            int run = cf_block_excl_scan(s, s_scan, &tot_);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int L = 4 * tid + k, d = L >> 4, w = L & 15;
+                cnt[w * CF_RDX_DIGITS + d] = (unsigned short)run;
+                run += v[k];
+            }
+        }
+        __syncthreads();
+        for (int g = g0; g < g1; ++g) { // sweep 2: scatter in lane order
+            const int pos = g * 64 + lane;
+            const bool valid = pos < n;
+            const unsigned id = valid ? idA[pos] : 0u;
+            const unsigned d = valid ? ((unsigned)skey[id] >> shift) & (CF_RDX_DIGITS - 1) : 0u;
+            const unsigned long long same = match(valid, d);
+            if (valid) {
+                const unsigned base = wc[d];
+                idB[base + (unsigned)__popcll(same & ((1ull << lane) - 1ull))] = (unsigned short)id;
+            }
+            // (the reads of wc[d] above and the update below are LDS operations of one wave: executed in order)
+            if (valid && lane == __ffsll((long long)same) - 1)
+                wc[d] += (unsigned short)__popcll(same);
+        }
+        __syncthreads();
+        unsigned short *t_ = idA;
+        idA = idB;
+        idB = t_;
+    }
+    __syncthreads();
+    // leaf starts: positions whose key differs from the previous one (block scan over per-thread chunks)
+    const int per = (n + 1023) / 1024;
+    const int b0 = tid * per, e0 = min(b0 + per, n);
+    int c = 0;
+    {
+        unsigned prev = (b0 > 0 && b0 < n) ? skey[idA[b0 - 1]] : 0u;
+        for (int r = b0; r < e0; ++r) {
+            const unsigned k = skey[idA[r]];
+            c += (r == 0) || (k != prev);
+            prev = k;
+        }
+    }
+    int n_seg;
+    const int seg_base = cf_block_excl_scan(c, s_scan, &n_seg);
+    int *s_seg = seg_all + (size_t)f * (cap + 1); // n_seg + 1 leaf starts (HBM scratch: written once, read once)
+    // The points in sorted order, gathered by all threads at once, so that a leaf's thread walks consecutive slots
+    // instead of one dependent HBM gather per point (twice).  They go into the LDS the sort no longer needs (the launch
+    // sizes it for a full frame) -- the per-leaf loops are chains of dependent loads, 100 cycles each from LDS against 500 from L2 --
+    // or, for larger frames, into HBM scratch.  (Measured on a 14.7 k-point frame before this: sort 125 k cycles,
+    // per-leaf loops 220 k.)
+    float2 *spts_g = spts_all + (size_t)f * cap;
+    const bool in_lds = (size_t)n * sizeof(float2) <= (size_t)lds_bytes;
+    {
+        int sidx = seg_base;
+        unsigned prev = (b0 > 0 && b0 < n) ? skey[idA[b0 - 1]] : 0u;
+        for (int r = b0; r < e0; ++r) {
+            const unsigned k = skey[idA[r]];
+            if ((r == 0) || (k != prev))
+                s_seg[sidx++] = r;
+            prev = k;
+        }
+    }
+    if (tid == 0)
+        s_seg[n_seg] = n;
+    __syncthreads(); // same workgroup: its own stores are visible to it after the barrier
+    if (leaf_keys_all) { // the leaves' paths (= Morton codes) while the keys are still there
+        for (int sg = tid; sg < n_seg; sg += 1024)
+            leaf_keys_all[(size_t)f * cap + sg] = (unsigned)skey[idA[s_seg[sg]]];
+    }
+    {
+        float2 v[16]; // n <= 16384
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int r = tid + k * 1024;
+            v[k] = r < n ? pts[idA[r]] : make_float2(0.0f, 0.0f);
+        }
+        __syncthreads(); // ids and keys have been read: their LDS is free
+        float2 *dst = in_lds ? reinterpret_cast<float2 *>(lds_raw) : spts_g;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int r = tid + k * 1024;
+            if (r < n)
+                dst[r] = v[k];
+        }
+    }
+    __syncthreads(); // same workgroup: its own stores (LDS or HBM) are visible to it after the barrier
+    // one thread per leaf: float centroid in original order, first point at minimum distance
+    auto medoids = [&](const auto *spts) {
+        for (int sg = tid; sg < n_seg; sg += 1024) {
+            const int r0 = s_seg[sg], r1 = s_seg[sg + 1];
+            float sx = 0.0f, sy = 0.0f;
+            for (int r = r0; r < r1; ++r) {
+                const float2 p = spts[r];
+                sx = __fadd_rn(sx, p.x);
+                sy = __fadd_rn(sy, p.y);
+            }
+            const float cntf = (float)(r1 - r0);
+            sx = __fdiv_rn(sx, cntf);
+            sy = __fdiv_rn(sy, cntf);
+            float best = 3.402823466e+38f;
+            int bi = r0;
+            for (int r = r0; r < r1; ++r) {
+                const float2 p = spts[r];
+                const float dx = __fadd_rn(p.x, -sx), dy = __fadd_rn(p.y, -sy);
+                // sqrtf, not __fsqrt_rn (see cf_downsample_kernel)
+                const float d = sqrtf(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+                if (d < best) {
+                    best = d;
+                    bi = r;
+                }
+            }
+            out[sg] = spts[bi];
+        }
+    };
+    if (in_lds)
+        medoids(reinterpret_cast<const float2 *>(lds_raw)); // (LDS address space: ds_read, not flat)
+    else
+        medoids(static_cast<const float2 *>(spts_g));
+    if (tid == 0) {
+        hdrs[f].n_seg = n_seg;
+        hdrs[f].n_out = n_seg;
+        hdrs[f].zlev = leaf_keys_all ? h.levels : -1;
+    }
+}
+
 // pcl.remove_outlier: keep a point iff more than min_points points (itself included) lie within the
 // radius; order preserved.  One workgroup per frame: counts (cloud tiled through LDS), scan, gather.
 //
@@ -425,14 +665,26 @@ extern "C" int sfe_cloud_filter_batch_dev(sfe_ctx *ctx, const double *d_pts, con
             n2 <<= 1;
         int *d_seg = (int *)sfe_scratch(ctx, 28, sizeof(int) * (per + 1) * (size_t)n_frames);
         d_lkeys = (unsigned *)sfe_scratch(ctx, 31, sizeof(unsigned) * per * (size_t)n_frames);
-        if (!d_seg || !d_lkeys)
+        float2 *d_spts = (float2 *)sfe_scratch(ctx, 40, sizeof(float2) * per * (size_t)n_frames);
+        if (!d_seg || !d_lkeys || !d_spts)
             return SFE_ERR_HIP;
         if (cap <= CF_SORT_CAP) {
-            // narrow keys first (every frame of a sonar fan qualifies), then the wide ones for what is left
-            SFE_HIP(ctx, hipFuncSetAttribute((const void *)cf_downsample_kernel<true, unsigned>,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * n2)));
-            hipLaunchKernelGGL((cf_downsample_kernel<true, unsigned>), dim3(n_frames), dim3(1024), 4 * n2, ctx->stream,
-                               d_p32, (long long)cap, d_hdr, d_ds, d_seg, (unsigned *)nullptr, 0LL, 0, d_lkeys);
+            // trees of <= 8 levels (every frame of a sonar fan at 0.5 m): radix sort of the indices; then the bitonic
+            // sort with 64-bit keys for the frames that marked themselves
+            static const bool bitonic32 = getenv("SFE_CF_BITONIC") != nullptr; // A/B: the round-1 narrow-key bitonic sort
+            if (bitonic32) {
+                SFE_HIP(ctx, hipFuncSetAttribute((const void *)cf_downsample_kernel<true, unsigned>,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * n2)));
+                hipLaunchKernelGGL((cf_downsample_kernel<true, unsigned>), dim3(n_frames), dim3(1024), 4 * n2, ctx->stream,
+                                   d_p32, (long long)cap, d_hdr, d_ds, d_seg, (unsigned *)nullptr, 0LL, 0, d_lkeys);
+            } else {
+                // indices + keys + counters for the sort, then (same bytes) every point of the frame in sorted order
+                const size_t rdx_smem = std::max<size_t>(3 * 2 * n2 + 2 * 16 * CF_RDX_DIGITS, sizeof(float2) * n2);
+                SFE_HIP(ctx, hipFuncSetAttribute((const void *)cf_downsample_radix_kernel,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)rdx_smem));
+                hipLaunchKernelGGL(cf_downsample_radix_kernel, dim3(n_frames), dim3(1024), rdx_smem, ctx->stream, d_p32,
+                                   (long long)cap, d_hdr, d_ds, d_seg, (int)n2, d_lkeys, d_spts, (int)rdx_smem);
+            }
             SFE_HIP(ctx, hipFuncSetAttribute((const void *)cf_downsample_kernel<true, unsigned long long>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(8 * n2)));
             hipLaunchKernelGGL((cf_downsample_kernel<true, unsigned long long>), dim3(n_frames), dim3(1024), 8 * n2,
