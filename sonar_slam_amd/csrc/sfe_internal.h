@@ -64,7 +64,7 @@ struct sfe_geom {
     // inverse map for sparse binary masks: for every polar pixel the canvas pixels that tap it with a
     // non-zero weight (CSR: offsets [polar_rows * polar_cols + 1], entries = linear canvas indices)
     int32_t *d_inv_off = nullptr;
-    uint32_t *d_inv_ent = nullptr;
+    uint2 *d_inv_ent = nullptr;     // {canvas index, its remap code}
 };
 
 int sfe_set_err(sfe_ctx *ctx, int code, const char *fmt, ...);

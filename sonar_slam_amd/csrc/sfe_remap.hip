@@ -357,12 +357,12 @@ __global__ __launch_bounds__(256) void extract_expand_kernel(const unsigned long
 // x SC_ROWS polar rows, which it stages (+1 halo row each side) as bits in LDS.
 #define SC_ROWS 64 // (16 measured 2 % slower: four times the workgroups, each with a handful of set pixels)
 #define SC_LIST 256 // set pixels a wave collects before it expands them
-#define SC_U 4      // candidates per lane whose dependent loads (inverse map -> code) overlap
+#define SC_U 4      // candidates per lane whose dependent loads (inverse map entry, taps) overlap; 8 measured 3 % slower
 __global__ __launch_bounds__(256) void extract_scatter_kernel(const uint32_t *__restrict__ bits,
                                                               const int32_t *__restrict__ nonbinary,
                                                               const uint32_t *__restrict__ code,
                                                               const int32_t *__restrict__ inv_off,
-                                                              const uint32_t *__restrict__ inv_ent,
+                                                              const uint2 *__restrict__ inv_ent,
                                                               unsigned long long *__restrict__ bitmap, int prows,
                                                               int pcols, unsigned rcp, int crows, int ccols, int wpr,
                                                               long long words_per_frame, int sc_rows)
@@ -432,12 +432,14 @@ __global__ __launch_bounds__(256) void extract_scatter_kernel(const uint32_t *__
                         else
                             hi = mid - 1;
                     }
-                    o[u] = k < total ? inv_ent[s_off[lo] + (uint32_t)(k - (int)s_excl[lo])] : 0xFFFFFFFFu;
+                    // one 8-byte entry = {canvas pixel, its remap code}: the code table itself (another scattered
+                    // 4-byte read per candidate, three cache lines per set pixel) is not touched here
+                    const uint2 e = k < total ? inv_ent[s_off[lo] + (uint32_t)(k - (int)s_excl[lo])]
+                                              : make_uint2(0xFFFFFFFFu, SFE_CODE_NONE);
+                    o[u] = e.x;
+                    cd[u] = e.y;
                     src_pi[u] = (int)s_list[j0 + lo]; // the set pixel this candidate was reached from
                 }
-#pragma unroll
-                for (int u = 0; u < SC_U; ++u)
-                    cd[u] = o[u] != 0xFFFFFFFFu ? code[o[u]] : SFE_CODE_NONE;
 #pragma unroll
                 for (int u = 0; u < SC_U; ++u) {
                     if (o[u] == 0xFFFFFFFFu)
@@ -674,7 +676,7 @@ int sfe_geom_create(sfe_ctx *ctx, const float *map_x, const float *map_y, int ca
     }
     // inverse map: polar pixel -> canvas pixels tapping it with a non-zero weight (same weights as the kernels)
     std::vector<int32_t> inv_off((size_t)polar_rows * polar_cols + 1, 0);
-    std::vector<uint32_t> inv_ent;
+    std::vector<uint2> inv_ent; // {canvas pixel, code[canvas pixel]}
     if (n < (1ull << 32)) {
         auto each_tap = [&](size_t o, auto &&fn) {
             const uint32_t cd = code[o];
@@ -699,12 +701,12 @@ int sfe_geom_create(sfe_ctx *ctx, const float *map_x, const float *map_y, int ca
         inv_ent.resize((size_t)inv_off.back());
         std::vector<int32_t> cur(inv_off.begin(), inv_off.end() - 1);
         for (size_t o = 0; o < n; ++o)
-            each_tap(o, [&](size_t pi) { inv_ent[(size_t)cur[pi]++] = (uint32_t)o; });
+            each_tap(o, [&](size_t pi) { inv_ent[(size_t)cur[pi]++] = make_uint2((uint32_t)o, code[o]); });
         if (hipMalloc((void **)&g->d_inv_off, inv_off.size() * 4) != hipSuccess ||
-            hipMalloc((void **)&g->d_inv_ent, std::max<size_t>(inv_ent.size(), 1) * 4) != hipSuccess ||
+            hipMalloc((void **)&g->d_inv_ent, std::max<size_t>(inv_ent.size(), 1) * sizeof(uint2)) != hipSuccess ||
             hipMemcpy(g->d_inv_off, inv_off.data(), inv_off.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
             (!inv_ent.empty() &&
-             hipMemcpy(g->d_inv_ent, inv_ent.data(), inv_ent.size() * 4, hipMemcpyHostToDevice) != hipSuccess)) {
+             hipMemcpy(g->d_inv_ent, inv_ent.data(), inv_ent.size() * sizeof(uint2), hipMemcpyHostToDevice) != hipSuccess)) {
             sfe_geom_destroy(g);
             return sfe_set_err(ctx, SFE_ERR_HIP, "inverse remap table upload failed");
         }
