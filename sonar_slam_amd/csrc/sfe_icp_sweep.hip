@@ -47,7 +47,7 @@
 #define SW_TCAP 8192   // target points resident in LDS
 #define SW_NS_MAX 64   // strips per target
 #define SW_PAD (SW_NS_MAX + 4) // sentinels: one in front, one behind every strip, two spare behind the last
-#define SW_GRID_MAX 8192 // cells of a target's witness grid (built in the prep kernel's LDS: 8 B per cell)
+#define SW_GRID_MAX 8192 // cells of a target's witness grid (built in the prep kernel's LDS: 4 B per cell)
 
 // Strip table of one target (built by the prep kernel, read by every job on that target).
 // Sorted-cloud layout (float2 positions): [0] NaN, then for every strip s its points ascending in x
@@ -343,51 +343,43 @@ __device__ __forceinline__ void sweep_knn_normals(const sfe_icp_params &P, const
 // Witness grid of one target (for the first iteration of every job on it, which has no previous neighbours to start
 // from): per cell the sorted position of a target point near the cell's centre -- any real point is a valid upper bound
 // of a query's neighbour distance; a near one is a good bound.  Built without searching: every point claims its own
-// cell (the point nearest to the centre wins: atomicMin on the distance bits, then the winner writes its position), then
+// cell (the point nearest to the centre wins: one atomicMin on (distance bits | position)), then
 // a few dilation sweeps hand witnesses to the empty cells around occupied ones (a cell takes, among its 8 neighbours'
 // witnesses, the one nearest to its own centre; in place, so a sweep carries them further than one cell).  Cells
 // that stay empty are far from every structure: queries there start the first iteration without a witness, as before.
 // (A per-cell nearest-neighbour search was tried first: the empty two thirds of a sonar fan's bounding box have their
 // nearest point metres away, and those searches cost 2 ms per 512 targets.)
-#define SW_GRID_SWEEPS 6
+#define SW_GRID_SWEEPS 4
 __device__ __forceinline__ void sweep_grid_witness(const StripTab &tab, const float2 *__restrict__ s_tgt,
-                                                   int *__restrict__ grid_out, int *grid, unsigned *gdist)
-{ // grid / gdist: LDS (SW_GRID_MAX entries each); grid_out: the target's slice of the HBM scratch
+                                                   int *__restrict__ grid_out, unsigned *grid)
+{ // grid: LDS, SW_GRID_MAX words: (distance to the cell centre, top 16 bits of its float pattern) << 16 | position
     const int gnx = tab.gnx, gny = tab.gny, ncell = gnx * gny, len = tab.len;
     const float cs = tab.ginv > 0.0f ? 1.0f / tab.ginv : 0.0f;
-    auto cell_of = [&](float2 q) {
-        float gxv = f_mul(f_add(q.x, -tab.gx0), tab.ginv), gyv = f_mul(f_add(q.y, -tab.gy0), tab.ginv);
-        gxv = fminf(fmaxf(gxv, 0.0f), (float)(gnx - 1));
-        gyv = fminf(fmaxf(gyv, 0.0f), (float)(gny - 1));
-        return (int)gyv * gnx + (int)gxv;
-    };
+    const float gx0 = tab.gx0, gy0 = tab.gy0, ginv = tab.ginv;
     auto centre_of = [&](int c) {
         const int iy = c / gnx, ix = c - iy * gnx;
-        return make_float2(tab.gx0 + ((float)ix + 0.5f) * cs, tab.gy0 + ((float)iy + 0.5f) * cs);
+        return make_float2(gx0 + ((float)ix + 0.5f) * cs, gy0 + ((float)iy + 0.5f) * cs);
     };
-    for (int c = threadIdx.x; c < ncell; c += ICP_THREADS) {
-        grid[c] = 0;
-        gdist[c] = 0x7F800000u;
+    for (int c = threadIdx.x; c < ncell; c += ICP_THREADS)
+        grid[c] = 0xFFFFFFFFu;
+    __syncthreads();
+    if (len < 65536) { // positions fit 16 bits (always for a target that lives in LDS)
+        for (int p = threadIdx.x + 1; p < len; p += ICP_THREADS) {
+            const float2 q = s_tgt[p];
+            if (!(fabsf(q.x) < INFINITY && fabsf(q.y) < INFINITY))
+                continue; // sentinels, non-finite points
+            float gxv = f_mul(f_add(q.x, -gx0), ginv), gyv = f_mul(f_add(q.y, -gy0), ginv);
+            gxv = fminf(fmaxf(gxv, 0.0f), (float)(gnx - 1));
+            gyv = fminf(fmaxf(gyv, 0.0f), (float)(gny - 1));
+            const int c = (int)gyv * gnx + (int)gxv;
+            const float2 m = centre_of(c);
+            // one atomic: the point nearest to the centre (to the 8 mantissa bits kept) wins, its position rides along
+            atomicMin(&grid[c], (__float_as_uint(dist2(m.x, m.y, q.x, q.y)) & 0xFFFF0000u) | (unsigned)p);
+        }
     }
     __syncthreads();
-    for (int p = threadIdx.x + 1; p < len; p += ICP_THREADS) {
-        const float2 q = s_tgt[p];
-        if (!(fabsf(q.x) < INFINITY && fabsf(q.y) < INFINITY))
-            continue; // sentinels, non-finite points
-        const int c = cell_of(q);
-        const float2 m = centre_of(c);
-        atomicMin(&gdist[c], __float_as_uint(dist2(m.x, m.y, q.x, q.y))); // d >= 0: bit order = value order
-    }
-    __syncthreads();
-    for (int p = threadIdx.x + 1; p < len; p += ICP_THREADS) {
-        const float2 q = s_tgt[p];
-        if (!(fabsf(q.x) < INFINITY && fabsf(q.y) < INFINITY))
-            continue;
-        const int c = cell_of(q);
-        const float2 m = centre_of(c);
-        if (gdist[c] == __float_as_uint(dist2(m.x, m.y, q.x, q.y)))
-            grid[c] = p; // equal distances: any of them
-    }
+    for (int c = threadIdx.x; c < ncell; c += ICP_THREADS)
+        grid[c] = (grid[c] == 0xFFFFFFFFu) ? 0u : (grid[c] & 0xFFFFu); // -> position, 0 = empty
     __syncthreads();
     for (int it = 0; it < SW_GRID_SWEEPS; ++it) {
         for (int c = threadIdx.x; c < ncell; c += ICP_THREADS) {
@@ -396,7 +388,7 @@ __device__ __forceinline__ void sweep_grid_witness(const StripTab &tab, const fl
             const int iy = c / gnx, ix = c - iy * gnx;
             const float2 m = centre_of(c);
             float best = INFINITY;
-            int bp = 0;
+            unsigned bp = 0;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int dx = (k < 3) ? k - 1 : (k == 3 ? -1 : (k == 4 ? 1 : k - 6));
@@ -404,7 +396,7 @@ __device__ __forceinline__ void sweep_grid_witness(const StripTab &tab, const fl
                 const int jx = ix + dx, jy = iy + dy;
                 if (jx < 0 || jx >= gnx || jy < 0 || jy >= gny)
                     continue;
-                const int w = grid[jy * gnx + jx];
+                const unsigned w = grid[jy * gnx + jx];
                 if (w != 0) {
                     const float2 t = s_tgt[w];
                     const float d = dist2(m.x, m.y, t.x, t.y);
@@ -420,7 +412,7 @@ __device__ __forceinline__ void sweep_grid_witness(const StripTab &tab, const fl
         __syncthreads();
     }
     for (int c = threadIdx.x; c < ncell; c += ICP_THREADS)
-        grid_out[c] = grid[c];
+        grid_out[c] = (int)grid[c];
 }
 
 // bitonic sort of n2 (power of two) 64-bit keys in HBM scratch by one workgroup (targets that do
@@ -663,7 +655,7 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_sweep_prep_kernel(sfe_icp_
                 sweep_knn_normals<ICP_KMAX>(P, S.tab, s_tgt, perm, nrm, nt);
         }
         if (grid_all)
-            sweep_grid_witness(S.tab, s_tgt, grid_all + (size_t)blockIdx.x * SW_GRID_MAX, s_grid, reinterpret_cast<unsigned *>(s_grid + SW_GRID_MAX));
+            sweep_grid_witness(S.tab, s_tgt, grid_all + (size_t)blockIdx.x * SW_GRID_MAX, reinterpret_cast<unsigned *>(s_grid));
     } else {
         bitonic_sort_global(keys, n2);
         for (int r = tid; r < nt; r += ICP_THREADS) {
@@ -684,7 +676,7 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_sweep_prep_kernel(sfe_icp_
                 sweep_knn_normals<ICP_KMAX>(P, S.tab, stgt, perm, nrm, nt);
         }
         if (grid_all)
-            sweep_grid_witness(S.tab, stgt, grid_all + (size_t)blockIdx.x * SW_GRID_MAX, s_grid, reinterpret_cast<unsigned *>(s_grid + SW_GRID_MAX));
+            sweep_grid_witness(S.tab, stgt, grid_all + (size_t)blockIdx.x * SW_GRID_MAX, reinterpret_cast<unsigned *>(s_grid));
     }
 }
 
@@ -1879,7 +1871,7 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
             return rc;
     }
 
-    const size_t prep_smem = ((sizeof(PrepShared) + 15) & ~(size_t)15) + 8 * (size_t)SW_GRID_MAX;
+    const size_t prep_smem = ((sizeof(PrepShared) + 15) & ~(size_t)15) + 4 * (size_t)SW_GRID_MAX;
     SFE_HIP(ctx, hipFuncSetAttribute((const void *)icp_sweep_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)prep_smem));
     hipLaunchKernelGGL(icp_sweep_prep_kernel, dim3(n_prep), dim3(ICP_THREADS), prep_smem, ps, *p,
