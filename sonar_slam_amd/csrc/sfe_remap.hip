@@ -365,16 +365,19 @@ __global__ __launch_bounds__(256) void extract_scatter_kernel(const uint32_t *__
                                                               const uint2 *__restrict__ inv_ent,
                                                               unsigned long long *__restrict__ bitmap, int prows,
                                                               int pcols, unsigned rcp, int crows, int ccols, int wpr,
-                                                              long long words_per_frame, int sc_rows)
+                                                              long long words_per_frame, int sc_rows, int xcd_contig)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_rows[]; // (sc_rows + 2) x pw words, then per-wave lists
-    // Workgroups are dealt to the 8 XCDs round robin in launch order (x fastest).  Row block -> XCD is
-    // arranged so that XCD k works on ONE contiguous eighth of the polar rows of every frame: its slice of the
-    // inverse map and of the code table (a ring of the canvas, ~3 MB of the 27 MB) then stays in that XCD's
-    // 4 MB L2 instead of every XCD streaming all of it from the fabric (-4 %).
+    // Workgroups are dealt to the 8 XCDs round robin in launch order (x fastest).  Mode 1 arranges row block -> XCD so
+    // that XCD k works on ONE contiguous eighth of the polar rows of every frame (its slice of the inverse map stays
+    // in that XCD's 4 MB L2: -4 % in round 1) -- but sonar detections sit in a few range bands, and the SQ counters of
+    // round 2 showed the XCDs 3x apart in work (VALU instructions per instance 1.08 M .. 4.65 M).  Mode 2 (default) rotates
+    // the row blocks from frame to frame instead, so that every XCD sees every band: -2.5 % against mode 1.
     int rb = blockIdx.x;
-    if ((gridDim.x & 7) == 0)
+    if ((gridDim.x & 7) == 0 && xcd_contig == 1)
         rb = (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
+    else if (xcd_contig == 2) // rotate the row blocks from frame to frame: every XCD sees every range band
+        rb = (int)((blockIdx.x + 5u * blockIdx.y) % gridDim.x);
     const int f = blockIdx.y, y0 = rb * sc_rows;
     if (nonbinary[f] != 0)
         return;
@@ -549,11 +552,12 @@ static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_f
             // sparse binary masks: inverse map (binary frames), dense pass only for frames with other values
             SFE_HIP(ctx, hipMemsetAsync(d_bm, 0, (size_t)nf * crows * wpr * sizeof(unsigned long long), ctx->stream));
             const int pw = g->polar_cols >> 5;
+            static const int sc_xcd = getenv("SFE_SC_XCD") ? atoi(getenv("SFE_SC_XCD")) : 2; // 2: rotate (measured -2.5 % against 1: contiguous eighths)
             static const int sc_rows = getenv("SFE_SC_ROWS") ? std::max(1, atoi(getenv("SFE_SC_ROWS"))) : SC_ROWS;
             hipLaunchKernelGGL(extract_scatter_kernel, dim3((unsigned)((g->polar_rows + sc_rows - 1) / sc_rows), nf),
                                dim3(256), ((size_t)(sc_rows + 2) * pw + 4 * (SC_LIST + 128)) * 4, ctx->stream, d_bits, d_nonbin,
                                (const uint32_t *)g->d_code, g->d_inv_off, g->d_inv_ent, d_bm, g->polar_rows,
-                               g->polar_cols, g->rcp, crows, g->cart_cols, wpr, wpf, sc_rows);
+                               g->polar_cols, g->rcp, crows, g->cart_cols, wpr, wpf, sc_rows, sc_xcd);
         }
         hipLaunchKernelGGL(extract_bits_kernel, dim3((unsigned)((scatter ? std::min(nf, 8) : nf) * tiles)), dim3(256),
                            g->lds_bytes, ctx->stream, m, d_bits, d_nonbin, (const uint32_t *)g->d_code, g->d_span,
