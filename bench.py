@@ -368,7 +368,7 @@ def main():
         ms_cfar_b = timed(kb.run_cfar, 5)
         ms_extract_b = timed(kb.run_extract, 5)
         ms_filter_b = 0.0 if args.no_filters else timed(kb.run_filter, 5)
-        extract_bytes = float(args.batch) * ROWS * COLS + 16.0 * float(res["counts"].sum())
+        extract_bytes = float(args.batch) * ROWS * COLS / (8.0 if kb.bit_masks else 1.0) + 16.0 * float(res["counts"].sum())
         ms_icp_b = timed(kb.run_icp, 2)
         iters_total = int(res["iters"].sum())
         icp_kernel = icp_utilisation(ctx, kb, ms_icp_b, iters_total, args.batch)
@@ -384,8 +384,16 @@ def main():
         def cfar_big():
             ctx._check(ctx.lib.sfe_cfar_u8_batch_dev(ctx.handle, big.ptr, nf, ROWS, COLS, 1, th, gh, 0, float(tau), 65,
                                                      bigm.ptr, None))
-        ms_cfar = timed(cfar_big, args.cfar_launches)
-        cfar_bytes = 2.0 * ROWS * COLS * nf                 # 1 B read + 1 B written per pixel
+        def cfar_big_bits():
+            ctx._check(ctx.lib.sfe_cfar_u8_bits_batch_dev(ctx.handle, big.ptr, nf, ROWS, COLS, 1, th, gh, 0, float(tau),
+                                                          65, bigm.ptr))
+        ms_cfar_bytes = timed(cfar_big, args.cfar_launches)
+        cfar_bytes_bytes = 2.0 * ROWS * COLS * nf           # 1 B read + 1 B written per pixel
+        # the kernel of the timed step stores the detections as bits (KeyframeBatch.bit_masks): 1 B read + 1 bit
+        # written per pixel -- fewer bytes than SURVEY 8d's figure, the fraction below is priced on what it moves
+        bits = kb.bit_masks
+        ms_cfar = timed(cfar_big_bits, args.cfar_launches) if bits else ms_cfar_bytes
+        cfar_bytes = (1.125 if bits else 2.0) * ROWS * COLS * nf
         cfar_gbs = cfar_bytes / (ms_cfar * 1e-3) / 1e9
         big.free()
         bigm.free()
@@ -394,7 +402,7 @@ def main():
         # process); only quoted when it was measured on the same launch shape
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "cfar_pmc.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "cfar_bits_pmc.json" if bits else "cfar_pmc.json")) as f:
                 pmc = json.load(f)
             if (pmc["frames_per_launch"], pmc["rows"], pmc["cols"]) == (nf, ROWS, COLS):
                 traffic = pmc["traffic_bytes_per_launch"]
@@ -416,10 +424,19 @@ def main():
                        "icp_converged_jobs": ok, "mean_icp_iters": iters_total / float(args.batch),
                        "mean_points_per_frame": float(res["counts"].mean()),
                        "max_points_per_frame": int(res["counts"].max()), "points_capacity": kb.cap},
-            "roofline": {"kernel": "cfar_u8_ring<20,5,SOCA>", "bound": "hbm", "achieved": cfar_gbs,
+            "roofline": {"kernel": "cfar_u8_ring<20,5,SOCA,%s>" % ("BITS" if bits else "bytes"), "bound": "hbm",
+                         "achieved": cfar_gbs,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cfar_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_note": "bytes/launch = 2*FETCH_SIZE + WRITE_SIZE from profiles/cfar_pmc.json",
-                         "bytes_per_launch": cfar_bytes, "ms_per_launch": ms_cfar, "frames_per_launch": nf},
+                         "traffic_note": "bytes/launch = 2*FETCH_SIZE + WRITE_SIZE from profiles/cfar%s_pmc.json"
+                                         % ("_bits" if bits else ""),
+                         "bytes_per_launch": cfar_bytes, "ms_per_launch": ms_cfar, "frames_per_launch": nf,
+                         "bytes_note": "1 B read + %s written per pixel" % ("1 bit" if bits else "1 B"),
+                         # the byte-mask form of the same kernel (what cfar.soca() of the drop-in returns, SURVEY 8d's
+                         # 2 B per pixel): slower per launch, higher fraction -- the bit store removes 7/8 of the
+                         # writes and leaves the kernel bound by its ~30 VALU instructions per 256-pixel row
+                         "byte_mask_kernel": {"ms_per_launch": ms_cfar_bytes, "bytes_per_launch": cfar_bytes_bytes,
+                                              "achieved": cfar_bytes_bytes / (ms_cfar_bytes * 1e-3) / 1e9,
+                                              "frac": cfar_bytes_bytes / (ms_cfar_bytes * 1e-3) / 1e9 / HBM_PEAK_GBS}},
             # the ICP kernels prune the search (exact strip-sweep NN): the work below is COUNTED by the kernel in a
             # separate profiled launch of the same batch (sfe_icp_get_profile), not derived from n_src * n_tgt
             "icp_kernel": icp_kernel,
@@ -428,11 +445,11 @@ def main():
                                            (("cfar", ms_cfar_b), ("extract", ms_extract_b), ("filters", ms_filter_b),
                                             ("icp", ms_icp_b))},
             # SURVEY 8d, on-the-fly form: R*B bytes of mask in + 16 B per extracted point out
-            "roofline_extract": {"kernel": "mask_pack + extract_scatter + extract_scan + extract_expand", "bound": "hbm",
+            "roofline_extract": {"kernel": ("" if kb.bit_masks else "mask_pack + ") + "extract_scatter + extract_scan + extract_expand", "bound": "hbm",
                                  "achieved": extract_bytes / (ms_extract_b * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": extract_bytes / (ms_extract_b * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                  "bytes_per_launch": extract_bytes, "ms_per_launch": ms_extract_b,
-                                 "note": "algorithmic bytes = R*B mask bytes + 16 B per point per frame; the kernels are "
+                                 "note": "algorithmic bytes = the R*B detections (bits when CFAR hands over bit streams) + 16 B per point per frame; the kernels are "
                                          "bound by gathers into the inverse remap tables (29 MB, scattered 4-byte reads), not "
                                          "by streaming"},
         }

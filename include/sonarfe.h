@@ -108,6 +108,16 @@ int sfe_cfar_f32(sfe_ctx *ctx, const float *img, int rows, int cols, int alg, in
 int sfe_cfar_u8_batch_dev(sfe_ctx *ctx, const uint8_t *d_img, int n_frames, int rows, int cols,
                           int alg, int train_hs, int guard_hs, int k, double tau,
                           int intensity_thr, uint8_t *d_mask, float *d_thr);
+/* The same detections as a bit stream, the form the batched extraction consumes: per frame
+ * SFE_BITS_WORDS(rows*cols) uint32 words, bit (iy*cols + ix) of the stream (LSB first) = mask[iy][ix],
+ * the last word of a frame is padding and written as 0.  For the windows of the register-ring kernel and
+ * cols % 32 == 0 the kernel stores the bits itself (the 0/1 byte mask of CFAR.detect, feature_extraction.py:223,
+ * never exists in memory); every other call runs the byte kernels into scratch and packs them.
+ * d_bits: n_frames * SFE_BITS_WORDS(rows*cols) words, 4-byte aligned. */
+#define SFE_BITS_WORDS(px) (((px) + 31) / 32 + 1)
+int sfe_cfar_u8_bits_batch_dev(sfe_ctx *ctx, const uint8_t *d_img, int n_frames, int rows, int cols,
+                               int alg, int train_hs, int guard_hs, int k, double tau,
+                               int intensity_thr, uint32_t *d_bits);
 /* tuning / A-B knob for the ring kernel: output rows per thread (0 = default) and
  * variant (0 = auto, 1 = force generic kernel, 2 = force ring kernel with prefetch depth 4, 3 = ring kernel depth 13) */
 int sfe_cfar_set_tuning(sfe_ctx *ctx, int tile_rows, int variant);
@@ -143,6 +153,9 @@ int sfe_extract_set_tuning(sfe_ctx *ctx, int variant);
  * (count is the true number even if it exceeds cap; only the first cap points are stored) */
 int sfe_extract_points_batch_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_frames,
                                  int64_t cap, double *d_pts, int32_t *d_counts);
+/* the same from the bit streams of sfe_cfar_u8_bits_batch_dev (polar_cols % 32 == 0 required) */
+int sfe_extract_points_bits_batch_dev(sfe_ctx *ctx, sfe_geom *g, const uint32_t *d_bits, int n_frames,
+                                      int64_t cap, double *d_pts, int32_t *d_counts);
 
 /* ---- point clouds: replaces bruce_slam.pcl (pcl.cpp:54-74,161-212) ------ */
 typedef struct sfe_icp_params {

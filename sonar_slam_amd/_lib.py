@@ -83,6 +83,8 @@ SIGNATURES = {
                                C.c_double, _u8p, _f32p]),
     "sfe_cfar_u8_batch_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_double, C.c_int, _vp, _vp]),
+    "sfe_cfar_u8_bits_batch_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                             C.c_int, C.c_int, C.c_double, C.c_int, _vp]),
     "sfe_cfar_set_tuning": (C.c_int, [_vp, C.c_int, C.c_int]),
     "sfe_geom_create": (C.c_int, [_vp, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_double, C.c_double, C.POINTER(_vp)]),
@@ -94,6 +96,7 @@ SIGNATURES = {
     "sfe_extract_points": (C.c_int, [_vp, _vp, _u8p, C.c_int64, _i64p, _f64p, _i64p]),
     "sfe_extract_set_tuning": (C.c_int, [_vp, C.c_int]),
     "sfe_extract_points_batch_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int64, _vp, _vp]),
+    "sfe_extract_points_bits_batch_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int64, _vp, _vp]),
     "sfe_match": (C.c_int, [_vp, _f32p, C.c_int, _f32p, C.c_int, C.c_float, _i32p, _f32p]),
     "sfe_match_knn": (C.c_int, [_vp, _f32p, C.c_int, _f32p, C.c_int, C.c_int, C.c_float, _i32p, _f32p]),
     "sfe_knn_density": (C.c_int, [_vp, _f32p, C.c_int, C.c_int, _f32p]),

@@ -76,11 +76,18 @@ typedef __amdgpu_buffer_rsrc_t sfe_rsrc_t; // 128-bit buffer resource (SGPRs)
 // of R-row groups (the last tile is shifted up so it ends at the last row) and the last 64-lane
 // chunk is shifted left so it ends at the last beam.  Overlapped outputs are recomputed with
 // identical values, so the body has no branches, no exec masking and no tail code.
-template <int T, int G, int ALG, int D>
+//
+// BITS: the detections leave the kernel bit-packed (bit iy*cols+ix of the frame's bit stream, LSB first: the
+// layout extract_scatter_kernel reads, sfe_remap.hip) instead of as 0/1 bytes: a lane folds its 4 decisions
+// into a nibble (one v_dot4), 8 lanes OR their nibbles into a 32-bit word over three DPP steps and one lane
+// of the 8 stores it -- the other 56 lanes aim past the end of the buffer, where the hardware drops the
+// store.  Needs cols % 32 == 0 (a row is a whole number of words and every 64-lane chunk starts on one).
+template <int T, int G, int ALG, int D, bool BITS>
 __global__ __launch_bounds__(256, 3) void cfar_u8_ring(const uint8_t *__restrict__ img,
                                                     uint8_t *__restrict__ mask, int rows, int cols,
                                                     int n_frames, int groups_per_tile,
-                                                    int tiles_per_frame, int chunks_per_row, CfarLut lut)
+                                                    int tiles_per_frame, int chunks_per_row,
+                                                    long long out_frame_bytes, CfarLut lut)
 {
     constexpr int H = T + G;
     constexpr int R = 2 * H + 2;
@@ -116,8 +123,13 @@ __global__ __launch_bounds__(256, 3) void cfar_u8_ring(const uint8_t *__restrict
     const size_t frame_bytes = (size_t)rows * cols;
     const sfe_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(img + (size_t)f * frame_bytes),
                                                              0, (int)frame_bytes, 0x00020000);
-    const sfe_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(mask + (size_t)f * frame_bytes, 0,
-                                                             (int)frame_bytes, 0x00020000);
+    const sfe_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(mask + (size_t)f * (size_t)out_frame_bytes, 0,
+                                                             (int)out_frame_bytes, 0x00020000);
+    // BITS: byte offset of this lane's word inside its row (lanes 0, 8, .. store), shift of its nibble
+    const uint32_t boff = (lane & 7) == 0 ? (uint32_t)(cx0 + lane) >> 1 : 0x80000000u;
+    const uint32_t nsh = (uint32_t)(lane & 7) * 4u;
+    if (BITS && wvf == wpf - 1 && lane == 0) // the pad word behind the last row (read by the extraction's taps)
+        __builtin_amdgcn_raw_buffer_store_b32(0u, dst, (uint32_t)(frame_bytes >> 3), 0, 0);
 
     // Rows outside the image are clamped instead of zero-filled: a window that touches them
     // belongs to a border row whose output is forced to 0 anyway, and prefix differences of
@@ -184,7 +196,15 @@ __global__ __launch_bounds__(256, 3) void cfar_u8_ring(const uint8_t *__restrict
             const int pr = rbase + rs * r; // image row of this output
             const uint32_t keep = (pr >= H && pr < rows - H) ? 0xffffffffu : 0u; // cfar.cpp:16,36
             o &= keep;
-            __builtin_amdgcn_raw_buffer_store_b32(o, dst, voff, pr * cols, 0);
+            if (BITS) {
+                uint32_t v = __builtin_amdgcn_udot4(o, 0x08040201u, 0u, false) << nsh;
+                v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
+                v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
+                v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false); // row_half_mirror
+                __builtin_amdgcn_raw_buffer_store_b32(v, dst, boff, pr * (cols >> 3), 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b32(o, dst, voff, pr * cols, 0);
+            }
 
             const uint32_t x = pre[(j + R - 1) % D]; // row r+H+1
             pre[(j + R - 1) % D] = ld(r + H + 1 + D);
@@ -687,22 +707,22 @@ static bool build_lut(int alg, int T, double tau, int intensity_thr, CfarLut *lu
     return true;
 }
 
-template <int T, int G, int D>
+template <int T, int G, int D, bool BITS>
 static void launch_ring(sfe_ctx *ctx, int alg, const uint8_t *d_img, uint8_t *d_mask, int rows, int cols,
-                        int n_frames, int groups, int tiles, const CfarLut &lut)
+                        int n_frames, int groups, int tiles, long long out_frame_bytes, const CfarLut &lut)
 {
     const int chunks = ((cols >> 2) + 63) / 64;
     const long long bpf = ((long long)tiles * chunks + 3) / 4;             // workgroups per frame
     const unsigned blocks = (unsigned)((((long long)n_frames + 7) / 8) * 8 * bpf); // frames padded to the 8 XCDs
     if (alg == SFE_CFAR_SOCA)
-        hipLaunchKernelGGL((cfar_u8_ring<T, G, SFE_CFAR_SOCA, D>), dim3(blocks), dim3(256), 0, ctx->stream, d_img,
-                           d_mask, rows, cols, n_frames, groups, tiles, chunks, lut);
+        hipLaunchKernelGGL((cfar_u8_ring<T, G, SFE_CFAR_SOCA, D, BITS>), dim3(blocks), dim3(256), 0, ctx->stream,
+                           d_img, d_mask, rows, cols, n_frames, groups, tiles, chunks, out_frame_bytes, lut);
     else if (alg == SFE_CFAR_GOCA)
-        hipLaunchKernelGGL((cfar_u8_ring<T, G, SFE_CFAR_GOCA, D>), dim3(blocks), dim3(256), 0, ctx->stream, d_img,
-                           d_mask, rows, cols, n_frames, groups, tiles, chunks, lut);
+        hipLaunchKernelGGL((cfar_u8_ring<T, G, SFE_CFAR_GOCA, D, BITS>), dim3(blocks), dim3(256), 0, ctx->stream,
+                           d_img, d_mask, rows, cols, n_frames, groups, tiles, chunks, out_frame_bytes, lut);
     else
-        hipLaunchKernelGGL((cfar_u8_ring<T, G, SFE_CFAR_CA, D>), dim3(blocks), dim3(256), 0, ctx->stream, d_img,
-                           d_mask, rows, cols, n_frames, groups, tiles, chunks, lut);
+        hipLaunchKernelGGL((cfar_u8_ring<T, G, SFE_CFAR_CA, D, BITS>), dim3(blocks), dim3(256), 0, ctx->stream,
+                           d_img, d_mask, rows, cols, n_frames, groups, tiles, chunks, out_frame_bytes, lut);
 }
 
 // R-row groups per tile.  Measured on MI355X (tools/cfar_sweep.py, 1024 frames of 1024x512, XCD-aware
@@ -736,9 +756,14 @@ static int launch_os_hist(sfe_ctx *ctx, const uint8_t *d_img, int n_frames, int 
     return 0;
 }
 
+// d_bits != nullptr: the ring kernel writes the bit-packed detections there (BITS variant) and d_mask is not used;
+// the caller has checked that the ring kernel applies (ring_bits_applicable).
 static int cfar_u8_dev(sfe_ctx *ctx, const uint8_t *d_img, int n_frames, int rows, int cols, int alg,
-                       int T, int G, int k, double tau, int intensity_thr, uint8_t *d_mask, float *d_thr)
+                       int T, int G, int k, double tau, int intensity_thr, uint8_t *d_mask, float *d_thr,
+                       uint32_t *d_bits = nullptr)
 {
+    if (d_bits)
+        d_mask = reinterpret_cast<uint8_t *>(d_bits);
     SFE_ARG(ctx, d_img && d_mask);
     SFE_ARG(ctx, n_frames >= 0 && rows >= 0 && cols >= 0);
     SFE_ARG(ctx, alg >= SFE_CFAR_CA && alg <= SFE_CFAR_OS);
@@ -774,16 +799,29 @@ static int cfar_u8_dev(sfe_ctx *ctx, const uint8_t *d_img, int n_frames, int row
         if (T == 20)
             groups = ctx->cfar_tile_rows > 0 ? groups : default_groups(ctx, rows, cols, n_frames, R);
         const int tiles = (rows + groups * R - 1) / (groups * R);
-        if (T == 20 && ctx->cfar_variant == 3)
-            launch_ring<20, 5, 13>(ctx, alg, d_img, d_mask, rows, cols, n_frames, groups, tiles, lut);
+        const long long fb = (long long)rows * cols;
+        if (d_bits) {
+            const long long bb = (fb / 32 + 1) * 4; // bytes per frame of the bit stream: one pad word (sfe_remap.hip)
+            if (T == 20)
+                launch_ring<20, 5, 4, true>(ctx, alg, d_img, d_mask, rows, cols, n_frames, groups, tiles, bb, lut);
+            else if (T == 16)
+                launch_ring<16, 4, 6, true>(ctx, alg, d_img, d_mask, rows, cols, n_frames, groups, tiles, bb, lut);
+            else if (T == 10)
+                launch_ring<10, 2, 13, true>(ctx, alg, d_img, d_mask, rows, cols, n_frames, groups, tiles, bb, lut);
+            else
+                launch_ring<8, 1, 5, true>(ctx, alg, d_img, d_mask, rows, cols, n_frames, groups, tiles, bb, lut);
+        } else if (T == 20 && ctx->cfar_variant == 3)
+            launch_ring<20, 5, 13, false>(ctx, alg, d_img, d_mask, rows, cols, n_frames, groups, tiles, fb, lut);
         else if (T == 20)
-            launch_ring<20, 5, 4>(ctx, alg, d_img, d_mask, rows, cols, n_frames, groups, tiles, lut);
+            launch_ring<20, 5, 4, false>(ctx, alg, d_img, d_mask, rows, cols, n_frames, groups, tiles, fb, lut);
         else if (T == 16)
-            launch_ring<16, 4, 6>(ctx, alg, d_img, d_mask, rows, cols, n_frames, groups, tiles, lut);
+            launch_ring<16, 4, 6, false>(ctx, alg, d_img, d_mask, rows, cols, n_frames, groups, tiles, fb, lut);
         else if (T == 10)
-            launch_ring<10, 2, 13>(ctx, alg, d_img, d_mask, rows, cols, n_frames, groups, tiles, lut);
+            launch_ring<10, 2, 13, false>(ctx, alg, d_img, d_mask, rows, cols, n_frames, groups, tiles, fb, lut);
         else
-            launch_ring<8, 1, 5>(ctx, alg, d_img, d_mask, rows, cols, n_frames, groups, tiles, lut);
+            launch_ring<8, 1, 5, false>(ctx, alg, d_img, d_mask, rows, cols, n_frames, groups, tiles, fb, lut);
+    } else if (d_bits) {
+        return sfe_set_err(ctx, SFE_ERR_ARG, "internal: bit-packed CFAR output asked of a non-ring window");
     } else if (slide) {
         const float *d_tab = nullptr;
         if (d_thr) { // thr = (float)(tau * s / T) per integer window sum s, with the reference's double expression
@@ -866,7 +904,47 @@ static int cfar_u8_dev(sfe_ctx *ctx, const uint8_t *d_img, int n_frames, int row
     return 0;
 }
 
+// the call the BITS ring kernel takes: a ring window, whole 32-bit words per row, no threshold map
+static bool ring_bits_applicable(const sfe_ctx *ctx, const uint8_t *d_img, int rows, int cols, int alg, int T, int G)
+{
+    const bool ring_window = (T == 20 && G == 5) || (T == 16 && G == 4) || (T == 10 && G == 2) || (T == 8 && G == 1);
+    static const bool off = getenv("SFE_CFAR_NO_BITS") != nullptr; // A/B: byte kernel + mask_pack
+    return !off && ring_window && alg != SFE_CFAR_OS && cols % 32 == 0 && cols >= 256 && rows >= 2 * (T + G) + 2 &&
+           (size_t)rows * cols < (1u << 30) && ctx->cfar_variant == 0 && reinterpret_cast<uintptr_t>(d_img) % 4 == 0;
+}
+
 extern "C" {
+
+int sfe_cfar_u8_bits_batch_dev(sfe_ctx *ctx, const uint8_t *d_img, int n_frames, int rows, int cols, int alg,
+                               int train_hs, int guard_hs, int k, double tau, int intensity_thr, uint32_t *d_bits)
+{
+    if (int rc = sfe_use(ctx))
+        return rc;
+    SFE_ARG(ctx, d_img && d_bits && n_frames >= 0 && rows >= 0 && cols >= 0);
+    SFE_ARG(ctx, reinterpret_cast<uintptr_t>(d_bits) % 4 == 0);
+    const long long px = (long long)rows * cols, wpf = (px + 31) / 32 + 1;
+    if (n_frames == 0 || px == 0)
+        return 0;
+    CfarLut probe;
+    if (ring_bits_applicable(ctx, d_img, rows, cols, alg, train_hs, guard_hs) && train_hs >= 1 &&
+        build_lut(alg, train_hs, tau, intensity_thr, &probe))
+        return cfar_u8_dev(ctx, d_img, n_frames, rows, cols, alg, train_hs, guard_hs, k, tau, intensity_thr, nullptr,
+                           nullptr, d_bits);
+    // every other window: the byte kernels into a scratch mask, a bounded number of frames at a time, then packed
+    const int chunk = (int)std::max<long long>(1, std::min<long long>(n_frames, (256ll << 20) / px));
+    uint8_t *d_tmp = (uint8_t *)sfe_scratch(ctx, 41, (size_t)chunk * px);
+    if (!d_tmp)
+        return SFE_ERR_HIP;
+    for (int f0 = 0; f0 < n_frames; f0 += chunk) {
+        const int nf = std::min(chunk, n_frames - f0);
+        if (int rc = cfar_u8_dev(ctx, d_img + (size_t)f0 * px, nf, rows, cols, alg, train_hs, guard_hs, k, tau,
+                                 intensity_thr, d_tmp, nullptr))
+            return rc;
+        if (int rc = sfe_mask_pack(ctx, d_tmp, nf, px, d_bits + (size_t)f0 * wpf, nullptr))
+            return rc;
+    }
+    return 0;
+}
 
 int sfe_cfar_set_tuning(sfe_ctx *ctx, int tile_rows, int variant)
 {

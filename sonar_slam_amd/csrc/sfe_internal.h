@@ -68,6 +68,8 @@ struct sfe_geom {
 };
 
 int sfe_set_err(sfe_ctx *ctx, int code, const char *fmt, ...);
+int sfe_mask_pack(sfe_ctx *ctx, const uint8_t *d_mask, int n_frames, long long px, uint32_t *d_bits,
+                  int32_t *d_nonbin); // sfe_remap.hip: byte mask -> bit stream
 void *sfe_scratch(sfe_ctx *ctx, int slot, size_t bytes);  // grow-only device scratch; nullptr on failure
 // Pinned staging: sfe_pinned_begin hands out a host block of >= bytes (waiting, if need be, for the copy that last
 // read it -- two launches ago); the caller fills it, enqueues its hipMemcpyAsync calls on `s` and then calls

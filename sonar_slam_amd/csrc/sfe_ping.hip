@@ -46,6 +46,9 @@ extern "C" int sfe_feature_extract_ping(sfe_ctx *ctx, sfe_geom *g, const uint8_t
     SFE_ARG(ctx, g && img && cloud_out && n_out && g->ctx == ctx && cap > 0 && cap <= 65536);
     const size_t np = (size_t)g->polar_rows * g->polar_cols, nc = (size_t)g->cart_rows * g->cart_cols;
     uint8_t *d_img = (uint8_t *)sfe_scratch(ctx, 32, np);
+    // detections: a bit stream when the rows are whole words (SFE_BITS_WORDS(np) words fit into np bytes for
+    // np >= 8), the 0/1 byte mask otherwise
+    const bool bits = (g->polar_cols & 31) == 0 && np >= 64;
     uint8_t *d_mask = (uint8_t *)sfe_scratch(ctx, 33, np);
     double *d_pts = (double *)sfe_scratch(ctx, 34, (size_t)cap * 16);
     // [0] raw point count, [1] filtered count, then the filtered float32 cloud: one block, one copy back
@@ -57,13 +60,17 @@ extern "C" int sfe_feature_extract_ping(sfe_ctx *ctx, sfe_geom *g, const uint8_t
         return SFE_ERR_HIP;
     memcpy(h_img, img, np);
     SFE_HIP(ctx, hipMemcpyAsync(d_img, h_img, np, hipMemcpyHostToDevice, ctx->stream));
-    if (int rc = sfe_cfar_u8_batch_dev(ctx, d_img, 1, g->polar_rows, g->polar_cols, alg, train_hs, guard_hs, k, tau,
-                                       intensity_thr, d_mask, nullptr))
+    if (int rc = bits ? sfe_cfar_u8_bits_batch_dev(ctx, d_img, 1, g->polar_rows, g->polar_cols, alg, train_hs, guard_hs,
+                                                   k, tau, intensity_thr, reinterpret_cast<uint32_t *>(d_mask))
+                      : sfe_cfar_u8_batch_dev(ctx, d_img, 1, g->polar_rows, g->polar_cols, alg, train_hs, guard_hs, k,
+                                              tau, intensity_thr, d_mask, nullptr))
         return rc;
     if (vis_out)
         if (int rc = sfe_remap_u8_dev(ctx, g, d_img, d_vis))
             return rc;
-    if (int rc = sfe_extract_points_batch_dev(ctx, g, d_mask, 1, cap, d_pts, d_res))
+    if (int rc = bits ? sfe_extract_points_bits_batch_dev(ctx, g, reinterpret_cast<const uint32_t *>(d_mask), 1, cap,
+                                                          d_pts, d_res)
+                      : sfe_extract_points_batch_dev(ctx, g, d_mask, 1, cap, d_pts, d_res))
         return rc;
     float *d_cloud = reinterpret_cast<float *>(d_res + 4);
     if (int rc = sfe_cloud_filter_batch_dev(ctx, d_pts, d_res, 1, cap, resolution, radius, min_points, d_cloud, d_res + 1))

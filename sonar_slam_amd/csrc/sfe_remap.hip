@@ -520,8 +520,29 @@ __global__ __launch_bounds__(256) void extract_scatter_kernel(const uint32_t *__
 }
 
 // ---------------------------------------------------------------------------------------------
+// byte mask -> bit stream (mask_pack_kernel) for n_frames frames of px pixels; d_nonbin (optional, n_frames ints,
+// zeroed by the caller) is set for frames holding a byte > 1
+int sfe_mask_pack(sfe_ctx *ctx, const uint8_t *d_mask, int n_frames, long long px, uint32_t *d_bits, int32_t *d_nonbin)
+{
+    const long long wpf = (px + 31) / 32 + 1;
+    if (!d_nonbin) {
+        d_nonbin = (int32_t *)sfe_scratch(ctx, 11, (size_t)std::max(n_frames, 1024) * 4);
+        if (!d_nonbin)
+            return SFE_ERR_HIP;
+    }
+    for (int f0 = 0; f0 < n_frames; f0 += 32768) { // gridDim.y <= 65535
+        const int nf = std::min(32768, n_frames - f0);
+        hipLaunchKernelGGL(mask_pack_kernel, dim3((unsigned)((wpf + 255) / 256), nf), dim3(256), 0, ctx->stream,
+                           d_mask + (size_t)f0 * px, d_bits + (size_t)f0 * wpf, d_nonbin, px, wpf);
+    }
+    SFE_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+// d_bits_in != nullptr: the frames arrive as bit streams (sfe_cfar_u8_bits_batch_dev: binary by construction) and
+// d_mask is not read
 static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_frames, long long cap,
-                       long long *d_rc, double *d_pts, int32_t *d_counts)
+                       long long *d_rc, double *d_pts, int32_t *d_counts, const uint32_t *d_bits_in = nullptr)
 {
     const int crows = g->cart_rows, wpr = g->words_per_row;
     static const int chunk = getenv("SFE_EXTRACT_CHUNK") ? std::max(1, atoi(getenv("SFE_EXTRACT_CHUNK"))) : 1024; // frames per pass: bounds the bitmap scratch (0.25 MB per frame), fewer passes = fewer launches
@@ -533,20 +554,22 @@ static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_f
         return SFE_ERR_HIP;
     const long long px = (long long)g->polar_rows * g->polar_cols;
     const long long wpf = (px + 31) / 32 + 1; // +1 pad word: a tap's word index may be one past the last row
-    uint32_t *d_bits = (uint32_t *)sfe_scratch(ctx, 10, (size_t)chunk * wpf * 4);
+    uint32_t *d_bits_own = d_bits_in ? nullptr : (uint32_t *)sfe_scratch(ctx, 10, (size_t)chunk * wpf * 4);
     int32_t *d_nonbin = (int32_t *)sfe_scratch(ctx, 11, (size_t)chunk * 4);
-    if (!d_bits || !d_nonbin)
+    if ((!d_bits_in && !d_bits_own) || !d_nonbin)
         return SFE_ERR_HIP;
     SFE_HIP(ctx, hipFuncSetAttribute((const void *)extract_bits_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      g->lds_bytes));
     for (int f0 = 0; f0 < n_frames; f0 += chunk) {
         const int nf = std::min(chunk, n_frames - f0);
-        const uint8_t *m = d_mask + (size_t)f0 * g->polar_rows * g->polar_cols;
+        const uint8_t *m = d_bits_in ? nullptr : d_mask + (size_t)f0 * g->polar_rows * g->polar_cols;
+        const uint32_t *d_bits = d_bits_in ? d_bits_in + (size_t)f0 * wpf : d_bits_own;
         const int word_groups = g->word_groups;
         const int tiles = g->tiles_per_frame;
         SFE_HIP(ctx, hipMemsetAsync(d_nonbin, 0, (size_t)nf * 4, ctx->stream));
-        hipLaunchKernelGGL(mask_pack_kernel, dim3((unsigned)((wpf + 255) / 256), nf), dim3(256), 0, ctx->stream, m,
-                           d_bits, d_nonbin, px, wpf);
+        if (!d_bits_in)
+            hipLaunchKernelGGL(mask_pack_kernel, dim3((unsigned)((wpf + 255) / 256), nf), dim3(256), 0, ctx->stream, m,
+                               d_bits_own, d_nonbin, px, wpf);
         const bool scatter = g->d_inv_off != nullptr && (g->polar_cols & 31) == 0 && ctx->extract_variant == 0;
         if (scatter) {
             // sparse binary masks: inverse map (binary frames), dense pass only for frames with other values
@@ -559,6 +582,7 @@ static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_f
                                (const uint32_t *)g->d_code, g->d_inv_off, g->d_inv_ent, d_bm, g->polar_rows,
                                g->polar_cols, g->rcp, crows, g->cart_cols, wpr, wpf, sc_rows, sc_xcd);
         }
+        if (!(scatter && d_bits_in)) // bit streams are binary: nothing is left for the general pass
         hipLaunchKernelGGL(extract_bits_kernel, dim3((unsigned)((scatter ? std::min(nf, 8) : nf) * tiles)), dim3(256),
                            g->lds_bytes, ctx->stream, m, d_bits, d_nonbin, (const uint32_t *)g->d_code, g->d_span,
                            g->d_tile_rows, d_bm, g->polar_rows, g->polar_cols, g->rcp, crows, g->cart_cols, wpr, word_groups,
@@ -792,6 +816,19 @@ int sfe_extract_points_batch_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mas
     if (n_frames == 0)
         return 0;
     return extract_dev(ctx, g, d_mask, n_frames, cap, nullptr, d_pts, d_counts);
+}
+
+int sfe_extract_points_bits_batch_dev(sfe_ctx *ctx, sfe_geom *g, const uint32_t *d_bits, int n_frames, int64_t cap,
+                                      double *d_pts, int32_t *d_counts)
+{
+    if (int rc = sfe_use(ctx))
+        return rc;
+    SFE_ARG(ctx, g && d_bits && d_counts && g->ctx == ctx && n_frames >= 0 && cap >= 0);
+    if ((g->polar_cols & 31) != 0)
+        return sfe_set_err(ctx, SFE_ERR_ARG, "bit-stream extraction needs polar_cols %% 32 == 0 (got %d)", g->polar_cols);
+    if (n_frames == 0)
+        return 0;
+    return extract_dev(ctx, g, nullptr, n_frames, cap, nullptr, d_pts, d_counts, d_bits);
 }
 
 int sfe_extract_points(sfe_ctx *ctx, sfe_geom *g, const uint8_t *mask, int64_t cap, int64_t *rc_out,

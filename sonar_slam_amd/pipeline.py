@@ -16,7 +16,10 @@ from .cfar import _gate_u8
 
 class KeyframeBatch(object):
     def __init__(self, ctx, geometry, cfar_params, alg, intensity_thr, icp_params, n_jobs,
-                 max_points=16384):
+                 max_points=16384, bit_masks=None):
+        """bit_masks: the detections go from CFAR to the extraction as bit streams
+        (sfe_cfar_u8_bits_batch_dev -> sfe_extract_points_bits_batch_dev) instead of 0/1 bytes; default:
+        whenever the geometry allows it (polar_cols % 32 == 0).  Same points either way."""
         self.ctx, self.geom = ctx, geometry
         self.alg = _L.ALG[alg]
         if alg == "OS":
@@ -30,8 +33,12 @@ class KeyframeBatch(object):
         self.rows, self.cols = geometry.polar_rows, geometry.polar_cols
         self.cap = int(max_points)
         fb = self.n * self.rows * self.cols
+        self.bit_masks = (self.cols % 32 == 0) if bit_masks is None else bool(bit_masks)
+        if self.bit_masks and self.cols % 32:
+            raise ValueError("bit_masks needs polar_cols % 32 == 0")
+        self.wpf = (self.rows * self.cols + 31) // 32 + 1      # SFE_BITS_WORDS
         self.d_img = ctx.alloc(fb)
-        self.d_mask = ctx.alloc(fb)
+        self.d_mask = ctx.alloc(self.n * self.wpf * 4 if self.bit_masks else fb)
         self.d_pts = ctx.alloc(self.n * self.cap * 16)
         self.d_cnt = ctx.alloc(self.n * 4)
         self.d_cnt.zero()                           # no extraction run yet = no points (results() checks them)
@@ -68,14 +75,19 @@ class KeyframeBatch(object):
     # ---- stages (enqueue only) ----
     def run_cfar(self):
         c = self.ctx
-        c._check(c.lib.sfe_cfar_u8_batch_dev(c.handle, self.d_img.ptr, self.n, self.rows, self.cols, self.alg,
-                                             self.train_hs, self.guard_hs, self.k, float(self.tau),
-                                             self.intensity_thr, self.d_mask.ptr, None))
+        if self.bit_masks:
+            c._check(c.lib.sfe_cfar_u8_bits_batch_dev(c.handle, self.d_img.ptr, self.n, self.rows, self.cols,
+                                                      self.alg, self.train_hs, self.guard_hs, self.k,
+                                                      float(self.tau), self.intensity_thr, self.d_mask.ptr))
+        else:
+            c._check(c.lib.sfe_cfar_u8_batch_dev(c.handle, self.d_img.ptr, self.n, self.rows, self.cols, self.alg,
+                                                 self.train_hs, self.guard_hs, self.k, float(self.tau),
+                                                 self.intensity_thr, self.d_mask.ptr, None))
 
     def run_extract(self):
         c = self.ctx
-        c._check(c.lib.sfe_extract_points_batch_dev(c.handle, self.geom.handle, self.d_mask.ptr, self.n,
-                                                    self.cap, self.d_pts.ptr, self.d_cnt.ptr))
+        fn = c.lib.sfe_extract_points_bits_batch_dev if self.bit_masks else c.lib.sfe_extract_points_batch_dev
+        c._check(fn(c.handle, self.geom.handle, self.d_mask.ptr, self.n, self.cap, self.d_pts.ptr, self.d_cnt.ptr))
 
     def run_filter(self, resolution=0.5, radius=1.0, min_points=5):
         """pcl.downsample + pcl.remove_outlier on the extracted clouds, device to device
@@ -151,7 +163,13 @@ class KeyframeBatch(object):
         return self.d_pts.download(np.float64, 2 * n, offset=j * self.cap * 16).reshape(n, 2)
 
     def mask(self, j):
+        """the 0/1 detection mask of frame j (peaks of feature_extraction.py:223-224)"""
         sz = self.rows * self.cols
+        if self.bit_masks:
+            w = self.d_mask.download(np.uint32, self.wpf, offset=j * self.wpf * 4)
+            if w[-1] != 0:
+                raise _L.SonarFEError("frame %d: the pad word of the bit stream is not 0" % j)
+            return np.unpackbits(w.view(np.uint8), bitorder="little")[:sz].reshape(self.rows, self.cols)
         return self.d_mask.download(np.uint8, sz, offset=j * sz).reshape(self.rows, self.cols)
 
     def free(self):

@@ -164,3 +164,57 @@ def test_hip_cfar_equals_the_reference_fixture():
         assert np.array_equal(got2[0], mask) and np.array_equal(got2[1], thr), key
         n += 1
     assert n == 48
+
+
+def _bits_call(ctx, frames, alg, p, gate):
+    """sfe_cfar_u8_bits_batch_dev on a stack of frames -> (0/1 masks unpacked on the host, pad words)"""
+    n, rows, cols = frames.shape
+    wpf = (rows * cols + 31) // 32 + 1
+    d_img, d_bits = ctx.alloc(frames.nbytes), ctx.alloc(n * wpf * 4)
+    try:
+        d_img.upload(frames)
+        d_bits.upload(np.full(n * wpf, 0xDEADBEEF, np.uint32))     # every word must be written by the call
+        k = p[2] if alg == "OS" else 0
+        ctx._check(ctx.lib.sfe_cfar_u8_bits_batch_dev(ctx.handle, d_img.ptr, n, rows, cols, _lib.ALG[alg], p[0], p[1],
+                                                      k, float(p[-1]), gate, d_bits.ptr))
+        ctx.sync()
+        w = d_bits.download(np.uint32, n * wpf).reshape(n, wpf)
+    finally:
+        d_img.free()
+        d_bits.free()
+    px = rows * cols
+    masks = np.stack([np.unpackbits(r.view(np.uint8), bitorder="little")[:px].reshape(rows, cols) for r in w])
+    tail = np.stack([np.unpackbits(r.view(np.uint8), bitorder="little")[px:] for r in w])
+    return masks, tail
+
+
+@pytest.mark.parametrize("alg", ALGS)
+@pytest.mark.parametrize("window", [(20, 5), (16, 4), (10, 2), (8, 1), (12, 3)])
+@pytest.mark.parametrize("shape", [(1024, 512), (200, 256), (130, 288), (96, 64), (70, 100)])
+def test_bit_stream_output_equals_the_oracle_mask(ctx, alg, window, shape):
+    """The BITS ring kernel ((20,5) .. (8,1) on whole-word rows) and the pack fallback (every other call) write the
+    same detections as the byte kernels: bit iy*cols+ix of the frame's stream, pad bits 0."""
+    rng = np.random.default_rng(abs(hash((alg, window, shape))) % 2**32)
+    frames = rng.integers(0, 256, (3,) + shape, dtype=np.uint8)
+    frames[1] = synth.sonar_frame(seed=5)[:shape[0], :shape[1]] if shape[1] <= 512 else frames[1]
+    p = (window[0], window[1], window[0] + 3, 1.2) if alg == "OS" else (window[0], window[1], 1.1)
+    for gate in (-1, 65):
+        masks, tail = _bits_call(ctx, frames, alg, p, gate)
+        assert not tail.any()
+        for f in range(len(frames)):
+            want = _oracle(frames[f], alg, p)
+            if gate >= 0:
+                want = oracle.gate(frames[f], want, gate)
+            assert np.array_equal(masks[f], want), (gate, f)
+
+
+def test_bit_stream_output_many_frames_shipped_window(ctx, shipped_cfar):
+    """more frames than XCDs, the frame count not a multiple of 8, structured frames and the extremes"""
+    p = _args(shipped_cfar, "SOCA")
+    frames = [synth.sonar_frame(seed=40 + s) for s in range(17)]
+    frames += [np.zeros((1024, 512), np.uint8), np.full((1024, 512), 255, np.uint8)]
+    frames = np.stack(frames)
+    masks, tail = _bits_call(ctx, frames, "SOCA", p, 65)
+    assert not tail.any()
+    for f in range(len(frames)):
+        assert np.array_equal(masks[f], oracle.gate(frames[f], _oracle(frames[f], "SOCA", p), 65)), f

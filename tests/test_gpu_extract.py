@@ -226,3 +226,49 @@ def test_fused_ping_call_equals_the_per_stage_chain_and_the_oracle(ctx, shipped_
     # an all-dark ping: no detections, empty cloud
     dark = SonarPing(np.zeros((1024, 512), np.uint8), oculus_bearings(512), 30.0 / 1024, ping_id=0)
     assert fe.callback(dark).shape == (0, 2)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_bit_stream_extraction_equals_the_byte_mask_path(ctx, shipped_cfar, variant):
+    """KeyframeBatch hands the detections to the extraction as bit streams (sfe_cfar_u8_bits_batch_dev ->
+    sfe_extract_points_bits_batch_dev): same masks and the same points as the 0/1 byte path and the oracle,
+    through the inverse map (variant 0) and the dense pass (variant 1)."""
+    from sonar_slam_amd.pipeline import KeyframeBatch
+    th, gh, tau = shipped_cfar.params["SOCA"]
+    fe = FeatureExtraction(ctx)
+    fe.Ntc, fe.Ngc, fe.Pfa, fe.rank, fe.alg, fe.threshold = 40, 10, 0.1, 10, "SOCA", 65
+    fe.configure()
+    frames = np.stack([synth.sonar_frame(seed=300 + s) for s in range(11)])
+    frames[3] = 0                                   # an empty frame between full ones
+    fe.generate_map_xy(SonarPing(frames[0], oculus_bearings(512), 30.0 / 1024))
+    mx, my = fe.map_x, fe.map_y
+    res = []
+    try:
+        ctx._check(ctx.lib.sfe_extract_set_tuning(ctx.handle, variant))
+        for bit_masks in (True, False):
+            kb = KeyframeBatch(ctx, fe.geometry, (th, gh, tau), "SOCA", 65, None, len(frames), max_points=20000,
+                               bit_masks=bit_masks)
+            kb.upload_frames(frames)
+            kb.run_cfar()
+            kb.run_extract()
+            ctx.sync()
+            res.append(([kb.mask(j) for j in range(kb.n)], [kb.points(j) for j in range(kb.n)]))
+            kb.free()
+    finally:
+        ctx._check(ctx.lib.sfe_extract_set_tuning(ctx.handle, 0))
+    for j in range(len(frames)):
+        want = oracle.gate(frames[j], oracle.cfar(frames[j], "SOCA", th, gh, tau), 65)
+        assert np.array_equal(res[0][0][j], want) and np.array_equal(res[1][0][j], want)
+        rc = oracle.nonzero(oracle.remap_u8(want, mx, my))
+        pts = oracle.px_to_m(rc, frames.shape[1], mx.shape[1], fe.geometry.width, fe.geometry.height)
+        assert np.array_equal(res[0][1][j], pts) and np.array_equal(res[1][1][j], pts)
+
+
+def test_bit_stream_extraction_refuses_ragged_rows(ctx):
+    g, mx, my, width, height = _geom(ctx, 100, 77, 0.1)
+    d = ctx.alloc(4096)
+    try:
+        with pytest.raises(Exception, match="polar_cols"):
+            ctx._check(ctx.lib.sfe_extract_points_bits_batch_dev(ctx.handle, g.handle, d.ptr, 1, 16, d.ptr, d.ptr))
+    finally:
+        d.free()

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--variants", default="2,3")
     ap.add_argument("--tiles", default="0,52,104,208,312,520,1024")
     ap.add_argument("--only", action="store_true", help="just run the default config a few times (for rocprof)")
+    ap.add_argument("--bits", action="store_true", help="the bit-stream kernel (sfe_cfar_u8_bits_batch_dev)")
     a = ap.parse_args()
     ctx = _lib.default_context()
     det = CFAR(40, 10, 0.1, 10)
@@ -34,6 +35,10 @@ def main():
         d_in.upload(base[:n], offset=f0 * fb)
 
     def launch():
+        if a.bits:
+            ctx._check(ctx.lib.sfe_cfar_u8_bits_batch_dev(ctx.handle, d_in.ptr, a.frames, a.rows, a.cols, 1, th, gh, 0,
+                                                          float(tau), 65, d_out.ptr))
+            return
         ctx._check(ctx.lib.sfe_cfar_u8_batch_dev(ctx.handle, d_in.ptr, a.frames, a.rows, a.cols, 1, th, gh, 0,
                                                  float(tau), 65, d_out.ptr, None))
 
@@ -45,7 +50,7 @@ def main():
             launch()
         return ctx.timer_stop() / a.reps
 
-    bytes_ = 2.0 * fb * a.frames
+    bytes_ = (1.125 if a.bits else 2.0) * fb * a.frames   # 1 B read + 1 B (1 bit) written per pixel
     if a.only:
         if len(a.tiles.split(",")) == 1:
             ctx._check(ctx.lib.sfe_cfar_set_tuning(ctx.handle, int(a.tiles), 0))
