@@ -1778,7 +1778,8 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
     // LDS share of a workgroup: two workgroups per CU when the batch has more jobs than CUs, else the whole CU
     static const int force_wide = getenv("SFE_SW_WIDE") ? atoi(getenv("SFE_SW_WIDE")) : -1; // A/B: 1 = one 128-VGPR workgroup per CU
     const bool wide = force_wide >= 0 ? force_wide != 0 : n_jobs <= ctx->n_cu;
-    const size_t lds_share = (wide ? 160 : 80) * (size_t)1024;
+    static const int force_share = getenv("SFE_SW_SHARE_KB") ? atoi(getenv("SFE_SW_SHARE_KB")) : 0; // A/B: LDS per workgroup
+    const size_t lds_share = (force_share > 0 ? force_share : (wide ? 160 : 80)) * (size_t)1024;
     static const bool no_ldsq = getenv("SFE_SW_NO_LDSQ") != nullptr; // A/B
     int q_tmax = 0, q_smax = 0;
     for (int j = 0; j < n_jobs; ++j) {
@@ -1924,9 +1925,15 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
                            (TCAP), (QCAP), pow2_floor(((SMEM)-ctl_bytes) / 8));                                        \
         SFE_LAUNCH_CHECK(ctx);                                                                                         \
     } while (0)
+    // A/B: VGPR budget of the LDS_Q build at two workgroups per CU.  Measured (4096 jobs of 5000 x 5000, p2plane30):
+    // 64 VGPRs 35.5 ms, 128 VGPRs 48.7 ms, 256 VGPRs 48.7 ms (profiles/r02_icp_vgpr_budget.txt) -- the builds with
+    // fewer spills lose by a third, so the 64-VGPR build stays although LDS, not registers, bounds the occupancy here
+    static const int minw = getenv("SFE_SW_MINW") ? atoi(getenv("SFE_SW_MINW")) : 8;
     if (n_q) {
         const size_t smem = ctl_bytes + 8 * (size_t)t_cap + 6 * (size_t)q_cap;
-        if (wide)
+        if (!wide && !d_prof && minw == 4)
+            SW_LAUNCH((icp_sweep_kernel<4, true, true, false>), n_q, d_ids, smem, t_cap, q_cap);
+        else if (wide)
             SW_LAUNCH((icp_sweep_kernel<4, true, true, false>), n_q, d_ids, smem, t_cap, q_cap);
         else if (d_prof)
             SW_LAUNCH((icp_sweep_kernel<8, true, true, true>), n_q, d_ids, smem, t_cap, q_cap);
