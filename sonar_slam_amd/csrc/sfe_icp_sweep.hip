@@ -1925,9 +1925,10 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
                            (TCAP), (QCAP), pow2_floor(((SMEM)-ctl_bytes) / 8));                                        \
         SFE_LAUNCH_CHECK(ctx);                                                                                         \
     } while (0)
-    // A/B: VGPR budget of the LDS_Q build at two workgroups per CU.  Measured (4096 jobs of 5000 x 5000, p2plane30):
-    // 64 VGPRs 35.5 ms, 128 VGPRs 48.7 ms, 256 VGPRs 48.7 ms (profiles/r02_icp_vgpr_budget.txt) -- the builds with
-    // fewer spills lose by a third, so the 64-VGPR build stays although LDS, not registers, bounds the occupancy here
+    // A/B: VGPR budget of the LDS_Q build.  A workgroup is 1024 threads = 4 waves per SIMD, so two workgroups per CU
+    // only fit at <= 64 VGPRs: measured (4096 jobs of 5000 x 5000, p2plane30) 64 VGPRs 35.4 ms, 72 VGPRs 51.4 ms,
+    // 128 VGPRs 48.6 ms (profiles/r02_icp_vgpr_budget.txt) -- one resident job per CU costs more than the 86 spilled
+    // VGPRs of the 64-VGPR build
     static const int minw = getenv("SFE_SW_MINW") ? atoi(getenv("SFE_SW_MINW")) : 8;
     if (n_q) {
         const size_t smem = ctl_bytes + 8 * (size_t)t_cap + 6 * (size_t)q_cap;
