@@ -445,7 +445,7 @@ def main():
                                            (("cfar", ms_cfar_b), ("extract", ms_extract_b), ("filters", ms_filter_b),
                                             ("icp", ms_icp_b))},
             # SURVEY 8d, on-the-fly form: R*B bytes of mask in + 16 B per extracted point out
-            "roofline_extract": {"kernel": ("" if kb.bit_masks else "mask_pack + ") + "extract_scatter + extract_scan + extract_expand", "bound": "hbm",
+            "roofline_extract": {"kernel": ("" if kb.bit_masks else "mask_pack + ") + "extract_scatter + extract_scan + extract_expand_words", "bound": "hbm",
                                  "achieved": extract_bytes / (ms_extract_b * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": extract_bytes / (ms_extract_b * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                  "bytes_per_launch": extract_bytes, "ms_per_launch": ms_extract_b,

@@ -221,20 +221,57 @@ __global__ __launch_bounds__(256) void extract_bits_kernel(const uint8_t *__rest
 // read as one flat stream (lane t takes words t, t + 1024, ...: coalesced); the few non-empty words add their
 // popcount to their row's LDS counter.
 #define SCAN_THREADS 1024
+// inclusive prefix sum over the 64 lanes of a wave: four DPP row shifts inside the rows of 16, then the row totals
+__device__ __forceinline__ int scan_wave_incl(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false); // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false); // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false); // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false); // row_shr:8
+    const int r0 = __builtin_amdgcn_readlane(v, 15), r1 = __builtin_amdgcn_readlane(v, 31),
+              r2 = __builtin_amdgcn_readlane(v, 47);
+    const int row = (threadIdx.x & 63) >> 4;
+    return v + (row > 0 ? r0 : 0) + (row > 1 ? r1 : 0) + (row > 2 ? r2 : 0);
+}
+#define SCAN_LDS_LIST 4096 // word-list entries held in LDS until their offsets are known (64 KiB; a sonar frame has 2-3 thousand)
+// Word list (list_cap > 0): the non-empty bitmap words of the frame for extract_expand_words_kernel, one int4 each:
+// {row << 16 | word of the row, number of the frame's points in front of it, the 64 bits}.  The words are collected
+// while the bitmap streams by (wave-aggregated append, any order).  A lane knows the set bits in front of its word
+// within its wave's 64 consecutive words from a wave scan of the popcounts; what a row leaves in the preceding 64-word
+// chunk (rows are <= 64 words here) goes through s_tail, and the row offsets are added once they stand.  (Counting the
+// row's earlier words per list entry afterwards -- the first version -- cost 40 us per 512 frames: every lane of a wave
+// reads another row, 64 cache lines per load instruction.)  A frame with more points than `cap` gets no list (a
+// word may be missing from it): it is queued in ovf_list for the per-point kernel, which stores its first cap points.
 __global__ __launch_bounds__(SCAN_THREADS) void extract_scan_kernel(const unsigned long long *__restrict__ bitmap,
                                                                     int32_t *__restrict__ row_count,
                                                                     int32_t *__restrict__ row_off,
-                                                                    int32_t *__restrict__ frame_count, int crows, int wpr)
+                                                                    int32_t *__restrict__ frame_count, int crows, int wpr,
+                                                                    int4 *__restrict__ wlist, int32_t *__restrict__ wlist_n,
+                                                                    int list_cap, long long cap,
+                                                                    int32_t *__restrict__ ovf_n, int32_t *__restrict__ ovf_list)
 {
-    extern __shared__ int s_cnt[]; // crows row counts, then SCAN_THREADS partial sums
-    int *s_part = s_cnt + crows;
-    const int f = blockIdx.x, tid = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) int s_cnt[]; // [SCAN_LDS_LIST int4 entries |] crows row counts |
+                                                                // SCAN_THREADS partial sums [| one tail per 64-word chunk]
+    __shared__ int s_nlist;
+    // the first SCAN_LDS_LIST entries wait in LDS for their offsets and reach the list in one piece; a denser frame's
+    // further entries go to the list at once and are completed there (read back by this workgroup: slow, rare)
+    int4 *s_list = reinterpret_cast<int4 *>(s_cnt);
+    int *s_cntp = s_cnt + (list_cap > 0 ? 4 * SCAN_LDS_LIST : 0);
+    int *s_part = s_cntp + crows;
+    int *s_tail = s_part + SCAN_THREADS;
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const unsigned long long *__restrict__ bm = bitmap + (long long)f * crows * wpr;
-    for (int i = tid; i < crows; i += SCAN_THREADS)
-        s_cnt[i] = 0;
-    __syncthreads();
+    int4 *__restrict__ wl = wlist ? wlist + (long long)f * list_cap : nullptr;
     const int nw = crows * wpr;
-    for (int i0 = tid; i0 < nw; i0 += 8 * SCAN_THREADS) { // eight loads in flight per lane
+    for (int i = tid; i < crows; i += SCAN_THREADS)
+        s_cntp[i] = 0;
+    if (list_cap > 0)
+        for (int i = tid; i < (nw + 63) / 64; i += SCAN_THREADS)
+            s_tail[i] = 0;
+    if (tid == 0)
+        s_nlist = 0;
+    __syncthreads();
+    for (int i0 = tid; i0 - lane < nw; i0 += 8 * SCAN_THREADS) { // eight loads in flight per lane; wave-uniform trip count
         unsigned long long wd[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -242,9 +279,45 @@ __global__ __launch_bounds__(SCAN_THREADS) void extract_scan_kernel(const unsign
             wd[u] = i < nw ? bm[i] : 0ull;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (wd[u])
-                atomicAdd(&s_cnt[(i0 + u * SCAN_THREADS) / wpr], __popcll(wd[u]));
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * SCAN_THREADS;
+            const int pc = __popcll(wd[u]);
+            if (list_cap <= 0) {
+                if (pc)
+                    atomicAdd(&s_cntp[i / wpr], pc);
+            } else {
+                const unsigned long long m = __ballot(pc != 0);
+                if (m) { // (wave-uniform)
+                    const int row = i / wpr;
+                    if (pc)
+                        atomicAdd(&s_cntp[row], pc);
+                    const int incl = scan_wave_incl(pc);
+                    const int excl = incl - pc;
+                    const int cstart = __builtin_amdgcn_readfirstlane(i - lane); // first word of the wave's chunk
+                    const int rs = row * wpr;                                    // first word of this lane's row
+                    // set bits of the row's earlier words inside this chunk (lane 0 holds excl = 0)
+                    const int before = excl - __builtin_amdgcn_ds_bpermute(4 * max(rs - cstart, 0), excl);
+                    // what the row that runs on into the next chunk has in this one
+                    const int rns = ((cstart + 64) / wpr) * wpr;
+                    const int tail = __builtin_amdgcn_readlane(incl, 63) -
+                                     __builtin_amdgcn_readlane(excl, min(max(rns - cstart, 0), 63));
+                    if (lane == 0 && rns < cstart + 64)
+                        s_tail[cstart >> 6] = tail;
+                    int base = 0;
+                    const int leader = __ffsll((long long)m) - 1;
+                    if (lane == leader)
+                        base = atomicAdd(&s_nlist, __popcll(m));
+                    base = __builtin_amdgcn_readlane(base, leader);
+                    const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+                    const int4 ent = make_int4((row << 16) | (i - rs), before, (int)(unsigned)(wd[u] & 0xFFFFFFFFull),
+                                               (int)(unsigned)(wd[u] >> 32));
+                    if (pc && slot < SCAN_LDS_LIST)
+                        s_list[slot] = ent;
+                    else if (pc && slot < list_cap)
+                        wl[slot] = ent;
+                }
+            }
+        }
     }
     __syncthreads();
     int32_t *__restrict__ cnt = row_count + (long long)f * crows;
@@ -253,8 +326,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void extract_scan_kernel(const unsign
     const int b = tid * per, e = min(b + per, crows);
     int s = 0;
     for (int i = b; i < e; ++i) {
-        cnt[i] = s_cnt[i];
-        s += s_cnt[i];
+        cnt[i] = s_cntp[i];
+        s += s_cntp[i];
     }
     s_part[tid] = s;
     __syncthreads();
@@ -267,84 +340,167 @@ __global__ __launch_bounds__(SCAN_THREADS) void extract_scan_kernel(const unsign
     int run = (tid == 0) ? 0 : s_part[tid - 1];
     for (int i = b; i < e; ++i) {
         off[i] = run;
-        run += s_cnt[i];
+        const int c = s_cntp[i];
+        s_cntp[i] = run; // from here on: the row's offset
+        run += c;
     }
+    const int total = s_part[SCAN_THREADS - 1];
     if (tid == SCAN_THREADS - 1)
-        frame_count[f] = s_part[SCAN_THREADS - 1];
+        frame_count[f] = total;
+    if (list_cap <= 0)
+        return;
+    __syncthreads(); // row offsets in s_cnt, the collected words in wl (written by this workgroup)
+    const bool listed = total <= cap && s_nlist <= list_cap; // (total <= cap implies the second: a word holds a point)
+    if (tid == 0) {
+        wlist_n[f] = listed ? s_nlist : 0;
+        if (!listed)
+            ovf_list[atomicAdd(ovf_n, 1)] = f;
+    }
+    if (!listed)
+        return;
+    const int n = s_nlist;
+    for (int e2 = tid; e2 < n; e2 += SCAN_THREADS) {
+        int4 ent = e2 < SCAN_LDS_LIST ? s_list[e2] : wl[e2];
+        const int row = ent.x >> 16, rs = row * wpr, cstart = (rs + (ent.x & 0xFFFF)) & ~63;
+        ent.y += s_cntp[row] + (rs < cstart ? s_tail[(cstart >> 6) - 1] : 0);
+        wl[e2] = ent;
+    }
 }
 
-// pass 3: one lane per POINT: point t of a frame lies in the last row whose offset is <= t (binary search in
-// the row offsets; empty rows share their successor's offset, so the last such row is the occupied one) and is
-// the (t - offset)-th set bit of that row's words in column order (= np.nonzero order); then metres in fp64,
-// operation by operation.  (One wave per canvas row, a lane per bitmap word -- the first version -- kept 5 lanes
-// of 64 busy: a row holds ~10 detections.  Also measured and slower than that: 8 rows per 512-thread workgroup,
-// and the expansion fused into the per-frame scan kernel.)
+// pass 3, word form: one lane per BYTE of a non-empty bitmap word (extract_scan_kernel's list; 8 lanes share a word):
+// the set bits of a word are consecutive points of the frame (np.nonzero order: row-major), the byte's first one
+// comes after the word's offset + the set bits of the lower bytes.  A lane walks its <= 8 bits -- next set bit,
+// column, metres from the px->m tables (sfe_geom: the fp64 expressions of feature_extraction.py:236-237 evaluated
+// once per row / column on the host instead of two fp64 divisions per point; staged in LDS), one 16-byte store; the
+// 8 lanes of a word write one contiguous run.  ~25 instructions per point against ~150 of the lane-per-point form
+// below (row search, k-th set bit of the row, divisions).  The kernel is a chain of dependent accesses (list length
+// -> entry -> tables -> store), so the next entry is fetched while the current one is expanded.
+#define EXPAND_WG 8 // workgroups per frame (a sonar frame has 2-3 thousand non-empty words, 8 lanes each)
+__global__ __launch_bounds__(256) void extract_expand_words_kernel(const int4 *__restrict__ wlist,
+                                                                   const int32_t *__restrict__ wlist_n, int list_cap,
+                                                                   long long *__restrict__ rc_out,
+                                                                   double *__restrict__ pts_out, long long cap, int crows,
+                                                                   int ccols, const double *__restrict__ ytab,
+                                                                   const double *__restrict__ xtab)
+{
+    extern __shared__ double s_tab[]; // crows y values, ccols x values
+    double *s_y = s_tab, *s_x = s_tab + crows;
+    const int f = blockIdx.y;
+    const int n = wlist_n[f];
+    const int4 *__restrict__ wl = wlist + (long long)f * list_cap;
+    const int sub = threadIdx.x & 7;
+    const int e0 = blockIdx.x * 32 + (threadIdx.x >> 3), stride = gridDim.x * 32;
+    if (blockIdx.x * 32 >= n)
+        return; // nothing for this workgroup (the list is short): skip the tables too
+    int4 nxt = e0 < n ? wl[e0] : make_int4(0, 0, 0, 0);
+    if (pts_out) {
+        for (int i = threadIdx.x; i < crows; i += 256)
+            s_y[i] = ytab[i];
+        for (int i = threadIdx.x; i < ccols; i += 256)
+            s_x[i] = xtab[i];
+    }
+    __syncthreads();
+    for (int e = e0; e < n; e += stride) {
+        const int4 ent = nxt;
+        if (e + stride < n)
+            nxt = wl[e + stride];
+        const unsigned long long word = ((unsigned long long)(unsigned)ent.w << 32) | (unsigned)ent.z;
+        unsigned bits = (unsigned)(word >> (8 * sub)) & 0xffu;
+        const int row = ent.x >> 16, c0 = (ent.x & 0xFFFF) * 64 + 8 * sub;
+        long long t = (long long)f * cap + ent.y + __popcll(word & ((1ull << (8 * sub)) - 1ull));
+        const double y = pts_out ? s_y[row] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (bits) {
+                const int col = c0 + __ffs((int)bits) - 1;
+                bits &= bits - 1;
+                if (rc_out)
+                    reinterpret_cast<longlong2 *>(rc_out)[t] = make_longlong2(row, col);
+                if (pts_out)
+                    reinterpret_cast<double2 *>(pts_out)[t] = make_double2(y, s_x[col]);
+                ++t;
+            }
+        }
+    }
+}
+
+// pass 3, point form: one lane per POINT: point t of a frame lies in the last row whose offset is <= t (binary
+// search in the row offsets; empty rows share their successor's offset, so the last such row is the occupied one) and
+// is the (t - offset)-th set bit of that row's words in column order (= np.nonzero order); then metres in fp64,
+// operation by operation.  The general form: it stores the first `cap` points of a frame whatever its count.  With
+// ovf_list it only serves the frames queued there (frames above the capacity, which the word form leaves alone:
+// normally none, the kernel then ends at once); A/B against the word form with SFE_EXPAND_POINTS=1.
 __global__ __launch_bounds__(256) void extract_expand_kernel(const unsigned long long *__restrict__ bitmap,
                                                              const int32_t *__restrict__ row_off,
                                                              const int32_t *__restrict__ frame_count,
                                                              long long *__restrict__ rc_out,
                                                              double *__restrict__ pts_out, long long cap,
                                                              int crows, int ccols, int wpr, double width,
-                                                             double height)
+                                                             double height, const int32_t *__restrict__ ovf_n,
+                                                             const int32_t *__restrict__ ovf_list)
 {
     extern __shared__ int32_t s_off[]; // the frame's row offsets: one coalesced fetch instead of a 10-step
                                        // chain of dependent loads per point
-    const int f = blockIdx.y;
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long n = min((long long)frame_count[f], cap);
-    if ((long long)blockIdx.x * 256 >= n)
-        return; // the whole workgroup is past the frame's last point
-    const int32_t *__restrict__ off = row_off + (long long)f * crows;
-    for (int i = threadIdx.x; i < crows; i += 256)
-        s_off[i] = off[i];
-    __syncthreads();
-    if (t >= n)
-        return;
-    int lo = 0, hi = crows - 1; // largest row with off[row] <= t
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (s_off[mid] <= t)
-            lo = mid;
-        else
-            hi = mid - 1;
-    }
-    const int row = lo;
-    int k = (int)(t - s_off[row]);
-    const unsigned long long *__restrict__ brow = bitmap + ((long long)f * crows + row) * wpr;
-    int col = -1;
-    for (int w0 = 0; w0 < wpr && col < 0; w0 += 8) { // eight independent loads in flight, then the selection
-        unsigned long long wd[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            wd[u] = (w0 + u < wpr) ? brow[w0 + u] : 0ull;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int c = __popcll(wd[u]);
-            if (col < 0 && k < c) {
-                unsigned long long word = wd[u];
-                for (; k > 0; --k)
-                    word &= word - 1;
-                col = (w0 + u) * 64 + __ffsll((long long)word) - 1;
-            }
-            if (col < 0)
-                k -= c;
+    const int nk = ovf_list ? *ovf_n : 1;
+    for (int k = 0; k < nk; ++k) {
+        const int f = ovf_list ? ovf_list[k] : (int)blockIdx.y;
+        const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+        const long long n = min((long long)frame_count[f], cap);
+        if ((long long)blockIdx.x * 256 >= n)
+            continue; // the whole workgroup is past the frame's last point
+        const int32_t *__restrict__ off = row_off + (long long)f * crows;
+        __syncthreads(); // (the previous frame's offsets are no longer read)
+        for (int i = threadIdx.x; i < crows; i += 256)
+            s_off[i] = off[i];
+        __syncthreads();
+        if (t >= n)
+            continue;
+        int lo = 0, hi = crows - 1; // largest row with off[row] <= t
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (s_off[mid] <= t)
+                lo = mid;
+            else
+                hi = mid - 1;
         }
-    }
-    if (col < 0)
-        return; // cannot happen: the offsets were counted from these very words
-    const long long dsto = ((long long)f * cap + t) * 2;
-    if (rc_out) {
-        rc_out[dsto] = row;
-        rc_out[dsto + 1] = col;
-    }
-    if (pts_out) {
-        // feature_extraction.py:236-237 in float64, operation by operation
-        const double half_cols = ccols / 2.;
-        const double y = (-1 * ((double)row / (double)crows) * height) + height;
-        double x = (double)col - half_cols;
-        x = (-1 * ((x / half_cols) * (width / 2.)));
-        pts_out[dsto] = y;
-        pts_out[dsto + 1] = x;
+        const int row = lo;
+        int kk = (int)(t - s_off[row]);
+        const unsigned long long *__restrict__ brow = bitmap + ((long long)f * crows + row) * wpr;
+        int col = -1;
+        for (int w0 = 0; w0 < wpr && col < 0; w0 += 8) { // eight independent loads in flight, then the selection
+            unsigned long long wd[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                wd[u] = (w0 + u < wpr) ? brow[w0 + u] : 0ull;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = __popcll(wd[u]);
+                if (col < 0 && kk < c) {
+                    unsigned long long word = wd[u];
+                    for (; kk > 0; --kk)
+                        word &= word - 1;
+                    col = (w0 + u) * 64 + __ffsll((long long)word) - 1;
+                }
+                if (col < 0)
+                    kk -= c;
+            }
+        }
+        if (col < 0)
+            continue; // cannot happen: the offsets were counted from these very words
+        const long long dsto = ((long long)f * cap + t) * 2;
+        if (rc_out) {
+            rc_out[dsto] = row;
+            rc_out[dsto + 1] = col;
+        }
+        if (pts_out) {
+            // feature_extraction.py:236-237 in float64, operation by operation
+            const double half_cols = ccols / 2.;
+            const double y = (-1 * ((double)row / (double)crows) * height) + height;
+            double x = (double)col - half_cols;
+            x = (-1 * ((x / half_cols) * (width / 2.)));
+            pts_out[dsto] = y;
+            pts_out[dsto + 1] = x;
+        }
     }
 }
 
@@ -560,6 +716,25 @@ static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_f
         return SFE_ERR_HIP;
     SFE_HIP(ctx, hipFuncSetAttribute((const void *)extract_bits_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      g->lds_bytes));
+    // word form of the expansion: a list of the non-empty bitmap words per frame (at most one per stored point)
+    static const bool points_form = getenv("SFE_EXPAND_POINTS") != nullptr; // A/B: lane-per-point expansion
+    const long long words_pf = (long long)crows * wpr;
+    const size_t tab_bytes = ((size_t)crows + g->cart_cols) * sizeof(double);
+    const bool use_words = !points_form && cap > 0 && std::min(words_pf, cap) <= (1ll << 24) && cap < (1ll << 31) &&
+                           wpr <= 64 && crows < 32768 && tab_bytes <= 144 * 1024 && g->d_ytab && g->d_xtab;
+    const int list_cap = use_words ? (int)std::min(words_pf, cap) : 0;
+    int4 *d_wlist = nullptr;
+    int32_t *d_wlist_n = nullptr, *d_ovf = nullptr; // d_ovf: [0] number of queued frames, [1..] their indices
+    if (use_words) {
+        const int nfc = std::min(chunk, n_frames);
+        d_wlist = (int4 *)sfe_scratch(ctx, 42, (size_t)nfc * list_cap * sizeof(int4));
+        d_wlist_n = (int32_t *)sfe_scratch(ctx, 43, (size_t)nfc * 4);
+        d_ovf = (int32_t *)sfe_scratch(ctx, 44, ((size_t)nfc + 1) * 4);
+        if (!d_wlist || !d_wlist_n || !d_ovf)
+            return SFE_ERR_HIP;
+        SFE_HIP(ctx, hipFuncSetAttribute((const void *)extract_expand_words_kernel,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)tab_bytes));
+    }
     for (int f0 = 0; f0 < n_frames; f0 += chunk) {
         const int nf = std::min(chunk, n_frames - f0);
         const uint8_t *m = d_bits_in ? nullptr : d_mask + (size_t)f0 * g->polar_rows * g->polar_cols;
@@ -587,14 +762,33 @@ static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_f
                            g->lds_bytes, ctx->stream, m, d_bits, d_nonbin, (const uint32_t *)g->d_code, g->d_span,
                            g->d_tile_rows, d_bm, g->polar_rows, g->polar_cols, g->rcp, crows, g->cart_cols, wpr, word_groups,
                            tiles, wpf, scatter ? 1 : 0, nf);
-        hipLaunchKernelGGL(extract_scan_kernel, dim3(nf), dim3(SCAN_THREADS), sizeof(int) * ((size_t)crows + SCAN_THREADS),
-                           ctx->stream, d_bm, d_rcnt, d_roff, d_counts + f0, crows, wpr);
-        if (cap > 0)
-            hipLaunchKernelGGL(extract_expand_kernel, dim3((unsigned)((cap + 255) / 256), nf), dim3(256),
-                               sizeof(int32_t) * (size_t)crows, ctx->stream,
-                               d_bm, d_roff, d_counts + f0, d_rc ? d_rc + (size_t)f0 * cap * 2 : nullptr,
-                               d_pts ? d_pts + (size_t)f0 * cap * 2 : nullptr, cap, crows, g->cart_cols, wpr, g->width,
-                               g->height);
+        if (use_words)
+            SFE_HIP(ctx, hipMemsetAsync(d_ovf, 0, 4, ctx->stream));
+        const size_t scan_lds = sizeof(int) * ((size_t)crows + SCAN_THREADS + (use_words ? (words_pf + 63) / 64 + 4 * SCAN_LDS_LIST : 0));
+        if (scan_lds > 48 * 1024)
+            SFE_HIP(ctx, hipFuncSetAttribute((const void *)extract_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)scan_lds));
+        hipLaunchKernelGGL(extract_scan_kernel, dim3(nf), dim3(SCAN_THREADS), scan_lds,
+                           ctx->stream, d_bm, d_rcnt, d_roff, d_counts + f0, crows, wpr, d_wlist, d_wlist_n,
+                           use_words ? list_cap : 0, cap, d_ovf, d_ovf ? d_ovf + 1 : nullptr);
+        if (cap > 0) {
+            long long *rc_f = d_rc ? d_rc + (size_t)f0 * cap * 2 : nullptr;
+            double *pts_f = d_pts ? d_pts + (size_t)f0 * cap * 2 : nullptr;
+            if (use_words) {
+                static const int expand_wg = getenv("SFE_EXPAND_WG") ? std::max(1, atoi(getenv("SFE_EXPAND_WG"))) : EXPAND_WG;
+                hipLaunchKernelGGL(extract_expand_words_kernel, dim3(expand_wg, nf), dim3(256), tab_bytes, ctx->stream,
+                                   d_wlist, d_wlist_n, list_cap, rc_f, pts_f, cap, crows, g->cart_cols, g->d_ytab, g->d_xtab);
+                // frames above the capacity (queued by the scan kernel; normally none): their first cap points
+                hipLaunchKernelGGL(extract_expand_kernel, dim3((unsigned)((cap + 255) / 256), 1), dim3(256),
+                                   sizeof(int32_t) * (size_t)crows, ctx->stream, d_bm, d_roff, d_counts + f0, rc_f, pts_f, cap,
+                                   crows, g->cart_cols, wpr, g->width, g->height, d_ovf, d_ovf + 1);
+            } else {
+                hipLaunchKernelGGL(extract_expand_kernel, dim3((unsigned)((cap + 255) / 256), nf), dim3(256),
+                                   sizeof(int32_t) * (size_t)crows, ctx->stream, d_bm, d_roff, d_counts + f0, rc_f, pts_f, cap,
+                                   crows, g->cart_cols, wpr, g->width, g->height, (const int32_t *)nullptr,
+                                   (const int32_t *)nullptr);
+            }
+        }
     }
     SFE_LAUNCH_CHECK(ctx);
     return 0;
@@ -739,6 +933,23 @@ int sfe_geom_create(sfe_ctx *ctx, const float *map_x, const float *map_y, int ca
             return sfe_set_err(ctx, SFE_ERR_HIP, "inverse remap table upload failed");
         }
     }
+    {
+        std::vector<double> ytab((size_t)cart_rows), xtab((size_t)cart_cols);
+        const double half_cols = cart_cols / 2.;
+        for (int r = 0; r < cart_rows; ++r)
+            ytab[(size_t)r] = (-1 * ((double)r / (double)cart_rows) * height) + height; // feature_extraction.py:237
+        for (int c = 0; c < cart_cols; ++c) {
+            double x = (double)c - half_cols;                                            // feature_extraction.py:236
+            xtab[(size_t)c] = (-1 * ((x / half_cols) * (width / 2.)));
+        }
+        if (hipMalloc((void **)&g->d_ytab, ytab.size() * 8) != hipSuccess ||
+            hipMalloc((void **)&g->d_xtab, xtab.size() * 8) != hipSuccess ||
+            hipMemcpy(g->d_ytab, ytab.data(), ytab.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(g->d_xtab, xtab.data(), xtab.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
+            sfe_geom_destroy(g);
+            return sfe_set_err(ctx, SFE_ERR_HIP, "px->m table upload failed");
+        }
+    }
     if (hipMalloc((void **)&g->d_code, n * 4) != hipSuccess ||
         hipMalloc((void **)&g->d_span, span.size() * 4) != hipSuccess ||
         hipMalloc((void **)&g->d_tile_rows, tile_rows.size() * 4) != hipSuccess) {
@@ -773,6 +984,10 @@ void sfe_geom_destroy(sfe_geom *g)
         (void)hipFree(g->d_inv_off);
     if (g->d_inv_ent)
         (void)hipFree(g->d_inv_ent);
+    if (g->d_ytab)
+        (void)hipFree(g->d_ytab);
+    if (g->d_xtab)
+        (void)hipFree(g->d_xtab);
     delete g;
 }
 

@@ -272,3 +272,34 @@ def test_bit_stream_extraction_refuses_ragged_rows(ctx):
             ctx._check(ctx.lib.sfe_extract_points_bits_batch_dev(ctx.handle, g.handle, d.ptr, 1, 16, d.ptr, d.ptr))
     finally:
         d.free()
+
+
+def test_batch_extraction_above_the_capacity_keeps_the_first_points(ctx, shipped_cfar):
+    """sonarfe.h: d_counts[f] is the true count even above cap, and the first cap points are stored.  Frames below
+    the capacity take the word-list expansion, frames above it the per-point kernel -- in one call."""
+    n, ranges, beams = 6, 1024, 512
+    g, mx, my, width, height = _geom(ctx, beams, ranges, 30.0 / 1024)
+    th, gh, tau = shipped_cfar.params["SOCA"]
+    frames = np.stack([synth.sonar_frame(seed=500 + s, n_blobs=(4 if s % 2 else 40)) for s in range(n)])
+    masks = np.stack([oracle.gate(f, oracle.cfar(f, "SOCA", th, gh, tau), 65) for f in frames])
+    want = [oracle.px_to_m(oracle.nonzero(oracle.remap_u8(m, mx, my)), ranges, mx.shape[1], width, height)
+            for m in masks]
+    sizes = sorted(len(w) for w in want)
+    cap = (sizes[2] + sizes[3]) // 2                      # half of the frames are above it
+    assert sizes[0] < cap < sizes[-1]
+    d_mask, d_pts, d_cnt = ctx.alloc(masks.nbytes), ctx.alloc(n * cap * 16), ctx.alloc(n * 4)
+    try:
+        d_mask.upload(masks)
+        d_pts.upload(np.full(n * cap * 2, -7.0))
+        ctx._check(ctx.lib.sfe_extract_points_batch_dev(ctx.handle, g.handle, d_mask.ptr, n, cap, d_pts.ptr, d_cnt.ptr))
+        ctx.sync()
+        cnt = d_cnt.download(np.int32, n)
+        pts = d_pts.download(np.float64, n * cap * 2).reshape(n, cap, 2)
+    finally:
+        for b in (d_mask, d_pts, d_cnt):
+            b.free()
+    for f in range(n):
+        assert cnt[f] == len(want[f])
+        k = min(cap, len(want[f]))
+        assert np.array_equal(pts[f, :k], want[f][:k]), f
+        assert np.all(pts[f, k:] == -7.0)                 # nothing is written behind a frame's points
