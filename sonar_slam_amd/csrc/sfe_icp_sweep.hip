@@ -209,6 +209,14 @@ __device__ __forceinline__ void sweep_knn_normals(const sfe_icp_params &P, const
                       // nothing can ever match it)
         float bd[KM];
         int bj[KM];
+        // The search runs twice at most.  First without the tie rule: equal distances are only NOTED (one compare per
+        // exchange step), the list orders by distance alone.  Two equal distances among a point's candidates are
+        // rare (exactly equal fp32 sums of squares); only then the point is searched again with the full rule
+        // (equal distances order by original index, which costs a compare, a branch and -- when taken -- two reads
+        // of the permutation per exchange step: about half of the instructions of an insertion).
+        auto search = [&](auto exact_tag) -> bool {
+        constexpr bool EXACT = decltype(exact_tag)::value;
+        bool tie_seen = false;
 #pragma unroll
         for (int k = 0; k < KM; ++k) {
             bd[k] = INFINITY;
@@ -222,15 +230,25 @@ __device__ __forceinline__ void sweep_knn_normals(const sfe_icp_params &P, const
                 // full list (the usual case, KM == k): the newcomer replaces the last entry and bubbles up
                 // with KM-1 compare-exchanges -- half the work of the count / shift / place form below.
                 // Equal distances order by original index (rare: the permutation is only read then).
-                if (d == kth && !(perm[j - 1] < perm[bj[KM - 1] - 1]))
-                    return;
+                if (d == kth) {
+                    if (!EXACT) {
+                        tie_seen = true;
+                        return;
+                    }
+                    if (!(perm[j - 1] < perm[bj[KM - 1] - 1]))
+                        return;
+                }
                 bd[KM - 1] = d;
                 bj[KM - 1] = j;
 #pragma unroll
                 for (int k = KM - 1; k >= 1; --k) {
                     bool up = bd[k] < bd[k - 1];
-                    if (bd[k] == bd[k - 1] && bj[k - 1] != 0)
-                        up = perm[bj[k] - 1] < perm[bj[k - 1] - 1];
+                    if (EXACT) {
+                        if (bd[k] == bd[k - 1] && bj[k - 1] != 0)
+                            up = perm[bj[k] - 1] < perm[bj[k - 1] - 1];
+                    } else {
+                        tie_seen |= bd[k] == bd[k - 1] && bd[k] < INFINITY;
+                    }
                     const float td = up ? bd[k - 1] : bd[k];
                     const int tj = up ? bj[k - 1] : bj[k];
                     bd[k - 1] = up ? bd[k] : bd[k - 1];
@@ -298,6 +316,10 @@ __device__ __forceinline__ void sweep_knn_normals(const sfe_icp_params &P, const
                 iR += okr ? 1 : 0;
             }
         }
+        return tie_seen;
+        };
+        if (K != KM || search(std::false_type{}))
+            search(std::true_type{});
         double sx = 0, sy = 0;
 #pragma unroll
         for (int k = 0; k < KM; ++k)
