@@ -567,14 +567,8 @@ __global__ __launch_bounds__(256) void extract_scatter_kernel(const uint32_t *__
                 off0 = inv_off[pi];
                 cnt = inv_off[pi + 1] - off0;
             }
-            int incl = cnt;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int v = __shfl_up(incl, d);
-                if (lane >= d)
-                    incl += v;
-            }
-            const int total = __shfl(incl, 63);
+            const int incl = scan_wave_incl(cnt);
+            const int total = __builtin_amdgcn_readlane(incl, 63);
             s_off[lane] = (uint32_t)off0;
             s_excl[lane] = (uint32_t)(incl - cnt);
             for (int k0 = lane; k0 < total; k0 += 64 * SC_U) { // SC_U independent candidates per lane in flight
@@ -640,14 +634,8 @@ __global__ __launch_bounds__(256) void extract_scatter_kernel(const uint32_t *__
             continue;
         // every lane appends the set bits of its own word behind those of the lanes before it (wave prefix sum of
         // the popcounts): a handful of steps for a sparse mask, where one ballot per bit position costs 32
-        int incl = pc;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int v = __shfl_up(incl, d);
-            if (lane >= d)
-                incl += v;
-        }
-        const int total = __shfl(incl, 63);
+        const int incl = scan_wave_incl(pc);
+        const int total = __builtin_amdgcn_readlane(incl, 63);
         if (total <= SC_LIST) {
             if (nset + total > SC_LIST)
                 flush();
