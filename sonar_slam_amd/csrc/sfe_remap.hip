@@ -539,9 +539,10 @@ __global__ __launch_bounds__(256) void extract_scatter_kernel(const uint32_t *__
         return;
     const int pw = pcols >> 5;
     const uint32_t *__restrict__ src = bits + (long long)f * words_per_frame;
+    // the staged rows are one contiguous run of the frame's words: [(y0 - 1) * pw, (y0 + sc_rows + 1) * pw)
     for (int i = threadIdx.x; i < (sc_rows + 2) * pw; i += 256) {
-        const int r = y0 - 1 + i / pw;
-        s_rows[i] = (r >= 0 && r < prows) ? src[(long long)r * pw + (i % pw)] : 0u; // rows outside the image: no taps
+        const long long gi = (long long)(y0 - 1) * pw + i;
+        s_rows[i] = (gi >= 0 && gi < (long long)prows * pw) ? src[gi] : 0u; // rows outside the image: no taps
     }
     __syncthreads();
     auto tap = [&](int y, int x) -> int { // bit (y, x) of the mask, 0 outside the image
@@ -613,13 +614,12 @@ __global__ __launch_bounds__(256) void extract_scatter_kernel(const uint32_t *__
                     // a canvas pixel is reached once per set tap: only the visit through its FIRST set tap
                     // with a non-zero weight (the taps the inverse map lists) writes, which removes the
                     // duplicate atomics on clustered detections
-                    const int sy = src_pi[u] / pcols, sx = src_pi[u] - sy * pcols;
-                    const int t_src = (sy - iy) * 2 + (sx - ix);
+                    // which tap of this canvas pixel the set pixel is: pi - (iy * pcols + ix) = dy * pcols + dx, dy, dx in {0, 1}
+                    const int dlt = src_pi[u] - (iy * pcols + ix);
+                    const int t_src = dlt >= pcols ? 2 + (dlt - pcols) : dlt;
                     const int first = (v00 && w00) ? 0 : (v01 && w01) ? 1 : (v10 && w10) ? 2 : 3;
-                    if (((acc + 16384) >> 15) != 0 && t_src == first) {
-                        const unsigned row = o[u] / (unsigned)ccols, col = o[u] - row * (unsigned)ccols;
-                        atomicOr(&bitmap[((long long)f * crows + row) * wpr + (col >> 6)], 1ull << (col & 63));
-                    }
+                    if (((acc + 16384) >> 15) != 0 && t_src == first) // o = bit index inside the frame's bitmap
+                        atomicOr(&bitmap[(long long)f * crows * wpr + (o[u] >> 6)], 1ull << (o[u] & 63u));
                 }
             }
         }
@@ -627,8 +627,8 @@ __global__ __launch_bounds__(256) void extract_scatter_kernel(const uint32_t *__
     };
     for (int c0 = wave * 64; c0 < sc_rows * pw; c0 += 4 * 64) {
         const int wi = c0 + lane;
-        const int r = y0 + wi / pw, w = wi % pw;
-        uint32_t word = (wi < sc_rows * pw && r < prows) ? s_rows[(r - (y0 - 1)) * pw + w] : 0u;
+        const int gw = y0 * pw + wi; // word index inside the frame: its pixels are gw * 32 .. gw * 32 + 31
+        uint32_t word = (wi < sc_rows * pw && gw < prows * pw) ? s_rows[pw + wi] : 0u;
         const int pc = __popc(word);
         if (!__ballot(pc != 0))
             continue;
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(256) void extract_scatter_kernel(const uint32_t *__
             int pos = nset + incl - pc;
             while (word) {
                 const int bb = __ffs((int)word) - 1;
-                s_list[pos++] = (uint32_t)(r * pcols + w * 32 + bb);
+                s_list[pos++] = (uint32_t)(gw * 32 + bb);
                 word &= word - 1u;
             }
             nset += total;
@@ -656,7 +656,7 @@ __global__ __launch_bounds__(256) void extract_scatter_kernel(const uint32_t *__
             if (nset + 64 > SC_LIST)
                 flush();
             if (set)
-                s_list[nset + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)(r * pcols + w * 32 + bb);
+                s_list[nset + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)(gw * 32 + bb);
             nset += __popcll(m);
         }
     }
@@ -910,8 +910,18 @@ int sfe_geom_create(sfe_ctx *ctx, const float *map_x, const float *map_y, int ca
             inv_off[i] += inv_off[i - 1];
         inv_ent.resize((size_t)inv_off.back());
         std::vector<int32_t> cur(inv_off.begin(), inv_off.end() - 1);
+        // entry = {bit index of the canvas pixel inside a frame's bitmap (row * words_per_row * 64 + col), its remap code}:
+        // the scatter kernel sets that bit without dividing by the canvas width
+        const bool bit_index_fits = (unsigned long long)cart_rows * g->words_per_row * 64ull < (1ull << 32) - 1;
+        if (!bit_index_fits) {
+            sfe_geom_destroy(g);
+            return sfe_set_err(ctx, SFE_ERR_ARG, "canvas %dx%d too large for the inverse map's 32-bit bit index", cart_rows, cart_cols);
+        }
         for (size_t o = 0; o < n; ++o)
-            each_tap(o, [&](size_t pi) { inv_ent[(size_t)cur[pi]++] = make_uint2((uint32_t)o, code[o]); });
+            each_tap(o, [&](size_t pi) {
+                const size_t row = o / (size_t)cart_cols, col = o - row * (size_t)cart_cols;
+                inv_ent[(size_t)cur[pi]++] = make_uint2((uint32_t)(row * (size_t)g->words_per_row * 64 + col), code[o]);
+            });
         if (hipMalloc((void **)&g->d_inv_off, inv_off.size() * 4) != hipSuccess ||
             hipMalloc((void **)&g->d_inv_ent, std::max<size_t>(inv_ent.size(), 1) * sizeof(uint2)) != hipSuccess ||
             hipMemcpy(g->d_inv_off, inv_off.data(), inv_off.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
