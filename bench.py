@@ -388,12 +388,14 @@ def main():
             ctx._check(ctx.lib.sfe_cfar_u8_bits_batch_dev(ctx.handle, big.ptr, nf, ROWS, COLS, 1, th, gh, 0, float(tau),
                                                           65, bigm.ptr))
         ms_cfar_bytes = timed(cfar_big, args.cfar_launches)
-        cfar_bytes_bytes = 2.0 * ROWS * COLS * nf           # 1 B read + 1 B written per pixel
-        # the kernel of the timed step stores the detections as bits (KeyframeBatch.bit_masks): 1 B read + 1 bit
-        # written per pixel -- fewer bytes than SURVEY 8d's figure, the fraction below is priced on what it moves
+        # the algorithmic bytes of the CFAR step are 1 B read + 1 B written per pixel, whatever the kernel
+        # does -- `roofline.achieved` is priced on that figure, as the contract asks.  The kernel of the timed step
+        # stores the detections as bits (KeyframeBatch.bit_masks): it MOVES 1 B + 1 bit per pixel, less than the
+        # algorithmic figure, and is no longer bound by HBM; `moved` prices it on what crosses the pins.
+        cfar_bytes = 2.0 * ROWS * COLS * nf
         bits = kb.bit_masks
         ms_cfar = timed(cfar_big_bits, args.cfar_launches) if bits else ms_cfar_bytes
-        cfar_bytes = (1.125 if bits else 2.0) * ROWS * COLS * nf
+        cfar_moved = (1.125 if bits else 2.0) * ROWS * COLS * nf
         cfar_gbs = cfar_bytes / (ms_cfar * 1e-3) / 1e9
         big.free()
         bigm.free()
@@ -430,13 +432,18 @@ def main():
                          "traffic_note": "bytes/launch = 2*FETCH_SIZE + WRITE_SIZE from profiles/cfar%s_pmc.json"
                                          % ("_bits" if bits else ""),
                          "bytes_per_launch": cfar_bytes, "ms_per_launch": ms_cfar, "frames_per_launch": nf,
-                         "bytes_note": "1 B read + %s written per pixel" % ("1 bit" if bits else "1 B"),
-                         # the byte-mask form of the same kernel (what cfar.soca() of the drop-in returns, SURVEY 8d's
-                         # 2 B per pixel): slower per launch, higher fraction -- the bit store removes 7/8 of the
-                         # writes and leaves the kernel bound by its ~30 VALU instructions per 256-pixel row
-                         "byte_mask_kernel": {"ms_per_launch": ms_cfar_bytes, "bytes_per_launch": cfar_bytes_bytes,
-                                              "achieved": cfar_bytes_bytes / (ms_cfar_bytes * 1e-3) / 1e9,
-                                              "frac": cfar_bytes_bytes / (ms_cfar_bytes * 1e-3) / 1e9 / HBM_PEAK_GBS}},
+                         "bytes_note": "SURVEY 8d: 1 B read + 1 B written per pixel",
+                         # what the kernel of the step really moves: the mask leaves it as 1 bit per pixel (no byte mask,
+                         # no pack pass), so its traffic is BELOW the algorithmic bytes and the kernel is bound by its
+                         # ~29 VALU instructions per 256-pixel row, not by HBM
+                         "moved": {"bytes_per_launch": cfar_moved, "achieved": cfar_moved / (ms_cfar * 1e-3) / 1e9,
+                                   "frac": cfar_moved / (ms_cfar * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "note": "1 B read + %s written per pixel" % ("1 bit" if bits else "1 B")},
+                         # the byte-mask form of the same kernel (what cfar.soca() of the drop-in returns): it moves
+                         # exactly the algorithmic bytes
+                         "byte_mask_kernel": {"ms_per_launch": ms_cfar_bytes, "bytes_per_launch": cfar_bytes,
+                                              "achieved": cfar_bytes / (ms_cfar_bytes * 1e-3) / 1e9,
+                                              "frac": cfar_bytes / (ms_cfar_bytes * 1e-3) / 1e9 / HBM_PEAK_GBS}},
             # the ICP kernels prune the search (exact strip-sweep NN): the work below is COUNTED by the kernel in a
             # separate profiled launch of the same batch (sfe_icp_get_profile), not derived from n_src * n_tgt
             "icp_kernel": icp_kernel,
