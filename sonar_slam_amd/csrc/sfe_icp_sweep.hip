@@ -742,9 +742,14 @@ struct SweepShared {
     unsigned sel_prefix, sel_k;
     unsigned n_none, n_exact; // census of the iteration, tallied where a query is settled
     int grid_skips;           // first iteration: queries that took a grid witness instead of searching in round 0
+    unsigned n_rechit[2];     // queries settled by their clearance record, this iteration / the one before
     int long_n, long_next, mid_n, wl_n[2];
     int flag_iterate, flag_status;
     float Ti[9];
+    float thist[ICP_MAX_HIST][6]; // T_iter of every iteration so far (rows 0 and 1): the movement bounds below
+    float mva[ICP_MAX_HIST], mvt[ICP_MAX_HIST]; // a query x = T0 * src has moved by at most mva[k] |x| + mvt[k] between
+                                                // iteration k and the current one
+    unsigned rmax_bits;           // largest |T0 * src| (float bits; >= 0 so the bit patterns order like the values)
     float hist_c[ICP_MAX_HIST], hist_s[ICP_MAX_HIST], hist_x[ICP_MAX_HIST], hist_y[ICP_MAX_HIST];
     long long prof_t, prof[16], prof_it[64], prof_b0;
     StripTab tab;
@@ -777,7 +782,19 @@ struct SweepShared {
 #define SW_INEXACT_OF(bpos) (-2 - (bpos))
 #define SW_OWN_DONE 0x80000000u // list entry flags of queries handed from the first to the second pass:
 #define SW_TIED 0x40000000u     // own strip finished / a tie with the current best was seen there
-#define SW_QMASK 0x3FFFFFFFu
+#define SW_PARTIAL 0x20000000u  // ... / the runner-up distance of what it has visited so far waits in Q.st[q].z
+#define SW_QMASK 0x1FFFFFFFu
+// Clearance records (steady-state iterations): a search looks a little further than it has to -- out to (1 + m)^2 x the
+// squared bound it would stop at -- and remembers R = distance from the query to the nearest target OTHER than its
+// neighbour (min of the runner-up among the visited candidates and the edge of the searched window), with the iteration
+// it was taken in.  In a later iteration the query has moved by at most mvb (a bound over all queries from the two
+// transforms): if its old neighbour, evaluated first as the witness, is closer than R - mvb, it is still THE nearest
+// target and nothing is searched; likewise a query beyond the cap C whose every target is provably beyond C.  Once
+// the clouds have converged (a few mm per iteration against neighbour distances of centimetres) almost every query
+// takes this path: the iteration costs a transform, one distance and the census.  Decisions and results are those of
+// the full search: the skip needs a strict gap (1e-5 relative, two orders above the fp32 rounding of the distances).
+#define SW_REC_MIN_ITER 12
+#define SW_REC_MARGIN 8 // percent: the search radius grows by 8 %, ~17 % more candidates
 
 struct SweepQ { // per-job views of the per-query scratch (the transformed query itself is never stored: whoever needs
                 // it again recomputes it from the source point, two affine maps with wave-uniform coefficients)
@@ -788,6 +805,8 @@ struct SweepQ { // per-job views of the per-query scratch (the transformed query
     int *mid;     // queries that outlived the first pass (compacted for the second)
     int *lng;     // queries handed to the cooperative tier this round
     int *order;   // all queries, neighbours in space next to each other (see the sort at the kernel start)
+    int *slot_of; // ... and the inverse: position of query q in that order
+    unsigned *rec; // clearance records, by position in `order` (the fresh pass streams through them)
     float2 *ssrc; // their source points in that order
     const int *perm;
 };
@@ -834,7 +853,8 @@ __device__ __forceinline__ int sweep_resolve_tie(const float2 *__restrict__ T, c
 // control block + 8 (n_tgt + pad) + 6 n_src bytes fit the workgroup's LDS share (5000 x 5000: 76 KB of 80).
 // PROF: per-phase cycle counters of workgroup 0 and launch-wide counts of the work done (candidate evaluations,
 // lower-bound probes); instantiated for the two-jobs-per-CU builds with an LDS-resident target only.
-template <int MINW, bool LDS_TGT, bool LDS_Q, bool PROF>
+// REC: the build with clearance records (below); chosen by the launcher for chains that run many iterations.
+template <int MINW, bool LDS_TGT, bool LDS_Q, bool PROF, bool REC>
 __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
     sfe_icp_params P, const SweepJob *__restrict__ jobs, const int *__restrict__ job_ids, const float2 *__restrict__ src_all,
     const float *__restrict__ guess_all, const float2 *__restrict__ stgt_all, const int *__restrict__ perm_all,
@@ -842,7 +862,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
     const int *__restrict__ grid_all, int4 *__restrict__ q_st_all, int *__restrict__ q_wl_all, float2 *__restrict__ q_ssrc_all,
     float *__restrict__ nn_d2_all,
     int *__restrict__ nn_pos_all, float *__restrict__ T_out, int *__restrict__ status_out,
-    int *__restrict__ iters_out, long long *prof, int *dbg, int sw_budget, int sw_budget_a, int sw_cache, int t_cap, int q_cap, int sort_chunk)
+    int *__restrict__ iters_out, long long *prof, int *dbg, int sw_budget, int sw_budget_a, int sw_cache, int t_cap, int q_cap, int sort_chunk, float sw_m)
 {
     static_assert(LDS_TGT || !LDS_Q, "LDS_Q needs the LDS-resident target layout");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -891,11 +911,13 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
             Q.pos[i] = pz;
         }
     };
-    Q.wl[0] = q_wl_all + 5 * J.q_off;
+    Q.wl[0] = q_wl_all + 7 * J.q_off;
     Q.wl[1] = Q.wl[0] + ns;
     Q.mid = Q.wl[1] + ns;
     Q.lng = Q.mid + ns;
     Q.order = Q.lng + ns;
+    Q.slot_of = Q.order + ns;
+    Q.rec = reinterpret_cast<unsigned *>(Q.slot_of + ns);
     Q.ssrc = q_ssrc_all + J.q_off;
     Q.perm = perm_all + J.tgt_off;
     const int *__restrict__ grid = (grid_all != nullptr && (sw_cache & 4) != 0) ? grid_all + (size_t)J.prep * SW_GRID_MAX : nullptr;
@@ -911,6 +933,8 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
     // wave-uniform work counters (PROF only): candidate distance evaluations of the lane-per-query tiers, of the
     // cooperative tier, witness evaluations, lower-bound probes
     unsigned long long c_eval = 0, c_coop = 0, c_wit = 0, c_lb = 0;
+    if (tid == 0)
+        S.rmax_bits = 0u;
     { // strip table -> LDS
         const int *tsrc = reinterpret_cast<const int *>(tab_all + J.prep);
         int *tdst = reinterpret_cast<int *>(&S.tab);
@@ -941,6 +965,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
     // original order.  Sorted once per job, in the LDS that will hold the target (chunks of 8192). ----
     {
         unsigned long long *skeys = reinterpret_cast<unsigned long long *>(lds_tgt);
+        float rloc = 0.0f; // largest |T0 * src| among this thread's queries (for the movement bounds of the clearance records)
         for (int c0 = 0; c0 < ns; c0 += sort_chunk) { // sort_chunk = the power of two of keys this LDS region holds
             const int n = min(sort_chunk, ns - c0);
             unsigned n2 = 2;
@@ -953,6 +978,8 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                     const float rx = affine1(T0[0], T0[1], T0[2], sp.x, sp.y);
                     const float ry = affine1(T0[3], T0[4], T0[5], sp.x, sp.y);
                     k = SW_KEY(strip_of(ry, S.tab.ylo, S.tab.inv_g, S.tab.ns), mono_key(rx), c0 + i);
+                    const float rr = sqrtf(f_add(f_mul(rx, rx), f_mul(ry, ry)));
+                    rloc = (rr > rloc || rr != rr) ? rr : rloc; // (a NaN sticks: no bound, no record is ever used)
                 }
                 skeys[i] = k;
             }
@@ -962,9 +989,12 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                 const int q = SW_KEY_ID(skeys[i]);
                 Q.order[c0 + i] = q;
                 Q.ssrc[c0 + i] = src[q];
+                Q.slot_of[q] = c0 + i;
+                Q.rec[c0 + i] = 0u; // no clearance record yet
             }
             __syncthreads();
         }
+        atomicMax(&S.rmax_bits, __float_as_uint(rloc)); // rloc >= 0 or NaN (whose pattern is above every finite one)
     }
     // sorted centred target (with its NaN sentinels: a NaN stops a walk direction) -> LDS
     if (LDS_TGT) {
@@ -1022,12 +1052,42 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
         return make_float2(affine1(Ti[0], Ti[1], Ti[2], rx, ry), affine1(Ti[3], Ti[4], Ti[5], rx, ry));
     };
     bool use_cache = false; // from the second iteration on: Q.pos / Q.st hold the previous iteration's results
+    const bool sw_rec = REC && (sw_cache & 16) != 0; // clearance records (0: A/B without them)
+    const float M2 = sw_uniform(f_mul(f_add(1.0f, sw_m), f_add(1.0f, sw_m)));
+    int rec_epoch = 0;
+    const float rmax = sw_uniform(f_mul(__uint_as_float(S.rmax_bits), 1.00001f));
+    int it = 0; // iteration index (the records carry it in 6 bits: they are used while it < ICP_MAX_HIST = 64)
     while (true) {
         SW_WATCH(wd_outer, P.max_iter + 2, 0)
         float Ti[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i)
             Ti[i] = sw_uniform(S.Ti[i]);
+        // movement bounds: |Ti x - Tk x| <= |A - Ak|_F |x| + |t - tk| for every query x = T0 * src, |x| <= rmax; the
+        // 3e-5 covers the fp32 rounding of the two transformed positions themselves (a few ulp of ~30 m each)
+        if (sw_rec && it < ICP_MAX_HIST) {
+            if (tid < it) {
+                const float a0 = f_add(Ti[0], -S.thist[tid][0]), a1 = f_add(Ti[1], -S.thist[tid][1]);
+                const float a3 = f_add(Ti[3], -S.thist[tid][3]), a4 = f_add(Ti[4], -S.thist[tid][4]);
+                const float tx = f_add(Ti[2], -S.thist[tid][2]), ty = f_add(Ti[5], -S.thist[tid][5]);
+                const float fa = sqrtf(f_add(f_add(f_mul(a0, a0), f_mul(a1, a1)), f_add(f_mul(a3, a3), f_mul(a4, a4))));
+                const float ft = sqrtf(f_add(f_mul(tx, tx), f_mul(ty, ty)));
+                S.mva[tid] = f_mul(fa, 1.0001f);
+                S.mvt[tid] = f_add(f_mul(ft, 1.0001f), 3e-5f);
+            } else if (tid == it) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+                    S.thist[it][i] = Ti[i];
+            }
+        }
+        // Per-iteration modes of the records (all wave-uniform; decided after the barrier below, where mvb is in place):
+        //   rec_on: this iteration's searches use the margin and leave records -- only once the last step moved the
+        //     queries by less than half of the largest margin a record can have (earlier no record would survive one
+        //     iteration, and the margin costs ~17 % more candidates per search);
+        //   records older than rec_epoch are ignored (searches of iterations without rec_on did not maintain them);
+        //   triage: the fresh pass only tests the records, the misses are searched as dense waves by the second pass --
+        //     when most queries of the previous iteration hit (a miss among 64 lanes makes the whole wave search).
+        bool rec_on = false, triage = false;
 
         // ---- A+B: cur = Ti * (T0 * src); exact NN for every pair that can matter.  Round 0 searches
         // for every query (lane i handles the queries i, i + 1024, ... of the spatial order), later rounds search again for the
@@ -1134,10 +1194,12 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
         // and tier it ends.
         if (tid < 256)
             S.hist0[tid] = 0;
+        const unsigned rechit_prev = (it > 0) ? S.n_rechit[(it - 1) & 1] : 0u; // (written last iteration, barriers since)
         if (tid == 0) {
             S.n_none = 0;
             S.n_exact = 0;
             S.grid_skips = 0;
+            S.n_rechit[it & 1] = 0u;
         }
         auto tally_settled = [&](bool is_none, bool is_exact, float best) { // called wave-uniformly
             const unsigned long long mn = __ballot(is_none), me = __ballot(is_exact);
@@ -1176,6 +1238,11 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                     S.wl_n[cur ^ 1] = 0;
                 }
                 __syncthreads();
+                if (round == 0 && sw_rec && use_cache && it < ICP_MAX_HIST) { // (it >= 1: mvb[it - 1] = the last step)
+                    rec_on = sw_uniform(f_add(f_mul(S.mva[it - 1], rmax), S.mvt[it - 1])) < 0.5f * sw_m * sqrtf(C);
+                    triage = rec_on && rec_epoch < it && 2u * rechit_prev >= (unsigned)ns && (sw_cache & 32) != 0;
+                }
+                const bool rec_use = rec_on && rec_epoch < it;
                 const int *wl = Q.wl[cur];
                 int *wl_next = Q.wl[cur ^ 1];
                 // -- tier 1: one lane per query.  The first pass (fresh queries only) transforms the query,
@@ -1188,24 +1255,32 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                 auto walk_pass = [&](const int *list, int n, bool fresh, int budget, bool last) {
                 float2 sp_next = make_float2(0, 0); // fresh pass: the next slice's source point is fetched a slice ahead
                 int q_next = 0;                     // ... and so is its index
+                unsigned rec_next = 0u;             // ... and its clearance record
                 if (fresh && tid < n) {
                     sp_next = Q.ssrc[tid];
                     q_next = Q.order[tid];
+                    if (rec_use)
+                        rec_next = Q.rec[tid];
                 }
+                const float sC = f_mul(sqrtf(C), 1.00001f); // (the cap of this round as a radius, for the records)
                 for (int k0 = 0; k0 < n; k0 += ICP_THREADS) {
                     const int slot = k0 + tid;
                     const bool valid = slot < n;
                     const float2 sp_cur = sp_next;
                     const int q_cur = q_next;
                     int prev = 0;
+                    const unsigned rec = rec_next; // clearance record of the query (0: none)
                     if (fresh && use_cache && valid)
                         prev = Pz(q_cur); // last iteration's result of this query (used after the transform)
                     if (fresh && slot + ICP_THREADS < n) {
                         sp_next = Q.ssrc[slot + ICP_THREADS];
                         q_next = Q.order[slot + ICP_THREADS];
+                        if (rec_use)
+                            rec_next = Q.rec[slot + ICP_THREADS];
                     }
                     int q = 0, bpos = 0;
                     float px = 0, py = 0, best = W2;
+                    float second = INFINITY; // smallest distance met so far to a target other than the (then) best one
                     bool tied = false, own_done = false;
                     if (valid) {
                         if (fresh) {
@@ -1223,6 +1298,8 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                             py = p.y;
                             bpos = -2 - Pz(q);
                             best = Dz(q);
+                            if (e & SW_PARTIAL) // handed on by the first pass: what it had seen
+                                second = __int_as_float(Q.st[q].z);
                         }
                     }
                     // What the previous iteration knew about this query (the cloud moves little between
@@ -1233,7 +1310,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                     // A `none` query stays none as long as it has moved less than its recorded clearance:
                     // |p - t| >= |p0 - t| - |p - p0| > maxDist for every target t (1e-5 relative slop on
                     // each term, two orders above the rounding of the fp32 distances involved).
-                    bool skip = false, grid_hit = false;
+                    bool skip = false, grid_hit = false, rec_hit = false;
                     if (fresh && use_cache && valid) {
                         const int w = prev >= 0 ? prev + 1 : (prev <= -3 ? -2 - prev : 0);
                         if (PROF)
@@ -1245,6 +1322,19 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                             if (dw < best) {
                                 best = dw;
                                 bpos = w;
+                                // Clearance record: every OTHER target was at least R away when the record was taken and
+                                // the query has moved by at most mvb since.  Still closer to its old neighbour than
+                                // R - mvb: that one is the nearest target, strictly; or beyond the cap with every target
+                                // provably beyond the cap: the search would end with exactly this upper bound.
+                                if (rec != 0u && (int)(rec & 63u) >= rec_epoch && dw < r2m_up) {
+                                    // |x| of the query's position x before T_iter: T_iter is a rotation + translation, so
+                                    // |x| = |p - t| (to the 1e-6 by which its rounded matrix is not orthonormal)
+                                    const float ux = f_add(px, -Ti[2]), uy = f_add(py, -Ti[5]);
+                                    const float xr = f_mul(sqrtf(f_add(f_mul(ux, ux), f_mul(uy, uy))), 1.0001f);
+                                    const float mv = f_add(f_mul(S.mva[rec & 63u], xr), S.mvt[rec & 63u]);
+                                    const float Ro = f_add(__uint_as_float(rec & ~63u), -mv);
+                                    rec_hit = f_mul(sqrtf(dw), 1.00001f) < Ro || (dw > C && sC < Ro);
+                                }
                             }
                         } else if (prev == SW_NONE) {
                             const int4 r = Q.st[q];
@@ -1280,7 +1370,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                     const int so = strip_of(py, ylo, inv_g, nst);
                     int s_up = own_done ? so + 1 : so, s_dn = so - 1;
                     // a query with a NaN coordinate has no neighbour (every d2 is NaN): nothing to visit
-                    bool lane_done = !valid || skip || grid_hit || !(px == px && py == py);
+                    bool lane_done = !valid || skip || grid_hit || rec_hit || !(px == px && py == py);
                     bool pending = false; // holds a strip it could not start or finish within the budget
                     bool own_fin = own_done;
                     int used = 0;
@@ -1289,7 +1379,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                         if (!lane_done) {
                             const float capv = (best < r2m_up) ? C : best; // nothing within maxDist yet: only `best` bounds the search
                             const float sb = best < capv ? best : capv;
-                            s = next_strip(tab, nst, so, s_up, s_dn, py, sb);
+                            s = next_strip(tab, nst, so, s_up, s_dn, py, rec_on ? f_mul(sb, M2) : sb);
                             lane_done = s < 0;
                         }
                         return s;
@@ -1300,7 +1390,16 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                     // their next strips -- the wave pays for its slowest LANE (sum over that lane's strips), not
                     // for the slowest lane of every round.
                     const int rtrips = fresh ? budget : sw_rtrips;
-                    int s = pick();
+                    if (rec_use && fresh) { // (wave-uniform branch)
+                        const unsigned long long mh = __ballot(rec_hit);
+                        if (mh && lane == 0)
+                            atomicAdd(&S.n_rechit[it & 1], (unsigned)__popcll(mh));
+                    }
+                    int s = -1;
+                    if (fresh && triage)
+                        pending = !lane_done; // not searched here: the second pass takes the misses as dense waves
+                    else
+                        s = pick();
                     int iL = 0, iR = 0;
                     bool fin = true; // not inside a strip
                     for (int rnd = 0; rnd < 4096; ++rnd) {
@@ -1340,16 +1439,22 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                                     const float dxr = f_add(px, -tr.x), er = f_mul(dxr, dxr);
                                     const float dyr = f_add(py, -tr.y), dr = f_add(er, f_mul(dyr, dyr));
                                     const float capv = (best < r2m_up) ? C : best;
-                                    const float sb = best < capv ? best : capv;   // stop bound (no NaNs here: plain select)
+                                    float sb = best < capv ? best : capv;   // stop bound (no NaNs here: plain select)
+                                    if (rec_on)
+                                        sb = f_mul(sb, M2); // (the records' margin: look a little further than necessary)
                                     const bool okl = el <= sb, okr = er <= sb;   // NaN sentinel -> false
                                     // a candidate at the position of the current best is the best itself (a witness,
-                                    // or a point met again by a search that started over): never a tie
+                                    // or a point met again by a search that started over): never a tie, never a runner-up
                                     tied |= okl && (dl == best) && (iL != bpos);
+                                    if (rec_on && okl && iL != bpos)
+                                        second = fminf(second, fmaxf(dl, best));
                                     if (okl && dl < best) {
                                         best = dl;
                                         bpos = iL;
                                     }
                                     tied |= okr && (dr == best) && (iR != bpos);
+                                    if (rec_on && okr && iR != bpos)
+                                        second = fminf(second, fmaxf(dr, best));
                                     if (okr && dr < best) {
                                         best = dr;
                                         bpos = iR;
@@ -1386,6 +1491,23 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                     }
                     if (is_susp || is_long)
                         setQ(q, best, SW_INEXACT_OF(bpos));
+                    if (rec_on && (is_exact || is_susp) && !rec_hit) {
+                        // a finished search: everything within sqrt(M2 x its final bound) has been evaluated
+                        unsigned r = 0u;
+                        if (!grid_hit && it < ICP_MAX_HIST) {
+                            const float capv = (best < r2m_up) ? C : best;
+                            const float edge = f_mul(best < capv ? best : capv, M2);
+                            const float R = f_mul(sqrtf(fminf(second, edge)), 0.99999f);
+                            r = (__float_as_uint(R) & ~63u) | (unsigned)it;
+                            if (!(R > 0.0f))
+                                r = 0u;
+                        }
+                        Q.rec[fresh ? slot : Q.slot_of[q]] = r;
+                    }
+                    if (rec_on && is_long) { // the next tier continues from what this one has seen; no record meanwhile
+                        Q.st[q].z = __float_as_int(second);
+                        Q.rec[fresh ? slot : Q.slot_of[q]] = 0u;
+                    }
                     tally_settled(is_none, is_exact, best);
                     if (__ballot(grid_hit) && lane == 0)
                         S.grid_skips = 1;
@@ -1408,7 +1530,8 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                             if (is_long) {
                                 // the own strip may be skipped by the next pass only if it was finished here
                                 // (everything in it within the then larger bound has been evaluated)
-                                const unsigned e = (unsigned)q | (own_fin ? SW_OWN_DONE : 0u) | (tied ? SW_TIED : 0u);
+                                const unsigned e = (unsigned)q | (own_fin ? SW_OWN_DONE : 0u) | (tied ? SW_TIED : 0u) |
+                                                   ((rec_on && !last) ? SW_PARTIAL : 0u);
                                 (last ? Q.lng : Q.mid)[base + __popcll(ml & below)] = (int)e;
                             }
                         }
@@ -1744,6 +1867,9 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
         if (!S.flag_iterate)
             break;
         use_cache = (sw_cache & 1) != 0;
+        if (!rec_on)
+            rec_epoch = it + 1;
+        ++it;
     }
 
     if (tid == 0) {
@@ -1857,7 +1983,7 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
     float *d_mean = (float *)sfe_scratch(ctx, 17, sizeof(float) * 2 * (size_t)n_prep);
     unsigned long long *d_gkeys = (unsigned long long *)sfe_scratch(ctx, 24, sizeof(unsigned long long) * (size_t)std::max(koff, 1LL));
     int4 *d_qst = (int4 *)sfe_scratch(ctx, 19, sizeof(int4) * (size_t)qoff);
-    int *d_qwl = (int *)sfe_scratch(ctx, 21, sizeof(int) * 5 * (size_t)qoff);
+    int *d_qwl = (int *)sfe_scratch(ctx, 21, sizeof(int) * 7 * (size_t)qoff);
     float2 *d_qssrc = (float2 *)sfe_scratch(ctx, 30, sizeof(float2) * (size_t)qoff);
     StripTab *d_tab = (StripTab *)sfe_scratch(ctx, 23, sizeof(StripTab) * (size_t)n_prep);
     int *d_grid = (int *)sfe_scratch(ctx, 38, sizeof(int) * (size_t)SW_GRID_MAX * (size_t)n_prep);
@@ -1913,11 +2039,15 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
     const int sw_cache = ((getenv("SFE_SW_CACHE") ? atoi(getenv("SFE_SW_CACHE")) : 1) & 1) |
                          ((getenv("SFE_SW_GRID") ? atoi(getenv("SFE_SW_GRID")) : 1) ? 4 : 0) |
                          ((getenv("SFE_SW_GRID_SKIP") ? atoi(getenv("SFE_SW_GRID_SKIP")) : 1) ? 8 : 0) | // bit 3: witnessed queries skip round 0
+                         ((getenv("SFE_SW_REC") ? atoi(getenv("SFE_SW_REC")) : 1) ? 16 : 0) | // bit 4: clearance records
+                         ((getenv("SFE_SW_TRIAGE") ? atoi(getenv("SFE_SW_TRIAGE")) : 1) ? 32 : 0) | // bit 5: ... with triage passes
 
                          ((getenv("SFE_SW_JUMP") ? atoi(getenv("SFE_SW_JUMP")) : 1) ? 2 : 0) |
                          // bits 16..23: margin (percent) of the next iteration's cap over this iteration's limit
                          (std::max(0, std::min(255, getenv("SFE_SW_MARGIN") ? atoi(getenv("SFE_SW_MARGIN")) : SW_CAP_MARGIN)) << 16) |
                          (std::max(1, std::min(255, getenv("SFE_SW_RTRIPS") ? atoi(getenv("SFE_SW_RTRIPS")) : SW_ROUND_TRIPS)) << 8);
+    // margin of the clearance records: a search looks this fraction further (in radius) than it has to
+    const float sw_m = 0.01f * (float)std::max(1, std::min(100, getenv("SFE_SW_RECM") ? atoi(getenv("SFE_SW_RECM")) : SW_REC_MARGIN));
     int *d_dbg = nullptr;
     if (debug) {
         d_dbg = (int *)sfe_scratch(ctx, 22, sizeof(int) * 8);
@@ -1944,7 +2074,7 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
         hipLaunchKernelGGL(KERNEL, dim3(N), dim3(ICP_THREADS), (SMEM), ctx->stream, *p, d_jobs, (IDS),                 \
                            (const float2 *)d_src, d_guess9, d_stgt, d_perm, d_snrm, d_mean, d_tab, d_grid, d_qst, d_qwl, d_qssrc, \
                            d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof, d_dbg, sw_budget, sw_budget_a, sw_cache, \
-                           (TCAP), (QCAP), pow2_floor(((SMEM)-ctl_bytes) / 8));                                        \
+                           (TCAP), (QCAP), pow2_floor(((SMEM)-ctl_bytes) / 8), sw_m);                                        \
         SFE_LAUNCH_CHECK(ctx);                                                                                         \
     } while (0)
     // A/B: VGPR budget of the LDS_Q build.  A workgroup is 1024 threads = 4 waves per SIMD, so two workgroups per CU
@@ -1952,33 +2082,43 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
     // 128 VGPRs 48.6 ms (profiles/r02_icp_vgpr_budget.txt) -- one resident job per CU costs more than the 86 spilled
     // VGPRs of the 64-VGPR build
     static const int minw = getenv("SFE_SW_MINW") ? atoi(getenv("SFE_SW_MINW")) : 8;
+    // The build with clearance records carries more per-lane state (the 64-VGPR budget makes every register count:
+    // the same chain runs ~10 % slower in it until the records start to hit), so it only takes chains that are set to
+    // run many iterations: a fixed count (no differential checker) of at least SW_REC_MIN_ITER.
+    const bool rec_build = (sw_cache & 16) != 0 && p->max_iter >= SW_REC_MIN_ITER && !p->use_diff_checker;
     if (n_q) {
         const size_t smem = ctl_bytes + 8 * (size_t)t_cap + 6 * (size_t)q_cap;
         if (!wide && !d_prof && minw == 4)
-            SW_LAUNCH((icp_sweep_kernel<4, true, true, false>), n_q, d_ids, smem, t_cap, q_cap);
+            SW_LAUNCH((icp_sweep_kernel<4, true, true, false, false>), n_q, d_ids, smem, t_cap, q_cap);
         else if (wide)
-            SW_LAUNCH((icp_sweep_kernel<4, true, true, false>), n_q, d_ids, smem, t_cap, q_cap);
+            SW_LAUNCH((icp_sweep_kernel<4, true, true, false, false>), n_q, d_ids, smem, t_cap, q_cap);
+        else if (d_prof && rec_build)
+            SW_LAUNCH((icp_sweep_kernel<8, true, true, true, true>), n_q, d_ids, smem, t_cap, q_cap);
         else if (d_prof)
-            SW_LAUNCH((icp_sweep_kernel<8, true, true, true>), n_q, d_ids, smem, t_cap, q_cap);
+            SW_LAUNCH((icp_sweep_kernel<8, true, true, true, false>), n_q, d_ids, smem, t_cap, q_cap);
+        else if (rec_build)
+            SW_LAUNCH((icp_sweep_kernel<8, true, true, false, true>), n_q, d_ids, smem, t_cap, q_cap);
         else
-            SW_LAUNCH((icp_sweep_kernel<8, true, true, false>), n_q, d_ids, smem, t_cap, q_cap);
+            SW_LAUNCH((icp_sweep_kernel<8, true, true, false, false>), n_q, d_ids, smem, t_cap, q_cap);
     }
     if (n_lds) {
         const size_t smem = ctl_bytes + sizeof(float2) * (SW_TCAP + SW_PAD);
         if (wide)
-            SW_LAUNCH((icp_sweep_kernel<4, true, false, false>), n_lds, d_ids + n_q, smem, SW_TCAP + SW_PAD, 0);
+            SW_LAUNCH((icp_sweep_kernel<4, true, false, false, false>), n_lds, d_ids + n_q, smem, SW_TCAP + SW_PAD, 0);
         else if (d_prof)
-            SW_LAUNCH((icp_sweep_kernel<8, true, false, true>), n_lds, d_ids + n_q, smem, SW_TCAP + SW_PAD, 0);
+            SW_LAUNCH((icp_sweep_kernel<8, true, false, true, false>), n_lds, d_ids + n_q, smem, SW_TCAP + SW_PAD, 0);
+        else if (rec_build)
+            SW_LAUNCH((icp_sweep_kernel<8, true, false, false, true>), n_lds, d_ids + n_q, smem, SW_TCAP + SW_PAD, 0);
         else
-            SW_LAUNCH((icp_sweep_kernel<8, true, false, false>), n_lds, d_ids + n_q, smem, SW_TCAP + SW_PAD, 0);
+            SW_LAUNCH((icp_sweep_kernel<8, true, false, false, false>), n_lds, d_ids + n_q, smem, SW_TCAP + SW_PAD, 0);
     }
     if (n_glb) {
         // the target stays in HBM / L2; the LDS behind the control block only serves the query sort
         const size_t smem_g = ctl_bytes + sizeof(unsigned long long) * SW_TCAP;
         if (wide)
-            SW_LAUNCH((icp_sweep_kernel<4, false, false, false>), n_glb, d_ids + n_q + n_lds, smem_g, SW_TCAP, 0);
+            SW_LAUNCH((icp_sweep_kernel<4, false, false, false, false>), n_glb, d_ids + n_q + n_lds, smem_g, SW_TCAP, 0);
         else
-            SW_LAUNCH((icp_sweep_kernel<8, false, false, false>), n_glb, d_ids + n_q + n_lds, smem_g, SW_TCAP, 0);
+            SW_LAUNCH((icp_sweep_kernel<8, false, false, false, false>), n_glb, d_ids + n_q + n_lds, smem_g, SW_TCAP, 0);
     }
 #undef SW_LAUNCH
     if (side) {
