@@ -794,6 +794,7 @@ struct SweepShared {
 // takes this path: the iteration costs a transform, one distance and the census.  Decisions and results are those of
 // the full search: the skip needs a strict gap (1e-5 relative, two orders above the fp32 rounding of the distances).
 #define SW_REC_MIN_ITER 12
+#define SW_REC_KAPPA 3.0f
 #define SW_REC_MARGIN 8 // percent: the search radius grows by 8 %, ~17 % more candidates
 
 struct SweepQ { // per-job views of the per-query scratch (the transformed query itself is never stored: whoever needs
@@ -862,7 +863,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
     const int *__restrict__ grid_all, int4 *__restrict__ q_st_all, int *__restrict__ q_wl_all, float2 *__restrict__ q_ssrc_all,
     float *__restrict__ nn_d2_all,
     int *__restrict__ nn_pos_all, float *__restrict__ T_out, int *__restrict__ status_out,
-    int *__restrict__ iters_out, long long *prof, int *dbg, int sw_budget, int sw_budget_a, int sw_cache, int t_cap, int q_cap, int sort_chunk, float sw_m)
+    int *__restrict__ iters_out, long long *prof, int *dbg, int sw_budget, int sw_budget_a, int sw_cache, int t_cap, int q_cap, int sort_chunk, float sw_m, float sw_kappa)
 {
     static_assert(LDS_TGT || !LDS_Q, "LDS_Q needs the LDS-resident target layout");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1070,7 +1071,12 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                 const float a0 = f_add(Ti[0], -S.thist[tid][0]), a1 = f_add(Ti[1], -S.thist[tid][1]);
                 const float a3 = f_add(Ti[3], -S.thist[tid][3]), a4 = f_add(Ti[4], -S.thist[tid][4]);
                 const float tx = f_add(Ti[2], -S.thist[tid][2]), ty = f_add(Ti[5], -S.thist[tid][5]);
-                const float fa = sqrtf(f_add(f_add(f_mul(a0, a0), f_mul(a1, a1)), f_add(f_mul(a3, a3), f_mul(a4, a4))));
+                // largest singular value of the 2x2 difference: s^2 = (F^2 + sqrt(F^4 - 4 det^2)) / 2 (for two rotations
+                // that is F / sqrt 2: the Frobenius norm alone would overstate the turn by 41 %); 1.001 for its rounding
+                const float f2 = f_add(f_add(f_mul(a0, a0), f_mul(a1, a1)), f_add(f_mul(a3, a3), f_mul(a4, a4)));
+                const float det = f_add(f_mul(a0, a4), -f_mul(a1, a3));
+                const float disc = fmaxf(f_add(f_mul(f2, f2), -f_mul(4.0f, f_mul(det, det))), 0.0f);
+                const float fa = f_mul(sqrtf(f_mul(0.5f, f_add(f2, sqrtf(disc)))), 1.001f);
                 const float ft = sqrtf(f_add(f_mul(tx, tx), f_mul(ty, ty)));
                 S.mva[tid] = f_mul(fa, 1.0001f);
                 S.mvt[tid] = f_add(f_mul(ft, 1.0001f), 3e-5f);
@@ -1088,6 +1094,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
         //   triage: the fresh pass only tests the records, the misses are searched as dense waves by the second pass --
         //     when most queries of the previous iteration hit (a miss among 64 lanes makes the whole wave search).
         bool rec_on = false, triage = false;
+        float mu2 = 0.0f; // additive part of the records' margin (squared): searched window = M2 * bound + mu2
 
         // ---- A+B: cur = Ti * (T0 * src); exact NN for every pair that can matter.  Round 0 searches
         // for every query (lane i handles the queries i, i + 1024, ... of the spatial order), later rounds search again for the
@@ -1239,8 +1246,13 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                 }
                 __syncthreads();
                 if (round == 0 && sw_rec && use_cache && it < ICP_MAX_HIST) { // (it >= 1: mvb[it - 1] = the last step)
-                    rec_on = sw_uniform(f_add(f_mul(S.mva[it - 1], rmax), S.mvt[it - 1])) < 0.5f * sw_m * sqrtf(C);
-                    triage = rec_on && rec_epoch < it && 2u * rechit_prev >= (unsigned)ns && (sw_cache & 32) != 0;
+                    const float mv_last = sw_uniform(f_add(f_mul(S.mva[it - 1], rmax), S.mvt[it - 1]));
+                    const float mu = f_mul(sw_kappa, mv_last);
+                    rec_on = mu < 0.5f * sqrtf(C); // (NaN -> off)
+                    mu2 = sw_uniform(f_mul(mu, mu));
+                    // (the first iteration with records has no count yet: the margin was sized for them to hold)
+                    triage = rec_on && rec_epoch < it && (rec_epoch == it - 1 || 2u * rechit_prev >= (unsigned)ns) &&
+                             (sw_cache & 32) != 0;
                 }
                 const bool rec_use = rec_on && rec_epoch < it;
                 const int *wl = Q.wl[cur];
@@ -1255,12 +1267,9 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                 auto walk_pass = [&](const int *list, int n, bool fresh, int budget, bool last) {
                 float2 sp_next = make_float2(0, 0); // fresh pass: the next slice's source point is fetched a slice ahead
                 int q_next = 0;                     // ... and so is its index
-                unsigned rec_next = 0u;             // ... and its clearance record
                 if (fresh && tid < n) {
                     sp_next = Q.ssrc[tid];
                     q_next = Q.order[tid];
-                    if (rec_use)
-                        rec_next = Q.rec[tid];
                 }
                 const float sC = f_mul(sqrtf(C), 1.00001f); // (the cap of this round as a radius, for the records)
                 for (int k0 = 0; k0 < n; k0 += ICP_THREADS) {
@@ -1269,14 +1278,14 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                     const float2 sp_cur = sp_next;
                     const int q_cur = q_next;
                     int prev = 0;
-                    const unsigned rec = rec_next; // clearance record of the query (0: none)
+                    // clearance record of the query (0: none); fetched here, not a slice ahead like the source point:
+                    // measured, the register that would carry it costs more than the latency of this coalesced read
+                    const unsigned rec = (fresh && rec_use && valid) ? Q.rec[slot] : 0u;
                     if (fresh && use_cache && valid)
                         prev = Pz(q_cur); // last iteration's result of this query (used after the transform)
                     if (fresh && slot + ICP_THREADS < n) {
                         sp_next = Q.ssrc[slot + ICP_THREADS];
                         q_next = Q.order[slot + ICP_THREADS];
-                        if (rec_use)
-                            rec_next = Q.rec[slot + ICP_THREADS];
                     }
                     int q = 0, bpos = 0;
                     float px = 0, py = 0, best = W2;
@@ -1379,7 +1388,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                         if (!lane_done) {
                             const float capv = (best < r2m_up) ? C : best; // nothing within maxDist yet: only `best` bounds the search
                             const float sb = best < capv ? best : capv;
-                            s = next_strip(tab, nst, so, s_up, s_dn, py, rec_on ? f_mul(sb, M2) : sb);
+                            s = next_strip(tab, nst, so, s_up, s_dn, py, rec_on ? f_add(f_mul(sb, M2), mu2) : sb);
                             lane_done = s < 0;
                         }
                         return s;
@@ -1441,7 +1450,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                                     const float capv = (best < r2m_up) ? C : best;
                                     float sb = best < capv ? best : capv;   // stop bound (no NaNs here: plain select)
                                     if (rec_on)
-                                        sb = f_mul(sb, M2); // (the records' margin: look a little further than necessary)
+                                        sb = f_add(f_mul(sb, M2), mu2); // (the records' margin: look a little further than necessary)
                                     const bool okl = el <= sb, okr = er <= sb;   // NaN sentinel -> false
                                     // a candidate at the position of the current best is the best itself (a witness,
                                     // or a point met again by a search that started over): never a tie, never a runner-up
@@ -1496,7 +1505,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                         unsigned r = 0u;
                         if (!grid_hit && it < ICP_MAX_HIST) {
                             const float capv = (best < r2m_up) ? C : best;
-                            const float edge = f_mul(best < capv ? best : capv, M2);
+                            const float edge = f_add(f_mul(best < capv ? best : capv, M2), mu2);
                             const float R = f_mul(sqrtf(fminf(second, edge)), 0.99999f);
                             r = (__float_as_uint(R) & ~63u) | (unsigned)it;
                             if (!(R > 0.0f))
@@ -1771,7 +1780,8 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
         SW_PROF(2);
         if (PROF && tid == 0 && chk.iters < 32) {
             S.prof_it[2 * chk.iters] = clock64() - S.prof_b0;
-            S.prof_it[2 * chk.iters + 1] = ((long long)__float_as_uint(C) << 32) | nexact;
+            S.prof_it[2 * chk.iters + 1] = ((long long)__float_as_uint(C) << 32) | (nexact & 0xFFFFu) |
+                                           ((S.n_rechit[it & 1] & 0xFFFFu) << 16); // (clouds of < 65536 points)
         }
 
         // ---- C: TrimmedDistOutlierFilter limit: exact order statistic by radix select ----
@@ -2048,6 +2058,9 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
                          (std::max(1, std::min(255, getenv("SFE_SW_RTRIPS") ? atoi(getenv("SFE_SW_RTRIPS")) : SW_ROUND_TRIPS)) << 8);
     // margin of the clearance records: a search looks this fraction further (in radius) than it has to
     const float sw_m = 0.01f * (float)std::max(1, std::min(100, getenv("SFE_SW_RECM") ? atoi(getenv("SFE_SW_RECM")) : SW_REC_MARGIN));
+    // ... plus sw_kappa x the largest movement of the last step (the steps shrink geometrically once ICP converges: a
+    // few times the last one covers all that are still to come)
+    const float sw_kappa = getenv("SFE_SW_RECK") ? (float)atof(getenv("SFE_SW_RECK")) : SW_REC_KAPPA;
     int *d_dbg = nullptr;
     if (debug) {
         d_dbg = (int *)sfe_scratch(ctx, 22, sizeof(int) * 8);
@@ -2074,7 +2087,7 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
         hipLaunchKernelGGL(KERNEL, dim3(N), dim3(ICP_THREADS), (SMEM), ctx->stream, *p, d_jobs, (IDS),                 \
                            (const float2 *)d_src, d_guess9, d_stgt, d_perm, d_snrm, d_mean, d_tab, d_grid, d_qst, d_qwl, d_qssrc, \
                            d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof, d_dbg, sw_budget, sw_budget_a, sw_cache, \
-                           (TCAP), (QCAP), pow2_floor(((SMEM)-ctl_bytes) / 8), sw_m);                                        \
+                           (TCAP), (QCAP), pow2_floor(((SMEM)-ctl_bytes) / 8), sw_m, sw_kappa);                                        \
         SFE_LAUNCH_CHECK(ctx);                                                                                         \
     } while (0)
     // A/B: VGPR budget of the LDS_Q build.  A workgroup is 1024 threads = 4 waves per SIMD, so two workgroups per CU

@@ -70,9 +70,9 @@ def main():
                         "%d/%d/%d/%d" % (cyc[16 + 24 + 4 * r], cyc[16 + 25 + 4 * r], cyc[16 + 26 + 4 * r], cyc[16 + 27 + 4 * r] // 1000)
                         for r in range(8)))
                 import struct
-                print("   per iteration (kcycles search, cap C, n_exact): " + " ".join(
-                    "%d/%.3g/%d" % (cyc[16 + 2 * i] // 1000, struct.unpack("f", struct.pack("I", (cyc[17 + 2 * i] >> 32) & 0xFFFFFFFF))[0],
-                                    cyc[17 + 2 * i] & 0xFFFFFFFF) for i in range(min(it, 32))))
+                print("   per iteration (kcycles search, cap C, n_exact, settled by a clearance record): " + " ".join(
+                    "%d/%.3g/%d/%d" % (cyc[16 + 2 * i] // 1000, struct.unpack("f", struct.pack("I", (cyc[17 + 2 * i] >> 32) & 0xFFFFFFFF))[0],
+                                       cyc[17 + 2 * i] & 0xFFFF, (cyc[17 + 2 * i] >> 16) & 0xFFFF) for i in range(min(it, 32))))
         ctx._check(ctx.lib.sfe_icp_set_tuning(ctx.handle, 0))
         kb.free()
 
