@@ -500,3 +500,39 @@ def test_knn_density_and_max_density_filter():
     pcl.srand(1)
     out2, desc2 = pcl.max_density_filter(pts, np.arange(len(pts), dtype=np.float32)[:, None], 10, md)
     assert np.array_equal(out2, out) and np.array_equal(desc2[:, 0].astype(int), np.nonzero(keep)[0])
+
+
+@pytest.mark.parametrize("mz", [0, 1])
+def test_clearance_records_over_long_chains_equal_brute_force(ctx, mz, monkeypatch):
+    """Chains with a fixed count of >= 12 iterations run the build with clearance records (a converged query whose old
+    neighbour is provably still the nearest is not searched again).  70 iterations: past convergence (every query
+    settled by its record), past the 64 iterations the records can number, with duplicated targets (ties never get a
+    usable record) and far outliers; transforms, iteration counts and statuses must equal the brute-force kernel's
+    bit for bit -- and the same with the records switched off."""
+    src, tgt, guess, _ = synth.scan_pair(seed=33, n_src=3000, n_tgt=2800)
+    tgt = np.concatenate([tgt, tgt[:300]]).astype(np.float32)
+    src[::53] += 35.0
+    p = icp_config.shipped_params(minimizer=mz, max_iter=70, use_diff_checker=0)
+    base = synth.pose_of(guess)
+    rng = np.random.default_rng(8)
+    guesses = [synth.pose_matrix(base[0] + dx, base[1] + dy, base[2] + dt).astype(np.float32)
+               for dx, dy, dt in rng.normal(0, [0.3, 0.3, 0.04], (4, 3))]
+    same, a, b = _sweep_vs_brute(ctx, p, src, tgt, guesses)
+    assert same, (a[0], b[0], a[2], b[2])
+    assert list(a[2]) == [70] * len(guesses)
+    monkeypatch.setenv("SFE_SW_REC", "0")
+    off = _with_variant(ctx, 0, lambda: _icp(p, ctx).compute_batch(src, tgt, guesses))
+    assert off[0] == a[0] and np.array_equal(off[1], a[1]) and np.array_equal(off[2], a[2])
+
+
+def test_clearance_records_with_results_in_hbm_scratch(ctx):
+    """A source too large for the per-query results to live in LDS next to the target (9000 x 3100 points: the
+    LDS_TGT build, results in HBM scratch) through the records build: equal to brute force."""
+    src, tgt, guess, _ = synth.scan_pair(seed=34, n_src=9000, n_tgt=2800)
+    tgt = np.concatenate([tgt, tgt[:300]]).astype(np.float32)
+    p = icp_config.shipped_params(minimizer=1, max_iter=40, use_diff_checker=0)
+    base = synth.pose_of(guess)
+    guesses = [synth.pose_matrix(base[0] + 0.2, base[1] - 0.1, base[2] + 0.03).astype(np.float32),
+               np.asarray(guess, np.float32)]
+    same, a, b = _sweep_vs_brute(ctx, p, src, tgt, guesses)
+    assert same, (a[0], b[0], a[2], b[2])
