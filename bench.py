@@ -39,6 +39,11 @@ def parse():
                          "tail is exposed; with several times more the dispatcher refills slots as jobs finish: -15 %% per job at 2048, "
                          "-19 %% at 4096)")
     ap.add_argument("--cfar-frames", type=int, default=1024, help="frames per launch for the CFAR roofline leg")
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="keyframe batches in flight per GPU: consecutive steps alternate between this many resident "
+                         "batches, each on its own context (stream + scratch), so the front end and the ICP preparation "
+                         "of step k+1 fill the CUs the iteration kernel of step k leaves idle (default 1 = one batch, serial; "
+                         "measured on MI355X: 114.6 k keyframes/s with 1, 116.3 k with 2, 118.9 k with 3)")
     ap.add_argument("--cfar-launches", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-keyframes", type=int, default=0,
@@ -308,51 +313,64 @@ def main():
         cpu = cpu_baseline(frames, srcs, tgts, guesses,
                            args.cpu_keyframes, det, host_fe,
                            args.icp_mode, not args.no_filters)
-    # one rank per GPU; SONARFE_BENCH_DEVICE pins every rank to one device (control-plane test on a 1-GPU box)
-    ctx = _lib.Context(int(os.environ.get("SONARFE_BENCH_DEVICE", local_rank)))
-    fe = FeatureExtraction(ctx)
-    fe.Ntc, fe.Ngc, fe.Pfa, fe.rank, fe.alg, fe.threshold = 40, 10, 0.1, 10, "SOCA", 65
-    fe.configure()
-    fe.generate_map_xy(SonarPing(frames[0], oculus_bearings(COLS), 30.0 / ROWS))
     if args.icp_mode == "p2plane30":
         icp_p = icp_config.shipped_params(minimizer=1, use_diff_checker=0, max_iter=30)
     else:
         icp_p = icp_config.shipped_params()
-
-    kb = KeyframeBatch(ctx, fe.geometry, det.params["SOCA"], "SOCA", 65, icp_p, args.batch)
-    kb.upload_frames(frames)
-    kb.upload_scan_pairs(srcs, tgts, guesses)
-    if not args.serial_prep:
-        # the scan pairs are resident and final: the preparation of the ICP targets (sort, strip table, normals)
-        # may run on the library's side stream, next to the front-end kernels of the same step (sonarfe.h,
-        # sfe_icp_set_tuning bit 3); the iteration kernel waits for both
-        ctx.sync()
-        ctx._check(ctx.lib.sfe_icp_set_tuning(ctx.handle, 8))
+    # one rank per GPU; SONARFE_BENCH_DEVICE pins every rank to one device (control-plane test on a 1-GPU box).
+    # `inflight` resident batches per rank, each with its own context (= its own streams and scratch): a replay that
+    # keeps two batches going is how the device stays busy across the serial phases of a step -- the work per step is
+    # the same, step k+1 is simply enqueued while step k still runs.
+    device = int(os.environ.get("SONARFE_BENCH_DEVICE", local_rank))
+    n_inflight = max(1, args.inflight)
+    ctxs, fes, kbs = [], [], []
+    for _ in range(n_inflight):
+        c = _lib.Context(device)
+        f = FeatureExtraction(c)
+        f.Ntc, f.Ngc, f.Pfa, f.rank, f.alg, f.threshold = 40, 10, 0.1, 10, "SOCA", 65
+        f.configure()
+        f.generate_map_xy(SonarPing(frames[0], oculus_bearings(COLS), 30.0 / ROWS))
+        b = KeyframeBatch(c, f.geometry, det.params["SOCA"], "SOCA", 65, icp_p, args.batch)
+        b.upload_frames(frames)
+        b.upload_scan_pairs(srcs, tgts, guesses)
+        if not args.serial_prep:
+            # the scan pairs are resident and final: the preparation of the ICP targets (sort, strip table, normals)
+            # may run on the library's side stream, next to the front-end kernels of the same step (sonarfe.h,
+            # sfe_icp_set_tuning bit 3); the iteration kernel waits for both
+            c.sync()
+            c._check(c.lib.sfe_icp_set_tuning(c.handle, 8))
+        b.run(not args.no_filters)   # set-up, not a warm-up step: the context's scratch is allocated on first use
+        c.sync()
+        ctxs.append(c)
+        fes.append(f)
+        kbs.append(b)
+    ctx, fe, kb = ctxs[0], fes[0], kbs[0]
 
     def barrier():
-        ctx.sync()
+        for c in ctxs:
+            c.sync()
         if dist is not None:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        kb.run(not args.no_filters)
+    for i in range(args.warmup):
+        kbs[i % n_inflight].run(not args.no_filters)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        kb.run(not args.no_filters)
-    ctx.sync()
+    for i in range(args.steps):
+        kbs[(args.warmup + i) % n_inflight].run(not args.no_filters)
     barrier()
     dt = time.perf_counter() - t0
+    kb_last = kbs[(args.warmup + args.steps - 1) % n_inflight]   # the batch of the last timed step
     if dist is not None:
         import torch
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
-    res = kb.results()
+    res = kb_last.results()
     ok = int((res["status"] == 0).sum())
     parity = None
     if rank == 0 and args.parity_jobs > 0:   # the timed step's own outputs, before anything overwrites them
-        parity = parity_check(kb, res, frames, srcs, tgts, guesses, det, fe, args.icp_mode, not args.no_filters,
+        parity = parity_check(kb_last, res, frames, srcs, tgts, guesses, det, fe, args.icp_mode, not args.no_filters,
                               args.parity_jobs)
 
     out = None
@@ -422,7 +440,7 @@ def main():
                                    % (args.batch, "" if args.no_filters else " -> downsample 0.5 -> remove_outlier 1.0/5",
                                       args.icp_mode),
                        "batch_per_gpu": args.batch, "icp_mode": args.icp_mode, "parallelism": "job farm x%d" % world,
-                       "icp_prep_stream": "main" if args.serial_prep else "side",
+                       "icp_prep_stream": "main" if args.serial_prep else "side", "batches_in_flight": n_inflight,
                        "icp_converged_jobs": ok, "mean_icp_iters": iters_total / float(args.batch),
                        "mean_points_per_frame": float(res["counts"].mean()),
                        "max_points_per_frame": int(res["counts"].max()), "points_capacity": kb.cap},
@@ -473,7 +491,8 @@ def main():
             # cpu_baseline.sample
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import live_latency
-            kb.free()
+            for b in kbs:
+                b.free()
             out["live_latency"] = live_latency.measure(ctx)
             out["live_latency"]["note"] = ("median host wall time per call: FeatureExtraction.callback on a 1024x512 ping "
                                            "(fused = sfe_feature_extract_ping, per_stage = the four per-stage calls), "
