@@ -29,10 +29,14 @@
  *     fallback anywhere: without a gfx950 device every compute entry point fails.
  *   - A/B knobs read from the environment (measurement only: every setting returns identical results):
  *     SFE_SW_STRIP_PTS, SFE_SW_BUDGET, SFE_SW_BUDGET_A, SFE_SW_RTRIPS, SFE_SW_MARGIN, SFE_SW_JUMP, SFE_SW_CACHE,
- *     SFE_SW_GRID, SFE_SW_GRID_SKIP, SFE_SW_NO_LDSQ, SFE_SW_WIDE (strip-sweep ICP: strip population, search budgets,
- *     cap margin, cap jump, iteration cache, first-iteration grid witnesses, results in LDS, one workgroup per CU),
- *     SFE_SC_ROWS, SFE_EXTRACT_CHUNK (extraction: polar rows per scatter workgroup, frames per pass),
- *     SFE_CFAR_NO_LDS_RING (sliding-sum CFAR without the LDS ring), SFE_ICP_DEBUG (watchdog report).
+ *     SFE_SW_GRID, SFE_SW_GRID_SKIP, SFE_SW_NO_LDSQ, SFE_SW_WIDE, SFE_SW_MINW, SFE_SW_SHARE_KB (strip-sweep ICP:
+ *     strip population, search budgets, cap margin, cap jump, iteration cache, first-iteration grid witnesses, results
+ *     in LDS, one workgroup per CU, VGPR budget, LDS share), SFE_SW_REC, SFE_SW_TRIAGE, SFE_SW_RECM, SFE_SW_RECK
+ *     (clearance records of long chains: on / off, triage pass, relative margin in percent, multiple of the last step),
+ *     SFE_SC_ROWS, SFE_SC_XCD, SFE_EXTRACT_CHUNK, SFE_EXPAND_POINTS, SFE_EXPAND_WG (extraction: polar rows per scatter
+ *     workgroup, row-block -> XCD map, frames per pass, per-point instead of word-list expansion, its workgroups per
+ *     frame), SFE_CFAR_NO_BITS, SFE_CFAR_NO_LDS_RING (CFAR: byte kernel + pack instead of the bit-stream kernel, sliding
+ *     sums without the LDS ring), SFE_CF_BITONIC (resident downsample by bitonic sort), SFE_ICP_DEBUG (watchdog report).
  *   - one sfe_ctx = one device + one HIP stream + its scratch; a ctx is not
  *     re-entrant (the reference's pybind calls hold the GIL and its ICP object is
  *     stateful, SURVEY 8b "Threading"); use one ctx per worker thread/process.
