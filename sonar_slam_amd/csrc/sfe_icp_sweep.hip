@@ -2097,7 +2097,9 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
     static const int minw = getenv("SFE_SW_MINW") ? atoi(getenv("SFE_SW_MINW")) : 8;
     // The build with clearance records carries more per-lane state (the 64-VGPR budget makes every register count:
     // the same chain runs ~10 % slower in it until the records start to hit), so it only takes chains that are set to
-    // run many iterations: a fixed count (no differential checker) of at least SW_REC_MIN_ITER.
+    // run many iterations: a fixed count (no differential checker) of at least SW_REC_MIN_ITER -- and only the builds of
+    // full batches with LDS-resident targets: for the one-workgroup-per-CU builds with the target in HBM (30 guesses x
+    // one 20 000 x 20 000 pair) the records cost more than they save (24.6 -> 30.9 ms, tools/hires_times.py).
     const bool rec_build = (sw_cache & 16) != 0 && p->max_iter >= SW_REC_MIN_ITER && !p->use_diff_checker;
     if (n_q) {
         const size_t smem = ctl_bytes + 8 * (size_t)t_cap + 6 * (size_t)q_cap;
