@@ -1,4 +1,4 @@
-"""The three pruning rules of the strip-sweep ICP search (sonar_slam_amd/csrc/sfe_icp_sweep.hip), checked in
+"""The pruning rules of the strip-sweep ICP search (sonar_slam_amd/csrc/sfe_icp_sweep.hip), checked in
 float32 on the CPU with numpy doing exactly the kernel's arithmetic.  The GPU tests compare whole ICP runs with
 the brute-force kernel; these fuzz each rule on its own, on inputs built to sit on the decision boundaries:
 
@@ -9,7 +9,8 @@ the brute-force kernel; these fuzz each rule on its own, on inputs built to sit 
      (smin = smallest y in the strips above; likewise below with smax);
   3. clearance: a query that stood at p0 with every target at d2 >= best0 > maxDist^2 and has moved to p with
      fl(|p - p0| * 1.00001) < fl(fl(sqrt(best0) * 0.99999) - fl(maxDist * 1.00001)) still has no target within
-     maxDist: d2(p, t) > maxDist^2 for every t.
+     maxDist: d2(p, t) > maxDist^2 for every t;
+  4. clearance records of matched queries (stated in front of its test below).
 """
 import numpy as np
 
@@ -108,3 +109,96 @@ def test_clearance_rule_never_hides_a_target_within_maxdist():
                 skipped += 1
                 assert (d2(p[0], p[1], t[:, 0], t[:, 1]) > r2m).all(), (case, frac, md, off)
     assert skipped > 2000                                      # the rule does fire on these inputs
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# 4. clearance records (icp_sweep_kernel<..., REC>): a finished search at p0 = Tk x leaves
+#        R = fl(fl(sqrt(min(runner-up d2, edge of the searched window))) * 0.99999), low 6 mantissa bits cleared,
+#    edge = fl(fl(min(best, C) * M2) + mu2).  Later, at p = Tnow x, with dw = d2(p, old neighbour) and
+#        mv = fl(fl(sigma * xr) + ft),  sigma = fl(fl(sigma_max(Anow - Ak)) * 1.001) * 1.0001,
+#        xr = fl(|p - tnow| * 1.0001),  ft = fl(fl(|tnow - tk| * 1.0001) + 3e-5),   Ro = fl(R - mv):
+#      A. fl(sqrt(dw) * 1.00001) < Ro  =>  the old neighbour is the strict nearest target of p;
+#      B. dw > C and fl(sqrt(C) * 1.00001) < Ro  =>  no target of p is within C.
+# ---------------------------------------------------------------------------------------------------------------
+def _affine(T, x):
+    """affine1 of the kernels: fl(fl(fl(a x) + fl(b y)) + c) for both rows of a float32 3x3"""
+    px = F(F(F(T[0, 0] * x[0]) + F(T[0, 1] * x[1])) + T[0, 2])
+    py = F(F(F(T[1, 0] * x[0]) + F(T[1, 1] * x[1])) + T[1, 2])
+    return px, py
+
+
+def _mat3_mul(a, b):
+    """mat3_mul of the kernels: every product and sum rounded to float32, columns left to right"""
+    c = np.zeros((3, 3), F)
+    for i in range(3):
+        for j in range(3):
+            s = F(a[i, 0] * b[0, j])
+            s = F(s + F(a[i, 1] * b[1, j]))
+            s = F(s + F(a[i, 2] * b[2, j]))
+            c[i, j] = s
+    return c
+
+
+def _step(theta, tx, ty):
+    c, s = F(np.cos(theta)), F(np.sin(theta))
+    return np.array([[c, -s, F(tx)], [s, c, F(ty)], [0, 0, 1]], F)
+
+
+def _movement_bound(Tk, Tn, px, py):
+    a0, a1 = F(Tn[0, 0] - Tk[0, 0]), F(Tn[0, 1] - Tk[0, 1])
+    a3, a4 = F(Tn[1, 0] - Tk[1, 0]), F(Tn[1, 1] - Tk[1, 1])
+    tx, ty = F(Tn[0, 2] - Tk[0, 2]), F(Tn[1, 2] - Tk[1, 2])
+    f2 = F(F(F(a0 * a0) + F(a1 * a1)) + F(F(a3 * a3) + F(a4 * a4)))
+    det = F(F(a0 * a4) - F(a1 * a3))
+    disc = max(F(F(f2 * f2) - F(F(4.0) * F(det * det))), F(0.0))
+    fa = F(F(np.sqrt(F(F(0.5) * F(f2 + F(np.sqrt(disc)))))) * F(1.001))
+    ft = F(np.sqrt(F(F(tx * tx) + F(ty * ty))))
+    mva, mvt = F(fa * F(1.0001)), F(F(ft * F(1.0001)) + F(3e-5))
+    ux, uy = F(px - Tn[0, 2]), F(py - Tn[1, 2])
+    xr = F(F(np.sqrt(F(F(ux * ux) + F(uy * uy)))) * F(1.0001))
+    return F(F(mva * xr) + mvt)
+
+
+def test_clearance_record_rule_never_keeps_a_wrong_neighbour():
+    rng = np.random.default_rng(4)
+    hits_a = hits_b = 0
+    M2 = F(F(1.08) * F(1.08))
+    for case in range(1500):
+        n = int(rng.integers(2, 120))
+        scale = float(rng.choice([0.2, 1.0, 5.0]))
+        centre = rng.uniform(-25, 25, 2)
+        t = (centre + rng.normal(0, scale, (n, 2))).astype(F)
+        if case % 5 == 0:
+            t = (np.round(t * 8) / 8).astype(F)                 # raster: equal distances, duplicates
+        # a chain of small rigid steps like T_iter (T <- step * T), float32 all the way
+        Tk = _mat3_mul(_step(rng.normal(0, 0.05), *rng.normal(0, 0.3, 2)), np.eye(3, dtype=F))
+        x = np.linalg.solve(Tk.astype(np.float64), np.r_[centre + rng.normal(0, scale * 0.3, 2), 1.0])[:2].astype(F)
+        p0 = _affine(Tk, x)
+        d0 = d2(p0[0], p0[1], t[:, 0], t[:, 1])
+        b = int(np.argmin(d0))                                  # (ties: lowest index, as the kernels resolve them)
+        others = np.delete(d0, b)
+        C = F(rng.choice([d0[b] * 4, d0[b] * 0.5, 0.0056, np.inf]))
+        mu = F(rng.choice([0.0, 1e-3, 1e-2]))
+        sb = min(d0[b], C) if np.isfinite(C) else d0[b]
+        edge = F(F(F(sb) * M2) + F(mu * mu))
+        R = F(F(np.sqrt(min(F(others.min()), edge))) * F(0.99999))
+        R = np.frombuffer(np.uint32(np.frombuffer(F(R).tobytes(), np.uint32)[0] & ~np.uint32(63)).tobytes(), F)[0]
+        gap = float(R) - float(np.sqrt(d0[b]))
+        sC = F(F(np.sqrt(C)) * F(1.00001)) if np.isfinite(C) else F(np.inf)
+        for frac in (0.0, 0.3, 0.9, 0.999, 1.0, 1.2, 3.0):
+            # further steps whose total motion is about frac x the gap the record leaves
+            amp = max(gap, 1e-4) * frac
+            Tn = Tk
+            for _ in range(int(rng.integers(1, 4))):
+                Tn = _mat3_mul(_step(rng.normal(0, amp / 60.0), *rng.normal(0, amp / 3.0, 2)), Tn)
+            px, py = _affine(Tn, x)
+            dn = d2(px, py, t[:, 0], t[:, 1])
+            dw = dn[b]
+            Ro = F(R - _movement_bound(Tk, Tn, px, py))
+            if F(F(np.sqrt(dw)) * F(1.00001)) < Ro:             # A: settled with (dw, b), no search
+                hits_a += 1
+                assert (np.delete(dn, b) > dw).all(), (case, frac)
+            elif np.isfinite(C) and dw > C and sC < Ro:         # B: settled as "beyond the cap", no search
+                hits_b += 1
+                assert (dn > C).all(), (case, frac)
+    assert hits_a > 1500 and hits_b > 50                        # both rules do fire on these inputs
