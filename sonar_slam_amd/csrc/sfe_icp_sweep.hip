@@ -799,7 +799,8 @@ struct SweepShared {
 
 struct SweepQ { // per-job views of the per-query scratch (the transformed query itself is never stored: whoever needs
                 // it again recomputes it from the source point, two affine maps with wave-uniform coefficients)
-    int4 *st;     // clearance record of a `none` query: (px, py, clearance) as float bits
+    int4 *st;     // clearance record of a `none` query: (px, py, clearance) as float bits; .z doubles as the runner-up
+                  // distance a search carries from the first pass to the second (records build)
     float *d2;    // best so far / final d2
     int *pos;     // >= 0 sorted position - 1 of the NN, SW_NONE, <= -2 inexact (SW_INEXACT_OF)
     int *wl[2];   // work lists of suspended queries (ping-pong between rounds)
