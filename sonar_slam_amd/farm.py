@@ -177,16 +177,16 @@ def _farm_worker(device, params_dict, backend, conn):
             msg = conn.recv()
             if msg[0] == "stop":
                 break
-            _, shm_name, lay, chunk = msg
+            _, shm_name, lay, chunk, seq = msg
             try:
                 if shm is None or shm.name != shm_name:
                     if shm is not None:
                         shm.close()
                     shm = shared_memory.SharedMemory(name=shm_name)
                 run(_views(shm.buf, lay), chunk)
-                conn.send(("ok", lay["n"]))
+                conn.send(("ok", lay["n"], seq))
             except Exception as e:
-                conn.send(("error", "%s: %s" % (type(e).__name__, e)))
+                conn.send(("error", "%s: %s" % (type(e).__name__, e), seq))
     except Exception as e:
         try:
             conn.send(("error", "%s: %s" % (type(e).__name__, e)))
@@ -233,6 +233,7 @@ class IcpFarm(object):
         self.chunk = int(chunk)
         self._backend = _backend
         self._workers = []
+        self._seq = 0           # request number, echoed by the worker: a stale reply can never answer a newer request
 
     def start(self):
         if self._workers:
@@ -268,29 +269,44 @@ class IcpFarm(object):
         from . import _lib
         self.start()
         world = len(self._workers)
-        sent = []
-        for rank, w in enumerate(self._workers):
+        # 1. validate and pack EVERY rank's jobs before any worker hears of this batch: a bad job (empty cloud, guess of
+        #    the wrong shape) raises here, with nothing in flight (a request left unanswered used to be read
+        #    as the reply of the NEXT run()).
+        packed = []
+        for rank in range(world):
             mine = [jobs[j] for j in shard(len(jobs), rank, world)]
-            src_pool, tgt_pool, ns_pts, nt_pts, rows, guesses = pack_jobs(mine)
-            lay = _layout(ns_pts, nt_pts, len(rows))
-            v = _views(w.block(lay["bytes"]).buf, lay)
-            o = 0
-            for c in src_pool:                      # one copy (and the float32 cast) per DISTINCT cloud
-                v["src"][o:o + len(c)] = c
-                o += len(c)
-            o = 0
-            for c in tgt_pool:
-                v["tgt"][o:o + len(c)] = c
-                o += len(c)
-            if rows:
-                v["jobs4"][:] = np.asarray(rows, np.int32)
-                v["guess"][:] = np.stack(guesses)
-            del v
-            w.conn.send(("run", w.shm.name, lay, self.chunk))   # the worker starts while the next block is packed
-            sent.append((w, lay, [len(gs) for _, _, gs in mine]))
+            packed.append((mine, pack_jobs(mine)))
+        self._seq += 1
+        seq = self._seq
+        sent = []
+        try:
+            # 2. fill the shared-memory blocks and start the workers one after the other
+            for w, (mine, (src_pool, tgt_pool, ns_pts, nt_pts, rows, guesses)) in zip(self._workers, packed):
+                lay = _layout(ns_pts, nt_pts, len(rows))
+                v = _views(w.block(lay["bytes"]).buf, lay)
+                o = 0
+                for c in src_pool:                      # one copy (and the float32 cast) per DISTINCT cloud
+                    v["src"][o:o + len(c)] = c
+                    o += len(c)
+                o = 0
+                for c in tgt_pool:
+                    v["tgt"][o:o + len(c)] = c
+                    o += len(c)
+                if rows:
+                    v["jobs4"][:] = np.asarray(rows, np.int32)
+                    v["guess"][:] = np.stack(guesses)
+                del v
+                w.conn.send(("run", w.shm.name, lay, self.chunk, seq))   # the worker starts while the next block is packed
+                sent.append((w, lay, [len(gs) for _, _, gs in mine]))
+        except BaseException:
+            # something failed between the first send and the last: every request already out is answered before the
+            # error leaves, so no worker is still reading a block (or owes a reply) when the caller tries again
+            for w, _, _ in sent:
+                self._recv_reply(w, seq)
+            raise
         per_rank, failure = [], None
         for w, lay, ks in sent:
-            tag, payload = self._recv(w)
+            tag, payload = self._recv_reply(w, seq)
             if tag != "ok":
                 failure = failure or "device %d: %s" % (w.device, payload)
                 continue
@@ -306,6 +322,16 @@ class IcpFarm(object):
         if failure:
             raise RuntimeError("IcpFarm worker failed: %s" % failure)
         return scatter_back(len(jobs), world, per_rank)
+
+    def _recv_reply(self, w, seq):
+        """the reply to request `seq` of worker w; a reply carrying an older number (a request abandoned by an
+        interrupted run) is discarded, never taken for this one"""
+        while True:
+            msg = self._recv(w)
+            if msg[0] == "error" and len(msg) == 2:       # worker died / start-up failure: no sequence number
+                return msg
+            if msg[2] == seq:
+                return msg[0], msg[1]
 
     def close(self):
         for w in self._workers:

@@ -18,6 +18,17 @@ def oracle_compute(device, params_dict):
     return "oracle worker %d (pid %d)" % (device, os.getpid()), run
 
 
+def slow_oracle_compute(device, params_dict):
+    """oracle_compute with a pause in front: a parent that reads results too early gets stale ones"""
+    import time
+    name, run = oracle_compute(device, params_dict)
+
+    def slow(v, chunk):
+        time.sleep(0.3)
+        run(v, chunk)
+    return name, slow
+
+
 def failing_compute(device, params_dict):
     def run(v, chunk):
         raise ValueError("boom on device %d" % device)

@@ -193,6 +193,34 @@ def test_persistent_two_worker_farm_over_shared_memory():
             f.run(batch(2))
 
 
+def test_farm_bad_job_leaves_no_request_in_flight():
+    """a job that fails validation on rank 1 used to leave rank 0's request unanswered, and the next run()
+    read that stale reply and took results the worker had not produced yet.  Now every rank is validated before
+    anything is sent, replies carry the request number, and the run after a caught error is correct."""
+    import oracle
+    from sonar_slam_amd import farm, icp_config, synth
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    p = icp_config.shipped_params()
+    good = [synth.scan_pair(seed=s, n_src=120, n_tgt=110) for s in range(4)]
+    jobs = [(s, t, [g]) for s, t, g, _ in good]
+    bad = list(jobs)
+    bad[1] = (np.zeros((0, 2), np.float32), good[1][1], [good[1][2]])      # job 1 -> rank 1: empty source cloud
+    with farm.IcpFarm(p, devices=[0, 1], _backend="farm_backend:slow_oracle_compute") as f:
+        for _ in range(2):
+            with pytest.raises(RuntimeError, match="empty source"):
+                f.run(bad)
+            out = f.run(jobs)
+            for (s, t, gs), (msgs, T, it) in zip(jobs, out):
+                st, To, ito = oracle.icp(s, t, gs[0], oracle.IcpParams(precision=1, **p.as_dict()))
+                assert msgs[0] == oracle.ICP_STATUS_MESSAGES[st] and it[0] == ito and np.array_equal(T[0], To)
+        # a stale reply (older request number) in the pipe is skipped, not taken for the current request
+        w = f._workers[0]
+        w.conn.send(("run", w.shm.name, farm._layout(0, 0, 0), 1, -7))
+        out = f.run(jobs)
+        st, To, _ = oracle.icp(*good[0][:3], oracle.IcpParams(precision=1, **p.as_dict()))
+        assert np.array_equal(out[0][1][0], To)
+
+
 def test_icp_object_has_no_silent_default_chain(tmp_path):
     """PM::ICP() has no chain until loadFromYaml (pcl.cpp:185-197); a missing YAML is an error here, not
     libpointmatcher's setDefault() chain."""
