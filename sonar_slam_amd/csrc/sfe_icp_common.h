@@ -95,10 +95,11 @@ __device__ __forceinline__ unsigned wave_inclusive_scan(unsigned v)
     return v + (row > 0 ? r0 : 0u) + (row > 1 ? r1 : 0u) + (row > 2 ? r2 : 0u);
 }
 
-// block-wide sum of NV doubles per thread; result valid in every thread
-template <int NV>
-__device__ __forceinline__ void block_sum(double (&v)[NV], double *s_red /* ICP_WAVES*NV + NV */)
+// block-wide sum of NV doubles per thread; result valid in every thread (NTH = threads of the workgroup)
+template <int NV, int NTH = ICP_THREADS>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double *s_red /* (NTH/64)*NV + NV */)
 {
+    constexpr int NWV = NTH / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -109,14 +110,14 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double *s_red /* ICP_
     __syncthreads();
     if (threadIdx.x < NV) {
         double s = 0;
-        for (int w = 0; w < ICP_WAVES; ++w) // fixed order: deterministic
+        for (int w = 0; w < NWV; ++w) // fixed order: deterministic
             s += s_red[w * NV + threadIdx.x];
-        s_red[ICP_WAVES * NV + threadIdx.x] = s;
+        s_red[NWV * NV + threadIdx.x] = s;
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NV; ++i)
-        v[i] = s_red[ICP_WAVES * NV + i];
+        v[i] = s_red[NWV * NV + i];
     __syncthreads();
 }
 

@@ -157,12 +157,13 @@ __device__ __forceinline__ int next_strip(const StripTab &tab, int ns, int so, i
     return -1;
 }
 
-// in-LDS bitonic sort of n2 (power of two) 64-bit keys, ascending
+// in-LDS bitonic sort of n2 (power of two) 64-bit keys, ascending (NT = threads of the workgroup)
+template <int NT>
 __device__ __forceinline__ void bitonic_sort_lds(unsigned long long *keys, unsigned n2)
 {
     for (unsigned k = 2; k <= n2; k <<= 1) {
         for (unsigned j = k >> 1; j > 0; j >>= 1) {
-            for (unsigned t = threadIdx.x; t < n2 / 2; t += ICP_THREADS) {
+            for (unsigned t = threadIdx.x; t < n2 / 2; t += NT) {
                 const unsigned i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
                 const unsigned l = i | j;
                 const unsigned long long a = keys[i], b = keys[l];
@@ -177,10 +178,11 @@ __device__ __forceinline__ void bitonic_sort_lds(unsigned long long *keys, unsig
     }
 }
 
+template <int NT>
 struct PrepShared {
     // first the sort keys, then (same bytes) the sorted cloud with its sentinels
     unsigned long long buf[SW_TCAP + SW_PAD + 4];
-    double red[ICP_WAVES * 2 + 2];
+    double red[(NT / 64) * 2 + 2];
     float mean[2];
     unsigned ykey[2], xkey[2]; // min / max order keys of the finite centred coordinates
     int cnt[SW_NS_MAX];
@@ -194,7 +196,7 @@ struct PrepShared {
 // PCA normals of the centred target: K nearest incl. the point itself, ordered by (d2, original
 // index) exactly like the brute-force scan (sfe_icp.hip).  s_tgt = sorted cloud in the strip layout
 // (in LDS or in HBM scratch).
-template <int KM> // capacity of the neighbour list (>= K): its loops are fully unrolled, so a snug KM pays
+template <int KM, int NT> // NT = threads of the workgroup; KM = capacity of the neighbour list (>= K): its loops are fully unrolled, so a snug KM pays
 __device__ __forceinline__ void sweep_knn_normals(const sfe_icp_params &P, const StripTab &tab,
                                                   const float2 *__restrict__ s_tgt, const int *__restrict__ perm,
                                                   float2 *__restrict__ snrm, int nt)
@@ -202,7 +204,7 @@ __device__ __forceinline__ void sweep_knn_normals(const sfe_icp_params &P, const
     const int tid = threadIdx.x;
     const int K = min(min(P.normals_knn, KM), nt);
     const int ns = tab.ns, len = tab.len;
-    for (int c = tid + 1; c < len; c += ICP_THREADS) { // positions; sentinels are skipped
+    for (int c = tid + 1; c < len; c += NT) { // positions; sentinels are skipped
         const float2 q = s_tgt[c];
         if (q.x != q.x && q.y != q.y)
             continue; // a sentinel (a cloud point that is NaN in both coordinates gets no normal either:
@@ -372,6 +374,7 @@ __device__ __forceinline__ void sweep_knn_normals(const sfe_icp_params &P, const
 // (A per-cell nearest-neighbour search was tried first: the empty two thirds of a sonar fan's bounding box have their
 // nearest point metres away, and those searches cost 2 ms per 512 targets.)
 #define SW_GRID_SWEEPS 4
+template <int NT>
 __device__ __forceinline__ void sweep_grid_witness(const StripTab &tab, const float2 *__restrict__ s_tgt,
                                                    int *__restrict__ grid_out, unsigned *grid)
 { // grid: LDS, SW_GRID_MAX words: (distance to the cell centre, top 16 bits of its float pattern) << 16 | position
@@ -382,11 +385,11 @@ __device__ __forceinline__ void sweep_grid_witness(const StripTab &tab, const fl
         const int iy = c / gnx, ix = c - iy * gnx;
         return make_float2(gx0 + ((float)ix + 0.5f) * cs, gy0 + ((float)iy + 0.5f) * cs);
     };
-    for (int c = threadIdx.x; c < ncell; c += ICP_THREADS)
+    for (int c = threadIdx.x; c < ncell; c += NT)
         grid[c] = 0xFFFFFFFFu;
     __syncthreads();
     if (len < 65536) { // positions fit 16 bits (always for a target that lives in LDS)
-        for (int p = threadIdx.x + 1; p < len; p += ICP_THREADS) {
+        for (int p = threadIdx.x + 1; p < len; p += NT) {
             const float2 q = s_tgt[p];
             if (!(fabsf(q.x) < INFINITY && fabsf(q.y) < INFINITY))
                 continue; // sentinels, non-finite points
@@ -400,11 +403,11 @@ __device__ __forceinline__ void sweep_grid_witness(const StripTab &tab, const fl
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < ncell; c += ICP_THREADS)
+    for (int c = threadIdx.x; c < ncell; c += NT)
         grid[c] = (grid[c] == 0xFFFFFFFFu) ? 0u : (grid[c] & 0xFFFFu); // -> position, 0 = empty
     __syncthreads();
     for (int it = 0; it < SW_GRID_SWEEPS; ++it) {
-        for (int c = threadIdx.x; c < ncell; c += ICP_THREADS) {
+        for (int c = threadIdx.x; c < ncell; c += NT) {
             if (grid[c] != 0)
                 continue;
             const int iy = c / gnx, ix = c - iy * gnx;
@@ -433,17 +436,18 @@ __device__ __forceinline__ void sweep_grid_witness(const StripTab &tab, const fl
         }
         __syncthreads();
     }
-    for (int c = threadIdx.x; c < ncell; c += ICP_THREADS)
+    for (int c = threadIdx.x; c < ncell; c += NT)
         grid_out[c] = (int)grid[c];
 }
 
 // bitonic sort of n2 (power of two) 64-bit keys in HBM scratch by one workgroup (targets that do
 // not fit LDS; once per target, the keys stay in L2)
+template <int NT>
 __device__ __forceinline__ void bitonic_sort_global(unsigned long long *keys, unsigned n2)
 {
     for (unsigned k = 2; k <= n2; k <<= 1) {
         for (unsigned j = k >> 1; j > 0; j >>= 1) {
-            for (unsigned t = threadIdx.x; t < n2 / 2; t += ICP_THREADS) {
+            for (unsigned t = threadIdx.x; t < n2 / 2; t += NT) {
                 const unsigned i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
                 const unsigned l = i | j;
                 const unsigned long long a = keys[i], b = keys[l];
@@ -464,7 +468,8 @@ __device__ __forceinline__ void bitonic_sort_global(unsigned long long *keys, un
 #define SW_KEY_X(k) ((unsigned)(((k) >> 24) & 0xFFFFFFFFull))
 #define SW_KEY_ID(k) ((int)((k) & 0xFFFFFFull))
 
-__global__ __launch_bounds__(ICP_THREADS, 4) void icp_sweep_prep_kernel(sfe_icp_params P,
+template <int NT>
+__global__ __launch_bounds__(NT, 4) void icp_sweep_prep_kernel(sfe_icp_params P,
                                                                         const SweepPrep *__restrict__ preps,
                                                                         const float2 *__restrict__ tgt_all,
                                                                         float2 *__restrict__ stgt_all,
@@ -476,8 +481,8 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_sweep_prep_kernel(sfe_icp_
                                                                         int *__restrict__ grid_all)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    PrepShared &S = *reinterpret_cast<PrepShared *>(smem_raw);
-    int *s_grid = reinterpret_cast<int *>(smem_raw + ((sizeof(PrepShared) + 15) & ~(size_t)15)); // witness grid + distances
+    PrepShared<NT> &S = *reinterpret_cast<PrepShared<NT> *>(smem_raw);
+    int *s_grid = reinterpret_cast<int *>(smem_raw + ((sizeof(PrepShared<NT>) + 15) & ~(size_t)15)); // witness grid + distances
     const SweepPrep J = preps[blockIdx.x];
     const int nt = J.n_tgt, ns = J.ns, tid = threadIdx.x, lane = threadIdx.x & 63;
     const float2 *__restrict__ tgt = tgt_all + J.tgt_start;
@@ -488,12 +493,12 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_sweep_prep_kernel(sfe_icp_
     // reference mean (fp64 accumulation, rounded to float), as the brute-force kernel
     {
         double m[2] = {0, 0};
-        for (int i = tid; i < nt; i += ICP_THREADS) {
+        for (int i = tid; i < nt; i += NT) {
             const float2 t = tgt[i];
             m[0] += t.x;
             m[1] += t.y;
         }
-        block_sum<2>(m, S.red);
+        block_sum<2, NT>(m, S.red);
         if (tid == 0) {
             S.mean[0] = (float)(m[0] / nt);
             S.mean[1] = (float)(m[1] / nt);
@@ -514,7 +519,7 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_sweep_prep_kernel(sfe_icp_
     // extent of the finite centred coordinates -> strip geometry
     {
         float ylo = INFINITY, yhi = -INFINITY, xlo = INFINITY, xhi = -INFINITY;
-        for (int i = tid; i < nt; i += ICP_THREADS) {
+        for (int i = tid; i < nt; i += NT) {
             const float2 t = tgt[i];
             const float x = f_add(t.x, -mx), y = f_add(t.y, -my);
             if (fabsf(y) < INFINITY) {
@@ -580,7 +585,7 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_sweep_prep_kernel(sfe_icp_
         n2 <<= 1;
     const bool in_lds = nt <= SW_TCAP;
     unsigned long long *keys = in_lds ? S.buf : gkeys_all + J.key_off;
-    for (unsigned i = tid; i < n2; i += ICP_THREADS) {
+    for (unsigned i = tid; i < n2; i += NT) {
         unsigned long long k = ~0ull;
         if (i < (unsigned)nt) {
             const float2 t = tgt[i];
@@ -621,26 +626,26 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_sweep_prep_kernel(sfe_icp_
     { // the table travels to HBM for the loop kernel
         const int *src = reinterpret_cast<const int *>(&S.tab);
         int *dst = reinterpret_cast<int *>(tab_all + blockIdx.x);
-        for (int i = tid; i < (int)(sizeof(StripTab) / sizeof(int)); i += ICP_THREADS)
+        for (int i = tid; i < (int)(sizeof(StripTab) / sizeof(int)); i += NT)
             dst[i] = src[i];
     }
     const int len = S.tab.len;
     // sentinels of the HBM copy
-    for (int s = tid; s <= ns; s += ICP_THREADS)
+    for (int s = tid; s <= ns; s += NT)
         stgt[s == 0 ? 0 : S.tab.sbeg[s] - 1] = make_float2(qnan, qnan);
     if (tid < 2)
         stgt[len + tid] = make_float2(qnan, qnan);
 
     float2 *nrm = snrm_all ? snrm_all + J.off : nullptr;
     if (in_lds) {
-        bitonic_sort_lds(S.buf, n2);
+        bitonic_sort_lds<NT>(S.buf, n2);
         // keys -> sorted centred cloud (registers -> same LDS bytes, in the strip layout)
-        constexpr int PER = SW_TCAP / ICP_THREADS;
+        constexpr int PER = SW_TCAP / NT;
         float2 v[PER];
         int id[PER], ps[PER];
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
-            const int r = k * ICP_THREADS + tid;
+            const int r = k * NT + tid;
             v[k] = make_float2(0, 0);
             id[k] = 0;
             ps[k] = 0;
@@ -655,32 +660,32 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_sweep_prep_kernel(sfe_icp_
         float2 *s_tgt = reinterpret_cast<float2 *>(S.buf);
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
-            if (k * ICP_THREADS + tid < nt) {
+            if (k * NT + tid < nt) {
                 s_tgt[ps[k]] = v[k];
                 stgt[ps[k]] = v[k];
                 perm[ps[k] - 1] = id[k];
             }
         }
-        for (int s = tid; s <= ns; s += ICP_THREADS)
+        for (int s = tid; s <= ns; s += NT)
             s_tgt[s == 0 ? 0 : S.tab.sbeg[s] - 1] = make_float2(qnan, qnan);
         if (tid < 2)
             s_tgt[len + tid] = make_float2(qnan, qnan);
         __syncthreads();
         if (P.minimizer == 1) {
             if (P.normals_knn <= 8)
-                sweep_knn_normals<8>(P, S.tab, s_tgt, perm, nrm, nt);
+                sweep_knn_normals<8, NT>(P, S.tab, s_tgt, perm, nrm, nt);
             else if (P.normals_knn <= 10)
-                sweep_knn_normals<10>(P, S.tab, s_tgt, perm, nrm, nt);
+                sweep_knn_normals<10, NT>(P, S.tab, s_tgt, perm, nrm, nt);
             else if (P.normals_knn <= 12)
-                sweep_knn_normals<12>(P, S.tab, s_tgt, perm, nrm, nt);
+                sweep_knn_normals<12, NT>(P, S.tab, s_tgt, perm, nrm, nt);
             else
-                sweep_knn_normals<ICP_KMAX>(P, S.tab, s_tgt, perm, nrm, nt);
+                sweep_knn_normals<ICP_KMAX, NT>(P, S.tab, s_tgt, perm, nrm, nt);
         }
         if (grid_all)
-            sweep_grid_witness(S.tab, s_tgt, grid_all + (size_t)blockIdx.x * SW_GRID_MAX, reinterpret_cast<unsigned *>(s_grid));
+            sweep_grid_witness<NT>(S.tab, s_tgt, grid_all + (size_t)blockIdx.x * SW_GRID_MAX, reinterpret_cast<unsigned *>(s_grid));
     } else {
-        bitonic_sort_global(keys, n2);
-        for (int r = tid; r < nt; r += ICP_THREADS) {
+        bitonic_sort_global<NT>(keys, n2);
+        for (int r = tid; r < nt; r += NT) {
             const unsigned long long key = keys[r];
             const int id = SW_KEY_ID(key), pos = r + SW_KEY_STRIP(key) + 1;
             stgt[pos] = make_float2(mono_inv(SW_KEY_X(key)), f_add(tgt[id].y, -my));
@@ -689,16 +694,16 @@ __global__ __launch_bounds__(ICP_THREADS, 4) void icp_sweep_prep_kernel(sfe_icp_
         __syncthreads();
         if (P.minimizer == 1) {
             if (P.normals_knn <= 8)
-                sweep_knn_normals<8>(P, S.tab, stgt, perm, nrm, nt);
+                sweep_knn_normals<8, NT>(P, S.tab, stgt, perm, nrm, nt);
             else if (P.normals_knn <= 10)
-                sweep_knn_normals<10>(P, S.tab, stgt, perm, nrm, nt);
+                sweep_knn_normals<10, NT>(P, S.tab, stgt, perm, nrm, nt);
             else if (P.normals_knn <= 12)
-                sweep_knn_normals<12>(P, S.tab, stgt, perm, nrm, nt);
+                sweep_knn_normals<12, NT>(P, S.tab, stgt, perm, nrm, nt);
             else
-                sweep_knn_normals<ICP_KMAX>(P, S.tab, stgt, perm, nrm, nt);
+                sweep_knn_normals<ICP_KMAX, NT>(P, S.tab, stgt, perm, nrm, nt);
         }
         if (grid_all)
-            sweep_grid_witness(S.tab, stgt, grid_all + (size_t)blockIdx.x * SW_GRID_MAX, reinterpret_cast<unsigned *>(s_grid));
+            sweep_grid_witness<NT>(S.tab, stgt, grid_all + (size_t)blockIdx.x * SW_GRID_MAX, reinterpret_cast<unsigned *>(s_grid));
     }
 }
 
@@ -735,8 +740,9 @@ __device__ __forceinline__ long long sw_uniform_ll(long long v)
 }
 
 // control block of a job; the LDS-resident variant places the sorted target right behind it
+template <int NT>
 struct SweepShared {
-    double red[ICP_WAVES * 10 + 10];
+    double red[(NT / 64) * 10 + 10];
     double acc[10];  // the reduced error-minimiser sums (read by the solving lane)
     unsigned hist[256], hist0[256];
     unsigned sel_prefix, sel_k;
@@ -856,8 +862,8 @@ __device__ __forceinline__ int sweep_resolve_tie(const float2 *__restrict__ T, c
 // PROF: per-phase cycle counters of workgroup 0 and launch-wide counts of the work done (candidate evaluations,
 // lower-bound probes); instantiated for the two-jobs-per-CU builds with an LDS-resident target only.
 // REC: the build with clearance records (below); chosen by the launcher for chains that run many iterations.
-template <int MINW, bool LDS_TGT, bool LDS_Q, bool PROF, bool REC>
-__global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
+template <int NT, int MINW, bool LDS_TGT, bool LDS_Q, bool PROF, bool REC>
+__global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
     sfe_icp_params P, const SweepJob *__restrict__ jobs, const int *__restrict__ job_ids, const float2 *__restrict__ src_all,
     const float *__restrict__ guess_all, const float2 *__restrict__ stgt_all, const int *__restrict__ perm_all,
     const float2 *__restrict__ snrm_all, const float *__restrict__ mean_all, const StripTab *__restrict__ tab_all,
@@ -868,7 +874,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
 {
     static_assert(LDS_TGT || !LDS_Q, "LDS_Q needs the LDS-resident target layout");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    SweepShared &S = *reinterpret_cast<SweepShared *>(smem_raw);
+    SweepShared<NT> &S = *reinterpret_cast<SweepShared<NT> *>(smem_raw);
 
     const int jb = __builtin_amdgcn_readfirstlane(job_ids[blockIdx.x]);
     SweepJob J = jobs[jb];
@@ -882,7 +888,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
     const int ns = J.n_src, nt = J.n_tgt;
     const float2 *__restrict__ src = src_all + J.src_start;
     const float2 *__restrict__ stgt = stgt_all + J.tgt_off;
-    float2 *lds_tgt = reinterpret_cast<float2 *>(smem_raw + ((sizeof(SweepShared) + 15) & ~(size_t)15));
+    float2 *lds_tgt = reinterpret_cast<float2 *>(smem_raw + ((sizeof(SweepShared<NT>) + 15) & ~(size_t)15));
     const float2 *__restrict__ T = LDS_TGT ? (const float2 *)lds_tgt : stgt; // sorted target incl. sentinels
     const float2 *__restrict__ snrm = snrm_all ? snrm_all + J.tgt_off : nullptr;
     SweepQ Q;
@@ -940,7 +946,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
     { // strip table -> LDS
         const int *tsrc = reinterpret_cast<const int *>(tab_all + J.prep);
         int *tdst = reinterpret_cast<int *>(&S.tab);
-        for (int i = tid; i < (int)(sizeof(StripTab) / sizeof(int)); i += ICP_THREADS)
+        for (int i = tid; i < (int)(sizeof(StripTab) / sizeof(int)); i += NT)
             tdst[i] = tsrc[i];
     }
 
@@ -973,7 +979,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
             unsigned n2 = 2;
             while (n2 < (unsigned)n)
                 n2 <<= 1;
-            for (unsigned i = tid; i < n2; i += ICP_THREADS) {
+            for (unsigned i = tid; i < n2; i += NT) {
                 unsigned long long k = ~0ull;
                 if (i < (unsigned)n) {
                     const float2 sp = src[c0 + i];
@@ -986,8 +992,8 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                 skeys[i] = k;
             }
             __syncthreads();
-            bitonic_sort_lds(skeys, n2);
-            for (int i = tid; i < n; i += ICP_THREADS) {
+            bitonic_sort_lds<NT>(skeys, n2);
+            for (int i = tid; i < n; i += NT) {
                 const int q = SW_KEY_ID(skeys[i]);
                 Q.order[c0 + i] = q;
                 Q.ssrc[c0 + i] = src[q];
@@ -1000,7 +1006,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
     }
     // sorted centred target (with its NaN sentinels: a NaN stops a walk direction) -> LDS
     if (LDS_TGT) {
-        for (int i = tid; i < nt + SW_PAD; i += ICP_THREADS)
+        for (int i = tid; i < nt + SW_PAD; i += NT)
             lds_tgt[i] = stgt[i];
     }
     IcpCheck chk = {S.hist_c, S.hist_s, S.hist_x, S.hist_y, 1, 0, 0};
@@ -1149,12 +1155,12 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                 }
             };
             if (!skip_tally) {
-            for (int base = 0; base < ns; base += SW_NQ * ICP_THREADS) {
+            for (int base = 0; base < ns; base += SW_NQ * NT) {
                 int pz[SW_NQ];
                 float dz[SW_NQ];
 #pragma unroll
                 for (int k = 0; k < SW_NQ; ++k) {
-                    const int i = base + k * ICP_THREADS + tid;
+                    const int i = base + k * NT + tid;
                     pz[k] = i < ns ? Pz(i) : SW_NONE;
                     dz[k] = i < ns ? Dz(i) : INFINITY;
                 }
@@ -1273,7 +1279,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                     q_next = Q.order[tid];
                 }
                 const float sC = f_mul(sqrtf(C), 1.00001f); // (the cap of this round as a radius, for the records)
-                for (int k0 = 0; k0 < n; k0 += ICP_THREADS) {
+                for (int k0 = 0; k0 < n; k0 += NT) {
                     const int slot = k0 + tid;
                     const bool valid = slot < n;
                     const float2 sp_cur = sp_next;
@@ -1284,9 +1290,9 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                     const unsigned rec = (fresh && rec_use && valid) ? Q.rec[slot] : 0u;
                     if (fresh && use_cache && valid)
                         prev = Pz(q_cur); // last iteration's result of this query (used after the transform)
-                    if (fresh && slot + ICP_THREADS < n) {
-                        sp_next = Q.ssrc[slot + ICP_THREADS];
-                        q_next = Q.order[slot + ICP_THREADS];
+                    if (fresh && slot + NT < n) {
+                        sp_next = Q.ssrc[slot + NT];
+                        q_next = Q.order[slot + NT];
                     }
                     int q = 0, bpos = 0;
                     float px = 0, py = 0, best = W2;
@@ -1810,7 +1816,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
         auto sums = [&](auto lo_tag) {
             constexpr int LO = decltype(lo_tag)::value;
             double a5[5] = {0, 0, 0, 0, 0};
-            for (int i = tid; i < ns; i += ICP_THREADS) {
+            for (int i = tid; i < ns; i += NT) {
                 const int id = Pz(i);
                 const float d = Dz(i);
                 const bool ok = id >= 0 && (!P.use_max_dist_filter || d <= r2_filter) &&
@@ -1852,7 +1858,7 @@ __global__ __launch_bounds__(ICP_THREADS, MINW) void icp_sweep_kernel(
                 for (int k = 0; k < 5; ++k)
                     a5[k] += t[LO + k];
             }
-            block_sum<5>(a5, S.red);
+            block_sum<5, NT>(a5, S.red);
             if (tid == 0) {
 #pragma unroll
                 for (int k = 0; k < 5; ++k)
@@ -1933,7 +1939,7 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
     std::vector<int> ids_q, ids_lds, ids_glb;
     std::map<std::pair<int, int>, int> seen; // many guesses on one pair share one prep
     long long toff = 0, qoff = 0, koff = 0;
-    const size_t ctl_bytes = (sizeof(SweepShared) + 15) & ~(size_t)15;
+    const size_t ctl_bytes = (sizeof(SweepShared<ICP_THREADS>) + 15) & ~(size_t)15;
     // LDS share of a workgroup: two workgroups per CU when the batch has more jobs than CUs, else the whole CU
     static const int force_wide = getenv("SFE_SW_WIDE") ? atoi(getenv("SFE_SW_WIDE")) : -1; // A/B: 1 = one 128-VGPR workgroup per CU
     const bool wide = force_wide >= 0 ? force_wide != 0 : n_jobs <= ctx->n_cu;
@@ -2031,10 +2037,10 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
             return rc;
     }
 
-    const size_t prep_smem = ((sizeof(PrepShared) + 15) & ~(size_t)15) + 4 * (size_t)SW_GRID_MAX;
-    SFE_HIP(ctx, hipFuncSetAttribute((const void *)icp_sweep_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+    const size_t prep_smem = ((sizeof(PrepShared<ICP_THREADS>) + 15) & ~(size_t)15) + 4 * (size_t)SW_GRID_MAX;
+    SFE_HIP(ctx, hipFuncSetAttribute((const void *)icp_sweep_prep_kernel<ICP_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)prep_smem));
-    hipLaunchKernelGGL(icp_sweep_prep_kernel, dim3(n_prep), dim3(ICP_THREADS), prep_smem, ps, *p,
+    hipLaunchKernelGGL(icp_sweep_prep_kernel<ICP_THREADS>, dim3(n_prep), dim3(ICP_THREADS), prep_smem, ps, *p,
                        d_preps, (const float2 *)d_tgt, d_stgt, d_perm, d_snrm, d_mean, d_gkeys, d_tab, d_grid);
     SFE_LAUNCH_CHECK(ctx);
     if (side) {
@@ -2105,36 +2111,36 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
     if (n_q) {
         const size_t smem = ctl_bytes + 8 * (size_t)t_cap + 6 * (size_t)q_cap;
         if (!wide && !d_prof && minw == 4)
-            SW_LAUNCH((icp_sweep_kernel<4, true, true, false, false>), n_q, d_ids, smem, t_cap, q_cap);
+            SW_LAUNCH((icp_sweep_kernel<ICP_THREADS, 4, true, true, false, false>), n_q, d_ids, smem, t_cap, q_cap);
         else if (wide)
-            SW_LAUNCH((icp_sweep_kernel<4, true, true, false, false>), n_q, d_ids, smem, t_cap, q_cap);
+            SW_LAUNCH((icp_sweep_kernel<ICP_THREADS, 4, true, true, false, false>), n_q, d_ids, smem, t_cap, q_cap);
         else if (d_prof && rec_build)
-            SW_LAUNCH((icp_sweep_kernel<8, true, true, true, true>), n_q, d_ids, smem, t_cap, q_cap);
+            SW_LAUNCH((icp_sweep_kernel<ICP_THREADS, 8, true, true, true, true>), n_q, d_ids, smem, t_cap, q_cap);
         else if (d_prof)
-            SW_LAUNCH((icp_sweep_kernel<8, true, true, true, false>), n_q, d_ids, smem, t_cap, q_cap);
+            SW_LAUNCH((icp_sweep_kernel<ICP_THREADS, 8, true, true, true, false>), n_q, d_ids, smem, t_cap, q_cap);
         else if (rec_build)
-            SW_LAUNCH((icp_sweep_kernel<8, true, true, false, true>), n_q, d_ids, smem, t_cap, q_cap);
+            SW_LAUNCH((icp_sweep_kernel<ICP_THREADS, 8, true, true, false, true>), n_q, d_ids, smem, t_cap, q_cap);
         else
-            SW_LAUNCH((icp_sweep_kernel<8, true, true, false, false>), n_q, d_ids, smem, t_cap, q_cap);
+            SW_LAUNCH((icp_sweep_kernel<ICP_THREADS, 8, true, true, false, false>), n_q, d_ids, smem, t_cap, q_cap);
     }
     if (n_lds) {
         const size_t smem = ctl_bytes + sizeof(float2) * (SW_TCAP + SW_PAD);
         if (wide)
-            SW_LAUNCH((icp_sweep_kernel<4, true, false, false, false>), n_lds, d_ids + n_q, smem, SW_TCAP + SW_PAD, 0);
+            SW_LAUNCH((icp_sweep_kernel<ICP_THREADS, 4, true, false, false, false>), n_lds, d_ids + n_q, smem, SW_TCAP + SW_PAD, 0);
         else if (d_prof)
-            SW_LAUNCH((icp_sweep_kernel<8, true, false, true, false>), n_lds, d_ids + n_q, smem, SW_TCAP + SW_PAD, 0);
+            SW_LAUNCH((icp_sweep_kernel<ICP_THREADS, 8, true, false, true, false>), n_lds, d_ids + n_q, smem, SW_TCAP + SW_PAD, 0);
         else if (rec_build)
-            SW_LAUNCH((icp_sweep_kernel<8, true, false, false, true>), n_lds, d_ids + n_q, smem, SW_TCAP + SW_PAD, 0);
+            SW_LAUNCH((icp_sweep_kernel<ICP_THREADS, 8, true, false, false, true>), n_lds, d_ids + n_q, smem, SW_TCAP + SW_PAD, 0);
         else
-            SW_LAUNCH((icp_sweep_kernel<8, true, false, false, false>), n_lds, d_ids + n_q, smem, SW_TCAP + SW_PAD, 0);
+            SW_LAUNCH((icp_sweep_kernel<ICP_THREADS, 8, true, false, false, false>), n_lds, d_ids + n_q, smem, SW_TCAP + SW_PAD, 0);
     }
     if (n_glb) {
         // the target stays in HBM / L2; the LDS behind the control block only serves the query sort
         const size_t smem_g = ctl_bytes + sizeof(unsigned long long) * SW_TCAP;
         if (wide)
-            SW_LAUNCH((icp_sweep_kernel<4, false, false, false, false>), n_glb, d_ids + n_q + n_lds, smem_g, SW_TCAP, 0);
+            SW_LAUNCH((icp_sweep_kernel<ICP_THREADS, 4, false, false, false, false>), n_glb, d_ids + n_q + n_lds, smem_g, SW_TCAP, 0);
         else
-            SW_LAUNCH((icp_sweep_kernel<8, false, false, false, false>), n_glb, d_ids + n_q + n_lds, smem_g, SW_TCAP, 0);
+            SW_LAUNCH((icp_sweep_kernel<ICP_THREADS, 8, false, false, false, false>), n_glb, d_ids + n_q + n_lds, smem_g, SW_TCAP, 0);
     }
 #undef SW_LAUNCH
     if (side) {
