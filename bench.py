@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--no-farm", action="store_true", help="skip the BASELINE configs[3] leg (job farm on this device)")
     ap.add_argument("--farm-jobs", type=int, default=10000)
     ap.add_argument("--no-latency", action="store_true", help="skip the live single-ping / single-scan-match latency leg")
+    ap.add_argument("--no-legs", action="store_true",
+                    help="skip the legs beyond the timed step: reference_chain, real_size, configs4_hires, float_oracle, stream_frames")
+    ap.add_argument("--small-legs", action="store_true", help="those legs at a fraction of their size (tests)")
     ap.add_argument("--serial-prep", action="store_true",
                     help="keep the ICP target preparation on the main stream (default: side stream, next to the front end)")
     return ap.parse_args()
@@ -485,14 +488,33 @@ def main():
                                       "counters_from": sq["source"].split(" ")[0]})
         except (OSError, KeyError, ValueError):
             pass
+        if not args.no_legs:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_legs
+            threads = usable_cores()
+            small = args.small_legs
+            mk = dict(minimizer=1, use_diff_checker=0, max_iter=30) if args.icp_mode == "p2plane30" else {}
+            # the 1e-4 bar of north_star against both forms of the oracle, on a sample large enough to show the float
+            # oracle's own noise; raises if the HIP path leaves the fp64-sum oracle
+            out["float_oracle"] = bench_legs.float_oracle(kb_last, res, srcs, tgts, guesses, mk, threads,
+                                                          sample=16 if small else 256)
+            out["reference_chain"] = bench_legs.reference_chain(ctx, kb, srcs, tgts, guesses, threads)
+            out["stream_frames"] = bench_legs.stream_frames(ctx, kb, not args.no_filters, steps=2 if small else 4,
+                                                            distinct=16 if small else 512)
+        if not args.no_latency or not args.no_legs:
+            for b in kbs:
+                b.free()
+        if not args.no_legs:
+            out["real_size"] = (bench_legs.real_size(ctx, threads, n_ssm=256, n_nssm=8, distinct=64) if small
+                                else bench_legs.real_size(ctx, threads))
+            out["configs4_hires"] = (bench_legs.configs4_hires(ctx, det, threads, n_pairs=2, n_frames=8, parity_pairs=1) if small
+                                     else bench_legs.configs4_hires(ctx, det, threads))
         if not args.no_latency:
             # the live single-item path of the ROS nodes (one ping / one scan match per call, host wall clock incl.
             # PCIe copies and the one synchronisation); the oracle's per-ping / per-match milliseconds are in
             # cpu_baseline.sample
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import live_latency
-            for b in kbs:
-                b.free()
             out["live_latency"] = live_latency.measure(ctx)
             out["live_latency"]["note"] = ("median host wall time per call: FeatureExtraction.callback on a 1024x512 ping "
                                            "(fused = sfe_feature_extract_ping, per_stage = the four per-stage calls), "

@@ -73,6 +73,7 @@ typedef struct sfe_geom sfe_geom;
 #define SFE_ICP_NAN_ROT 3    /* "abs rotation norm not a number" */
 #define SFE_ICP_NAN_TRANS 4  /* "abs translation norm not a number" */
 #define SFE_ICP_SINGULAR 5   /* point-to-plane normal system not positive definite */
+#define SFE_ICP_SPLIT_TIMEOUT 6 /* internal: the workgroups sharing one large job lost each other (never seen in practice) */
 
 /* ---- library / context ------------------------------------------------- */
 const char *sfe_version(void);
@@ -89,6 +90,17 @@ int sfe_free(sfe_ctx *ctx, void *dptr);
 int sfe_memcpy_h2d(sfe_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int sfe_memcpy_d2h(sfe_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 int sfe_memset(sfe_ctx *ctx, void *dst_dev, int value, size_t bytes);
+
+/* Streamed inputs (feature_extraction.py:196-217: every ping arrives from the host).  Pinned host memory and uploads on
+ * the context's copy stream, next to the kernels on its main stream:
+ *   sfe_memcpy_h2d_async  enqueue-only upload from a sfe_host_alloc block
+ *   sfe_stream_fence(0)   kernels enqueued from now on wait for every upload enqueued so far
+ *   sfe_stream_fence(1)   uploads enqueued from now on wait for every kernel enqueued so far (their input buffer is free)
+ *   sfe_stream_fence(2)   the host waits for the uploads */
+int sfe_host_alloc(sfe_ctx *ctx, size_t bytes, void **hptr);
+int sfe_host_free(sfe_ctx *ctx, void *hptr);
+int sfe_memcpy_h2d_async(sfe_ctx *ctx, void *dst_dev, const void *src_pinned, size_t bytes);
+int sfe_stream_fence(sfe_ctx *ctx, int what);
 
 /* HIP-event stopwatch on the ctx's stream (used by bench.py for per-kernel time) */
 int sfe_timer_start(sfe_ctx *ctx);
@@ -246,6 +258,13 @@ int sfe_icp_batch_dev(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_src,
                       const int32_t *src_off, const float *d_tgt, const int32_t *tgt_off,
                       const float *d_guess9, int n_jobs, float *d_T9, int32_t *d_status,
                       int32_t *d_iters);
+
+/* the same with a job table: jobs4 (host, n_jobs x 4) = (src_start, n_src, tgt_start, n_tgt) in points into the resident
+ * clouds, so that jobs may share clouds -- the <= 30 guesses of compute_icp_with_cov on one pair (slam.py:346-358), one
+ * target matched against many sources; jobs naming the same target slice share its preparation */
+int sfe_icp_jobs_dev(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_src, const float *d_tgt,
+                     const int32_t *jobs4, const float *d_guess9, int n_jobs, float *d_T9, int32_t *d_status,
+                     int32_t *d_iters);
 
 /* Device-resident tail of FeatureExtraction.callback (feature_extraction.py:241-249) for a batch:
  * pcl.downsample(points, resolution) then pcl.remove_outlier(points, radius, min_points) on the

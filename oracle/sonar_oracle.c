@@ -251,8 +251,9 @@ typedef struct {
     int n_nodes;
 } kd_tree;
 
-static const float *g_kd_sort_pts;
-static int g_kd_sort_dim;
+/* (thread-local: bench.py and the soak tools call the oracle from several threads, ctypes releases the GIL) */
+static __thread const float *g_kd_sort_pts;
+static __thread int g_kd_sort_dim;
 static int kd_cmp(const void *a, const void *b)
 {
     const int ia = *(const int *)a, ib = *(const int *)b;

@@ -25,6 +25,7 @@ ICP_STATUS_MESSAGES = {
     3: "abs rotation norm not a number",
     4: "abs translation norm not a number",
     5: "point-to-plane system not positive definite",
+    6: "internal: split job timed out",
 }
 
 
@@ -75,6 +76,10 @@ SIGNATURES = {
     "sfe_memcpy_h2d": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     "sfe_memcpy_d2h": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     "sfe_memset": (C.c_int, [_vp, _vp, C.c_int, C.c_size_t]),
+    "sfe_host_alloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    "sfe_host_free": (C.c_int, [_vp, _vp]),
+    "sfe_memcpy_h2d_async": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "sfe_stream_fence": (C.c_int, [_vp, C.c_int]),
     "sfe_timer_start": (C.c_int, [_vp]),
     "sfe_timer_stop": (C.c_int, [_vp, _f32p]),
     "sfe_cfar_u8": (C.c_int, [_vp, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -115,6 +120,7 @@ SIGNATURES = {
     "sfe_icp_get_profile": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_longlong)]),
     "sfe_icp_batch_dev": (C.c_int, [_vp, C.POINTER(IcpParams), _vp, _i32p, _vp, _i32p, _vp, C.c_int,
                                     _vp, _vp, _vp]),
+    "sfe_icp_jobs_dev": (C.c_int, [_vp, C.POINTER(IcpParams), _vp, _vp, _i32p, _vp, C.c_int, _vp, _vp, _vp]),
     "sfe_cloud_filter_batch_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_int,
                                              _vp, _vp]),
     "sfe_costgrid_create": (C.c_int, [_vp, _i32p, _i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
@@ -166,6 +172,13 @@ class DeviceBuffer(object):
         assert offset + arr.nbytes <= self.nbytes
         dst = _vp(self.ptr.value + offset)
         self.ctx._check(self.ctx.lib.sfe_memcpy_h2d(self.ctx.handle, dst, arr.ctypes.data, arr.nbytes))
+
+    def upload_async(self, pinned, offset=0):
+        """enqueue-only upload from a ``Context.host_alloc`` array on the context's copy stream (order it against
+        the kernels with ``Context.fence``)"""
+        assert offset + pinned.nbytes <= self.nbytes
+        dst = _vp(self.ptr.value + offset)
+        self.ctx._check(self.ctx.lib.sfe_memcpy_h2d_async(self.ctx.handle, dst, pinned.ctypes.data, pinned.nbytes))
 
     def download(self, dtype, count, offset=0):
         out = np.empty(count, dtype)
@@ -219,6 +232,27 @@ class Context(object):
 
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
+
+    def host_alloc(self, shape, dtype=np.uint8):
+        """pinned host array (sfe_host_alloc); free it with ``host_free`` (the array must not be used afterwards)"""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = _vp()
+        self._check(self.lib.sfe_host_alloc(self.handle, n, C.byref(p)))
+        buf = (C.c_char * max(n, 1)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p
+        return arr
+
+    def host_free(self, arr):
+        p = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
+        if p is not None:
+            self._check(self.lib.sfe_host_free(self.handle, p))
+
+    def fence(self, what):
+        """0: kernels behind the uploads enqueued so far; 1: uploads behind the kernels enqueued so far;
+        2: the host waits for the uploads (sfe_stream_fence)"""
+        self._check(self.lib.sfe_stream_fence(self.handle, int(what)))
 
     def timer_start(self):
         self._check(self.lib.sfe_timer_start(self.handle))

@@ -123,6 +123,9 @@ int sfe_ctx_create(int device, sfe_ctx **out)
     c->n_cu = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_compute, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_prep, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_loop, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->pin[0].ev, hipEventDisableTiming) != hipSuccess ||
@@ -142,6 +145,7 @@ void sfe_ctx_destroy(sfe_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamSynchronize(ctx->stream2);
+    (void)hipStreamSynchronize(ctx->stream_copy);
     for (auto &b : ctx->scratch)
         if (b.p)
             (void)hipFree(b.p);
@@ -158,6 +162,9 @@ void sfe_ctx_destroy(sfe_ctx *ctx)
     (void)hipEventDestroy(ctx->ev1);
     (void)hipEventDestroy(ctx->ev_prep);
     (void)hipEventDestroy(ctx->ev_loop);
+    (void)hipEventDestroy(ctx->ev_copy);
+    (void)hipEventDestroy(ctx->ev_compute);
+    (void)hipStreamDestroy(ctx->stream_copy);
     (void)hipStreamDestroy(ctx->stream2);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -219,6 +226,54 @@ int sfe_memcpy_d2h(sfe_ctx *ctx, void *dst_host, const void *src_dev, size_t byt
         return rc;
     SFE_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
     SFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// ---- streamed inputs: pinned host memory, uploads on a copy stream next to the kernels ----
+int sfe_host_alloc(sfe_ctx *ctx, size_t bytes, void **hptr)
+{
+    if (int rc = sfe_use(ctx))
+        return rc;
+    SFE_ARG(ctx, hptr);
+    *hptr = nullptr;
+    SFE_HIP(ctx, hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return 0;
+}
+
+int sfe_host_free(sfe_ctx *ctx, void *hptr)
+{
+    if (int rc = sfe_use(ctx))
+        return rc;
+    SFE_HIP(ctx, hipStreamSynchronize(ctx->stream_copy));
+    if (hptr)
+        SFE_HIP(ctx, hipHostFree(hptr));
+    return 0;
+}
+
+int sfe_memcpy_h2d_async(sfe_ctx *ctx, void *dst_dev, const void *src_pinned, size_t bytes)
+{
+    if (int rc = sfe_use(ctx))
+        return rc;
+    SFE_ARG(ctx, dst_dev && src_pinned);
+    SFE_HIP(ctx, hipMemcpyAsync(dst_dev, src_pinned, bytes, hipMemcpyHostToDevice, ctx->stream_copy));
+    SFE_HIP(ctx, hipEventRecord(ctx->ev_copy, ctx->stream_copy));
+    return 0;
+}
+
+int sfe_stream_fence(sfe_ctx *ctx, int what)
+{
+    if (int rc = sfe_use(ctx))
+        return rc;
+    if (what == 0) { // kernels enqueued from now on run behind every upload enqueued so far
+        SFE_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_copy, 0));
+    } else if (what == 1) { // uploads enqueued from now on run behind every kernel enqueued so far
+        SFE_HIP(ctx, hipEventRecord(ctx->ev_compute, ctx->stream));
+        SFE_HIP(ctx, hipStreamWaitEvent(ctx->stream_copy, ctx->ev_compute, 0));
+    } else if (what == 2) { // host waits for the uploads
+        SFE_HIP(ctx, hipStreamSynchronize(ctx->stream_copy));
+    } else {
+        return sfe_set_err(ctx, SFE_ERR_ARG, "sfe_stream_fence: what = %d", what);
+    }
     return 0;
 }
 

@@ -812,6 +812,17 @@ int sfe_icp_batch_dev(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_src,
     return icp_launch(ctx, p, d_src, d_tgt, jobs4.data(), d_guess9, n_jobs, d_T9, d_status, d_iters);
 }
 
+int sfe_icp_jobs_dev(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_src, const float *d_tgt, const int32_t *jobs4,
+                     const float *d_guess9, int n_jobs, float *d_T9, int32_t *d_status, int32_t *d_iters)
+{
+    if (int rc = sfe_use(ctx))
+        return rc;
+    SFE_ARG(ctx, d_src && d_tgt && jobs4 && d_guess9 && d_T9 && d_status && d_iters && n_jobs >= 0);
+    if (n_jobs == 0)
+        return 0;
+    return icp_launch(ctx, p, d_src, d_tgt, jobs4, d_guess9, n_jobs, d_T9, d_status, d_iters);
+}
+
 int sfe_icp_compute_guesses(sfe_ctx *ctx, const sfe_icp_params *p, const float *src, int n_src, const float *tgt,
                             int n_tgt, const float *guesses9, int n_guesses, float *T_out9, int32_t *status,
                             int32_t *iters)

@@ -47,7 +47,20 @@
 #define SW_TCAP 8192   // target points resident in LDS
 #define SW_NS_MAX 64   // strips per target
 #define SW_PAD (SW_NS_MAX + 4) // sentinels: one in front, one behind every strip, two spare behind the last
-#define SW_GRID_MAX 8192 // cells of a target's witness grid (built in the prep kernel's LDS: 4 B per cell)
+#define SW_GRID_MAX 8192 // most cells a target's witness grid can have (built in the prep kernel's LDS: 4 B per cell)
+// Job tiers (the scan matches bruce_slam itself produces are 10^2..10^3 points, slam.py:769,1032): the
+// same kernels instantiated for one-wave and four-wave workgroups, several jobs per CU, chosen by the launcher from
+// n_src / n_tgt.  {threads, target capacity of the prep kernel's LDS, witness-grid cells}
+#define SW_T0_NT 64
+#define SW_T0_TCAP 512
+#define SW_T0_GRID 512
+#define SW_T1_NT 256
+#define SW_T1_TCAP 2048
+#define SW_T1_GRID 2048
+// Many-to-one batches on large clouds (BASELINE configs[4]: 30 guesses x one 20 000 x 20 000 pair, slam.py:346-358): a
+// job is split over up to SW_MG_MAX workgroups (queries by strip band), which meet in a per-job sync area
+#define SW_MG_MAX 16
+#define SW_MG_WORDS 272 // 32-bit words one exchange can carry (a 256-bin histogram + scalars)
 
 // Strip table of one target (built by the prep kernel, read by every job on that target).
 // Sorted-cloud layout (float2 positions): [0] NaN, then for every strip s its points ascending in x
@@ -63,7 +76,8 @@ struct StripTab {
     // grid[iy * gnx + ix] = sorted position of the target point nearest to the cell's centre (0: none)
     float gx0, gy0, ginv;
     int gnx, gny;
-    int pad_[2];
+    int grid_off64; // this target's slice of the witness-grid scratch starts at int 64 * grid_off64
+    int pad_;
     int sbeg[SW_NS_MAX + 1];
     float smin[SW_NS_MAX];    // smallest y of any point in strips >= s (+inf if none)
     float smax[SW_NS_MAX];    // largest y of any point in strips <= s (-inf if none)
@@ -73,12 +87,16 @@ struct SweepPrep {
     int tgt_start, n_tgt, ns, pad_;
     long long off;     // offset (points) of this target's slice of the sorted-cloud scratch (stride n_tgt + SW_PAD)
     long long key_off; // targets beyond the LDS capacity: offset of their sort keys in HBM scratch
+    long long grid_off; // offset (ints, a multiple of 64) of its witness grid
 };
 
 struct SweepJob {
     int src_start, n_src, n_tgt, prep;
     long long tgt_off; // = SweepPrep.off of its target
     long long q_off;   // offset (points) of this job's slice of the per-query scratch
+    int out;           // index of the caller's job (guess, T_out, status, iterations) this record works for
+    int grp, ngrp;     // split jobs: this record is share `grp` of `ngrp` (1: the whole job)
+    int sync;          // ... and their sync area is number `sync`
 };
 
 // order-preserving map float -> uint32 (NaN of either sign sorts last)
@@ -178,10 +196,10 @@ __device__ __forceinline__ void bitonic_sort_lds(unsigned long long *keys, unsig
     }
 }
 
-template <int NT>
+template <int NT, int TCAP>
 struct PrepShared {
     // first the sort keys, then (same bytes) the sorted cloud with its sentinels
-    unsigned long long buf[SW_TCAP + SW_PAD + 4];
+    unsigned long long buf[TCAP + SW_PAD + 4];
     double red[(NT / 64) * 2 + 2];
     float mean[2];
     unsigned ykey[2], xkey[2]; // min / max order keys of the finite centred coordinates
@@ -468,9 +486,12 @@ __device__ __forceinline__ void bitonic_sort_global(unsigned long long *keys, un
 #define SW_KEY_X(k) ((unsigned)(((k) >> 24) & 0xFFFFFFFFull))
 #define SW_KEY_ID(k) ((int)((k) & 0xFFFFFFull))
 
-template <int NT>
+// NT threads; targets of up to TCAP points are sorted (and their normals / witness grid built) in LDS; GM = most cells
+// of the witness grid.  prep_ids[blockIdx.x] = the target this workgroup prepares (one launch per tier).
+template <int NT, int TCAP, int GM>
 __global__ __launch_bounds__(NT, 4) void icp_sweep_prep_kernel(sfe_icp_params P,
                                                                         const SweepPrep *__restrict__ preps,
+                                                                        const int *__restrict__ prep_ids,
                                                                         const float2 *__restrict__ tgt_all,
                                                                         float2 *__restrict__ stgt_all,
                                                                         int *__restrict__ perm_all,
@@ -481,9 +502,10 @@ __global__ __launch_bounds__(NT, 4) void icp_sweep_prep_kernel(sfe_icp_params P,
                                                                         int *__restrict__ grid_all)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    PrepShared<NT> &S = *reinterpret_cast<PrepShared<NT> *>(smem_raw);
-    int *s_grid = reinterpret_cast<int *>(smem_raw + ((sizeof(PrepShared<NT>) + 15) & ~(size_t)15)); // witness grid + distances
-    const SweepPrep J = preps[blockIdx.x];
+    PrepShared<NT, TCAP> &S = *reinterpret_cast<PrepShared<NT, TCAP> *>(smem_raw);
+    int *s_grid = reinterpret_cast<int *>(smem_raw + ((sizeof(PrepShared<NT, TCAP>) + 15) & ~(size_t)15)); // witness grid + distances
+    const int pid = __builtin_amdgcn_readfirstlane(prep_ids[blockIdx.x]);
+    const SweepPrep J = preps[pid];
     const int nt = J.n_tgt, ns = J.ns, tid = threadIdx.x, lane = threadIdx.x & 63;
     const float2 *__restrict__ tgt = tgt_all + J.tgt_start;
     float2 *__restrict__ stgt = stgt_all + J.off;
@@ -502,8 +524,8 @@ __global__ __launch_bounds__(NT, 4) void icp_sweep_prep_kernel(sfe_icp_params P,
         if (tid == 0) {
             S.mean[0] = (float)(m[0] / nt);
             S.mean[1] = (float)(m[1] / nt);
-            mean_all[2 * blockIdx.x] = S.mean[0];
-            mean_all[2 * blockIdx.x + 1] = S.mean[1];
+            mean_all[2 * pid] = S.mean[0];
+            mean_all[2 * pid + 1] = S.mean[1];
             S.ykey[0] = S.xkey[0] = 0xFFFFFFFFu;
             S.ykey[1] = S.xkey[1] = 0u;
         }
@@ -551,14 +573,14 @@ __global__ __launch_bounds__(NT, 4) void icp_sweep_prep_kernel(sfe_icp_params P,
             const float inv = (y1 > y0) ? (float)ns / f_add(y1, -y0) : 0.0f;
             S.tab.inv_g = (inv < INFINITY) ? inv : 0.0f;
             S.tab.ext_x = (x1 >= x0) ? f_add(x1, -x0) : 0.0f;
-            // witness grid over the bounding box: about one cell per target point, at most SW_GRID_MAX cells
+            // witness grid over the bounding box: about one cell per target point, at most GM cells
             const float ex = (x1 >= x0) ? f_add(x1, -x0) : 0.0f, ey = (y1 >= y0) ? f_add(y1, -y0) : 0.0f;
             float cs = sqrtf(fmaxf(ex, 1e-30f) * fmaxf(ey, 1e-30f) / (float)max(nt, 1));
-            cs = fmaxf(cs, sqrtf(fmaxf(ex, 1e-30f) * fmaxf(ey, 1e-30f) / (float)(SW_GRID_MAX / 2)));
+            cs = fmaxf(cs, sqrtf(fmaxf(ex, 1e-30f) * fmaxf(ey, 1e-30f) / (float)(GM / 2)));
             if (!(cs > 0.0f) || !(cs < INFINITY))
                 cs = 1.0f;
             int gnx = (int)fminf(ex / cs, 4096.0f) + 1, gny = (int)fminf(ey / cs, 4096.0f) + 1;
-            while ((long long)gnx * gny > SW_GRID_MAX) { // a very elongated box
+            while ((long long)gnx * gny > GM) { // a very elongated box
                 if (gnx >= gny)
                     gnx = (gnx + 1) / 2;
                 else
@@ -568,6 +590,8 @@ __global__ __launch_bounds__(NT, 4) void icp_sweep_prep_kernel(sfe_icp_params P,
             S.tab.gy0 = (y1 >= y0) ? y0 : 0.0f;
             S.tab.gnx = gnx;
             S.tab.gny = gny;
+            S.tab.grid_off64 = (int)(J.grid_off / 64);
+            S.tab.pad_ = 0;
             // one cell size for both axes, large enough that gnx x gny cells cover the box
             const float csx = ex / (float)gnx, csy = ey / (float)gny;
             const float csz = fmaxf(fmaxf(csx, csy), 1e-30f);
@@ -583,7 +607,7 @@ __global__ __launch_bounds__(NT, 4) void icp_sweep_prep_kernel(sfe_icp_params P,
     unsigned n2 = 2;
     while (n2 < (unsigned)nt)
         n2 <<= 1;
-    const bool in_lds = nt <= SW_TCAP;
+    const bool in_lds = nt <= TCAP;
     unsigned long long *keys = in_lds ? S.buf : gkeys_all + J.key_off;
     for (unsigned i = tid; i < n2; i += NT) {
         unsigned long long k = ~0ull;
@@ -625,7 +649,7 @@ __global__ __launch_bounds__(NT, 4) void icp_sweep_prep_kernel(sfe_icp_params P,
     __syncthreads();
     { // the table travels to HBM for the loop kernel
         const int *src = reinterpret_cast<const int *>(&S.tab);
-        int *dst = reinterpret_cast<int *>(tab_all + blockIdx.x);
+        int *dst = reinterpret_cast<int *>(tab_all + pid);
         for (int i = tid; i < (int)(sizeof(StripTab) / sizeof(int)); i += NT)
             dst[i] = src[i];
     }
@@ -640,7 +664,7 @@ __global__ __launch_bounds__(NT, 4) void icp_sweep_prep_kernel(sfe_icp_params P,
     if (in_lds) {
         bitonic_sort_lds<NT>(S.buf, n2);
         // keys -> sorted centred cloud (registers -> same LDS bytes, in the strip layout)
-        constexpr int PER = SW_TCAP / NT;
+        constexpr int PER = TCAP / NT;
         float2 v[PER];
         int id[PER], ps[PER];
 #pragma unroll
@@ -682,7 +706,7 @@ __global__ __launch_bounds__(NT, 4) void icp_sweep_prep_kernel(sfe_icp_params P,
                 sweep_knn_normals<ICP_KMAX, NT>(P, S.tab, s_tgt, perm, nrm, nt);
         }
         if (grid_all)
-            sweep_grid_witness<NT>(S.tab, s_tgt, grid_all + (size_t)blockIdx.x * SW_GRID_MAX, reinterpret_cast<unsigned *>(s_grid));
+            sweep_grid_witness<NT>(S.tab, s_tgt, grid_all + J.grid_off, reinterpret_cast<unsigned *>(s_grid));
     } else {
         bitonic_sort_global<NT>(keys, n2);
         for (int r = tid; r < nt; r += NT) {
@@ -703,7 +727,7 @@ __global__ __launch_bounds__(NT, 4) void icp_sweep_prep_kernel(sfe_icp_params P,
                 sweep_knn_normals<ICP_KMAX, NT>(P, S.tab, stgt, perm, nrm, nt);
         }
         if (grid_all)
-            sweep_grid_witness<NT>(S.tab, stgt, grid_all + (size_t)blockIdx.x * SW_GRID_MAX, reinterpret_cast<unsigned *>(s_grid));
+            sweep_grid_witness<NT>(S.tab, stgt, grid_all + J.grid_off, reinterpret_cast<unsigned *>(s_grid));
     }
 }
 
@@ -739,8 +763,10 @@ __device__ __forceinline__ long long sw_uniform_ll(long long v)
     return (long long)(((unsigned long long)hi << 32) | lo);
 }
 
-// control block of a job; the LDS-resident variant places the sorted target right behind it
-template <int NT>
+// control block of a job; the LDS-resident variant places the sorted target right behind it.  The profile counters
+// and the transform history of the clearance records only take room in the builds that use them (the small-job tiers
+// run many workgroups per CU: every KB of control block is a job less per CU).
+template <int NT, bool PROF, bool REC>
 struct SweepShared {
     double red[(NT / 64) * 10 + 10];
     double acc[10];  // the reduced error-minimiser sums (read by the solving lane)
@@ -752,12 +778,14 @@ struct SweepShared {
     int long_n, long_next, mid_n, wl_n[2];
     int flag_iterate, flag_status;
     float Ti[9];
-    float thist[ICP_MAX_HIST][6]; // T_iter of every iteration so far (rows 0 and 1): the movement bounds below
-    float mva[ICP_MAX_HIST], mvt[ICP_MAX_HIST]; // a query x = T0 * src has moved by at most mva[k] |x| + mvt[k] between
-                                                // iteration k and the current one
+    float thist[REC ? ICP_MAX_HIST : 1][6]; // T_iter of every iteration so far (rows 0 and 1): the movement bounds below
+    float mva[REC ? ICP_MAX_HIST : 1], mvt[REC ? ICP_MAX_HIST : 1]; // a query x = T0 * src has moved by at most
+                                                // mva[k] |x| + mvt[k] between iteration k and the current one
     unsigned rmax_bits;           // largest |T0 * src| (float bits; >= 0 so the bit patterns order like the values)
     float hist_c[ICP_MAX_HIST], hist_s[ICP_MAX_HIST], hist_x[ICP_MAX_HIST], hist_y[ICP_MAX_HIST];
-    long long prof_t, prof[16], prof_it[64], prof_b0;
+    long long prof_t, prof[PROF ? 16 : 1], prof_it[PROF ? 64 : 1], prof_b0;
+    unsigned xr[16]; // split jobs: the scalars of an exchange between the workgroups of a job
+    int xabort;      // ... and its time-out flag
     StripTab tab;
 };
 
@@ -862,7 +890,11 @@ __device__ __forceinline__ int sweep_resolve_tie(const float2 *__restrict__ T, c
 // PROF: per-phase cycle counters of workgroup 0 and launch-wide counts of the work done (candidate evaluations,
 // lower-bound probes); instantiated for the two-jobs-per-CU builds with an LDS-resident target only.
 // REC: the build with clearance records (below); chosen by the launcher for chains that run many iterations.
-template <int NT, int MINW, bool LDS_TGT, bool LDS_Q, bool PROF, bool REC>
+// MULTI: the job is one of J.ngrp shares of a caller's job (its queries: one band of strips, gathered by
+// icp_split_kernel).  Every share runs the whole loop on its own queries; what an iteration decides from ALL queries --
+// the census of a search round, the histograms of the radix select, the sums of the error minimiser -- is exchanged
+// through the job's sync area (xreduce below) and every share takes the same decisions and solves the same system.
+template <int NT, int MINW, bool LDS_TGT, bool LDS_Q, bool PROF, bool REC, bool MULTI>
 __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
     sfe_icp_params P, const SweepJob *__restrict__ jobs, const int *__restrict__ job_ids, const float2 *__restrict__ src_all,
     const float *__restrict__ guess_all, const float2 *__restrict__ stgt_all, const int *__restrict__ perm_all,
@@ -870,11 +902,14 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
     const int *__restrict__ grid_all, int4 *__restrict__ q_st_all, int *__restrict__ q_wl_all, float2 *__restrict__ q_ssrc_all,
     float *__restrict__ nn_d2_all,
     int *__restrict__ nn_pos_all, float *__restrict__ T_out, int *__restrict__ status_out,
-    int *__restrict__ iters_out, long long *prof, int *dbg, int sw_budget, int sw_budget_a, int sw_cache, int t_cap, int q_cap, int sort_chunk, float sw_m, float sw_kappa)
+    int *__restrict__ iters_out, long long *prof, int *dbg, int sw_budget, int sw_budget_a, int sw_cache, int t_cap, int q_cap, int sort_chunk, float sw_m, float sw_kappa,
+    unsigned long long *__restrict__ sync_all)
 {
     static_assert(LDS_TGT || !LDS_Q, "LDS_Q needs the LDS-resident target layout");
+    static_assert(!MULTI || !PROF, "the profile build runs whole jobs");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    SweepShared<NT> &S = *reinterpret_cast<SweepShared<NT> *>(smem_raw);
+    using Shared = SweepShared<NT, PROF, REC>;
+    Shared &S = *reinterpret_cast<Shared *>(smem_raw);
 
     const int jb = __builtin_amdgcn_readfirstlane(job_ids[blockIdx.x]);
     SweepJob J = jobs[jb];
@@ -883,12 +918,16 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
     J.n_src = __builtin_amdgcn_readfirstlane(J.n_src);
     J.n_tgt = __builtin_amdgcn_readfirstlane(J.n_tgt);
     J.prep = __builtin_amdgcn_readfirstlane(J.prep);
+    J.out = __builtin_amdgcn_readfirstlane(J.out);
+    J.grp = __builtin_amdgcn_readfirstlane(J.grp);
+    J.ngrp = __builtin_amdgcn_readfirstlane(J.ngrp);
+    J.sync = __builtin_amdgcn_readfirstlane(J.sync);
     J.tgt_off = sw_uniform_ll(J.tgt_off);
     J.q_off = sw_uniform_ll(J.q_off);
     const int ns = J.n_src, nt = J.n_tgt;
     const float2 *__restrict__ src = src_all + J.src_start;
     const float2 *__restrict__ stgt = stgt_all + J.tgt_off;
-    float2 *lds_tgt = reinterpret_cast<float2 *>(smem_raw + ((sizeof(SweepShared<NT>) + 15) & ~(size_t)15));
+    float2 *lds_tgt = reinterpret_cast<float2 *>(smem_raw + ((sizeof(Shared) + 15) & ~(size_t)15));
     const float2 *__restrict__ T = LDS_TGT ? (const float2 *)lds_tgt : stgt; // sorted target incl. sentinels
     const float2 *__restrict__ snrm = snrm_all ? snrm_all + J.tgt_off : nullptr;
     SweepQ Q;
@@ -928,8 +967,7 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
     Q.rec = reinterpret_cast<unsigned *>(Q.slot_of + ns);
     Q.ssrc = q_ssrc_all + J.q_off;
     Q.perm = perm_all + J.tgt_off;
-    const int *__restrict__ grid = (grid_all != nullptr && (sw_cache & 4) != 0) ? grid_all + (size_t)J.prep * SW_GRID_MAX : nullptr;
-    const float *guess = guess_all + 9 * (size_t)jb;
+    const float *guess = guess_all + 9 * (size_t)J.out;
     const int tid = threadIdx.x, lane = threadIdx.x & 63;
     const float mx = sw_uniform(mean_all[2 * J.prep]), my = sw_uniform(mean_all[2 * J.prep + 1]);
 
@@ -941,8 +979,10 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
     // wave-uniform work counters (PROF only): candidate distance evaluations of the lane-per-query tiers, of the
     // cooperative tier, witness evaluations, lower-bound probes
     unsigned long long c_eval = 0, c_coop = 0, c_wit = 0, c_lb = 0;
-    if (tid == 0)
+    if (tid == 0) {
         S.rmax_bits = 0u;
+        S.xabort = 0;
+    }
     { // strip table -> LDS
         const int *tsrc = reinterpret_cast<const int *>(tab_all + J.prep);
         int *tdst = reinterpret_cast<int *>(&S.tab);
@@ -964,6 +1004,89 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
             T0[i] = sw_uniform(T0[i]);
     }
     __syncthreads(); // strip table in place
+
+    // ---- split jobs: what the shares of a job tell each other ----
+    // R2 of the hand-off recipe (cdna_hip_programming.md, Guideline 16): the data is the flag.  A share publishes its
+    // words as 8-byte granules {epoch, value} (one sc1 store each, no fence) in its row of the job's sync area and
+    // reads the same words of EVERY share until their tags show this epoch.  Consecutive exchanges alternate between
+    // two banks: a share can be one exchange ahead of the slowest one, never two (it needs everybody's words of the
+    // exchange in between).  Every share adds the rows up in share order, so all of them hold the same totals, take
+    // the same decisions and run the same number of rounds and iterations.  The area is zeroed before every launch
+    // (tag 0 = nothing yet).  A wait of more than ~2 s (a share that never became resident: the launcher only splits
+    // jobs when all shares fit the device at once) gives up and the job reports SFE_ICP_SPLIT_TIMEOUT.
+    typedef __attribute__((address_space(1))) unsigned long long gu64;
+    unsigned xepoch = 0;
+    gu64 *xsync = MULTI ? (gu64 *)(sync_all + (size_t)J.sync * (size_t)(2 * SW_MG_MAX * SW_MG_WORDS)) : nullptr;
+    auto xpoll = [&](gu64 *g, unsigned epoch) -> unsigned {
+        unsigned long long x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(x >> 32) != epoch) {
+            const unsigned long long t0 = wall_clock64(); // 100 MHz
+            while (true) {
+                __builtin_amdgcn_s_sleep(8);
+                x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(x >> 32) == epoch)
+                    break;
+                if (wall_clock64() - t0 > 200000000ull) {
+                    S.xabort = 1;
+                    break;
+                }
+            }
+        }
+        return (unsigned)x;
+    };
+    auto xbail = [&]() { // (all threads, after a barrier)
+        if (tid == 0 && J.grp == 0) {
+            for (int i = 0; i < 9; ++i)
+                T_out[9 * (size_t)J.out + i] = guess[i];
+            status_out[J.out] = SFE_ICP_SPLIT_TIMEOUT;
+            iters_out[J.out] = 0;
+        }
+        __builtin_amdgcn_endpgm();
+    };
+    // vals[0..n) (LDS, n <= SW_MG_WORDS) -> their sums over the shares; called by every thread
+    auto xreduce_u32 = [&](unsigned *vals, int n) {
+        __syncthreads(); // the words are final
+        ++xepoch;
+        gu64 *bank = xsync + (size_t)(xepoch & 1u) * (SW_MG_MAX * SW_MG_WORDS);
+        for (int t = tid; t < n; t += NT)
+            __hip_atomic_store(bank + J.grp * SW_MG_WORDS + t, ((unsigned long long)xepoch << 32) | vals[t], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        for (int t = tid; t < n; t += NT) {
+            unsigned sum = 0;
+            for (int w = 0; w < J.ngrp; ++w)
+                sum += xpoll(bank + w * SW_MG_WORDS + t, xepoch);
+            vals[t] = sum;
+        }
+        __syncthreads();
+        if (S.xabort)
+            xbail();
+    };
+    // S.acc[0..10) -> their sums over the shares (fp64, added in share order: the same bits in every share)
+    auto xreduce_acc = [&]() {
+        __syncthreads();
+        ++xepoch;
+        gu64 *bank = xsync + (size_t)(xepoch & 1u) * (SW_MG_MAX * SW_MG_WORDS);
+        if (tid < 20)
+            __hip_atomic_store(bank + J.grp * SW_MG_WORDS + tid,
+                               ((unsigned long long)xepoch << 32) | reinterpret_cast<const unsigned *>(S.acc)[tid],
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        double tot = 0.0;
+        if (tid < 10) {
+            for (int w = 0; w < J.ngrp; ++w) {
+                const unsigned lo = xpoll(bank + w * SW_MG_WORDS + 2 * tid, xepoch);
+                const unsigned hi = xpoll(bank + w * SW_MG_WORDS + 2 * tid + 1, xepoch);
+                tot += __hiloint2double((int)hi, (int)lo);
+            }
+        }
+        __syncthreads(); // every word has been read from S.acc and published before S.acc is rewritten
+        if (tid < 10)
+            S.acc[tid] = tot;
+        __syncthreads();
+        if (S.xabort)
+            xbail();
+    };
+    const int *__restrict__ grid = (grid_all != nullptr && (sw_cache & 4) != 0)
+                                       ? grid_all + 64 * (size_t)__builtin_amdgcn_readfirstlane(S.tab.grid_off64) : nullptr;
 
     // ---- processing order of the queries: sorted by (strip, x) of their position under the guess, so that
     // the 64 lanes of a wave search for neighbours in space: same strips, windows of similar length, same LDS
@@ -1123,8 +1246,8 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
             const bool skip_tally = top_tallied && shift == 24;
             unsigned *hist = skip_tally ? S.hist0 : S.hist;
             if (!skip_tally) {
-            if (tid < 256)
-                S.hist[tid] = 0;
+            for (int b = tid; b < 256; b += NT)
+                S.hist[b] = 0;
             __syncthreads();
             }
             const unsigned prefix = S.sel_prefix;
@@ -1170,6 +1293,8 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
             }
             __syncthreads();
             }
+            if (MULTI)
+                xreduce_u32(hist, 256); // the histogram of ALL shares (every share then picks the same bin)
             if (tid < 64) { // one wave: rank-in-histogram by shuffles instead of a 256-step serial walk
                 const unsigned k = S.sel_k;
                 const unsigned h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2],
@@ -1206,8 +1331,8 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
         // of the top byte of their distances (= the first pass of the radix select) -- is tallied where a query is
         // settled: `none` and `exact` are final for the iteration, so every query is counted once, in whatever round
         // and tier it ends.
-        if (tid < 256)
-            S.hist0[tid] = 0;
+        for (int b = tid; b < 256; b += NT)
+            S.hist0[b] = 0;
         const unsigned rechit_prev = (it > 0) ? S.n_rechit[(it - 1) & 1] : 0u; // (written last iteration, barriers since)
         if (tid == 0) {
             S.n_none = 0;
@@ -1748,10 +1873,27 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
                     S.prof_it[27 + 4 * round] = t_ - S.prof_b0;
                 }
                 // -- census (tallied on the way, see tally_settled) --
-                nfin = (unsigned)ns - S.n_none;
-                nexact = S.n_exact;
+                const int nsusp_mine = S.wl_n[cur ^ 1]; // this workgroup's suspended queries: the next round's work list
+                int nsusp = nsusp_mine;                 // ... and those of the whole job: what the round decides from
+                bool grid_skipped = S.grid_skips != 0;
+                if (MULTI) {
+                    if (tid == 0) {
+                        S.xr[0] = S.n_none;
+                        S.xr[1] = S.n_exact;
+                        S.xr[2] = (unsigned)nsusp_mine;
+                        S.xr[3] = grid_skipped ? 1u : 0u;
+                        S.xr[4] = (unsigned)ns;
+                    }
+                    xreduce_u32(S.xr, 5);
+                    nfin = S.xr[4] - S.xr[0];
+                    nexact = S.xr[1];
+                    nsusp = (int)S.xr[2];
+                    grid_skipped = S.xr[3] != 0u;
+                } else {
+                    nfin = (unsigned)ns - S.n_none;
+                    nexact = S.n_exact;
+                }
                 SW_PROF(8);
-                const int nsusp = S.wl_n[cur ^ 1];
                 bool done;
                 if (P.use_trimmed_filter && nfin > 0) {
                     ksel = (P.trim_ratio >= 1.0f) ? nfin - 1 : (unsigned)f_mul((float)nfin, P.trim_ratio);
@@ -1762,7 +1904,7 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
                 // queries that took a grid witness instead of searching are suspended WITHOUT the guarantee "neighbour
                 // beyond the cap" the other suspended ones carry: the round that searches them must follow, whatever
                 // the census says (they exist only in round 0 of the first iteration, and only while C < Cmax)
-                if (round == 0 && S.grid_skips != 0 && nsusp != 0)
+                if (round == 0 && grid_skipped && nsusp != 0)
                     done = false;
                 if (!done && (C >= Cmax || nsusp == 0)) {
                     // the k-th finite distance exceeds MaxDist^2 (or every neighbour is already known)
@@ -1781,7 +1923,7 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
                     C = sw_uniform((round >= 12) ? Cmax : fminf(fmaxf(4.0f * C, Cinit), Cmax));
                 }
                 cur ^= 1;
-                nwork = nsusp;
+                nwork = nsusp_mine;
             }
         }
         SW_PROF(2);
@@ -1867,6 +2009,8 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
         };
         sums(std::integral_constant<int, 0>());
         sums(std::integral_constant<int, 5>());
+        if (MULTI)
+            xreduce_acc(); // the sums over the queries of every share
         SW_PROF(4);
 
         // ---- E: solve, compose, check (one lane) ----
@@ -1889,9 +2033,9 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
         ++it;
     }
 
-    if (tid == 0) {
+    if (tid == 0 && (!MULTI || J.grp == 0)) { // (every share of a split job holds the same result: share 0 reports it)
         const int status = S.flag_status;
-        float *To = T_out + 9 * (size_t)jb;
+        float *To = T_out + 9 * (size_t)J.out;
         if (status == SFE_ICP_OK) {
             const float Tfwd[9] = {1, 0, mx, 0, 1, my, 0, 0, 1};
             float Ti[9], tmp[9], res[9];
@@ -1905,9 +2049,9 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
             for (int i = 0; i < 9; ++i) // pcl.cpp:203,207-210: T stays the guess
                 To[i] = guess[i];
         }
-        status_out[jb] = status;
-        iters_out[jb] = chk.iters;
-        if (PROF && jb == 0) {
+        status_out[J.out] = status;
+        iters_out[J.out] = chk.iters;
+        if (PROF && blockIdx.x == 0) {
             for (int i = 0; i < 16; ++i)
                 prof[i] = S.prof[i];
             for (int i = 0; i < 64; ++i)
@@ -1926,27 +2070,249 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// host side: job tables, scratch, two launches.  jobs4 = n_jobs x (src_start, n_src, tgt_start,
+// split: one workgroup per job that is shared by several workgroups of the loop kernel (MULTI)
+// ---------------------------------------------------------------------------------------------
+// The queries are dealt to the job's `ngrp` shares by the strip of their position under the guess -- bands of strips
+// holding about the same number of queries -- and every share's source points are gathered into one contiguous slice
+// (original order inside a share), so that a share is an ordinary job record on a cloud of its own.  The records of
+// the shares (jobs[first .. first + ngrp), filled by the host with the caller's cloud) get their n_src, src_start (in
+// the gathered cloud) and q_off here.
+template <int NT>
+__global__ __launch_bounds__(NT) void icp_split_kernel(SweepJob *__restrict__ jobs, const int *__restrict__ split_first,
+                                                       const float2 *__restrict__ src_all, const float *__restrict__ guess_all,
+                                                       const float *__restrict__ mean_all, const StripTab *__restrict__ tab_all,
+                                                       float2 *__restrict__ gsrc_all)
+{
+    __shared__ int s_cnt[SW_NS_MAX], s_grp[SW_NS_MAX], s_goff[SW_MG_MAX + 1], s_run[SW_MG_MAX];
+    __shared__ int s_w[NT / 64][SW_MG_MAX];
+    const int j0 = split_first[blockIdx.x];
+    const SweepJob J = jobs[j0];
+    const int n = J.n_src, G = min(J.ngrp, SW_MG_MAX), tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float2 *__restrict__ src = src_all + J.src_start;
+    const float mx = mean_all[2 * J.prep], my = mean_all[2 * J.prep + 1];
+    const StripTab *tab = tab_all + J.prep;
+    const float ylo = tab->ylo, inv_g = tab->inv_g;
+    const int nst = tab->ns;
+    float T0[9];
+    {
+        const float Tinv[9] = {1, 0, -mx, 0, 1, -my, 0, 0, 1};
+        float g[9];
+        for (int i = 0; i < 9; ++i)
+            g[i] = guess_all[9 * (size_t)J.out + i];
+        mat3_mul(Tinv, g, T0);
+    }
+    if (tid < SW_NS_MAX)
+        s_cnt[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += NT) {
+        const float2 sp = src[i];
+        atomicAdd(&s_cnt[strip_of(affine1(T0[3], T0[4], T0[5], sp.x, sp.y), ylo, inv_g, nst)], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        long long cum = 0;
+        for (int g = 0; g <= SW_MG_MAX; ++g)
+            s_goff[g] = 0;
+        for (int st = 0; st < SW_NS_MAX; ++st) { // strip -> share: the share its middle query falls into
+            const int c = st < nst ? s_cnt[st] : 0;
+            int g = (int)(((2 * cum + c) * G) / (2 * (long long)max(n, 1)));
+            g = min(max(g, 0), G - 1);
+            s_grp[st] = g;
+            s_goff[g + 1] += c;
+            cum += c;
+        }
+        for (int g = 0; g < SW_MG_MAX; ++g) { // counts -> offsets
+            s_goff[g + 1] += s_goff[g];
+            s_run[g] = 0;
+        }
+    }
+    __syncthreads();
+    for (int base = 0; base < n; base += NT) {
+        const int i = base + tid;
+        const bool valid = i < n;
+        float2 sp = make_float2(0, 0);
+        int g = -1;
+        if (valid) {
+            sp = src[i];
+            g = s_grp[strip_of(affine1(T0[3], T0[4], T0[5], sp.x, sp.y), ylo, inv_g, nst)];
+        }
+        unsigned long long mine = 0;
+        for (int gg = 0; gg < G; ++gg) {
+            const unsigned long long m = __ballot(g == gg);
+            if (g == gg)
+                mine = m;
+            if (lane == 0)
+                s_w[wave][gg] = __popcll(m);
+        }
+        __syncthreads();
+        if (tid < G) { // this chunk's queries of share `tid`: where each wave's run starts
+            int acc = s_run[tid];
+            for (int w = 0; w < NT / 64; ++w) {
+                const int t = s_w[w][tid];
+                s_w[w][tid] = acc;
+                acc += t;
+            }
+            s_run[tid] = acc;
+        }
+        __syncthreads();
+        if (valid)
+            gsrc_all[J.q_off + s_goff[g] + s_w[wave][g] + __popcll(mine & ((1ull << lane) - 1ull))] = sp;
+        __syncthreads();
+    }
+    if (tid < J.ngrp) {
+        const int g = min(tid, SW_MG_MAX - 1);
+        jobs[j0 + tid].src_start = (int)(J.q_off + s_goff[g]);
+        jobs[j0 + tid].n_src = (tid < G) ? s_goff[g + 1] - s_goff[g] : 0;
+        jobs[j0 + tid].q_off = J.q_off + s_goff[g];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side: job tables, scratch, the prep / split / loop launches.  jobs4 = n_jobs x (src_start, n_src, tgt_start,
 // n_tgt) in points.
 // ---------------------------------------------------------------------------------------------
+namespace {
+struct SweepLaunchArgs {
+    sfe_ctx *ctx;
+    const sfe_icp_params *p;
+    const SweepJob *d_jobs;
+    const float2 *d_src;
+    const float *d_guess9;
+    const float2 *d_stgt;
+    const int *d_perm;
+    const float2 *d_snrm;
+    const float *d_mean;
+    const StripTab *d_tab;
+    const int *d_grid;
+    int4 *d_qst;
+    int *d_qwl;
+    float2 *d_qssrc;
+    float *d_nn_d2;
+    int *d_nn_pos;
+    float *d_T9;
+    int32_t *d_status, *d_iters;
+    long long *d_prof;
+    int *d_dbg;
+    int sw_budget, sw_budget_a, sw_cache;
+    float sw_m, sw_kappa;
+    unsigned long long *d_sync;
+};
+
+int pow2_floor(size_t v)
+{
+    size_t p = 1;
+    while (2 * p <= v)
+        p *= 2;
+    return (int)p;
+}
+
+// bytes of the control block of one instantiation (the dynamic LDS behind it is 16-byte aligned)
+template <int NT, bool PROF, bool REC>
+constexpr size_t sweep_ctl_bytes()
+{
+    return (sizeof(SweepShared<NT, PROF, REC>) + 15) & ~(size_t)15;
+}
+
+// one launch of the loop kernel: n workgroups, job ids d_ids[0..n), `body` bytes of LDS behind the control block
+template <int NT, int MINW, bool LDS_TGT, bool LDS_Q, bool PROF, bool REC, bool MULTI>
+int sweep_launch_loop(const SweepLaunchArgs &a, int n, const int *d_ids, size_t body, int t_cap, int q_cap)
+{
+    sfe_ctx *ctx = a.ctx;
+    auto kernel = icp_sweep_kernel<NT, MINW, LDS_TGT, LDS_Q, PROF, REC, MULTI>;
+    const size_t smem = sweep_ctl_bytes<NT, PROF, REC>() + body;
+    SFE_HIP(ctx, hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(kernel, dim3(n), dim3(NT), smem, ctx->stream, *a.p, a.d_jobs, d_ids, a.d_src, a.d_guess9, a.d_stgt,
+                       a.d_perm, a.d_snrm, a.d_mean, a.d_tab, a.d_grid, a.d_qst, a.d_qwl, a.d_qssrc, a.d_nn_d2, a.d_nn_pos,
+                       a.d_T9, a.d_status, a.d_iters, a.d_prof, a.d_dbg, a.sw_budget, a.sw_budget_a, a.sw_cache, t_cap, q_cap,
+                       pow2_floor(body / 8), a.sw_m, a.sw_kappa, a.d_sync);
+    SFE_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+template <int NT, int TCAP, int GM>
+int sweep_launch_prep(sfe_ctx *ctx, hipStream_t ps, const sfe_icp_params *p, int n, const SweepPrep *d_preps, const int *d_pids,
+                      const float2 *d_tgt, float2 *d_stgt, int *d_perm, float2 *d_snrm, float *d_mean,
+                      unsigned long long *d_gkeys, StripTab *d_tab, int *d_grid)
+{
+    auto kernel = icp_sweep_prep_kernel<NT, TCAP, GM>;
+    const size_t smem = ((sizeof(PrepShared<NT, TCAP>) + 15) & ~(size_t)15) + 4 * (size_t)GM;
+    SFE_HIP(ctx, hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(kernel, dim3(n), dim3(NT), smem, ps, *p, d_preps, d_pids, d_tgt, d_stgt, d_perm, d_snrm, d_mean, d_gkeys,
+                       d_tab, d_grid);
+    SFE_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+} // namespace
+
 int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_src, const float *d_tgt,
                          const int32_t *jobs4, const float *d_guess9, int n_jobs, float *d_T9, int32_t *d_status,
                          int32_t *d_iters)
 {
     std::vector<SweepPrep> preps;
-    std::vector<SweepJob> jobs((size_t)n_jobs);
-    // three kinds of jobs, one launch each: target AND per-query results in LDS / target in LDS / target in HBM scratch
-    std::vector<int> ids_q, ids_lds, ids_glb;
+    std::vector<SweepJob> jobs;
+    jobs.reserve((size_t)n_jobs);
+    // Job classes, one launch of the loop kernel each:
+    //   t0 / t1  small jobs: one-wave / four-wave workgroups, target AND per-query results in LDS, many jobs per CU
+    //   q        1024-thread workgroups, target AND per-query results in LDS
+    //   lds      ... target in LDS, results in HBM scratch
+    //   glb      ... target in HBM scratch (beyond SW_TCAP points)
+    //   multi    ... target in HBM scratch, the job shared by several workgroups (many-to-one batches on large clouds)
+    std::vector<int> ids_t0, ids_t1, ids_q, ids_lds, ids_glb, ids_multi, split_first;
+    std::vector<int> pids[3]; // targets by prep tier
     std::map<std::pair<int, int>, int> seen; // many guesses on one pair share one prep
-    long long toff = 0, qoff = 0, koff = 0;
-    const size_t ctl_bytes = (sizeof(SweepShared<ICP_THREADS>) + 15) & ~(size_t)15;
-    // LDS share of a workgroup: two workgroups per CU when the batch has more jobs than CUs, else the whole CU
-    static const int force_wide = getenv("SFE_SW_WIDE") ? atoi(getenv("SFE_SW_WIDE")) : -1; // A/B: 1 = one 128-VGPR workgroup per CU
-    const bool wide = force_wide >= 0 ? force_wide != 0 : n_jobs <= ctx->n_cu;
-    static const int force_share = getenv("SFE_SW_SHARE_KB") ? atoi(getenv("SFE_SW_SHARE_KB")) : 0; // A/B: LDS per workgroup
+    long long toff = 0, qoff = 0, koff = 0, goff = 0;
+    // (knobs are read per call, not once per process: the tests switch them between calls)
+    // tiers (A/B: SFE_SW_TIERS=0 sends every job to the 1024-thread kernels)
+    const int tiers_on = env_int("SFE_SW_TIERS", 1);
+    const int t0_src = env_int("SFE_SW_T0_SRC", 384), t1_src = env_int("SFE_SW_T1_SRC", 2048);
+    // LDS share of a 1024-thread workgroup: two per CU when the batch has more jobs than CUs, else the whole CU
+    const int force_wide = env_int("SFE_SW_WIDE", -1); // A/B: 1 = one 128-VGPR workgroup per CU
+    const int force_share = env_int("SFE_SW_SHARE_KB", 0); // A/B: LDS per workgroup
+    const bool no_ldsq = getenv("SFE_SW_NO_LDSQ") != nullptr; // A/B
+    const int multi_on = env_int("SFE_SW_MULTI", 1);           // A/B: 0 = never split a job
+    const int multi_min_src = env_int("SFE_SW_MULTI_MIN_SRC", 8192);
+    const int multi_share_min = env_int("SFE_SW_MULTI_SHARE_MIN", 1024); // fewest queries worth a workgroup
+    const int multi_force = env_int("SFE_SW_MULTI_G", 0);     // A/B: shares per job
+    // ~96 points per strip on average (measured optimum 96-128 on 5000-point clouds: fewer queries need a
+    // second strip, a little more to walk in each), one strip (= a plain x sweep) for small clouds
+    const int strip_pts = std::max(1, env_int("SFE_SW_STRIP_PTS", 96));
+
+    // first pass: sizes -> how many big jobs there are (decides `wide` and whether big jobs are split)
+    int n_big = 0, n_t2 = 0;
+    auto tier_of = [&](int n_src, int n_tgt) {
+        if (tiers_on && n_src <= std::min(t0_src, 4096) && n_tgt <= SW_T0_TCAP)
+            return 0;
+        if (tiers_on && n_src <= std::min(t1_src, 8192) && n_tgt <= SW_T1_TCAP)
+            return 1;
+        return 2;
+    };
+    for (int j = 0; j < n_jobs; ++j) {
+        const int32_t *q = jobs4 + 4 * (size_t)j;
+        if (tier_of(q[1], q[3]) == 2) {
+            ++n_t2;
+            if (q[3] > SW_TCAP && q[1] >= multi_min_src)
+                ++n_big;
+        }
+    }
+    const bool wide = force_wide >= 0 ? force_wide != 0 : n_t2 <= ctx->n_cu;
     const size_t lds_share = (force_share > 0 ? force_share : (wide ? 160 : 80)) * (size_t)1024;
-    static const bool no_ldsq = getenv("SFE_SW_NO_LDSQ") != nullptr; // A/B
-    int q_tmax = 0, q_smax = 0;
+    // Shares per big job: all workgroups of the launch must be resident at once (one 128-VGPR workgroup per CU) -- only
+    // when the 1024-thread jobs of this call are the big ones alone and G x n_big fits the CUs
+    int mg = 1;
+    if (multi_on && n_big > 0 && n_big == n_t2 && wide) {
+        mg = std::min(SW_MG_MAX, ctx->n_cu / n_big);
+        if (multi_force > 0)
+            mg = std::min(std::min(multi_force, SW_MG_MAX), std::max(1, ctx->n_cu / n_big));
+    }
+    constexpr size_t ctl_q = sweep_ctl_bytes<ICP_THREADS, false, true>(); // (the largest control block of the LDS_Q builds)
+    int q_tmax = 0, q_smax = 0, t0_tmax = 0, t0_smax = 0, t1_tmax = 0, t1_smax = 0;
+    int n_sync = 0;
     for (int j = 0; j < n_jobs; ++j) {
         const int32_t *q = jobs4 + 4 * (size_t)j;
         const auto key = std::make_pair((int)q[2], (int)q[3]);
@@ -1959,40 +2325,65 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
                 while (n2 < q[3])
                     n2 <<= 1;
             }
-            // ~96 points per strip on average (measured optimum 96-128 on 5000-point clouds: fewer queries need a
-            // second strip, a little more to walk in each), one strip (= a plain x sweep) for small clouds
-            static const int strip_pts = getenv("SFE_SW_STRIP_PTS") ? std::max(1, atoi(getenv("SFE_SW_STRIP_PTS"))) : 96;
             const int n_strips = std::max(1, std::min(SW_NS_MAX, (int)q[3] / strip_pts));
-            preps.push_back({q[2], q[3], n_strips, 0, toff, koff});
+            const int pt = !tiers_on ? 2 : (q[3] <= SW_T0_TCAP ? 0 : (q[3] <= SW_T1_TCAP ? 1 : 2));
+            pids[pt].push_back((int)preps.size());
+            preps.push_back({q[2], q[3], n_strips, 0, toff, koff, goff});
             toff += q[3] + SW_PAD;
             koff += n2;
+            goff += pt == 0 ? SW_T0_GRID : (pt == 1 ? SW_T1_GRID : SW_GRID_MAX);
         }
         const SweepPrep &pr = preps[(size_t)it->second];
-        jobs[(size_t)j] = {q[0], q[1], q[3], it->second, pr.off, qoff};
+        const int tier = tier_of(q[1], q[3]);
+        int shares = 1;
+        if (tier == 2 && mg > 1 && q[3] > SW_TCAP && q[1] >= multi_min_src)
+            shares = std::max(1, std::min(mg, (int)q[1] / std::max(1, multi_share_min)));
+        const int rec0 = (int)jobs.size();
+        for (int g = 0; g < shares; ++g) // (the shares of a split job: the split kernel fills in their clouds)
+            jobs.push_back({q[0], q[1], q[3], it->second, pr.off, qoff, j, g, shares, shares > 1 ? n_sync : 0});
         qoff += q[1];
-        const bool fits_q = !no_ldsq && q[3] <= SW_TCAP &&
-                            ctl_bytes + 8 * (size_t)(q[3] + SW_PAD) + 6 * (size_t)q[1] + 16 <= lds_share;
-        if (fits_q) {
-            ids_q.push_back(j);
-            q_tmax = std::max(q_tmax, (int)q[3]);
-            q_smax = std::max(q_smax, (int)q[1]);
+        if (shares > 1) {
+            split_first.push_back(rec0);
+            for (int g = 0; g < shares; ++g)
+                ids_multi.push_back(rec0 + g);
+            ++n_sync;
+        } else if (tier == 0) {
+            ids_t0.push_back(rec0);
+            t0_tmax = std::max(t0_tmax, (int)q[3]);
+            t0_smax = std::max(t0_smax, (int)q[1]);
+        } else if (tier == 1) {
+            ids_t1.push_back(rec0);
+            t1_tmax = std::max(t1_tmax, (int)q[3]);
+            t1_smax = std::max(t1_smax, (int)q[1]);
         } else {
-            (q[3] <= SW_TCAP ? ids_lds : ids_glb).push_back(j);
+            const bool fits_q = !no_ldsq && q[3] <= SW_TCAP &&
+                                ctl_q + 8 * (size_t)(q[3] + SW_PAD) + 6 * (size_t)q[1] + 16 <= lds_share;
+            if (fits_q) {
+                ids_q.push_back(rec0);
+                q_tmax = std::max(q_tmax, (int)q[3]);
+                q_smax = std::max(q_smax, (int)q[1]);
+            } else {
+                (q[3] <= SW_TCAP ? ids_lds : ids_glb).push_back(rec0);
+            }
         }
     }
     // the LDS_Q launch is sized by the largest target and the largest source among its jobs
     int t_cap = q_tmax + SW_PAD, q_cap = (q_smax + 3) & ~3;
-    if (!ids_q.empty() && ctl_bytes + 8 * (size_t)t_cap + 6 * (size_t)q_cap > lds_share) {
+    if (!ids_q.empty() && ctl_q + 8 * (size_t)t_cap + 6 * (size_t)q_cap > lds_share) {
         ids_lds.insert(ids_lds.end(), ids_q.begin(), ids_q.end()); // odd mix of shapes: keep the results in HBM
         std::sort(ids_lds.begin(), ids_lds.end());
         ids_q.clear();
     }
-    const int n_prep = (int)preps.size();
-    const int n_q = (int)ids_q.size(), n_lds = (int)ids_lds.size(), n_glb = (int)ids_glb.size();
-    // the three tables travel as ONE block: [preps | jobs | job ids: LDS_Q jobs, LDS-resident targets, HBM-resident targets]
+    const int n_prep = (int)preps.size(), n_rec = (int)jobs.size();
+    const int n_t0 = (int)ids_t0.size(), n_t1 = (int)ids_t1.size(), n_q = (int)ids_q.size(), n_lds = (int)ids_lds.size(),
+              n_glb = (int)ids_glb.size(), n_multi = (int)ids_multi.size(), n_split = (int)split_first.size();
+    // the tables travel as ONE block: [preps | job records | job ids by class | share-0 records of the split jobs |
+    // prep ids by tier]
     const size_t o_jobs = (sizeof(SweepPrep) * (size_t)n_prep + 15) & ~(size_t)15;
-    const size_t o_ids = (o_jobs + sizeof(SweepJob) * (size_t)n_jobs + 15) & ~(size_t)15;
-    const size_t tab_bytes = o_ids + sizeof(int) * (size_t)n_jobs;
+    const size_t o_ids = (o_jobs + sizeof(SweepJob) * (size_t)n_rec + 15) & ~(size_t)15;
+    const size_t o_split = o_ids + sizeof(int) * (size_t)n_rec;
+    const size_t o_pids = o_split + sizeof(int) * (size_t)n_split;
+    const size_t tab_bytes = o_pids + sizeof(int) * (size_t)n_prep;
     char *d_tables = (char *)sfe_scratch(ctx, 12, tab_bytes);
     float2 *d_stgt = (float2 *)sfe_scratch(ctx, 14, sizeof(float2) * (size_t)toff);
     int *d_perm = (int *)sfe_scratch(ctx, 15, sizeof(int) * (size_t)toff);
@@ -2003,15 +2394,27 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
     int *d_qwl = (int *)sfe_scratch(ctx, 21, sizeof(int) * 7 * (size_t)qoff);
     float2 *d_qssrc = (float2 *)sfe_scratch(ctx, 30, sizeof(float2) * (size_t)qoff);
     StripTab *d_tab = (StripTab *)sfe_scratch(ctx, 23, sizeof(StripTab) * (size_t)n_prep);
-    int *d_grid = (int *)sfe_scratch(ctx, 38, sizeof(int) * (size_t)SW_GRID_MAX * (size_t)n_prep);
+    int *d_grid = (int *)sfe_scratch(ctx, 38, sizeof(int) * (size_t)goff);
     float *d_nn_d2 = (float *)sfe_scratch(ctx, 5, sizeof(float) * (size_t)qoff);
     int *d_nn_pos = (int *)sfe_scratch(ctx, 6, sizeof(int) * (size_t)qoff);
     if (!d_tables || !d_stgt || !d_perm || (p->minimizer == 1 && !d_snrm) || !d_mean || !d_gkeys || !d_qst || !d_qwl || !d_qssrc || !d_tab || !d_grid ||
         !d_nn_d2 || !d_nn_pos)
         return SFE_ERR_HIP;
+    // split jobs: the gathered source clouds of the shares and the sync areas
+    float2 *d_gsrc = nullptr;
+    unsigned long long *d_sync = nullptr;
+    const size_t sync_bytes = sizeof(unsigned long long) * 2 * SW_MG_MAX * SW_MG_WORDS * (size_t)n_sync;
+    if (n_split) {
+        d_gsrc = (float2 *)sfe_scratch(ctx, 46, sizeof(float2) * (size_t)qoff);
+        d_sync = (unsigned long long *)sfe_scratch(ctx, 45, sync_bytes);
+        if (!d_gsrc || !d_sync)
+            return SFE_ERR_HIP;
+    }
     SweepPrep *d_preps = (SweepPrep *)d_tables;
     SweepJob *d_jobs = (SweepJob *)(d_tables + o_jobs);
     int *d_ids = (int *)(d_tables + o_ids);
+    int *d_split = (int *)(d_tables + o_split);
+    int *d_pids = (int *)(d_tables + o_pids);
     // Tuning bit 3: the caller vouches that the clouds and guesses of this batch are final (nothing enqueued on
     // ctx->stream still writes them).  The job tables and the prep kernel then go to the side stream and run next to
     // whatever precedes this call on ctx->stream (a batch pipeline enqueues the front end of the same step there:
@@ -2025,49 +2428,63 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
         if (!h)
             return SFE_ERR_HIP;
         memcpy(h, preps.data(), sizeof(SweepPrep) * (size_t)n_prep);
-        memcpy(h + o_jobs, jobs.data(), sizeof(SweepJob) * (size_t)n_jobs);
-        if (n_q)
-            memcpy(h + o_ids, ids_q.data(), sizeof(int) * (size_t)n_q);
-        if (n_lds)
-            memcpy(h + o_ids + sizeof(int) * (size_t)n_q, ids_lds.data(), sizeof(int) * (size_t)n_lds);
-        if (n_glb)
-            memcpy(h + o_ids + sizeof(int) * (size_t)(n_q + n_lds), ids_glb.data(), sizeof(int) * (size_t)n_glb);
+        memcpy(h + o_jobs, jobs.data(), sizeof(SweepJob) * (size_t)n_rec);
+        int *hi = (int *)(h + o_ids);
+        for (const std::vector<int> *v : {&ids_t0, &ids_t1, &ids_q, &ids_lds, &ids_glb, &ids_multi}) {
+            if (!v->empty())
+                memcpy(hi, v->data(), sizeof(int) * v->size());
+            hi += v->size();
+        }
+        if (n_split)
+            memcpy(h + o_split, split_first.data(), sizeof(int) * (size_t)n_split);
+        int *hp = (int *)(h + o_pids);
+        for (int t = 0; t < 3; ++t) {
+            if (!pids[t].empty())
+                memcpy(hp, pids[t].data(), sizeof(int) * pids[t].size());
+            hp += pids[t].size();
+        }
         SFE_HIP(ctx, hipMemcpyAsync(d_tables, h, tab_bytes, hipMemcpyHostToDevice, ps));
         if (int rc = sfe_pinned_end(ctx, ps))
             return rc;
     }
-
-    const size_t prep_smem = ((sizeof(PrepShared<ICP_THREADS>) + 15) & ~(size_t)15) + 4 * (size_t)SW_GRID_MAX;
-    SFE_HIP(ctx, hipFuncSetAttribute((const void *)icp_sweep_prep_kernel<ICP_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)prep_smem));
-    hipLaunchKernelGGL(icp_sweep_prep_kernel<ICP_THREADS>, dim3(n_prep), dim3(ICP_THREADS), prep_smem, ps, *p,
-                       d_preps, (const float2 *)d_tgt, d_stgt, d_perm, d_snrm, d_mean, d_gkeys, d_tab, d_grid);
-    SFE_LAUNCH_CHECK(ctx);
+    {
+        const int np0 = (int)pids[0].size(), np1 = (int)pids[1].size(), np2 = (int)pids[2].size();
+        if (np0)
+            if (int rc = sweep_launch_prep<SW_T0_NT, SW_T0_TCAP, SW_T0_GRID>(ctx, ps, p, np0, d_preps, d_pids, (const float2 *)d_tgt, d_stgt,
+                                                                          d_perm, d_snrm, d_mean, d_gkeys, d_tab, d_grid))
+                return rc;
+        if (np1)
+            if (int rc = sweep_launch_prep<SW_T1_NT, SW_T1_TCAP, SW_T1_GRID>(ctx, ps, p, np1, d_preps, d_pids + np0, (const float2 *)d_tgt,
+                                                                          d_stgt, d_perm, d_snrm, d_mean, d_gkeys, d_tab, d_grid))
+                return rc;
+        if (np2)
+            if (int rc = sweep_launch_prep<ICP_THREADS, SW_TCAP, SW_GRID_MAX>(ctx, ps, p, np2, d_preps, d_pids + np0 + np1,
+                                                                           (const float2 *)d_tgt, d_stgt, d_perm, d_snrm, d_mean, d_gkeys,
+                                                                           d_tab, d_grid))
+                return rc;
+    }
+    if (n_split) { // behind the prep (it needs the strip tables), in front of the loop
+        SFE_HIP(ctx, hipMemsetAsync(d_sync, 0, sync_bytes, ps));
+        hipLaunchKernelGGL(icp_split_kernel<ICP_THREADS>, dim3(n_split), dim3(ICP_THREADS), 0, ps, d_jobs, d_split,
+                           (const float2 *)d_src, d_guess9, d_mean, d_tab, d_gsrc);
+        SFE_LAUNCH_CHECK(ctx);
+    }
     if (side) {
         SFE_HIP(ctx, hipEventRecord(ctx->ev_prep, ps));
         SFE_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prep, 0));
     }
     static const bool debug = getenv("SFE_ICP_DEBUG") != nullptr;
-    const int sw_budget = getenv("SFE_SW_BUDGET") ? atoi(getenv("SFE_SW_BUDGET")) : SW_BUDGET;
-    const int sw_budget_a = getenv("SFE_SW_BUDGET_A") ? atoi(getenv("SFE_SW_BUDGET_A")) : SW_BUDGET_A;
     // bit 0: witness / clearance cache (0: A/B without it); bits 8..15: walk trips per second-pass round
     // bit 1: the cap of a repeated round comes from the queries' upper bounds (0: grows 4x)
     // bit 2: grid witnesses in the first iteration (0: A/B without them)
-    const int sw_cache = ((getenv("SFE_SW_CACHE") ? atoi(getenv("SFE_SW_CACHE")) : 1) & 1) |
-                         ((getenv("SFE_SW_GRID") ? atoi(getenv("SFE_SW_GRID")) : 1) ? 4 : 0) |
-                         ((getenv("SFE_SW_GRID_SKIP") ? atoi(getenv("SFE_SW_GRID_SKIP")) : 1) ? 8 : 0) | // bit 3: witnessed queries skip round 0
-                         ((getenv("SFE_SW_REC") ? atoi(getenv("SFE_SW_REC")) : 1) ? 16 : 0) | // bit 4: clearance records
-                         ((getenv("SFE_SW_TRIAGE") ? atoi(getenv("SFE_SW_TRIAGE")) : 1) ? 32 : 0) | // bit 5: ... with triage passes
-
-                         ((getenv("SFE_SW_JUMP") ? atoi(getenv("SFE_SW_JUMP")) : 1) ? 2 : 0) |
+    const int sw_cache = (env_int("SFE_SW_CACHE", 1) & 1) | (env_int("SFE_SW_GRID", 1) ? 4 : 0) |
+                         (env_int("SFE_SW_GRID_SKIP", 1) ? 8 : 0) | // bit 3: witnessed queries skip round 0
+                         (env_int("SFE_SW_REC", 1) ? 16 : 0) |      // bit 4: clearance records
+                         (env_int("SFE_SW_TRIAGE", 1) ? 32 : 0) |   // bit 5: ... with triage passes
+                         (env_int("SFE_SW_JUMP", 1) ? 2 : 0) |
                          // bits 16..23: margin (percent) of the next iteration's cap over this iteration's limit
-                         (std::max(0, std::min(255, getenv("SFE_SW_MARGIN") ? atoi(getenv("SFE_SW_MARGIN")) : SW_CAP_MARGIN)) << 16) |
-                         (std::max(1, std::min(255, getenv("SFE_SW_RTRIPS") ? atoi(getenv("SFE_SW_RTRIPS")) : SW_ROUND_TRIPS)) << 8);
-    // margin of the clearance records: a search looks this fraction further (in radius) than it has to
-    const float sw_m = 0.01f * (float)std::max(1, std::min(100, getenv("SFE_SW_RECM") ? atoi(getenv("SFE_SW_RECM")) : SW_REC_MARGIN));
-    // ... plus sw_kappa x the largest movement of the last step (the steps shrink geometrically once ICP converges: a
-    // few times the last one covers all that are still to come)
-    const float sw_kappa = getenv("SFE_SW_RECK") ? (float)atof(getenv("SFE_SW_RECK")) : SW_REC_KAPPA;
+                         (std::max(0, std::min(255, env_int("SFE_SW_MARGIN", SW_CAP_MARGIN))) << 16) |
+                         (std::max(1, std::min(255, env_int("SFE_SW_RTRIPS", SW_ROUND_TRIPS))) << 8);
     int *d_dbg = nullptr;
     if (debug) {
         d_dbg = (int *)sfe_scratch(ctx, 22, sizeof(int) * 8);
@@ -2080,69 +2497,117 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
         return SFE_ERR_HIP;
     if (d_prof)
         SFE_HIP(ctx, hipMemsetAsync(d_prof, 0, sizeof(long long) * SFE_ICP_PROF_N, ctx->stream));
-    // one launch per kind; up to one job per CU the 128-VGPR build wins (no spills, measured +8 %), beyond that two
-    // 64-VGPR workgroups per CU overlap each other's serial phases (measured +14 % at 512 jobs)
-    auto pow2_floor = [](size_t v) {
-        size_t p = 1;
-        while (2 * p <= v)
-            p *= 2;
-        return (int)p;
-    };
-#define SW_LAUNCH(KERNEL, N, IDS, SMEM, TCAP, QCAP)                                                                    \
-    do {                                                                                                               \
-        SFE_HIP(ctx, hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SMEM))); \
-        hipLaunchKernelGGL(KERNEL, dim3(N), dim3(ICP_THREADS), (SMEM), ctx->stream, *p, d_jobs, (IDS),                 \
-                           (const float2 *)d_src, d_guess9, d_stgt, d_perm, d_snrm, d_mean, d_tab, d_grid, d_qst, d_qwl, d_qssrc, \
-                           d_nn_d2, d_nn_pos, d_T9, d_status, d_iters, d_prof, d_dbg, sw_budget, sw_budget_a, sw_cache, \
-                           (TCAP), (QCAP), pow2_floor(((SMEM)-ctl_bytes) / 8), sw_m, sw_kappa);                                        \
-        SFE_LAUNCH_CHECK(ctx);                                                                                         \
-    } while (0)
+    SweepLaunchArgs a;
+    a.ctx = ctx;
+    a.p = p;
+    a.d_jobs = d_jobs;
+    a.d_src = (const float2 *)d_src;
+    a.d_guess9 = d_guess9;
+    a.d_stgt = d_stgt;
+    a.d_perm = d_perm;
+    a.d_snrm = d_snrm;
+    a.d_mean = d_mean;
+    a.d_tab = d_tab;
+    a.d_grid = d_grid;
+    a.d_qst = d_qst;
+    a.d_qwl = d_qwl;
+    a.d_qssrc = d_qssrc;
+    a.d_nn_d2 = d_nn_d2;
+    a.d_nn_pos = d_nn_pos;
+    a.d_T9 = d_T9;
+    a.d_status = d_status;
+    a.d_iters = d_iters;
+    a.d_prof = d_prof;
+    a.d_dbg = d_dbg;
+    a.sw_budget = env_int("SFE_SW_BUDGET", SW_BUDGET);
+    a.sw_budget_a = env_int("SFE_SW_BUDGET_A", SW_BUDGET_A);
+    a.sw_cache = sw_cache;
+    // margin of the clearance records: a search looks this fraction further (in radius) than it has to ...
+    a.sw_m = 0.01f * (float)std::max(1, std::min(100, env_int("SFE_SW_RECM", SW_REC_MARGIN)));
+    // ... plus sw_kappa x the largest movement of the last step (the steps shrink geometrically once ICP converges: a
+    // few times the last one covers all that are still to come)
+    a.sw_kappa = getenv("SFE_SW_RECK") ? (float)atof(getenv("SFE_SW_RECK")) : SW_REC_KAPPA;
+    a.d_sync = d_sync;
+    // The build with clearance records carries more per-lane state (the 64-VGPR budget makes every register count:
+    // the same chain runs ~10 % slower in it until the records start to hit), so it only takes chains that are set to
+    // run many iterations: a fixed count (no differential checker) of at least SW_REC_MIN_ITER -- and only the builds
+    // with LDS-resident targets: for the one-workgroup-per-CU builds with the target in HBM (30 guesses x one
+    // 20 000 x 20 000 pair) the records cost more than they save (24.6 -> 30.9 ms, tools/hires_times.py).
+    const bool rec_build = (sw_cache & 16) != 0 && p->max_iter >= SW_REC_MIN_ITER && !p->use_diff_checker;
     // A/B: VGPR budget of the LDS_Q build.  A workgroup is 1024 threads = 4 waves per SIMD, so two workgroups per CU
     // only fit at <= 64 VGPRs: measured (4096 jobs of 5000 x 5000, p2plane30) 64 VGPRs 35.4 ms, 72 VGPRs 51.4 ms,
     // 128 VGPRs 48.6 ms (profiles/r02_icp_vgpr_budget.txt) -- one resident job per CU costs more than the 86 spilled
     // VGPRs of the 64-VGPR build
-    static const int minw = getenv("SFE_SW_MINW") ? atoi(getenv("SFE_SW_MINW")) : 8;
-    // The build with clearance records carries more per-lane state (the 64-VGPR budget makes every register count:
-    // the same chain runs ~10 % slower in it until the records start to hit), so it only takes chains that are set to
-    // run many iterations: a fixed count (no differential checker) of at least SW_REC_MIN_ITER -- and only the builds of
-    // full batches with LDS-resident targets: for the one-workgroup-per-CU builds with the target in HBM (30 guesses x
-    // one 20 000 x 20 000 pair) the records cost more than they save (24.6 -> 30.9 ms, tools/hires_times.py).
-    const bool rec_build = (sw_cache & 16) != 0 && p->max_iter >= SW_REC_MIN_ITER && !p->use_diff_checker;
+    int rc = 0;
+    const int *ids = d_ids;
+    if (n_t0) { // one wave per job (no workgroup barrier costs anything), 128 VGPRs, up to 16 jobs per CU
+        const int tc = t0_tmax + SW_PAD, qc = (t0_smax + 3) & ~3;
+        const size_t body = 8 * (size_t)tc + 6 * (size_t)qc;
+        rc = rec_build ? sweep_launch_loop<SW_T0_NT, 4, true, true, false, true, false>(a, n_t0, ids, body, tc, qc)
+                       : sweep_launch_loop<SW_T0_NT, 4, true, true, false, false, false>(a, n_t0, ids, body, tc, qc);
+        if (rc)
+            return rc;
+        ids += n_t0;
+    }
+    if (n_t1) { // four waves per job, 128 VGPRs, up to 4 jobs per CU
+        const int tc = t1_tmax + SW_PAD, qc = (t1_smax + 3) & ~3;
+        const size_t body = 8 * (size_t)tc + 6 * (size_t)qc;
+        rc = rec_build ? sweep_launch_loop<SW_T1_NT, 4, true, true, false, true, false>(a, n_t1, ids, body, tc, qc)
+                       : sweep_launch_loop<SW_T1_NT, 4, true, true, false, false, false>(a, n_t1, ids, body, tc, qc);
+        if (rc)
+            return rc;
+        ids += n_t1;
+    }
+    // 1024-thread jobs: up to one job per CU the 128-VGPR build wins (no spills, measured +8 %), beyond that two
+    // 64-VGPR workgroups per CU overlap each other's serial phases (measured +14 % at 512 jobs)
     if (n_q) {
-        const size_t smem = ctl_bytes + 8 * (size_t)t_cap + 6 * (size_t)q_cap;
-        if (!wide && !d_prof && minw == 4)
-            SW_LAUNCH((icp_sweep_kernel<ICP_THREADS, 4, true, true, false, false>), n_q, d_ids, smem, t_cap, q_cap);
-        else if (wide)
-            SW_LAUNCH((icp_sweep_kernel<ICP_THREADS, 4, true, true, false, false>), n_q, d_ids, smem, t_cap, q_cap);
+        const size_t body = 8 * (size_t)t_cap + 6 * (size_t)q_cap;
+        if (wide)
+            rc = sweep_launch_loop<ICP_THREADS, 4, true, true, false, false, false>(a, n_q, ids, body, t_cap, q_cap);
         else if (d_prof && rec_build)
-            SW_LAUNCH((icp_sweep_kernel<ICP_THREADS, 8, true, true, true, true>), n_q, d_ids, smem, t_cap, q_cap);
+            rc = sweep_launch_loop<ICP_THREADS, 8, true, true, true, true, false>(a, n_q, ids, body, t_cap, q_cap);
         else if (d_prof)
-            SW_LAUNCH((icp_sweep_kernel<ICP_THREADS, 8, true, true, true, false>), n_q, d_ids, smem, t_cap, q_cap);
+            rc = sweep_launch_loop<ICP_THREADS, 8, true, true, true, false, false>(a, n_q, ids, body, t_cap, q_cap);
         else if (rec_build)
-            SW_LAUNCH((icp_sweep_kernel<ICP_THREADS, 8, true, true, false, true>), n_q, d_ids, smem, t_cap, q_cap);
+            rc = sweep_launch_loop<ICP_THREADS, 8, true, true, false, true, false>(a, n_q, ids, body, t_cap, q_cap);
         else
-            SW_LAUNCH((icp_sweep_kernel<ICP_THREADS, 8, true, true, false, false>), n_q, d_ids, smem, t_cap, q_cap);
+            rc = sweep_launch_loop<ICP_THREADS, 8, true, true, false, false, false>(a, n_q, ids, body, t_cap, q_cap);
+        if (rc)
+            return rc;
+        ids += n_q;
     }
     if (n_lds) {
-        const size_t smem = ctl_bytes + sizeof(float2) * (SW_TCAP + SW_PAD);
+        const size_t body = sizeof(float2) * (SW_TCAP + SW_PAD);
         if (wide)
-            SW_LAUNCH((icp_sweep_kernel<ICP_THREADS, 4, true, false, false, false>), n_lds, d_ids + n_q, smem, SW_TCAP + SW_PAD, 0);
+            rc = sweep_launch_loop<ICP_THREADS, 4, true, false, false, false, false>(a, n_lds, ids, body, SW_TCAP + SW_PAD, 0);
         else if (d_prof)
-            SW_LAUNCH((icp_sweep_kernel<ICP_THREADS, 8, true, false, true, false>), n_lds, d_ids + n_q, smem, SW_TCAP + SW_PAD, 0);
+            rc = sweep_launch_loop<ICP_THREADS, 8, true, false, true, false, false>(a, n_lds, ids, body, SW_TCAP + SW_PAD, 0);
         else if (rec_build)
-            SW_LAUNCH((icp_sweep_kernel<ICP_THREADS, 8, true, false, false, true>), n_lds, d_ids + n_q, smem, SW_TCAP + SW_PAD, 0);
+            rc = sweep_launch_loop<ICP_THREADS, 8, true, false, false, true, false>(a, n_lds, ids, body, SW_TCAP + SW_PAD, 0);
         else
-            SW_LAUNCH((icp_sweep_kernel<ICP_THREADS, 8, true, false, false, false>), n_lds, d_ids + n_q, smem, SW_TCAP + SW_PAD, 0);
+            rc = sweep_launch_loop<ICP_THREADS, 8, true, false, false, false, false>(a, n_lds, ids, body, SW_TCAP + SW_PAD, 0);
+        if (rc)
+            return rc;
+        ids += n_lds;
     }
     if (n_glb) {
         // the target stays in HBM / L2; the LDS behind the control block only serves the query sort
-        const size_t smem_g = ctl_bytes + sizeof(unsigned long long) * SW_TCAP;
-        if (wide)
-            SW_LAUNCH((icp_sweep_kernel<ICP_THREADS, 4, false, false, false, false>), n_glb, d_ids + n_q + n_lds, smem_g, SW_TCAP, 0);
-        else
-            SW_LAUNCH((icp_sweep_kernel<ICP_THREADS, 8, false, false, false, false>), n_glb, d_ids + n_q + n_lds, smem_g, SW_TCAP, 0);
+        const size_t body = sizeof(unsigned long long) * SW_TCAP;
+        rc = wide ? sweep_launch_loop<ICP_THREADS, 4, false, false, false, false, false>(a, n_glb, ids, body, SW_TCAP, 0)
+                  : sweep_launch_loop<ICP_THREADS, 8, false, false, false, false, false>(a, n_glb, ids, body, SW_TCAP, 0);
+        if (rc)
+            return rc;
+        ids += n_glb;
     }
-#undef SW_LAUNCH
+    if (n_multi) { // every share on a CU of its own, all of them resident (mg x n_big <= CUs); their clouds were gathered
+        const size_t body = sizeof(unsigned long long) * SW_TCAP;
+        SweepLaunchArgs am = a;
+        am.d_src = d_gsrc;
+        rc = sweep_launch_loop<ICP_THREADS, 4, false, false, false, false, true>(am, n_multi, ids, body, SW_TCAP, 0);
+        if (rc)
+            return rc;
+        ids += n_multi;
+    }
     if (side) {
         SFE_HIP(ctx, hipEventRecord(ctx->ev_loop, ctx->stream));
         ctx->icp_loop_pending = true;

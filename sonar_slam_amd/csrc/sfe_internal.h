@@ -22,6 +22,11 @@ struct sfe_ctx {
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_prep = nullptr, ev_loop = nullptr;
     bool icp_loop_pending = false;
+    // copy stream of the streamed-input path (sfe_memcpy_h2d_async): uploads from pinned host memory run next to the
+    // kernels on `stream`; ev_copy = behind the last upload, ev_compute = where the kernels stood when the caller last
+    // said "everything enqueued so far has consumed its input" (sfe_stream_fence)
+    hipStream_t stream_copy = nullptr;
+    hipEvent_t ev_copy = nullptr, ev_compute = nullptr;
     std::string err;
     struct Buf {
         void *p = nullptr;

@@ -178,3 +178,47 @@ class KeyframeBatch(object):
                   self.d_T, self.d_status, self.d_iters):
             if b is not None:
                 b.free()
+
+
+class ScanMatchBatch(object):
+    """Device-resident scan-match jobs with a job table (sfe_icp_jobs_dev): the distinct clouds are uploaded once and
+    a job names a (source, target) pair by index, so the <= 30 guesses of ``compute_icp_with_cov`` on one pair
+    (slam.py:346-358), or one target matched against many sources, share their clouds -- and the target's preparation."""
+
+    def __init__(self, ctx, icp_params, sources, targets, jobs, guesses):
+        """sources / targets: lists of distinct N_i x 2 float32 clouds; jobs: [(source index, target index)];
+        guesses: len(jobs) x 3 x 3."""
+        self.ctx, self.icp_params = ctx, icp_params
+        self.n = len(jobs)
+        assert len(guesses) == self.n and self.n > 0
+        so = np.concatenate([[0], np.cumsum([len(s) for s in sources])]).astype(np.int64)
+        to = np.concatenate([[0], np.cumsum([len(t) for t in targets])]).astype(np.int64)
+        self.jobs4 = np.ascontiguousarray([(so[a], so[a + 1] - so[a], to[b], to[b + 1] - to[b]) for a, b in jobs], np.int32)
+        src = np.ascontiguousarray(np.concatenate(sources), np.float32)
+        tgt = np.ascontiguousarray(np.concatenate(targets), np.float32)
+        g = np.ascontiguousarray(np.asarray(guesses, np.float32).reshape(self.n, 9))
+        self.d_src, self.d_tgt, self.d_guess = ctx.alloc(src.nbytes), ctx.alloc(tgt.nbytes), ctx.alloc(g.nbytes)
+        self.d_src.upload(src)
+        self.d_tgt.upload(tgt)
+        self.d_guess.upload(g)
+        self.d_T = ctx.alloc(self.n * 36)
+        self.d_status = ctx.alloc(self.n * 4)
+        self.d_iters = ctx.alloc(self.n * 4)
+
+    def run(self):
+        """enqueue only"""
+        c = self.ctx
+        c._check(c.lib.sfe_icp_jobs_dev(c.handle, _C.byref(self.icp_params), self.d_src.ptr, self.d_tgt.ptr,
+                                        _L.ptr(self.jobs4, _C.c_int32), self.d_guess.ptr, self.n, self.d_T.ptr,
+                                        self.d_status.ptr, self.d_iters.ptr))
+
+    def results(self):
+        self.ctx.sync()
+        return {"T": self.d_T.download(np.float32, self.n * 9).reshape(self.n, 3, 3),
+                "status": self.d_status.download(np.int32, self.n),
+                "iters": self.d_iters.download(np.int32, self.n)}
+
+    def free(self):
+        for b in (self.d_src, self.d_tgt, self.d_guess, self.d_T, self.d_status, self.d_iters):
+            if b is not None:
+                b.free()

@@ -141,10 +141,10 @@ def test_resident_batch_refuses_a_frame_above_its_point_capacity(ctx):
     big.free()
 
 
-def _bench(extra, env=None, launcher=()):
+def _bench(extra, env=None, launcher=(), legs=False):
     cmd = [sys.executable] + list(launcher) + [os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1",
                                                "--batch", "16", "--cfar-frames", "64", "--cfar-launches", "2",
-                                               "--no-cpu-baseline"] + extra
+                                               "--no-cpu-baseline"] + ([] if legs else ["--no-legs"]) + extra
     e = dict(os.environ)
     e.update(env or {})
     r = subprocess.run(cmd, cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
@@ -160,6 +160,25 @@ def test_bench_line_carries_its_own_parity_sample():
     assert pc["jobs"] == 4 and pc["frames_bit_exact"] == 4 and pc["icp_max_pose_diff"] <= 1e-4
     assert out["config"]["max_points_per_frame"] <= out["config"]["points_capacity"]
     assert out["roofline"]["frac"] > 0 and out["n_gpus"] == 1
+
+
+def test_bench_legs_carry_their_own_parity_samples():
+    """the legs beyond the timed step (reduced sizes): the shipped chain on the timed pairs, the job shapes of the live
+    system on the small-job tiers, BASELINE configs[4] with split jobs, the float-oracle statistic, streamed frames --
+    each checks a sample against the oracle and the line is only printed when all of them hold"""
+    out = _bench(["--gpus", "1", "--parity-jobs", "2", "--small-legs", "--no-latency", "--no-farm"], legs=True)
+    assert out["reference_chain"]["parity"]["max_pose_diff_vs_f64_oracle"] <= 1e-6
+    rs = out["real_size"]
+    assert rs["ssm"]["all_jobs_on_1024_thread_workgroups"]["bit_identical_results"]
+    assert rs["ssm"]["parity"]["jobs"] > 0 and rs["nssm"]["parity"]["jobs"] > 0
+    c4 = out["configs4_hires"]
+    assert c4["frames"]["frames_bit_exact_vs_oracle"] == 2 and c4["frames"]["roofline"]["frac"] > 0
+    for chain in ("p2plane30", "reference_chain"):
+        assert c4[chain]["parity"]["max_pose_diff_vs_f64_oracle"] <= 1e-5
+        assert c4[chain]["one_batch_split_vs_unsplit_max_pose_diff"] <= 1e-5
+    assert out["float_oracle"]["jobs"] >= 2
+    sf = out["stream_frames"]
+    assert sf["keyframes_per_s_streamed"] > 0 and 0.0 <= sf["overlap_fraction"] <= 1.0
 
 
 def test_bench_two_ranks_on_one_device():

@@ -17,6 +17,18 @@ TOL_TIGHT = 1e-6
 TOL_REF = 1e-4
 
 
+@pytest.fixture(autouse=True, params=["tiers", "one-size"])
+def job_tiers(request, monkeypatch):
+    """Every test of this module runs twice: with the launcher's job tiers (one-wave workgroups for scan matches of a
+    few hundred points, four-wave ones up to ~2000, 1024 threads beyond; large many-to-one jobs split over several
+    workgroups) and with every job on the 1024-thread kernels, unsplit (what round 2 shipped).  The knobs are read
+    per call (sfe_icp_sweep_launch)."""
+    if request.param == "one-size":
+        monkeypatch.setenv("SFE_SW_TIERS", "0")
+        monkeypatch.setenv("SFE_SW_MULTI", "0")
+    return request.param
+
+
 def _pose_diff(Ta, Tb):
     a, b = synth.pose_of(Ta), synth.pose_of(Tb)
     return max(abs(a[0] - b[0]), abs(a[1] - b[1]), abs(np.arctan2(np.sin(a[2] - b[2]), np.cos(a[2] - b[2]))))
@@ -241,11 +253,14 @@ def test_sweep_search_equals_brute_force_bit_for_bit(ctx, mz):
     assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
 
 
-def test_hires_many_to_one_batch_sweep_equals_brute_force(ctx):
+def test_hires_many_to_one_batch_sweep_equals_brute_force(ctx, job_tiers):
     """BASELINE configs[4] shape: 20k-point clouds (target beyond the LDS capacity: sorted in HBM
     scratch, walked through L2), several guesses on one pair.  Too large for the CPU oracle in a
     test, so the exhaustive GPU kernel is the checker here (it is oracle-checked at 9000 points
-    above)."""
+    above).  Unsplit, the sweep is bit-identical to it.  Split over several workgroups (the default for
+    this shape) the discrete decisions -- matches, trimmed limit, iteration count -- are the same and
+    the fp64 sums are added in another order (per share, then over the shares): statuses and
+    iteration counts equal, poses within 1e-6."""
     src, tgt, guess, _ = synth.scan_pair(seed=33, n_src=20000, n_tgt=20000)
     base = synth.pose_of(guess)
     rng = np.random.default_rng(9)
@@ -256,7 +271,90 @@ def test_hires_many_to_one_batch_sweep_equals_brute_force(ctx):
         a = _with_variant(ctx, 0, lambda: _icp(p, ctx).compute_batch(src, tgt, guesses))
         b = _with_variant(ctx, 4, lambda: _icp(p, ctx).compute_batch(src, tgt, guesses))
         assert a[0] == b[0] and all(m == "success" for m in a[0])
-        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        assert np.array_equal(a[2], b[2])
+        if job_tiers == "one-size":
+            assert np.array_equal(a[1], b[1])
+        else:
+            assert max(_pose_diff(x, y) for x, y in zip(a[1], b[1])) < TOL_TIGHT
+
+
+@pytest.mark.parametrize("shares", [0, 2, 3, 16])
+def test_split_job_takes_the_decisions_of_the_unsplit_one(ctx, monkeypatch, shares):
+    """A job shared by several workgroups (sfe_icp_sweep.hip, MULTI): 30-iteration chains of both minimisers and the
+    shipped chain with its differential stop, 3 guesses on one 20 000 x 12 000 pair; any number of shares (0 = the
+    launcher's choice) must reproduce status and iteration count of the unsplit run and its pose to 1e-6.  The source
+    has far outliers and a band without any point, so some shares hold few queries."""
+    src, tgt, guess, _ = synth.scan_pair(seed=41, n_src=20000, n_tgt=12000)
+    src[::53] += 45.0
+    base = synth.pose_of(guess)
+    rng = np.random.default_rng(10)
+    guesses = [synth.pose_matrix(base[0] + dx, base[1] + dy, base[2] + dt).astype(np.float32)
+               for dx, dy, dt in rng.normal(0, [0.3, 0.3, 0.05], (3, 3))]
+    for over in (dict(minimizer=1, max_iter=30, use_diff_checker=0), dict(minimizer=0, max_iter=30, use_diff_checker=0), {}):
+        p = icp_config.shipped_params(**over)
+        monkeypatch.setenv("SFE_SW_MULTI", "0")
+        ref = _icp(p, ctx).compute_batch(src, tgt, guesses)
+        monkeypatch.setenv("SFE_SW_MULTI", "1")
+        monkeypatch.setenv("SFE_SW_TIERS", "1")
+        if shares:
+            monkeypatch.setenv("SFE_SW_MULTI_G", str(shares))
+        got = _icp(p, ctx).compute_batch(src, tgt, guesses)
+        assert got[0] == ref[0] and all(m == "success" for m in got[0]), (over, got[0])
+        assert np.array_equal(got[2], ref[2]), (over, got[2], ref[2])
+        assert max(_pose_diff(x, y) for x, y in zip(got[1], ref[1])) < TOL_TIGHT
+
+
+def test_split_job_with_empty_shares(ctx, monkeypatch):
+    """all queries in two thin bands of strips: most of the 16 shares get no query at all and still take part in
+    every exchange"""
+    src, tgt, guess, _ = synth.scan_pair(seed=42, n_src=9000, n_tgt=9000)
+    big_t = np.concatenate([tgt, tgt + np.float32(0.013)]).astype(np.float32)
+    keep = (np.abs(src[:, 1] - np.median(src[:, 1])) < 0.4) | (src[:, 1] > np.quantile(src[:, 1], 0.97))
+    band = np.concatenate([src[keep]] * 6)[:8800].astype(np.float32)
+    monkeypatch.setenv("SFE_SW_MULTI_MIN_SRC", "4096")
+    monkeypatch.setenv("SFE_SW_MULTI_SHARE_MIN", "64")
+    p = icp_config.shipped_params(minimizer=1, max_iter=10, use_diff_checker=0)
+    monkeypatch.setenv("SFE_SW_MULTI", "0")
+    ref = _icp(p, ctx).compute_batch(band, big_t, [guess])
+    monkeypatch.setenv("SFE_SW_MULTI", "1")
+    monkeypatch.setenv("SFE_SW_TIERS", "1")
+    got = _icp(p, ctx).compute_batch(band, big_t, [guess])
+    assert got[0] == ref[0] and np.array_equal(got[2], ref[2])
+    assert _pose_diff(got[1][0], ref[1][0]) < TOL_TIGHT
+
+
+def test_small_job_tiers_in_one_batch_equal_brute_force_and_the_oracle(ctx, job_tiers):
+    """the job shapes bruce_slam produces (slam.py:769,1032: clouds of 10^2..10^3 points) side by side in one device
+    batch: one-wave, four-wave and 1024-thread workgroups, one launch each; bit-identical to the brute-force kernel,
+    a sample against the oracle"""
+    from sonar_slam_amd.CFAR import CFAR
+    from sonar_slam_amd.feature_extraction import FeatureExtraction, SonarPing, oculus_bearings
+    from sonar_slam_amd.pipeline import KeyframeBatch
+    rng = np.random.default_rng(3)
+    sizes = [(int(a), int(b)) for a, b in zip(rng.integers(40, 380, 40), rng.integers(40, 500, 40))]
+    sizes += [(int(a), int(b)) for a, b in zip(rng.integers(400, 2000, 24), rng.integers(500, 2040, 24))]
+    sizes += [(384, 512), (385, 512), (384, 513), (2048, 2048), (2049, 2048), (3000, 300), (200, 3000), (5000, 5000), (1, 1), (2, 700)]
+    pairs = [synth.scan_pair(seed=700 + i, n_src=a, n_tgt=b) for i, (a, b) in enumerate(sizes)]
+    fe = FeatureExtraction(ctx)
+    fe.Ntc, fe.Ngc, fe.Pfa, fe.rank, fe.alg, fe.threshold = 40, 10, 0.1, 10, "SOCA", 65
+    fe.configure()
+    fe.generate_map_xy(SonarPing(np.zeros((64, 64), np.uint8), oculus_bearings(64), 0.25))
+    for over in ({}, dict(minimizer=1, max_iter=30, use_diff_checker=0)):
+        p = icp_config.shipped_params(**over)
+        out = {}
+        for variant in (0, 4):
+            kb = KeyframeBatch(ctx, fe.geometry, CFAR(40, 10, 0.1, 10).params["SOCA"], "SOCA", 65, p, len(pairs))
+            kb.upload_scan_pairs([q[0] for q in pairs], [q[1] for q in pairs], [q[2] for q in pairs])
+            _with_variant(ctx, variant, lambda: (kb.run_icp(), ctx.sync()))
+            out[variant] = kb.results()
+            kb.free()
+        for k in ("T", "status", "iters"):
+            assert np.array_equal(out[0][k], out[4][k], equal_nan=True), (k, over)
+        for j in (0, 7, 41, 50, 64, 66, 70):
+            st, To, ito = oracle.icp(pairs[j][0], pairs[j][1], pairs[j][2], oracle.shipped_icp_params(precision=1, **over))
+            assert st == out[0]["status"][j] and ito == out[0]["iters"][j], (j, over)
+            if st == 0:
+                assert _pose_diff(out[0]["T"][j], To) < TOL_TIGHT, (j, over)
 
 
 def test_mixed_size_device_batch(ctx):

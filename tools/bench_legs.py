@@ -1,0 +1,351 @@
+"""Legs of the bench line beyond the timed BASELINE configs[1] step (bench.py imports this):
+
+  reference_chain   the timed batch's scan pairs through the chain bruce_slam ships (icp.yaml:17-28)
+  real_size         the job shapes bruce_slam itself produces (slam.py:769,1032): SSM-like scan matches of 200..1000 points
+                    and NSSM batches of 30 guesses x one 800-point pair, small-job tiers vs the 1024-thread kernels
+  configs4_hires    BASELINE configs[4]: 2048 x 1024 frames through CFAR + extraction, 20 000-point many-to-one batches
+  float_oracle      how often the oracle in float (PointMatcher<float>) is further than 1e-4 from the HIP path, next to
+                    its distance from ITSELF with fp64 sums
+  stream_frames     the step with its frames arriving from pinned host memory on a copy stream
+
+Every leg that computes poses checks a sample of them against the CPU oracle (as the checker, after its own timed
+region) and raises on a mismatch: a line whose work is wrong is not printed."""
+import os
+import time
+from multiprocessing.pool import ThreadPool
+
+import numpy as np
+
+HBM_PEAK_GBS = 8000.0
+
+
+def pose_diff(Ta, Tb):
+    dth = np.arctan2(Ta[1, 0], Ta[0, 0]) - np.arctan2(Tb[1, 0], Tb[0, 0])
+    return float(max(abs(Ta[0, 2] - Tb[0, 2]), abs(Ta[1, 2] - Tb[1, 2]), abs(np.arctan2(np.sin(dth), np.cos(dth)))))
+
+
+def timed(ctx, fn, reps):
+    """HIP events on the library's stream around `reps` back-to-back calls (after one untimed call)"""
+    fn()
+    ctx.sync()
+    ctx.timer_start()
+    for _ in range(reps):
+        fn()
+    return ctx.timer_stop() / reps
+
+
+def oracle_many(jobs, params_kw, threads):
+    """[(src, tgt, guess)] -> [(status, T, iters)] for the oracle with fp64 sums and in float, exact kd-tree, on `threads`
+    host threads (ctypes releases the GIL; the oracle keeps no shared state besides the kd-tree switch)"""
+    import oracle
+    oracle.set_kdtree(1)
+    try:
+        def one(job):
+            s, t, g = job
+            return (oracle.icp(s, t, g, oracle.shipped_icp_params(precision=1, **params_kw)),
+                    oracle.icp(s, t, g, oracle.shipped_icp_params(precision=0, **params_kw)))
+        with ThreadPool(max(1, threads)) as tp:
+            return tp.map(one, jobs, chunksize=1)
+    finally:
+        oracle.set_kdtree(0)
+
+
+def check_against_oracle(name, jobs, got, params_kw, threads, tol64=1e-6):
+    """got = (T, status, iters) arrays of `jobs`.  Status and iteration count must equal the oracle with fp64 sums and
+    the pose must be within tol64 of it (same discrete decisions); the distance to the oracle in float is reported next
+    to that oracle's distance from its own fp64 version."""
+    T, status, iters = got
+    ref = oracle_many(jobs, params_kw, threads)
+    worst64 = worst32 = spread = 0.0
+    beyond = 0
+    for j, ((st64, T64, it64), (st32, T32, it32)) in enumerate(ref):
+        if int(status[j]) != st64 or int(iters[j]) != it64:
+            raise AssertionError("%s: job %d status/iterations (%d, %d) vs the oracle's (%d, %d)"
+                                 % (name, j, status[j], iters[j], st64, it64))
+        if st64 != 0:
+            continue
+        d64 = pose_diff(T[j], T64)
+        if not d64 <= tol64:
+            raise AssertionError("%s: job %d pose is %.3e from the oracle (fp64 sums), tolerance %.1e" % (name, j, d64, tol64))
+        worst64 = max(worst64, d64)
+        if st32 == 0:
+            d32 = pose_diff(T[j], T32)
+            worst32 = max(worst32, d32)
+            spread = max(spread, pose_diff(T32, T64))
+            beyond += d32 > 1e-4
+    return {"jobs": len(jobs), "max_pose_diff_vs_f64_oracle": worst64, "max_pose_diff_vs_float_oracle": worst32,
+            "float_oracle_beyond_1e-4": "%d / %d" % (beyond, len(jobs)),
+            "float_oracle_vs_its_own_f64_sums_max": spread}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def reference_chain(ctx, kb, srcs, tgts, guesses, threads, sample=8):
+    """The timed batch's scan pairs through the chain bruce_slam ships: point-to-point, 40-iteration cap, differential
+    stop (icp.yaml:17-28) -- the only chain with reference meaning; the headline step runs configs[1]'s 30 forced
+    point-to-plane iterations."""
+    from sonar_slam_amd import icp_config
+    keep = kb.icp_params
+    kb.icp_params = icp_config.shipped_params()
+    try:
+        ms = timed(ctx, kb.run_icp, 3)
+        res = kb.results()
+    finally:
+        kb.icp_params = keep
+    n = kb.n
+    picks = sorted(set(int(round(i * (n - 1) / max(1, sample - 1))) for i in range(sample)))
+    par = check_against_oracle("reference_chain", [(srcs[j], tgts[j], guesses[j]) for j in picks],
+                               (res["T"][picks], res["status"][picks], res["iters"][picks]), {}, threads)
+    return {"workload": "%d x 5000x5000 scan matches, icp.yaml as shipped (point-to-point, <= 40 iterations, "
+                        "differential stop)" % n,
+            "ms_per_launch": ms, "jobs_per_s": n / (ms * 1e-3), "mean_iters": float(res["iters"].mean()),
+            "converged": int((res["status"] == 0).sum()), "parity": par}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def real_size(ctx, threads, n_ssm=16384, n_nssm=512, distinct=2048):
+    """The jobs bruce_slam produces: feature clouds of 10^2..10^3 points.  SSM-like: independent scan matches
+    of 200..1000 x 200..1000 points (slam.py:769); NSSM-like: 30 guesses on one 800 x 800 pair (slam.py:346-358,1032).
+    Resident clouds, one launch set per batch; the same batch again with SFE_SW_TIERS=0 = every job on a 1024-thread
+    workgroup (round 2's only shape)."""
+    from sonar_slam_amd import icp_config, synth
+    from sonar_slam_amd.pipeline import ScanMatchBatch
+    rng = np.random.default_rng(11)
+    p = icp_config.shipped_params()
+    out = {}
+    # --- SSM: `distinct` pairs generated, tiled to n_ssm jobs as separate clouds with separate guesses
+    sizes = [(int(a), int(b)) for a, b in zip(rng.integers(200, 1001, distinct), rng.integers(200, 1001, distinct))]
+    pairs = [synth.scan_pair(seed=5000 + i, n_src=a, n_tgt=b) for i, (a, b) in enumerate(sizes)]
+    srcs = [pairs[j % distinct][0] for j in range(n_ssm)]
+    tgts = [pairs[j % distinct][1] for j in range(n_ssm)]
+    gs = [(pairs[j % distinct][2].astype(np.float64) @ synth.pose_matrix(*rng.normal(0, [0.05, 0.05, 0.005]))).astype(np.float32)
+          for j in range(n_ssm)]
+    b = ScanMatchBatch(ctx, p, srcs, tgts, [(j, j) for j in range(n_ssm)], gs)
+    ms = timed(ctx, b.run, 3)
+    res = b.results()
+    picks = list(range(0, n_ssm, max(1, n_ssm // 16)))[:16]
+    par = check_against_oracle("real_size.ssm", [(srcs[j], tgts[j], gs[j]) for j in picks],
+                               (res["T"][picks], res["status"][picks], res["iters"][picks]), {}, threads)
+    os.environ["SFE_SW_TIERS"] = "0"
+    try:
+        ms_1024 = timed(ctx, b.run, 2)
+        res_1024 = b.results()
+    finally:
+        del os.environ["SFE_SW_TIERS"]
+    same = bool(np.array_equal(res["T"], res_1024["T"]) and np.array_equal(res["iters"], res_1024["iters"]))
+    b.free()
+    out["ssm"] = {"workload": "%d independent scan matches, 200..1000 x 200..1000 points (%d distinct pairs), icp.yaml as shipped"
+                              % (n_ssm, distinct),
+                  "ms_per_launch": ms, "jobs_per_s": n_ssm / (ms * 1e-3), "mean_iters": float(res["iters"].mean()),
+                  "converged": int((res["status"] == 0).sum()),
+                  "all_jobs_on_1024_thread_workgroups": {"ms_per_launch": ms_1024, "jobs_per_s": n_ssm / (ms_1024 * 1e-3),
+                                                         "bit_identical_results": same},
+                  "speedup_over_1024_thread_workgroups": ms_1024 / ms, "parity": par}
+    # --- one size (500 x 500): the figure VERDICT r2 item 2 asks for
+    pairs5 = [synth.scan_pair(seed=9000 + i, n_src=500, n_tgt=500) for i in range(1024)]
+    n5 = 8192
+    b = ScanMatchBatch(ctx, p, [pairs5[j % 1024][0] for j in range(n5)], [pairs5[j % 1024][1] for j in range(n5)],
+                       [(j, j) for j in range(n5)], [pairs5[j % 1024][2] for j in range(n5)])
+    ms5 = timed(ctx, b.run, 3)
+    os.environ["SFE_SW_TIERS"] = "0"
+    try:
+        ms5_1024 = timed(ctx, b.run, 2)
+    finally:
+        del os.environ["SFE_SW_TIERS"]
+    b.free()
+    out["at_500_points"] = {"jobs": n5, "jobs_per_s": n5 / (ms5 * 1e-3), "jobs_per_s_1024_thread_workgroups": n5 / (ms5_1024 * 1e-3),
+                            "speedup": ms5_1024 / ms5}
+    # --- NSSM: 30 guesses per pair
+    npair = [synth.scan_pair(seed=7000 + i, n_src=800, n_tgt=800) for i in range(n_nssm)]
+    jobs, gs = [], []
+    for i, (s, t, g, _) in enumerate(npair):
+        for _ in range(30):
+            jobs.append((i, i))
+            gs.append((g.astype(np.float64) @ synth.pose_matrix(*rng.normal(0, [0.1, 0.1, 0.01]))).astype(np.float32))
+    b = ScanMatchBatch(ctx, p, [q[0] for q in npair], [q[1] for q in npair], jobs, gs)
+    ms = timed(ctx, b.run, 3)
+    res = b.results()
+    picks = list(range(0, len(jobs), max(1, len(jobs) // 16)))[:16]
+    par = check_against_oracle("real_size.nssm", [(npair[jobs[j][0]][0], npair[jobs[j][1]][1], gs[j]) for j in picks],
+                               (res["T"][picks], res["status"][picks], res["iters"][picks]), {}, threads)
+    b.free()
+    out["nssm"] = {"workload": "%d batches of 30 guesses x one 800x800 pair (slam.py:346-358), icp.yaml as shipped" % n_nssm,
+                   "ms_per_launch": ms, "batches_per_s": n_nssm / (ms * 1e-3), "jobs_per_s": len(jobs) / (ms * 1e-3),
+                   "mean_iters": float(res["iters"].mean()), "parity": par}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def configs4_hires(ctx, det, threads, n_pairs=16, n_frames=256, parity_pairs=2):
+    """BASELINE configs[4]: 2048 x 1024 frames (1024 beams x 2048 bins) through CFAR + extraction with the CFAR roofline at
+    that shape; the many-to-one ICP batch: 30 guesses (slam.yaml:34) x one 20 000 x 20 000 pair, n_pairs such batches per
+    launch, both chains; ONE batch alone = the latency of a loop closure's covariance estimate (slam.py:346-358)."""
+    from sonar_slam_amd import icp_config, synth
+    from sonar_slam_amd.feature_extraction import FeatureExtraction, SonarPing, oculus_bearings
+    from sonar_slam_amd.pipeline import KeyframeBatch, ScanMatchBatch
+    ROWS, COLS, NP, NG = 2048, 1024, 20000, 30
+    out = {}
+    # --- frames
+    fe = FeatureExtraction(ctx)
+    fe.Ntc, fe.Ngc, fe.Pfa, fe.rank, fe.alg, fe.threshold = 40, 10, 0.1, 10, "SOCA", 65
+    fe.configure()
+    base = [synth.sonar_frame(seed=300 + s, rows=ROWS, cols=COLS, n_blobs=120) for s in range(16)]
+    frames = np.stack([base[j % 16] for j in range(n_frames)])
+    fe.generate_map_xy(SonarPing(frames[0], oculus_bearings(COLS), 30.0 / ROWS))
+    kb = KeyframeBatch(ctx, fe.geometry, det.params["SOCA"], "SOCA", 65, icp_config.shipped_params(), n_frames, max_points=65536)
+    kb.upload_frames(frames)
+    ms_cfar = timed(ctx, kb.run_cfar, 10)
+    ms_ext = timed(ctx, kb.run_extract, 5)
+    counts = kb.results()["counts"]
+    import oracle
+    th, gh, tau = det.params["SOCA"]
+    for j in (0, n_frames - 1):      # two frames against the oracle, bit for bit
+        m = oracle.gate(frames[j], oracle.cfar(frames[j], "SOCA", th, gh, tau), 65)
+        if not np.array_equal(kb.mask(j), m):
+            raise AssertionError("configs4_hires: CFAR mask of frame %d differs from the oracle" % j)
+        rc = oracle.nonzero(oracle.remap_u8(m, fe.map_x, fe.map_y))
+        if not np.array_equal(kb.points(j), oracle.px_to_m(rc, fe.rows, fe.cols, fe.width, fe.height)):
+            raise AssertionError("configs4_hires: extracted points of frame %d differ from the oracle" % j)
+    kb.free()
+    cfar_bytes = 2.0 * ROWS * COLS * n_frames
+    out["frames"] = {"workload": "%d frames 2048x1024 (16 distinct), SOCA-CFAR + gate -> remap + nonzero + px->m" % n_frames,
+                     "cfar_ms_per_launch": ms_cfar, "extract_ms_per_launch": ms_ext, "mean_points_per_frame": float(counts.mean()),
+                     "roofline": {"kernel": "cfar_u8_ring<20,5,SOCA,BITS>", "bound": "hbm", "bytes_per_launch": cfar_bytes,
+                                  "achieved": cfar_bytes / (ms_cfar * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": cfar_bytes / (ms_cfar * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "note": "SURVEY 8d bytes (1 B read + 1 B written per pixel); the kernel stores bits, "
+                                          "so it moves 1.125 B per pixel: x 0.5625 for the bytes that cross the pins"},
+                     "frames_bit_exact_vs_oracle": 2}
+    # --- many-to-one batches
+    rng = np.random.default_rng(4)
+    pairs = [synth.scan_pair(seed=400 + i, n_src=NP, n_tgt=NP) for i in range(n_pairs)]
+    jobs, gs = [], []
+    for i, (s, t, g, _) in enumerate(pairs):
+        b0 = synth.pose_of(g)
+        for dx, dy, dt in rng.normal(0, [0.3, 0.3, 0.05], (NG, 3)):
+            jobs.append((i, i))
+            gs.append(synth.pose_matrix(b0[0] + dx, b0[1] + dy, b0[2] + dt).astype(np.float32))
+    for name, kw in (("p2plane30", dict(minimizer=1, use_diff_checker=0, max_iter=30)), ("reference_chain", {})):
+        p = icp_config.shipped_params(**kw)
+        full = ScanMatchBatch(ctx, p, [q[0] for q in pairs], [q[1] for q in pairs], jobs, gs)
+        ms_full = timed(ctx, full.run, 2)
+        res = full.results()
+        full.free()
+        one = ScanMatchBatch(ctx, p, [pairs[0][0]], [pairs[0][1]], [(0, 0)] * NG, gs[:NG])
+        ms_one = timed(ctx, one.run, 5)
+        res_one = one.results()
+        os.environ["SFE_SW_MULTI"] = "0"
+        try:
+            ms_one_unsplit = timed(ctx, one.run, 2)
+            res_unsplit = one.results()
+        finally:
+            del os.environ["SFE_SW_MULTI"]
+        one.free()
+        if not (np.array_equal(res_one["iters"], res_unsplit["iters"]) and np.array_equal(res_one["status"], res_unsplit["status"])):
+            raise AssertionError("configs4_hires: split and unsplit runs disagree on status / iterations")
+        d_split = max(pose_diff(a, b) for a, b in zip(res_one["T"], res_unsplit["T"]))
+        # parity: parity_pairs x 30 guesses of the FULL batch against the kd-tree oracle
+        pj = [j for j in range(len(jobs)) if jobs[j][0] < parity_pairs]
+        par = check_against_oracle("configs4_hires." + name, [(pairs[jobs[j][0]][0], pairs[jobs[j][1]][1], gs[j]) for j in pj],
+                                   (res["T"][pj], res["status"][pj], res["iters"][pj]), kw, threads, tol64=1e-5)
+        iters = float(res["iters"].sum())
+        out[name] = {"workload": "%d batches of %d guesses x one %dx%d pair per launch" % (n_pairs, NG, NP, NP),
+                     "ms_per_launch": ms_full, "batches_per_s": n_pairs / (ms_full * 1e-3), "jobs_per_s": len(jobs) / (ms_full * 1e-3),
+                     "mean_iters": iters / len(jobs), "converged": int((res["status"] == 0).sum()),
+                     "one_batch_ms": ms_one, "one_batch_ms_unsplit": ms_one_unsplit,
+                     "one_batch_split_vs_unsplit_max_pose_diff": d_split,
+                     "exhaustive_pair_evals_per_launch": float(NP) * NP * iters, "parity": par}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def float_oracle(kb, res, srcs, tgts, guesses, params_kw, threads, sample=256):
+    """the north_star bar reads 'poses within 1e-4 of the reference CPU path'.  Against the oracle with
+    fp64 sums the HIP path agrees to 1e-6 (checked here on `sample` jobs of the timed batch, raising otherwise); the
+    oracle in float -- libpointmatcher's own precision -- is itself further than 1e-4 from its fp64 version on about one
+    bench-like pair in a hundred (a stop-rule or trimmed-set decision flips on sequential float sums over thousands of
+    products), and on exactly those the HIP path differs from it as well."""
+    n = kb.n
+    picks = sorted(set(int(round(i * (n - 1) / max(1, sample - 1))) for i in range(sample)))
+    return check_against_oracle("float_oracle", [(srcs[j], tgts[j], guesses[j]) for j in picks],
+                                (res["T"][picks], res["status"][picks], res["iters"][picks]), params_kw, threads)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def stream_frames(ctx, kb, filters, steps=4, distinct=512, seed0=20000):
+    """The step with its frames arriving from the host (feature_extraction.py:196-217: every ping does): `distinct`
+    frames in pinned memory, uploaded on the context's copy stream into the batch that is NOT being computed on (two
+    frame buffers), against the step's kernels on the main stream.  Reports the streamed rate next to the resident one
+    of the same loop, the PCIe rate the uploads achieve alone, and how much of the shorter of the two is hidden."""
+    from sonar_slam_amd import synth
+    n, rows, cols = kb.n, kb.rows, kb.cols
+    distinct = min(distinct, n)
+    pool = ctx.host_alloc((distinct, rows, cols), np.uint8)
+    for i in range(distinct):
+        pool[i] = synth.sonar_frame(seed=seed0 + i, rows=rows, cols=cols)
+    frame_b = rows * cols
+    other = ctx.alloc(n * frame_b)           # the second frame buffer
+    bufs = [kb.d_img, other]
+
+    def upload(buf):
+        for f0 in range(0, n, distinct):
+            m = min(distinct, n - f0)
+            buf.upload_async(pool[:m], offset=f0 * frame_b)
+
+    def step(buf):
+        keep = kb.d_img
+        kb.d_img = buf
+        try:
+            kb.run(filters)
+        finally:
+            kb.d_img = keep
+
+    # the uploads alone
+    upload(bufs[0])
+    ctx.fence(2)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        upload(bufs[k % 2])
+    ctx.fence(2)
+    t_copy = (time.perf_counter() - t0) / steps
+    # the kernels alone (frames resident: what the headline times)
+    step(bufs[0])
+    ctx.sync()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(bufs[k % 2])
+    ctx.sync()
+    t_comp = (time.perf_counter() - t0) / steps
+    # streamed: upload of step k+1 next to the kernels of step k
+    upload(bufs[0])
+    ctx.fence(2)
+    ctx.sync()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        ctx.fence(0)                 # this step's kernels behind this step's upload
+        kb_buf = bufs[k % 2]
+        keep = kb.d_img
+        kb.d_img = kb_buf
+        try:
+            kb.run_cfar()            # the only kernel that reads the frames
+            ctx.fence(1)             # the next upload overwrites the OTHER buffer, read by the previous step's CFAR: behind it
+            upload(bufs[(k + 1) % 2])   # (also behind the last step: `steps` uploads inside the timed region)
+            kb.run_extract()
+            if filters:
+                kb.run_filter()
+            kb.run_icp()
+        finally:
+            kb.d_img = keep
+    ctx.sync()
+    ctx.fence(2)
+    t_stream = (time.perf_counter() - t0) / steps
+    res = kb.results()
+    other.free()
+    ctx.host_free(pool)
+    hidden = (t_copy + t_comp - t_stream) / max(1e-12, min(t_copy, t_comp))
+    return {"workload": "%d keyframes per step, frames uploaded from pinned host memory (%d distinct frames, %d MiB per step)"
+                        % (n, distinct, n * frame_b // (1 << 20)),
+            "keyframes_per_s_streamed": n / t_stream, "keyframes_per_s_resident_same_loop": n / t_comp,
+            "ms_per_step_streamed": 1e3 * t_stream, "ms_per_step_resident": 1e3 * t_comp, "ms_upload_alone": 1e3 * t_copy,
+            "pcie_gb_per_s_upload_alone": n * frame_b / t_copy / 1e9, "pcie_gb_per_s_while_streaming": n * frame_b / t_stream / 1e9,
+            "overlap_fraction": max(0.0, min(1.0, hidden)), "converged": int((res["status"] == 0).sum()),
+            "note": "overlap_fraction = (upload alone + kernels alone - streamed) / min(upload alone, kernels alone)"}
