@@ -43,6 +43,11 @@ def match(ref, pts, knn, max_dist, ctx=None):
     ctx = ctx or _L.default_context()
     ref = _cloud(ref, "match(ref)")
     pts = _cloud(pts, "match(in)")
+    if knn > len(ref):
+        # libnabo: "Requesting more points (k) than available in cloud" (a std::runtime_error -> RuntimeError through
+        # pybind); knn_density mirrors the same throw
+        raise RuntimeError("pcl.match: knn = %d exceeds the %d points of the reference cloud (libnabo throws)"
+                           % (knn, len(ref)))
     ids = _np.full((knn, len(pts)), -1, _np.int32)
     d2 = _np.full((knn, len(pts)), _np.inf, _np.float32)
     if len(pts):
@@ -336,8 +341,15 @@ class ICP(object):
         return st, T, it
 
     def getCovariance(self):
-        """errorMinimizer->getCovariance() (pcl.cpp:213).  libpointmatcher's base ErrorMinimizer
-        returns a zero dim x dim matrix unless the point-to-plane minimiser estimated one (the
-        shipped chain is point-to-point); no caller in the reference reads it (grep).  Returned:
-        3 x 3 zeros -- a documented deviation for a point-to-plane chain."""
-        return _np.zeros((3, 3), _np.float32)
+        """errorMinimizer->getCovariance() (pcl.cpp:213).  For the shipped point-to-point chain libpointmatcher's
+        base ``ErrorMinimizer::getCovariance`` logs a warning and returns ``Matrix::Zero(6, 6)`` (restated from its
+        published source, unpinned like the rest of pcl.cpp's third-party behaviour): 6 x 6 float32 zeros here.
+        ``PointToPlaneErrorMinimizer`` overrides it with Censi's estimate from its 3-D normal equations and
+        ``sensorStdDev``; the reference cannot run that chain (icp.yaml configures no normals) and the 2-D form
+        is not defined anywhere, so a point-to-plane chain raises instead of returning a made-up matrix.  No
+        caller in the reference reads either (grep)."""
+        if self._chain().minimizer == 1:
+            raise NotImplementedError("ICP.getCovariance for a point-to-plane chain: libpointmatcher's Censi estimate "
+                                      "is 3-D only and the reference never runs this chain; use "
+                                      "SLAM.compute_icp_with_cov's sampled covariance (slam.py:325-387)")
+        return _np.zeros((6, 6), _np.float32)

@@ -236,7 +236,49 @@ def test_icp_object_has_no_silent_default_chain(tmp_path):
     f.write_text(SHIPPED_ICP_YAML)
     icp.loadFromYaml(str(f))
     assert icp.params.as_dict() == icp_config.shipped_params().as_dict()
-    assert np.array_equal(icp.getCovariance(), np.zeros((3, 3), np.float32))
+    assert np.array_equal(icp.getCovariance(), np.zeros((6, 6), np.float32))     # ErrorMinimizer's base: Zero(6, 6)
+    icp.setParams(icp_config.shipped_params(minimizer=1))
+    with pytest.raises(NotImplementedError, match="point-to-plane"):
+        icp.getCovariance()
+    with pytest.raises(RuntimeError, match="libnabo"):
+        pcl.match(np.zeros((2, 2), np.float32), np.zeros((5, 2), np.float32), 3, 1.0, ctx=object())
+
+
+def test_shims_bind_every_name_the_reference_modules_define():
+    """cfar.cpp:194-204 and pcl.cpp:176-213 by name and arity: every m.def / .def of the two pybind modules exists in
+    the shims and accepts the reference's positional arguments (overloads included)."""
+    import inspect
+
+    from sonar_slam_amd import cfar, pcl
+
+    def accepts(fn, n_args):
+        sig = inspect.signature(fn)
+        pos = [p for p in sig.parameters.values() if p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD)]
+        var = any(p.kind == p.VAR_POSITIONAL for p in sig.parameters.values())
+        required = sum(p.default is p.empty for p in pos)
+        return required <= n_args and (var or n_args <= len(pos))
+    # cfar.cpp:10,30,53,76,98,120,145,170: (img, train_hs, guard_hs, tau), os adds k before tau
+    for name, n in (("ca", 4), ("soca", 4), ("goca", 4), ("os", 5), ("ca2", 4), ("soca2", 4), ("goca2", 4), ("os2", 5)):
+        assert accepts(getattr(cfar, name), n), name
+    # pcl.cpp:178-184
+    assert accepts(pcl.remove_outlier, 3)                       # (points, radius, min_points)
+    assert accepts(pcl.density_filter, 4) and accepts(pcl.density_filter, 5)   # (pts, knn, min, max) / (pts, desc, knn, min, max)
+    assert accepts(pcl.downsample, 2) and accepts(pcl.downsample, 3)           # (pts, res) / (pts, desc, res)
+    assert accepts(pcl.match, 4)                                # (ref, in, knn, max_dist)
+    # pcl.cpp:185-213: class ICP
+    assert accepts(pcl.ICP, 0)
+    for name, n in (("loadFromYaml", 1), ("compute", 3), ("getCovariance", 0)):
+        assert accepts(getattr(pcl.ICP(), name), n), name
+    # and the reference's own source names nothing else
+    ref = os.path.join("/root/reference/bruce_slam/src/bruce_slam/cpp")
+    if os.path.isdir(ref):     # (present in the build container only)
+        import re
+        for fname, mod in (("cfar.cpp", cfar), ("pcl.cpp", pcl)):
+            text = open(os.path.join(ref, fname)).read()
+            for name in re.findall(r'm\.def\("(\w+)"', text):
+                assert hasattr(mod, name), (fname, name)
+            for name in re.findall(r'\.def\("(\w+)"', text):
+                assert hasattr(mod, name) or hasattr(pcl.ICP, name), (fname, name)
 
 
 def test_glibc_rand_restatement_and_density_filter_surface():
