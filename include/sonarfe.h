@@ -102,6 +102,9 @@ int sfe_host_free(sfe_ctx *ctx, void *hptr);
 int sfe_memcpy_h2d_async(sfe_ctx *ctx, void *dst_dev, const void *src_pinned, size_t bytes);
 int sfe_stream_fence(sfe_ctx *ctx, int what);
 
+/* debug: the first `bytes` of the library's scratch buffer `slot` (intermediate results of the kernels) */
+int sfe_debug_read_scratch(sfe_ctx *ctx, int slot, void *dst_host, size_t bytes);
+
 /* HIP-event stopwatch on the ctx's stream (used by bench.py for per-kernel time) */
 int sfe_timer_start(sfe_ctx *ctx);
 int sfe_timer_stop(sfe_ctx *ctx, float *elapsed_ms); /* records, syncs, returns ms */

@@ -80,6 +80,7 @@ SIGNATURES = {
     "sfe_host_free": (C.c_int, [_vp, _vp]),
     "sfe_memcpy_h2d_async": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     "sfe_stream_fence": (C.c_int, [_vp, C.c_int]),
+    "sfe_debug_read_scratch": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t]),
     "sfe_timer_start": (C.c_int, [_vp]),
     "sfe_timer_stop": (C.c_int, [_vp, _f32p]),
     "sfe_cfar_u8": (C.c_int, [_vp, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -285,6 +285,17 @@ int sfe_memset(sfe_ctx *ctx, void *dst_dev, int value, size_t bytes)
     return 0;
 }
 
+// debug: copy the first `bytes` of scratch slot `slot` to the host (the kernels' intermediate results: tools/dbg_*.py)
+int sfe_debug_read_scratch(sfe_ctx *ctx, int slot, void *dst_host, size_t bytes)
+{
+    if (int rc = sfe_use(ctx))
+        return rc;
+    SFE_ARG(ctx, slot >= 0 && slot < SFE_NSCRATCH && dst_host && ctx->scratch[slot].p && ctx->scratch[slot].cap >= bytes);
+    SFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SFE_HIP(ctx, hipMemcpy(dst_host, ctx->scratch[slot].p, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int sfe_timer_start(sfe_ctx *ctx)
 {
     if (int rc = sfe_use(ctx))

@@ -1194,8 +1194,8 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
 #pragma unroll
         for (int i = 0; i < 9; ++i)
             Ti[i] = sw_uniform(S.Ti[i]);
-        // movement bounds: |Ti x - Tk x| <= |A - Ak|_F |x| + |t - tk| for every query x = T0 * src, |x| <= rmax; the
-        // 3e-5 covers the fp32 rounding of the two transformed positions themselves (a few ulp of ~30 m each)
+        // movement bounds: |Ti x - Tk x| <= |A - Ak|_F |x| + |t - tk| for every query x = T0 * src, |x| <= rmax, plus
+        // the fp32 rounding of the two transformed positions themselves
         if (sw_rec && it < ICP_MAX_HIST) {
             if (tid < it) {
                 const float a0 = f_add(Ti[0], -S.thist[tid][0]), a1 = f_add(Ti[1], -S.thist[tid][1]);
@@ -1209,7 +1209,11 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
                 const float fa = f_mul(sqrtf(f_mul(0.5f, f_add(f2, sqrtf(disc)))), 1.001f);
                 const float ft = sqrtf(f_add(f_mul(tx, tx), f_mul(ty, ty)));
                 S.mva[tid] = f_mul(fa, 1.0001f);
-                S.mvt[tid] = f_add(f_mul(ft, 1.0001f), 3e-5f);
+                // the two positions themselves are rounded: 3 roundings each, relative to |a x| + |b y| + |c| <= 1.5 (|x| + |t|),
+                // so 2 x 3 x 2^-24 x 1.5 (rmax + |t|) = 5.4e-7 (rmax + |t|) -- 3e-5 m up to a 50 m extent, scaled with the
+                // data beyond (a fixed constant is only right for sonar-range coordinates)
+                const float tmag = fmaxf(f_add(fabsf(Ti[2]), fabsf(Ti[5])), f_add(fabsf(S.thist[tid][2]), fabsf(S.thist[tid][5])));
+                S.mvt[tid] = f_add(f_mul(ft, 1.0001f), fmaxf(3e-5f, f_mul(6e-7f, f_add(rmax, tmag))));
             } else if (tid == it) {
 #pragma unroll
                 for (int i = 0; i < 6; ++i)
@@ -1451,7 +1455,7 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
                     // A `none` query stays none as long as it has moved less than its recorded clearance:
                     // |p - t| >= |p0 - t| - |p - p0| > maxDist for every target t (1e-5 relative slop on
                     // each term, two orders above the rounding of the fp32 distances involved).
-                    bool skip = false, grid_hit = false, rec_hit = false;
+                    bool skip = false, grid_hit = false, grid_defer = false, rec_hit = false;
                     if (fresh && use_cache && valid) {
                         const int w = prev >= 0 ? prev + 1 : (prev <= -3 ? -2 - prev : 0);
                         if (PROF)
@@ -1507,13 +1511,29 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
                                 grid_hit = P.use_trimmed_filter && C < Cmax && dw < r2m_up && (sw_cache & 8) != 0; // (a witness just beyond maxDist settles nothing)
                             }
                         }
+                        // A query WITHOUT a usable witness (an empty cell far from every structure, a witness beyond maxDist)
+                        // would now walk its whole maxDist window -- nothing bounds it until it meets a target -- while the
+                        // witnessed queries of its wave, and after the pass the whole workgroup, wait for it.  It is put off
+                        // to the same forced next round instead, where it searches next to everybody else.  (Suspended
+                        // without any guarantee, like the witnessed ones; it holds no match: best >= r2m_up.)
+                        grid_defer = !grid_hit && P.use_trimmed_filter && C < Cmax && (sw_cache & 8) != 0 && (sw_cache & 64) != 0 &&
+                                     px == px && py == py;
                     }
                     const int so = strip_of(py, ylo, inv_g, nst);
                     int s_up = own_done ? so + 1 : so, s_dn = so - 1;
                     // a query with a NaN coordinate has no neighbour (every d2 is NaN): nothing to visit
-                    bool lane_done = !valid || skip || grid_hit || rec_hit || !(px == px && py == py);
+                    bool lane_done = !valid || skip || grid_hit || grid_defer || rec_hit || !(px == px && py == py);
                     bool pending = false; // holds a strip it could not start or finish within the budget
                     bool own_fin = own_done;
+                    // A query that comes to a later pass still WITHOUT any target within maxDist (put off without a
+                    // witness, or nothing met within the first pass's budget) has nothing that bounds its search: its
+                    // window is the whole maxDist box, hundreds to thousands of candidates, and the other 63 lanes of its
+                    // wave would wait while it walks them four at a time until the budget runs out.  It goes to the
+                    // cooperative tier at once (256 candidates per trip).
+                    if (!fresh && last && !lane_done && !(best < r2m_up) && (sw_cache & 128) != 0) {
+                        pending = true;
+                        lane_done = true;
+                    }
                     int used = 0;
                     auto pick = [&]() { // the lane's next strip, -1 (and lane_done) when nothing is left within its bound
                         int s = -1;
@@ -1547,7 +1567,7 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
                         if (!__ballot(s >= 0))
                             break;
                         if ((fresh && rnd >= 1) || used >= budget) { // out of budget: whoever still holds a strip is handed on
-                            pending = s >= 0;
+                            pending = pending || s >= 0; // (a lane sent straight to the cooperative tier holds no strip and stays pending)
                             break;
                         }
                         ++used;
@@ -1615,10 +1635,10 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
                     const bool is_long = valid && pending;
                     const bool settled = valid && !is_long;
                     const bool found = best < r2m_up; // <=> some target with d2 <= maxDist^2 was met (best starts at W2 >= r2m_up)
-                    const bool is_none = settled && !found;
+                    const bool is_none = settled && !found && !grid_defer;
                     // (a grid-witnessed query of the first iteration has not searched anything yet: never exact)
                     const bool is_exact = settled && found && best <= C && !grid_hit;
-                    const bool is_susp = settled && found && (!(best <= C) || grid_hit);
+                    const bool is_susp = settled && ((found && (!(best <= C) || grid_hit)) || grid_defer);
                     if (is_none) {
                         setQ(q, INFINITY, SW_NONE);
                         if (!skip) // a full search: every target is at least sqrt(best) away from (px, py)
@@ -1650,7 +1670,7 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
                         Q.rec[fresh ? slot : Q.slot_of[q]] = 0u;
                     }
                     tally_settled(is_none, is_exact, best);
-                    if (__ballot(grid_hit) && lane == 0)
+                    if (__ballot(grid_hit || grid_defer) && lane == 0)
                         S.grid_skips = 1;
                     { // wave-aggregated appends
                         const unsigned long long ms = __ballot(is_susp), ml = __ballot(is_long);
@@ -2283,12 +2303,34 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
     // second strip, a little more to walk in each), one strip (= a plain x sweep) for small clouds
     const int strip_pts = std::max(1, env_int("SFE_SW_STRIP_PTS", 96));
 
+    // The small workgroups buy throughput (many jobs per CU), not latency: ONE scan match of 200 points is done sooner by
+    // 256 threads (one slice of queries per pass) than by 64 (four slices, one after the other).  So the one-wave tier is
+    // only used when the call brings enough such jobs to fill the device with them (the live node's single scan
+    // match takes the four-wave kernel).
+    const int t0_min_jobs = env_int("SFE_SW_T0_MIN_JOBS", 2 * ctx->n_cu), t1_min_jobs = env_int("SFE_SW_T1_MIN_JOBS", 1);
+    auto fits0 = [&](int n_src, int n_tgt) { return tiers_on && n_src <= std::min(t0_src, 4096) && n_tgt <= SW_T0_TCAP; };
+    auto fits1 = [&](int n_src, int n_tgt) { return tiers_on && n_src <= std::min(t1_src, 8192) && n_tgt <= SW_T1_TCAP; };
+    int n_fit0 = 0, n_fit1 = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const int32_t *q = jobs4 + 4 * (size_t)j;
+        if (fits0(q[1], q[3]))
+            ++n_fit0;
+        else if (fits1(q[1], q[3]))
+            ++n_fit1;
+    }
+    const bool use_t0 = n_fit0 >= t0_min_jobs;
+    const bool use_t1 = n_fit1 + (use_t0 ? 0 : n_fit0) >= std::max(1, t1_min_jobs);
+    // ... and with only a few small jobs in the call the four-wave kernel takes those of at most one slice of queries
+    // (measured, one scan match alone: 200 points 261 us with 256 threads, 282 with 1024, 464 with 64; 1000 points 508 us
+    // with 256 threads, 341 with 1024)
+    const bool few_small = n_fit0 + n_fit1 < 2 * ctx->n_cu;
+    const int t1_few_src = env_int("SFE_SW_T1_FEW_SRC", 320);
     // first pass: sizes -> how many big jobs there are (decides `wide` and whether big jobs are split)
     int n_big = 0, n_t2 = 0;
     auto tier_of = [&](int n_src, int n_tgt) {
-        if (tiers_on && n_src <= std::min(t0_src, 4096) && n_tgt <= SW_T0_TCAP)
+        if (use_t0 && fits0(n_src, n_tgt))
             return 0;
-        if (tiers_on && n_src <= std::min(t1_src, 8192) && n_tgt <= SW_T1_TCAP)
+        if (use_t1 && fits1(n_src, n_tgt) && (!few_small || n_src <= t1_few_src))
             return 1;
         return 2;
     };
@@ -2326,7 +2368,8 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
                     n2 <<= 1;
             }
             const int n_strips = std::max(1, std::min(SW_NS_MAX, (int)q[3] / strip_pts));
-            const int pt = !tiers_on ? 2 : (q[3] <= SW_T0_TCAP ? 0 : (q[3] <= SW_T1_TCAP ? 1 : 2));
+            // (the target's preparation follows the same rule: one wave only when the call fills the device with such jobs)
+            const int pt = (use_t0 && q[3] <= SW_T0_TCAP) ? 0 : ((use_t1 && q[3] <= SW_T1_TCAP) ? 1 : 2);
             pids[pt].push_back((int)preps.size());
             preps.push_back({q[2], q[3], n_strips, 0, toff, koff, goff});
             toff += q[3] + SW_PAD;
@@ -2481,6 +2524,8 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
                          (env_int("SFE_SW_GRID_SKIP", 1) ? 8 : 0) | // bit 3: witnessed queries skip round 0
                          (env_int("SFE_SW_REC", 1) ? 16 : 0) |      // bit 4: clearance records
                          (env_int("SFE_SW_TRIAGE", 1) ? 32 : 0) |   // bit 5: ... with triage passes
+                         (env_int("SFE_SW_GRID_DEFER", 1) ? 64 : 0) | // bit 6: first iteration: queries without a witness wait for round 1
+                         (env_int("SFE_SW_UNBOUNDED_COOP", 1) ? 128 : 0) | // bit 7: later passes: unbounded queries -> cooperative tier
                          (env_int("SFE_SW_JUMP", 1) ? 2 : 0) |
                          // bits 16..23: margin (percent) of the next iteration's cap over this iteration's limit
                          (std::max(0, std::min(255, env_int("SFE_SW_MARGIN", SW_CAP_MARGIN))) << 16) |
@@ -2552,6 +2597,12 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
     if (n_t1) { // four waves per job, 128 VGPRs, up to 4 jobs per CU
         const int tc = t1_tmax + SW_PAD, qc = (t1_smax + 3) & ~3;
         const size_t body = 8 * (size_t)tc + 6 * (size_t)qc;
+        const int t1_minw = env_int("SFE_SW_T1_MINW", 4); // A/B: 8 = 64 VGPRs, up to 8 jobs per CU
+        if (d_prof && !rec_build)
+            rc = sweep_launch_loop<SW_T1_NT, 4, true, true, true, false, false>(a, n_t1, ids, body, tc, qc);
+        else if (t1_minw == 8 && !rec_build)
+            rc = sweep_launch_loop<SW_T1_NT, 8, true, true, false, false, false>(a, n_t1, ids, body, tc, qc);
+        else
         rc = rec_build ? sweep_launch_loop<SW_T1_NT, 4, true, true, false, true, false>(a, n_t1, ids, body, tc, qc)
                        : sweep_launch_loop<SW_T1_NT, 4, true, true, false, false, false>(a, n_t1, ids, body, tc, qc);
         if (rc)

@@ -283,6 +283,20 @@ def stream_frames(ctx, kb, filters, steps=4, distinct=512, seed0=20000):
     for i in range(distinct):
         pool[i] = synth.sonar_frame(seed=seed0 + i, rows=rows, cols=cols)
     frame_b = rows * cols
+    # the batch stores at most kb.cap points per frame: a frame above it would be truncated (an error on the resident
+    # path), so such frames are screened out here -- one untimed pass over the pool, offenders replaced by a neighbour
+    replaced = 0
+    for f0 in range(0, distinct, n):
+        m = min(n, distinct - f0)
+        kb.d_img.upload(pool[f0:f0 + m], offset=0)
+        kb.run_cfar()
+        kb.run_extract()
+        ctx.sync()
+        cnt = kb.d_cnt.download(np.int32, m)
+        good = np.flatnonzero(cnt <= kb.cap)
+        for i in np.flatnonzero(cnt > kb.cap):
+            pool[f0 + i] = pool[f0 + good[i % len(good)]]
+            replaced += 1
     other = ctx.alloc(n * frame_b)           # the second frame buffer
     bufs = [kb.d_img, other]
 
@@ -342,8 +356,9 @@ def stream_frames(ctx, kb, filters, steps=4, distinct=512, seed0=20000):
     other.free()
     ctx.host_free(pool)
     hidden = (t_copy + t_comp - t_stream) / max(1e-12, min(t_copy, t_comp))
-    return {"workload": "%d keyframes per step, frames uploaded from pinned host memory (%d distinct frames, %d MiB per step)"
-                        % (n, distinct, n * frame_b // (1 << 20)),
+    return {"workload": "%d keyframes per step, frames uploaded from pinned host memory (%d distinct frames, %d of them "
+                        "replaced by another because they exceed the batch's point capacity; %d MiB per step)"
+                        % (n, distinct, replaced, n * frame_b // (1 << 20)),
             "keyframes_per_s_streamed": n / t_stream, "keyframes_per_s_resident_same_loop": n / t_comp,
             "ms_per_step_streamed": 1e3 * t_stream, "ms_per_step_resident": 1e3 * t_comp, "ms_upload_alone": 1e3 * t_copy,
             "pcie_gb_per_s_upload_alone": n * frame_b / t_copy / 1e9, "pcie_gb_per_s_while_streaming": n * frame_b / t_stream / 1e9,
