@@ -119,9 +119,25 @@ __device__ __forceinline__ int strip_of(float y, float ylo, float inv_g, int ns)
     return (int)v;
 }
 
+// Sorted target of a job whose cloud does not fit LDS (beyond SW_TCAP points): positions [lo, lo + n) -- the strips its
+// queries live in and as many around them as the LDS holds -- are read from LDS, everything else from the HBM scratch
+// copy (through L2).  A walk is a chain of dependent reads: one LDS latency per step instead of one L2 round trip.
+struct TgtWin {
+    const float2 *g; // the whole sorted cloud (HBM scratch)
+    const float2 *l; // LDS copy of positions [lo, lo + n)
+    int lo;
+    unsigned n;
+    __device__ __forceinline__ float2 operator[](int j) const
+    {
+        const unsigned o = (unsigned)(j - lo);
+        return o < n ? l[o] : g[j];
+    }
+};
+
 // first position in [lo, hi) whose x is not < px (hi if there is none; NaN x counts as "not <").
 // Convergent form: every lane of the wave must call it, lanes without work pass lo == hi.
-__device__ __forceinline__ int strip_lower_bound(const float2 *__restrict__ T, int lo, int hi, float px)
+template <class TV>
+__device__ __forceinline__ int strip_lower_bound(const TV &T, int lo, int hi, float px)
 {
     while (__ballot(lo < hi)) {
         const int mid = (lo + hi) >> 1;
@@ -137,7 +153,8 @@ __device__ __forceinline__ int strip_lower_bound(const float2 *__restrict__ T, i
 }
 
 // the same for one lane on its own (rare paths)
-__device__ __forceinline__ int strip_lower_bound_lane(const float2 *__restrict__ T, int lo, int hi, float px)
+template <class TV>
+__device__ __forceinline__ int strip_lower_bound_lane(const TV &T, int lo, int hi, float px)
 {
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
@@ -217,12 +234,12 @@ struct PrepShared {
 template <int KM, int NT> // NT = threads of the workgroup; KM = capacity of the neighbour list (>= K): its loops are fully unrolled, so a snug KM pays
 __device__ __forceinline__ void sweep_knn_normals(const sfe_icp_params &P, const StripTab &tab,
                                                   const float2 *__restrict__ s_tgt, const int *__restrict__ perm,
-                                                  float2 *__restrict__ snrm, int nt)
-{
+                                                  float2 *__restrict__ snrm, int nt, int c_begin = 0, int c_stride = NT)
+{ // (c_begin, c_stride: the positions this workgroup takes when several share a target, icp_sweep_normals_kernel)
     const int tid = threadIdx.x;
     const int K = min(min(P.normals_knn, KM), nt);
     const int ns = tab.ns, len = tab.len;
-    for (int c = tid + 1; c < len; c += NT) { // positions; sentinels are skipped
+    for (int c = c_begin + tid + 1; c < len; c += c_stride) { // positions; sentinels are skipped
         const float2 q = s_tgt[c];
         if (q.x != q.x && q.y != q.y)
             continue; // a sentinel (a cloud point that is NaN in both coordinates gets no normal either:
@@ -458,13 +475,43 @@ __device__ __forceinline__ void sweep_grid_witness(const StripTab &tab, const fl
         grid_out[c] = (int)grid[c];
 }
 
-// bitonic sort of n2 (power of two) 64-bit keys in HBM scratch by one workgroup (targets that do
-// not fit LDS; once per target, the keys stay in L2)
-template <int NT>
-__device__ __forceinline__ void bitonic_sort_global(unsigned long long *keys, unsigned n2)
+// bitonic sort of n2 (power of two, > CH) 64-bit keys in HBM scratch by one workgroup (targets that do not fit LDS; once
+// per target).  Only the exchange steps whose partners lie >= CH keys apart go through memory; every run of steps with
+// closer partners is done on CH-key chunks staged in LDS (`chunk`, CH keys): of the 120 steps of a 32 768-key sort 3
+// touch HBM, the rest run at LDS speed (0.7 -> ~0.2 ms for a 20 000-point cloud).
+template <int NT, int CH>
+__device__ __forceinline__ void bitonic_sort_global(unsigned long long *keys, unsigned n2, unsigned long long *chunk)
 {
-    for (unsigned k = 2; k <= n2; k <<= 1) {
-        for (unsigned j = k >> 1; j > 0; j >>= 1) {
+    // all steps (k', j) with k_lo <= k' <= k_hi, j < CH of the network, applied to every CH-aligned chunk: for k' < CH that
+    // is the whole sub-network of the chunk, for k' >= CH the tail j = CH/2 .. 1 of merge step k' (k_lo == k_hi then)
+    auto chunk_steps = [&](unsigned k_lo, unsigned k_hi) {
+        for (unsigned c0 = 0; c0 < n2; c0 += CH) {
+            for (unsigned t = threadIdx.x; t < CH; t += NT)
+                chunk[t] = keys[c0 + t];
+            __syncthreads();
+            for (unsigned k = k_lo; k <= k_hi; k <<= 1) {
+                for (unsigned j = (k >> 1 < CH ? k >> 1 : CH >> 1); j > 0; j >>= 1) {
+                    for (unsigned t = threadIdx.x; t < CH / 2; t += NT) {
+                        const unsigned i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                        const unsigned l = i | j;
+                        const unsigned long long a = chunk[i], b = chunk[l];
+                        const bool up = ((c0 + i) & k) == 0;
+                        if ((a > b) == up) {
+                            chunk[i] = b;
+                            chunk[l] = a;
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            for (unsigned t = threadIdx.x; t < CH; t += NT)
+                keys[c0 + t] = chunk[t];
+            __syncthreads(); // same workgroup, same CU: its L1 sees its own write-through stores
+        }
+    };
+    chunk_steps(2, CH); // every chunk sorted (ascending or descending by its place in the network)
+    for (unsigned k = 2 * CH; k <= n2; k <<= 1) {
+        for (unsigned j = k >> 1; j >= CH; j >>= 1) {
             for (unsigned t = threadIdx.x; t < n2 / 2; t += NT) {
                 const unsigned i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
                 const unsigned l = i | j;
@@ -475,8 +522,9 @@ __device__ __forceinline__ void bitonic_sort_global(unsigned long long *keys, un
                     keys[l] = a;
                 }
             }
-            __syncthreads(); // same workgroup, same CU: its L1 sees its own write-through stores
+            __syncthreads();
         }
+        chunk_steps(k, k);
     }
 }
 
@@ -708,7 +756,7 @@ __global__ __launch_bounds__(NT, 4) void icp_sweep_prep_kernel(sfe_icp_params P,
         if (grid_all)
             sweep_grid_witness<NT>(S.tab, s_tgt, grid_all + J.grid_off, reinterpret_cast<unsigned *>(s_grid));
     } else {
-        bitonic_sort_global<NT>(keys, n2);
+        bitonic_sort_global<NT, TCAP>(keys, n2, S.buf); // (n2 > TCAP here; S.buf holds TCAP + SW_PAD + 4 keys)
         for (int r = tid; r < nt; r += NT) {
             const unsigned long long key = keys[r];
             const int id = SW_KEY_ID(key), pos = r + SW_KEY_STRIP(key) + 1;
@@ -716,7 +764,7 @@ __global__ __launch_bounds__(NT, 4) void icp_sweep_prep_kernel(sfe_icp_params P,
             perm[pos - 1] = id;
         }
         __syncthreads();
-        if (P.minimizer == 1) {
+        if (P.minimizer == 1 && J.pad_ == 0) { // (pad_ = 1: icp_sweep_normals_kernel computes them, many workgroups per target)
             if (P.normals_knn <= 8)
                 sweep_knn_normals<8, NT>(P, S.tab, stgt, perm, nrm, nt);
             else if (P.normals_knn <= 10)
@@ -729,6 +777,39 @@ __global__ __launch_bounds__(NT, 4) void icp_sweep_prep_kernel(sfe_icp_params P,
         if (grid_all)
             sweep_grid_witness<NT>(S.tab, stgt, grid_all + J.grid_off, reinterpret_cast<unsigned *>(s_grid));
     }
+}
+
+// PCA normals of the targets that do not fit LDS (sorted in HBM scratch by their prep workgroup): a 20 000-point cloud
+// keeps ONE workgroup busy for over a millisecond with them -- longer than a many-to-one batch on that cloud then
+// iterates per share -- so they are dealt to gridDim.y workgroups per target here.  Same function, same neighbours.
+template <int NT>
+__global__ __launch_bounds__(NT, 4) void icp_sweep_normals_kernel(sfe_icp_params P, const SweepPrep *__restrict__ preps,
+                                                                  const int *__restrict__ prep_ids,
+                                                                  const float2 *__restrict__ stgt_all, const int *__restrict__ perm_all,
+                                                                  float2 *__restrict__ snrm_all, const StripTab *__restrict__ tab_all)
+{
+    __shared__ StripTab s_tab;
+    const int pid = __builtin_amdgcn_readfirstlane(prep_ids[blockIdx.x]);
+    const SweepPrep J = preps[pid];
+    {
+        const int *src = reinterpret_cast<const int *>(tab_all + pid);
+        int *dst = reinterpret_cast<int *>(&s_tab);
+        for (int i = threadIdx.x; i < (int)(sizeof(StripTab) / sizeof(int)); i += NT)
+            dst[i] = src[i];
+    }
+    __syncthreads();
+    const float2 *stgt = stgt_all + J.off;
+    const int *perm = perm_all + J.off;
+    float2 *nrm = snrm_all + J.off;
+    const int c0 = blockIdx.y * NT, cs = gridDim.y * NT;
+    if (P.normals_knn <= 8)
+        sweep_knn_normals<8, NT>(P, s_tab, stgt, perm, nrm, J.n_tgt, c0, cs);
+    else if (P.normals_knn <= 10)
+        sweep_knn_normals<10, NT>(P, s_tab, stgt, perm, nrm, J.n_tgt, c0, cs);
+    else if (P.normals_knn <= 12)
+        sweep_knn_normals<12, NT>(P, s_tab, stgt, perm, nrm, J.n_tgt, c0, cs);
+    else
+        sweep_knn_normals<ICP_KMAX, NT>(P, s_tab, stgt, perm, nrm, J.n_tgt, c0, cs);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -786,6 +867,7 @@ struct SweepShared {
     long long prof_t, prof[PROF ? 16 : 1], prof_it[PROF ? 64 : 1], prof_b0;
     unsigned xr[16]; // split jobs: the scalars of an exchange between the workgroups of a job
     int xabort;      // ... and its time-out flag
+    int win_smin, win_smax, win_lo, win_n; // WIN: strips of this workgroup's queries; the target positions held in LDS
     StripTab tab;
 };
 
@@ -849,7 +931,8 @@ struct SweepQ { // per-job views of the per-query scratch (the transformed query
 
 // ties at the final best: lowest original index among the points at distance `best`, found by
 // searching the final window once more (rare)
-__device__ __forceinline__ int sweep_resolve_tie(const float2 *__restrict__ T, const StripTab &tab, const SweepQ &Q,
+template <class TV>
+__device__ __forceinline__ int sweep_resolve_tie(const TV &T, const StripTab &tab, const SweepQ &Q,
                                                  float px, float py, float best)
 {
     int bo = 0x7FFFFFFF, bp = 0;
@@ -894,7 +977,9 @@ __device__ __forceinline__ int sweep_resolve_tie(const float2 *__restrict__ T, c
 // icp_split_kernel).  Every share runs the whole loop on its own queries; what an iteration decides from ALL queries --
 // the census of a search round, the histograms of the radix select, the sums of the error minimiser -- is exchanged
 // through the job's sync area (xreduce below) and every share takes the same decisions and solves the same system.
-template <int NT, int MINW, bool LDS_TGT, bool LDS_Q, bool PROF, bool REC, bool MULTI>
+// WIN (targets beyond SW_TCAP points): the part of the sorted target around this workgroup's queries is held in LDS
+// (TgtWin), t_cap = its capacity in points.
+template <int NT, int MINW, bool LDS_TGT, bool LDS_Q, bool PROF, bool REC, bool MULTI, bool WIN = false>
 __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
     sfe_icp_params P, const SweepJob *__restrict__ jobs, const int *__restrict__ job_ids, const float2 *__restrict__ src_all,
     const float *__restrict__ guess_all, const float2 *__restrict__ stgt_all, const int *__restrict__ perm_all,
@@ -907,6 +992,7 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
 {
     static_assert(LDS_TGT || !LDS_Q, "LDS_Q needs the LDS-resident target layout");
     static_assert(!MULTI || !PROF, "the profile build runs whole jobs");
+    static_assert(!WIN || !LDS_TGT, "a window is for targets that do not fit LDS");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     using Shared = SweepShared<NT, PROF, REC>;
     Shared &S = *reinterpret_cast<Shared *>(smem_raw);
@@ -928,7 +1014,12 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
     const float2 *__restrict__ src = src_all + J.src_start;
     const float2 *__restrict__ stgt = stgt_all + J.tgt_off;
     float2 *lds_tgt = reinterpret_cast<float2 *>(smem_raw + ((sizeof(Shared) + 15) & ~(size_t)15));
-    const float2 *__restrict__ T = LDS_TGT ? (const float2 *)lds_tgt : stgt; // sorted target incl. sentinels
+    using TV = std::conditional_t<WIN, TgtWin, const float2 *>;
+    TV T; // sorted target incl. sentinels
+    if constexpr (WIN)
+        T = TgtWin{stgt, lds_tgt, 0, 0u}; // (the window is chosen and filled behind the query sort)
+    else
+        T = LDS_TGT ? (const float2 *)lds_tgt : stgt;
     const float2 *__restrict__ snrm = snrm_all ? snrm_all + J.tgt_off : nullptr;
     SweepQ Q;
     Q.st = q_st_all + J.q_off;
@@ -982,6 +1073,8 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
     if (tid == 0) {
         S.rmax_bits = 0u;
         S.xabort = 0;
+        S.win_smin = 0x7FFFFFFF;
+        S.win_smax = -1;
     }
     { // strip table -> LDS
         const int *tsrc = reinterpret_cast<const int *>(tab_all + J.prep);
@@ -1097,6 +1190,7 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
     {
         unsigned long long *skeys = reinterpret_cast<unsigned long long *>(lds_tgt);
         float rloc = 0.0f; // largest |T0 * src| among this thread's queries (for the movement bounds of the clearance records)
+        int smin_l = 0x7FFFFFFF, smax_l = -1; // WIN: the strips this thread's queries start in
         for (int c0 = 0; c0 < ns; c0 += sort_chunk) { // sort_chunk = the power of two of keys this LDS region holds
             const int n = min(sort_chunk, ns - c0);
             unsigned n2 = 2;
@@ -1108,7 +1202,12 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
                     const float2 sp = src[c0 + i];
                     const float rx = affine1(T0[0], T0[1], T0[2], sp.x, sp.y);
                     const float ry = affine1(T0[3], T0[4], T0[5], sp.x, sp.y);
-                    k = SW_KEY(strip_of(ry, S.tab.ylo, S.tab.inv_g, S.tab.ns), mono_key(rx), c0 + i);
+                    const int st_ = strip_of(ry, S.tab.ylo, S.tab.inv_g, S.tab.ns);
+                    k = SW_KEY(st_, mono_key(rx), c0 + i);
+                    if (WIN) {
+                        smin_l = min(smin_l, st_);
+                        smax_l = max(smax_l, st_);
+                    }
                     const float rr = sqrtf(f_add(f_mul(rx, rx), f_mul(ry, ry)));
                     rloc = (rr > rloc || rr != rr) ? rr : rloc; // (a NaN sticks: no bound, no record is ever used)
                 }
@@ -1126,11 +1225,58 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
             __syncthreads();
         }
         atomicMax(&S.rmax_bits, __float_as_uint(rloc)); // rloc >= 0 or NaN (whose pattern is above every finite one)
+        if (WIN && smax_l >= 0) {
+            atomicMin(&S.win_smin, smin_l);
+            atomicMax(&S.win_smax, smax_l);
+        }
     }
     // sorted centred target (with its NaN sentinels: a NaN stops a walk direction) -> LDS
     if (LDS_TGT) {
         for (int i = tid; i < nt + SW_PAD; i += NT)
             lds_tgt[i] = stgt[i];
+    }
+    if constexpr (WIN) {
+        // The window: whole strips, in the sorted cloud's own layout (the sentinel in front of the first strip and the one
+        // behind the last included).  From the band of strips the queries start in -- shrunk from both ends if the
+        // band alone exceeds the capacity (an unsplit job: its queries are everywhere), else grown by whole strips on both
+        // sides while they fit.  Reads outside fall back to HBM, so any window is correct; a good one is fast.
+        __syncthreads();
+        if (tid == 0) {
+            const int nst_ = S.tab.ns;
+            int a = S.win_smin, b = S.win_smax + 1, lo = 0, n = 0;
+            if (S.win_smax >= 0 && t_cap > 0) {
+                auto len = [&](int a_, int b_) { return S.tab.sbeg[b_] - S.tab.sbeg[a_] + 1; };
+                while (b - a > 1 && len(a, b) > t_cap) {
+                    if ((b - a) & 1)
+                        --b;
+                    else
+                        ++a;
+                }
+                if (len(a, b) <= t_cap) {
+                    for (bool grow = true; grow;) {
+                        grow = false;
+                        if (a > 0 && len(a - 1, b) <= t_cap) {
+                            --a;
+                            grow = true;
+                        }
+                        if (b < nst_ && len(a, b + 1) <= t_cap) {
+                            ++b;
+                            grow = true;
+                        }
+                    }
+                    lo = S.tab.sbeg[a] - 1;
+                    n = len(a, b);
+                }
+            }
+            S.win_lo = lo;
+            S.win_n = n;
+        }
+        __syncthreads();
+        const int wlo = __builtin_amdgcn_readfirstlane(S.win_lo), wn = __builtin_amdgcn_readfirstlane(S.win_n);
+        for (int i = tid; i < wn; i += NT)
+            lds_tgt[i] = stgt[wlo + i];
+        T.lo = wlo;
+        T.n = (unsigned)wn;
     }
     IcpCheck chk = {S.hist_c, S.hist_s, S.hist_x, S.hist_y, 1, 0, 0};
     if (tid == 0) {
@@ -2234,11 +2380,11 @@ constexpr size_t sweep_ctl_bytes()
 }
 
 // one launch of the loop kernel: n workgroups, job ids d_ids[0..n), `body` bytes of LDS behind the control block
-template <int NT, int MINW, bool LDS_TGT, bool LDS_Q, bool PROF, bool REC, bool MULTI>
+template <int NT, int MINW, bool LDS_TGT, bool LDS_Q, bool PROF, bool REC, bool MULTI, bool WIN = false>
 int sweep_launch_loop(const SweepLaunchArgs &a, int n, const int *d_ids, size_t body, int t_cap, int q_cap)
 {
     sfe_ctx *ctx = a.ctx;
-    auto kernel = icp_sweep_kernel<NT, MINW, LDS_TGT, LDS_Q, PROF, REC, MULTI>;
+    auto kernel = icp_sweep_kernel<NT, MINW, LDS_TGT, LDS_Q, PROF, REC, MULTI, WIN>;
     const size_t smem = sweep_ctl_bytes<NT, PROF, REC>() + body;
     SFE_HIP(ctx, hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(kernel, dim3(n), dim3(NT), smem, ctx->stream, *a.p, a.d_jobs, d_ids, a.d_src, a.d_guess9, a.d_stgt,
@@ -2285,6 +2431,7 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
     //   multi    ... target in HBM scratch, the job shared by several workgroups (many-to-one batches on large clouds)
     std::vector<int> ids_t0, ids_t1, ids_q, ids_lds, ids_glb, ids_multi, split_first;
     std::vector<int> pids[3]; // targets by prep tier
+    std::vector<int> pids_nrm; // ... and those whose normals take a kernel of their own
     std::map<std::pair<int, int>, int> seen; // many guesses on one pair share one prep
     long long toff = 0, qoff = 0, koff = 0, goff = 0;
     // (knobs are read per call, not once per process: the tests switch them between calls)
@@ -2371,7 +2518,11 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
             // (the target's preparation follows the same rule: one wave only when the call fills the device with such jobs)
             const int pt = (use_t0 && q[3] <= SW_T0_TCAP) ? 0 : ((use_t1 && q[3] <= SW_T1_TCAP) ? 1 : 2);
             pids[pt].push_back((int)preps.size());
-            preps.push_back({q[2], q[3], n_strips, 0, toff, koff, goff});
+            // (targets sorted in HBM scratch get their normals from icp_sweep_normals_kernel: pad_ = 1)
+            const int nrm_later = (q[3] > SW_TCAP && p->minimizer == 1 && env_int("SFE_SW_NORMALS_SPLIT", 1)) ? 1 : 0;
+            if (nrm_later)
+                pids_nrm.push_back((int)preps.size());
+            preps.push_back({q[2], q[3], n_strips, nrm_later, toff, koff, goff});
             toff += q[3] + SW_PAD;
             koff += n2;
             goff += pt == 0 ? SW_T0_GRID : (pt == 1 ? SW_T1_GRID : SW_GRID_MAX);
@@ -2426,7 +2577,8 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
     const size_t o_ids = (o_jobs + sizeof(SweepJob) * (size_t)n_rec + 15) & ~(size_t)15;
     const size_t o_split = o_ids + sizeof(int) * (size_t)n_rec;
     const size_t o_pids = o_split + sizeof(int) * (size_t)n_split;
-    const size_t tab_bytes = o_pids + sizeof(int) * (size_t)n_prep;
+    const size_t o_pnrm = o_pids + sizeof(int) * (size_t)n_prep;
+    const size_t tab_bytes = o_pnrm + sizeof(int) * pids_nrm.size();
     char *d_tables = (char *)sfe_scratch(ctx, 12, tab_bytes);
     float2 *d_stgt = (float2 *)sfe_scratch(ctx, 14, sizeof(float2) * (size_t)toff);
     int *d_perm = (int *)sfe_scratch(ctx, 15, sizeof(int) * (size_t)toff);
@@ -2486,6 +2638,8 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
                 memcpy(hp, pids[t].data(), sizeof(int) * pids[t].size());
             hp += pids[t].size();
         }
+        if (!pids_nrm.empty())
+            memcpy(h + o_pnrm, pids_nrm.data(), sizeof(int) * pids_nrm.size());
         SFE_HIP(ctx, hipMemcpyAsync(d_tables, h, tab_bytes, hipMemcpyHostToDevice, ps));
         if (int rc = sfe_pinned_end(ctx, ps))
             return rc;
@@ -2505,6 +2659,17 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
                                                                            (const float2 *)d_tgt, d_stgt, d_perm, d_snrm, d_mean, d_gkeys,
                                                                            d_tab, d_grid))
                 return rc;
+    }
+    if (!pids_nrm.empty()) { // behind the prep (sorted cloud, strip table), 1024 points per workgroup and pass
+        int tmax = 0;
+        for (int pid : pids_nrm)
+            tmax = std::max(tmax, preps[(size_t)pid].n_tgt);
+        const int per = std::max(1, std::min(32, std::min((tmax + 2 * ICP_THREADS - 1) / (2 * ICP_THREADS),
+                                                          std::max(1, 2 * ctx->n_cu / (int)pids_nrm.size()))));
+        hipLaunchKernelGGL(icp_sweep_normals_kernel<ICP_THREADS>, dim3((unsigned)pids_nrm.size(), (unsigned)per), dim3(ICP_THREADS), 0, ps,
+                           *p, d_preps, (const int *)(d_tables + o_pnrm), (const float2 *)d_stgt, (const int *)d_perm, d_snrm,
+                           (const StripTab *)d_tab);
+        SFE_LAUNCH_CHECK(ctx);
     }
     if (n_split) { // behind the prep (it needs the strip tables), in front of the loop
         SFE_HIP(ctx, hipMemsetAsync(d_sync, 0, sync_bytes, ps));
@@ -2641,11 +2806,26 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
             return rc;
         ids += n_lds;
     }
+    // Targets beyond SW_TCAP points stay in HBM scratch and are read through L2.  SFE_SW_WIN=1 (A/B) holds as much of the
+    // sorted target as fits next to the control block in LDS instead (TgtWin: the strips around the workgroup's queries;
+    // 19 700 of a 20 000-point cloud's 20 068 positions), one workgroup per CU.  Measured, 30 guesses x one 20 000 x
+    // 20 000 pair over 8 shares: 7.97 ms with the window, 7.82 without; 16 batches unsplit: 62.4 / 60.1 ms -- the target
+    // is L2-resident and sixteen waves per workgroup hide its latency; every read pays the window test.  Off by default.
+    const int win_on = env_int("SFE_SW_WIN", 0);
+    constexpr size_t ctl_g = sweep_ctl_bytes<ICP_THREADS, false, false>();
+    int glb_tmax = 0;
+    for (int j = 0; j < n_jobs; ++j)
+        if (jobs4[4 * (size_t)j + 3] > SW_TCAP)
+            glb_tmax = std::max(glb_tmax, (int)jobs4[4 * (size_t)j + 3]);
+    const int win_cap = std::min(glb_tmax + SW_PAD, (int)((160 * 1024 - ctl_g - 64) / 8));
+    const size_t body_win = 8 * (size_t)std::max(win_cap, SW_TCAP); // (the query sort uses the same bytes first)
     if (n_glb) {
-        // the target stays in HBM / L2; the LDS behind the control block only serves the query sort
-        const size_t body = sizeof(unsigned long long) * SW_TCAP;
-        rc = wide ? sweep_launch_loop<ICP_THREADS, 4, false, false, false, false, false>(a, n_glb, ids, body, SW_TCAP, 0)
-                  : sweep_launch_loop<ICP_THREADS, 8, false, false, false, false, false>(a, n_glb, ids, body, SW_TCAP, 0);
+        const size_t body = sizeof(unsigned long long) * SW_TCAP; // without a window the LDS behind the control block only serves the query sort
+        if (win_on)
+            rc = sweep_launch_loop<ICP_THREADS, 4, false, false, false, false, false, true>(a, n_glb, ids, body_win, win_cap, 0);
+        else
+            rc = wide ? sweep_launch_loop<ICP_THREADS, 4, false, false, false, false, false>(a, n_glb, ids, body, SW_TCAP, 0)
+                      : sweep_launch_loop<ICP_THREADS, 8, false, false, false, false, false>(a, n_glb, ids, body, SW_TCAP, 0);
         if (rc)
             return rc;
         ids += n_glb;
@@ -2654,7 +2834,8 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
         const size_t body = sizeof(unsigned long long) * SW_TCAP;
         SweepLaunchArgs am = a;
         am.d_src = d_gsrc;
-        rc = sweep_launch_loop<ICP_THREADS, 4, false, false, false, false, true>(am, n_multi, ids, body, SW_TCAP, 0);
+        rc = win_on ? sweep_launch_loop<ICP_THREADS, 4, false, false, false, false, true, true>(am, n_multi, ids, body_win, win_cap, 0)
+                    : sweep_launch_loop<ICP_THREADS, 4, false, false, false, false, true>(am, n_multi, ids, body, SW_TCAP, 0);
         if (rc)
             return rc;
         ids += n_multi;
