@@ -432,6 +432,15 @@ def main():
         except (OSError, KeyError, ValueError):
             pass
 
+        extract_traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "extract_pmc.json")) as f:
+                epmc = json.load(f)
+            if (epmc["rows"], epmc["cols"]) == (ROWS, COLS):
+                extract_traffic = epmc["traffic_bytes_per_frame"] * args.batch
+        except (OSError, KeyError, ValueError):
+            pass
+
         value = args.batch * args.steps * world / dt
         out = {
             "metric": "keyframes/sec (CFAR+ICP) on 512x1024 sonar, 5k-pt pairs",
@@ -476,7 +485,9 @@ def main():
             "roofline_extract": {"kernel": ("" if kb.bit_masks else "mask_pack + ") + "extract_scatter + extract_scan + extract_expand_words", "bound": "hbm",
                                  "achieved": extract_bytes / (ms_extract_b * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": extract_bytes / (ms_extract_b * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                 "bytes_per_launch": extract_bytes, "ms_per_launch": ms_extract_b,
+                                 "bytes_per_launch": extract_bytes, "ms_per_launch": ms_extract_b, "traffic": extract_traffic,
+                                 "traffic_note": "bytes/launch from the committed PMC passes (profiles/extract_pmc.json: per-frame "
+                                                 "FETCH_SIZE x 2 + WRITE_SIZE of the stage's kernels, scaled to this launch's frames)",
                                  "note": "algorithmic bytes = the R*B detections (bits when CFAR hands over bit streams) + 16 B per point per frame; the kernels are "
                                          "bound by gathers into the inverse remap tables (29 MB, scattered 4-byte reads), not "
                                          "by streaming"},
