@@ -2235,6 +2235,8 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
     }
 }
 
+#include "sfe_icp_tiny.h"
+
 // ---------------------------------------------------------------------------------------------
 // split: one workgroup per job that is shared by several workgroups of the loop kernel (MULTI)
 // ---------------------------------------------------------------------------------------------
@@ -2424,13 +2426,16 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
     std::vector<SweepJob> jobs;
     jobs.reserve((size_t)n_jobs);
     // Job classes, one launch of the loop kernel each:
+    //   tiny     clouds of a few hundred points: one wave per job, exhaustive search (sfe_icp_tiny.h)
     //   t0 / t1  small jobs: one-wave / four-wave workgroups, target AND per-query results in LDS, many jobs per CU
     //   q        1024-thread workgroups, target AND per-query results in LDS
     //   lds      ... target in LDS, results in HBM scratch
     //   glb      ... target in HBM scratch (beyond SW_TCAP points)
     //   multi    ... target in HBM scratch, the job shared by several workgroups (many-to-one batches on large clouds)
-    std::vector<int> ids_t0, ids_t1, ids_q, ids_lds, ids_glb, ids_multi, split_first;
+    std::vector<int> ids_tiny, ids_t0, ids_t1, ids_q, ids_lds, ids_glb, ids_multi, split_first;
     std::vector<int> pids[3]; // targets by prep tier
+    std::vector<int> prep_tier; // ... of every target
+    std::vector<char> prep_need; // a target only tiny point-to-point jobs use is not prepared (they take its mean themselves)
     std::vector<int> pids_nrm; // ... and those whose normals take a kernel of their own
     std::map<std::pair<int, int>, int> seen; // many guesses on one pair share one prep
     long long toff = 0, qoff = 0, koff = 0, goff = 0;
@@ -2449,6 +2454,13 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
     // ~96 points per strip on average (measured optimum 96-128 on 5000-point clouds: fewer queries need a
     // second strip, a little more to walk in each), one strip (= a plain x sweep) for small clouds
     const int strip_pts = std::max(1, env_int("SFE_SW_STRIP_PTS", 96));
+    // clouds of a few hundred points: the exhaustive one-wave kernel (A/B: SFE_SW_TINY=0)
+    const int tiny_on = env_int("SFE_SW_TINY", 1);
+    const long long tiny_pairs = env_int("SFE_SW_TINY_PAIRS", (p->use_diff_checker || p->max_iter < SW_REC_MIN_ITER)
+                                                                    ? SW_TINY_PAIRS_SHORT : SW_TINY_PAIRS_LONG);
+    auto is_tiny = [&](int n_src, int n_tgt) {
+        return tiny_on && n_src <= SW_TINY_MAX && n_tgt <= SW_TINY_MAX && (long long)n_src * n_tgt <= tiny_pairs;
+    };
 
     // The small workgroups buy throughput (many jobs per CU), not latency: ONE scan match of 200 points is done sooner by
     // 256 threads (one slice of queries per pass) than by 64 (four slices, one after the other).  So the one-wave tier is
@@ -2483,7 +2495,7 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
     };
     for (int j = 0; j < n_jobs; ++j) {
         const int32_t *q = jobs4 + 4 * (size_t)j;
-        if (tier_of(q[1], q[3]) == 2) {
+        if (!is_tiny(q[1], q[3]) && tier_of(q[1], q[3]) == 2) {
             ++n_t2;
             if (q[3] > SW_TCAP && q[1] >= multi_min_src)
                 ++n_big;
@@ -2500,7 +2512,7 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
             mg = std::min(std::min(multi_force, SW_MG_MAX), std::max(1, ctx->n_cu / n_big));
     }
     constexpr size_t ctl_q = sweep_ctl_bytes<ICP_THREADS, false, true>(); // (the largest control block of the LDS_Q builds)
-    int q_tmax = 0, q_smax = 0, t0_tmax = 0, t0_smax = 0, t1_tmax = 0, t1_smax = 0;
+    int q_tmax = 0, q_smax = 0, t0_tmax = 0, t0_smax = 0, t1_tmax = 0, t1_smax = 0, tiny_tmax = 0, tiny_smax = 0;
     int n_sync = 0;
     for (int j = 0; j < n_jobs; ++j) {
         const int32_t *q = jobs4 + 4 * (size_t)j;
@@ -2517,7 +2529,8 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
             const int n_strips = std::max(1, std::min(SW_NS_MAX, (int)q[3] / strip_pts));
             // (the target's preparation follows the same rule: one wave only when the call fills the device with such jobs)
             const int pt = (use_t0 && q[3] <= SW_T0_TCAP) ? 0 : ((use_t1 && q[3] <= SW_T1_TCAP) ? 1 : 2);
-            pids[pt].push_back((int)preps.size());
+            prep_tier.push_back(pt);
+            prep_need.push_back(0);
             // (targets sorted in HBM scratch get their normals from icp_sweep_normals_kernel: pad_ = 1)
             const int nrm_later = (q[3] > SW_TCAP && p->minimizer == 1 && env_int("SFE_SW_NORMALS_SPLIT", 1)) ? 1 : 0;
             if (nrm_later)
@@ -2528,7 +2541,10 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
             goff += pt == 0 ? SW_T0_GRID : (pt == 1 ? SW_T1_GRID : SW_GRID_MAX);
         }
         const SweepPrep &pr = preps[(size_t)it->second];
-        const int tier = tier_of(q[1], q[3]);
+        const bool tiny = is_tiny(q[1], q[3]);
+        const int tier = tiny ? -1 : tier_of(q[1], q[3]);
+        if (!tiny || p->minimizer == 1)
+            prep_need[(size_t)it->second] = 1;
         int shares = 1;
         if (tier == 2 && mg > 1 && q[3] > SW_TCAP && q[1] >= multi_min_src)
             shares = std::max(1, std::min(mg, (int)q[1] / std::max(1, multi_share_min)));
@@ -2541,6 +2557,10 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
             for (int g = 0; g < shares; ++g)
                 ids_multi.push_back(rec0 + g);
             ++n_sync;
+        } else if (tiny) {
+            ids_tiny.push_back(rec0);
+            tiny_tmax = std::max(tiny_tmax, (int)q[3]);
+            tiny_smax = std::max(tiny_smax, (int)q[1]);
         } else if (tier == 0) {
             ids_t0.push_back(rec0);
             t0_tmax = std::max(t0_tmax, (int)q[3]);
@@ -2561,6 +2581,9 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
             }
         }
     }
+    for (size_t pid = 0; pid < preps.size(); ++pid)
+        if (prep_need[pid])
+            pids[prep_tier[pid]].push_back((int)pid);
     // the LDS_Q launch is sized by the largest target and the largest source among its jobs
     int t_cap = q_tmax + SW_PAD, q_cap = (q_smax + 3) & ~3;
     if (!ids_q.empty() && ctl_q + 8 * (size_t)t_cap + 6 * (size_t)q_cap > lds_share) {
@@ -2569,6 +2592,7 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
         ids_q.clear();
     }
     const int n_prep = (int)preps.size(), n_rec = (int)jobs.size();
+    const int n_tiny = (int)ids_tiny.size();
     const int n_t0 = (int)ids_t0.size(), n_t1 = (int)ids_t1.size(), n_q = (int)ids_q.size(), n_lds = (int)ids_lds.size(),
               n_glb = (int)ids_glb.size(), n_multi = (int)ids_multi.size(), n_split = (int)split_first.size();
     // the tables travel as ONE block: [preps | job records | job ids by class | share-0 records of the split jobs |
@@ -2625,7 +2649,7 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
         memcpy(h, preps.data(), sizeof(SweepPrep) * (size_t)n_prep);
         memcpy(h + o_jobs, jobs.data(), sizeof(SweepJob) * (size_t)n_rec);
         int *hi = (int *)(h + o_ids);
-        for (const std::vector<int> *v : {&ids_t0, &ids_t1, &ids_q, &ids_lds, &ids_glb, &ids_multi}) {
+        for (const std::vector<int> *v : {&ids_tiny, &ids_t0, &ids_t1, &ids_q, &ids_lds, &ids_glb, &ids_multi}) {
             if (!v->empty())
                 memcpy(hi, v->data(), sizeof(int) * v->size());
             hi += v->size();
@@ -2750,6 +2774,16 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
     // VGPRs of the 64-VGPR build
     int rc = 0;
     const int *ids = d_ids;
+    if (n_tiny) { // one wave per job, everything in LDS (sfe_icp_tiny.h)
+        const int tc = ((tiny_tmax + SW_TINY_CH - 1) / SW_TINY_CH + 1) * SW_TINY_CH, qc = (tiny_smax + 3) & ~3; // (whole chunks + one of padding)
+        const size_t smem = ((sizeof(TinyShared) + 15) & ~(size_t)15) + sizeof(float2) * (size_t)tc * (p->minimizer == 1 ? 2 : 1) +
+                            6 * (size_t)qc;
+        hipLaunchKernelGGL(icp_tiny_kernel, dim3(n_tiny), dim3(SW_TINY_NT), smem, ctx->stream, *p, d_jobs, ids, d_preps,
+                           (const float2 *)d_src, (const float2 *)d_tgt, d_guess9, (const int *)d_perm, (const float2 *)d_snrm,
+                           (const float *)d_mean, (const StripTab *)d_tab, d_T9, d_status, d_iters, tc, qc);
+        SFE_LAUNCH_CHECK(ctx);
+        ids += n_tiny;
+    }
     if (n_t0) { // one wave per job (no workgroup barrier costs anything), 128 VGPRs, up to 16 jobs per CU
         const int tc = t0_tmax + SW_PAD, qc = (t0_smax + 3) & ~3;
         const size_t body = 8 * (size_t)tc + 6 * (size_t)qc;

@@ -19,13 +19,15 @@ TOL_REF = 1e-4
 
 @pytest.fixture(autouse=True, params=["tiers", "one-size"])
 def job_tiers(request, monkeypatch):
-    """Every test of this module runs twice: with the launcher's job tiers (one-wave workgroups for scan matches of a
-    few hundred points, four-wave ones up to ~2000, 1024 threads beyond; large many-to-one jobs split over several
-    workgroups) and with every job on the 1024-thread kernels, unsplit (what round 2 shipped).  The knobs are read
+    """Every test of this module runs twice: with the launcher's job classes (the exhaustive one-wave kernel for clouds
+    of a few hundred points, one-wave / four-wave workgroups of the strip sweep up to ~2000 points, 1024 threads beyond;
+    large many-to-one jobs split over several workgroups) and with every job on the 1024-thread sweep kernels, unsplit
+    (what round 2 shipped).  The knobs are read
     per call (sfe_icp_sweep_launch)."""
     if request.param == "one-size":
         monkeypatch.setenv("SFE_SW_TIERS", "0")
         monkeypatch.setenv("SFE_SW_MULTI", "0")
+        monkeypatch.setenv("SFE_SW_TINY", "0")
     return request.param
 
 

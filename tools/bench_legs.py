@@ -105,8 +105,8 @@ def reference_chain(ctx, kb, srcs, tgts, guesses, threads, sample=8):
 def real_size(ctx, threads, n_ssm=16384, n_nssm=512, distinct=2048):
     """The jobs bruce_slam produces: feature clouds of 10^2..10^3 points.  SSM-like: independent scan matches
     of 200..1000 x 200..1000 points (slam.py:769); NSSM-like: 30 guesses on one 800 x 800 pair (slam.py:346-358,1032).
-    Resident clouds, one launch set per batch; the same batch again with SFE_SW_TIERS=0 = every job on a 1024-thread
-    workgroup (round 2's only shape)."""
+    Resident clouds, one launch set per batch; the same batch again with SFE_SW_TIERS=0 SFE_SW_TINY=0 = every job on a
+    1024-thread workgroup of the strip sweep (round 2's only shape)."""
     from sonar_slam_amd import icp_config, synth
     from sonar_slam_amd.pipeline import ScanMatchBatch
     rng = np.random.default_rng(11)
@@ -125,12 +125,12 @@ def real_size(ctx, threads, n_ssm=16384, n_nssm=512, distinct=2048):
     picks = list(range(0, n_ssm, max(1, n_ssm // 16)))[:16]
     par = check_against_oracle("real_size.ssm", [(srcs[j], tgts[j], gs[j]) for j in picks],
                                (res["T"][picks], res["status"][picks], res["iters"][picks]), {}, threads)
-    os.environ["SFE_SW_TIERS"] = "0"
+    os.environ.update(SFE_SW_TIERS="0", SFE_SW_TINY="0")
     try:
         ms_1024 = timed(ctx, b.run, 2)
         res_1024 = b.results()
     finally:
-        del os.environ["SFE_SW_TIERS"]
+        del os.environ["SFE_SW_TIERS"], os.environ["SFE_SW_TINY"]
     same = bool(np.array_equal(res["T"], res_1024["T"]) and np.array_equal(res["iters"], res_1024["iters"]))
     b.free()
     out["ssm"] = {"workload": "%d independent scan matches, 200..1000 x 200..1000 points (%d distinct pairs), icp.yaml as shipped"
@@ -146,11 +146,11 @@ def real_size(ctx, threads, n_ssm=16384, n_nssm=512, distinct=2048):
     b = ScanMatchBatch(ctx, p, [pairs5[j % 1024][0] for j in range(n5)], [pairs5[j % 1024][1] for j in range(n5)],
                        [(j, j) for j in range(n5)], [pairs5[j % 1024][2] for j in range(n5)])
     ms5 = timed(ctx, b.run, 3)
-    os.environ["SFE_SW_TIERS"] = "0"
+    os.environ.update(SFE_SW_TIERS="0", SFE_SW_TINY="0")
     try:
         ms5_1024 = timed(ctx, b.run, 2)
     finally:
-        del os.environ["SFE_SW_TIERS"]
+        del os.environ["SFE_SW_TIERS"], os.environ["SFE_SW_TINY"]
     b.free()
     out["at_500_points"] = {"jobs": n5, "jobs_per_s": n5 / (ms5 * 1e-3), "jobs_per_s_1024_thread_workgroups": n5 / (ms5_1024 * 1e-3),
                             "speedup": ms5_1024 / ms5}

@@ -23,9 +23,9 @@ for n_pts, n_jobs in ((200, 16384), (500, 8192), (1000, 4096)):
         b = ScanMatchBatch(ctx, p, [pairs[j % 1024][0] for j in range(n_jobs)], [pairs[j % 1024][1] for j in range(n_jobs)],
                            [(j, j) for j in range(n_jobs)], [pairs[j % 1024][2] for j in range(n_jobs)])
         ref = None
-        for label, env in (("tiers default", {}), ("1024-thread only", {"SFE_SW_TIERS": "0"}),
-                           ("one wave per job", {"SFE_SW_T0_SRC": "1024"}), ("four waves, 64 VGPRs", {"SFE_SW_T1_MINW": "8", "SFE_SW_T0_SRC": "0"}),
-                           ("four waves, 128 VGPRs", {"SFE_SW_T0_SRC": "0"})):
+        for label, env in (("default", {}), ("no tiny kernel", {"SFE_SW_TINY": "0"}), ("1024-thread only", {"SFE_SW_TIERS": "0", "SFE_SW_TINY": "0"}),
+                           ("tiny up to 400k pairs", {"SFE_SW_TINY_PAIRS": "400000"}),
+                           ):
             os.environ.update(env)
             try:
                 ms = timed(ctx, b.run, 3)
