@@ -456,7 +456,11 @@ def main():
                        "icp_converged_jobs": ok, "mean_icp_iters": iters_total / float(args.batch),
                        "mean_points_per_frame": float(res["counts"].mean()),
                        "max_points_per_frame": int(res["counts"].max()), "points_capacity": kb.cap},
+            # achieved / frac are priced on SURVEY 8d's ALGORITHMIC bytes (2 B per pixel), as the contract asks; the kernel of
+            # the step writes bits, moves 1.125 B per pixel and is limited by VALU issue, not by HBM: `moved` and `limiter`
+            # say so next to it, `byte_mask_kernel` is the form that really moves the algorithmic bytes
             "roofline": {"kernel": "cfar_u8_ring<20,5,SOCA,%s>" % ("BITS" if bits else "bytes"), "bound": "hbm",
+                         "limiter": "valu issue (~29 VALU per 256-pixel row and wave)" if bits else "hbm",
                          "achieved": cfar_gbs,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cfar_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_note": "bytes/launch = 2*FETCH_SIZE + WRITE_SIZE from profiles/cfar%s_pmc.json"
