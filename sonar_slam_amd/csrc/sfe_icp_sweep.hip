@@ -988,7 +988,7 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
     float *__restrict__ nn_d2_all,
     int *__restrict__ nn_pos_all, float *__restrict__ T_out, int *__restrict__ status_out,
     int *__restrict__ iters_out, long long *prof, int *dbg, int sw_budget, int sw_budget_a, int sw_cache, int t_cap, int q_cap, int sort_chunk, float sw_m, float sw_kappa,
-    unsigned long long *__restrict__ sync_all)
+    unsigned long long *__restrict__ sync_all, int sw_cache2)
 {
     static_assert(LDS_TGT || !LDS_Q, "LDS_Q needs the LDS-resident target layout");
     static_assert(!MULTI || !PROF, "the profile build runs whole jobs");
@@ -1374,6 +1374,8 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
         //   triage: the fresh pass only tests the records, the misses are searched as dense waves by the second pass --
         //     when most queries of the previous iteration hit (a miss among 64 lanes makes the whole wave search).
         bool rec_on = false, triage = false;
+        const int sw_umax = (sw_cache2 >> 8) & 0xFFFF;           // most points of a wave's union window
+        const bool union_on = it < (sw_cache2 & 255) && sw_umax > 0; // iterations that use the union scan
         float mu2 = 0.0f; // additive part of the records' margin (squared): searched window = M2 * bound + mu2
 
         // ---- A+B: cur = Ti * (T0 * src); exact NN for every pair that can matter.  Round 0 searches
@@ -1671,6 +1673,102 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
                     bool lane_done = !valid || skip || grid_hit || grid_defer || rec_hit || !(px == px && py == py);
                     bool pending = false; // holds a strip it could not start or finish within the budget
                     bool own_fin = own_done;
+                    // ---- union scan (the wide windows of the first iterations) ----
+                    // While the clouds are still decimetres apart a query's window holds dozens of candidates and the
+                    // lane-private walks run at a third of the lanes (a wave pays for its longest walk, ~200 instructions
+                    // per evaluated candidate all told).  The 64 queries of a wave are neighbours in space (sorted by strip
+                    // and x), so their windows overlap: the wave takes the UNION -- per strip the positions between
+                    // min(px) - r and max(px) + r, r = the largest bound any of its lanes holds -- and every lane evaluates
+                    // every point of it against its own query: broadcast LDS reads, no cursors, no divergence, 5.5 VALU per
+                    // pair (chunk minima by v_min3, then the chunk that first attained the minimum is looked at again for
+                    // the position; equal minima elsewhere = a possible tie, resolved the usual way).  A superset of every
+                    // lane's own window, so each lane has searched completely when the scan ends.  Only lanes that hold a
+                    // bound take part (a target within maxDist is known); a union beyond sw_umax points falls back to the walks.
+                    if (LDS_TGT && union_on && !rec_on) { // (a search that leaves clearance records must know its runner-up: the walks do)
+                        const bool part = !lane_done && best < r2m_up;
+                        if (__ballot(part)) {
+                            const float ru = f_add(f_mul(sqrtf(-wave_min(part ? -fminf(best, C) : 0.0f)), 1.0001f), 1e-6f);
+                            const float ux0 = f_add(wave_min(part ? px : INFINITY), -ru), ux1 = f_add(-wave_min(part ? -px : INFINITY), ru);
+                            const float uy0 = f_add(wave_min(part ? py : INFINITY), -ru), uy1 = f_add(-wave_min(part ? -py : INFINITY), ru);
+                            const int s_lo = __builtin_amdgcn_readfirstlane(strip_of(uy0, ylo, inv_g, nst));
+                            const int s_hi = __builtin_amdgcn_readfirstlane(strip_of(uy1, ylo, inv_g, nst));
+                            // 64-ary search in [first, sent): first position whose x is not < xq (incl = false) / is > xq (incl = true)
+                            auto coop_bound = [&](int first, int sent, float xq, bool incl) {
+                                int lo = first, hi = sent;
+                                for (int g2 = 0; g2 < 8 && hi - lo > 64; ++g2) {
+                                    const int step = (hi - lo + 63) >> 6;
+                                    const int pp = lo + lane * step;
+                                    const bool inb = pp < hi;
+                                    const float x = T[inb ? pp : lo].x;
+                                    const int c = __popcll(__ballot(inb && (incl ? x <= xq : x < xq)));
+                                    if (c == 0) {
+                                        hi = lo;
+                                    } else {
+                                        const int nlo = lo + (c - 1) * step + 1;
+                                        hi = min(lo + c * step, hi);
+                                        lo = nlo;
+                                    }
+                                }
+                                const int pp = lo + lane;
+                                const bool inb = pp < hi;
+                                const float x = T[inb ? pp : lo].x;
+                                return lo + __popcll(__ballot(inb && (incl ? x <= xq : x < xq)));
+                            };
+                            // the union's range in every strip it touches (lane k keeps strip s_lo + k's), and its size
+                            int my_lo = 0, my_hi = 0, total = 0;
+                            for (int su = s_lo; su <= s_hi; ++su) {
+                                const int first = tab.sbeg[su], sent = tab.sbeg[su + 1] - 1;
+                                const int a = coop_bound(first, sent, ux0, false), b = coop_bound(first, sent, ux1, true);
+                                if (lane == su - s_lo) {
+                                    my_lo = a;
+                                    my_hi = b;
+                                }
+                                total += max(b - a, 0);
+                            }
+                            if (total <= sw_umax) {
+                                if (PROF)
+                                    c_eval += (unsigned long long)total * (unsigned long long)__popcll(__ballot(part));
+                                float bs = __uint_as_float(__float_as_uint(best) + 1u); // (the witness is found again like any other point)
+                                int bch = -1, bsent = 0;
+                                bool eqc = false;
+                                for (int su = s_lo; su <= s_hi; ++su) {
+                                    const int a = __builtin_amdgcn_readlane(my_lo, su - s_lo), b = __builtin_amdgcn_readlane(my_hi, su - s_lo);
+                                    const int sent = tab.sbeg[su + 1] - 1; // the strip's NaN sentinel pads its last chunk
+                                    for (int jb = a; jb < b; jb += 16) {
+                                        float cmin = INFINITY;
+#pragma unroll
+                                        for (int k = 0; k < 16; k += 2) {
+                                            const float2 t0 = T[min(jb + k, sent)], t1 = T[min(jb + k + 1, sent)];
+                                            cmin = fminf(fminf(cmin, dist2(px, py, t0.x, t0.y)), dist2(px, py, t1.x, t1.y));
+                                        }
+                                        if (cmin < bs) {
+                                            bs = cmin;
+                                            bch = jb;
+                                            bsent = sent;
+                                            eqc = false;
+                                        } else if (cmin == bs) {
+                                            eqc = true;
+                                        }
+                                    }
+                                }
+                                if (part && bch >= 0) {
+                                    int hits = 0, pos = 0;
+                                    for (int k = 0; k < 16; ++k) {
+                                        const int j = min(bch + k, bsent);
+                                        const float2 t = T[j];
+                                        if (dist2(px, py, t.x, t.y) == bs) {
+                                            pos = hits ? pos : j;
+                                            ++hits;
+                                        }
+                                    }
+                                    best = bs;
+                                    bpos = pos;
+                                    tied = eqc || hits > 1;
+                                    lane_done = true; // searched completely
+                                }
+                            }
+                        }
+                    }
                     // A query that comes to a later pass still WITHOUT any target within maxDist (put off without a
                     // witness, or nothing met within the first pass's budget) has nothing that bounds its search: its
                     // window is the whole maxDist box, hundreds to thousands of candidates, and the other 63 lanes of its
@@ -2361,7 +2459,7 @@ struct SweepLaunchArgs {
     int32_t *d_status, *d_iters;
     long long *d_prof;
     int *d_dbg;
-    int sw_budget, sw_budget_a, sw_cache;
+    int sw_budget, sw_budget_a, sw_cache, sw_cache2;
     float sw_m, sw_kappa;
     unsigned long long *d_sync;
 };
@@ -2392,7 +2490,7 @@ int sweep_launch_loop(const SweepLaunchArgs &a, int n, const int *d_ids, size_t 
     hipLaunchKernelGGL(kernel, dim3(n), dim3(NT), smem, ctx->stream, *a.p, a.d_jobs, d_ids, a.d_src, a.d_guess9, a.d_stgt,
                        a.d_perm, a.d_snrm, a.d_mean, a.d_tab, a.d_grid, a.d_qst, a.d_qwl, a.d_qssrc, a.d_nn_d2, a.d_nn_pos,
                        a.d_T9, a.d_status, a.d_iters, a.d_prof, a.d_dbg, a.sw_budget, a.sw_budget_a, a.sw_cache, t_cap, q_cap,
-                       pow2_floor(body / 8), a.sw_m, a.sw_kappa, a.d_sync);
+                       pow2_floor(body / 8), a.sw_m, a.sw_kappa, a.d_sync, a.sw_cache2);
     SFE_LAUNCH_CHECK(ctx);
     return 0;
 }
@@ -2756,6 +2854,14 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
     a.sw_budget = env_int("SFE_SW_BUDGET", SW_BUDGET);
     a.sw_budget_a = env_int("SFE_SW_BUDGET_A", SW_BUDGET_A);
     a.sw_cache = sw_cache;
+    // union scan of the first iterations: bits 0..7 = iterations that use it, bits 8..23 = most points of a union window.
+    // Measured (1024 jobs of 5000 x 5000, search cycles of workgroup 0 per iteration, walks -> union): iteration 0
+    // 997 k -> 828 k, iteration 1 486 k -> 659 k, iteration 2 324 k -> 585 k: only the first iteration's windows (bounds
+    // from grid witnesses, ~0.9 m) are wide enough for the union of 64 neighbours' windows (~400 points) to beat the
+    // private walks; from the second iteration on a query's old neighbour bounds it to a few dozen candidates.  Whole
+    // launch: p2plane30 8.78-8.87 -> 8.64-8.76 ms, shipped chain 4.07 -> 3.93-4.00 ms per 1024 jobs.
+    a.sw_cache2 = std::max(0, std::min(255, env_int("SFE_SW_UNION_ITERS", 1))) |
+                  (std::max(0, std::min(65535, env_int("SFE_SW_UNION_MAX", 768))) << 8);
     // margin of the clearance records: a search looks this fraction further (in radius) than it has to ...
     a.sw_m = 0.01f * (float)std::max(1, std::min(100, env_int("SFE_SW_RECM", SW_REC_MARGIN)));
     // ... plus sw_kappa x the largest movement of the last step (the steps shrink geometrically once ICP converges: a
