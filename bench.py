@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--no-farm", action="store_true", help="skip the BASELINE configs[3] leg (job farm on this device)")
     ap.add_argument("--farm-jobs", type=int, default=10000)
     ap.add_argument("--no-latency", action="store_true", help="skip the live single-ping / single-scan-match latency leg")
+    ap.add_argument("--distinct-frames", type=int, default=256,
+                    help="distinct synthetic pings behind the batch's frames (tiled to --batch); beyond the first 32 they are "
+                         "screened on the device, untimed: a ping with more points than the batch's capacity is left out")
     ap.add_argument("--no-legs", action="store_true",
                     help="skip the legs beyond the timed step: reference_chain, real_size, configs4_hires, float_oracle, stream_frames")
     ap.add_argument("--small-legs", action="store_true", help="those legs at a fraction of their size (tests)")
@@ -348,6 +351,32 @@ def main():
         fes.append(f)
         kbs.append(b)
     ctx, fe, kb = ctxs[0], fes[0], kbs[0]
+    # More distinct pings than the 32 the CPU baseline sampled (the data-dependent kernels saw 32 patterns):
+    # candidates are generated and screened on the device, untimed -- a ping whose detections exceed the batch's point
+    # capacity would be an error on the resident path -- and the batch's frames are re-tiled over the accepted ones.
+    n_distinct = min(args.batch, 32)
+    if args.distinct_frames > 32 and args.batch > 32:
+        from sonar_slam_amd import synth
+        want = min(args.distinct_frames, args.batch)
+        accepted = [frames[j] for j in range(32)]
+        seed = 1000 * rank + 32
+        while len(accepted) < want and seed < 1000 * rank + 32 + 2 * want:
+            cand = np.stack([synth.sonar_frame(seed=seed + j) for j in range(min(64, args.batch))])
+            seed += len(cand)
+            kb.d_img.upload(cand, offset=0)
+            kb.run_cfar()
+            kb.run_extract()
+            ctx.sync()
+            cnt = kb.d_cnt.download(np.int32, len(cand))
+            accepted += [cand[j] for j in range(len(cand)) if cnt[j] <= kb.cap]
+        accepted = accepted[:want]
+        n_distinct = len(accepted)
+        frames = np.stack([accepted[j % n_distinct] for j in range(args.batch)])
+        for b in kbs:
+            b.upload_frames(frames)
+            b.run(not args.no_filters)
+        for c in ctxs:
+            c.sync()
 
     def barrier():
         for c in ctxs:
@@ -451,7 +480,7 @@ def main():
                                    " -> remap+nonzero+px2m%s -> 5000x5000-pt ICP (%s)"
                                    % (args.batch, "" if args.no_filters else " -> downsample 0.5 -> remove_outlier 1.0/5",
                                       args.icp_mode),
-                       "batch_per_gpu": args.batch, "icp_mode": args.icp_mode, "parallelism": "job farm x%d" % world,
+                       "batch_per_gpu": args.batch, "distinct_frames": n_distinct, "icp_mode": args.icp_mode, "parallelism": "job farm x%d" % world,
                        "icp_prep_stream": "main" if args.serial_prep else "side", "batches_in_flight": n_inflight,
                        "icp_converged_jobs": ok, "mean_icp_iters": iters_total / float(args.batch),
                        "mean_points_per_frame": float(res["counts"].mean()),
