@@ -92,6 +92,31 @@ def test_float_images_take_the_float_path(alg):
     assert np.array_equal(FN[alg](img.astype(np.float64), *p), mo)
 
 
+@pytest.mark.parametrize("shape", [(1024, 512), (300, 260), (131, 128), (64, 516), (52, 4)])
+def test_os_behind_a_gate_counts_candidates_only(shape, monkeypatch):
+    """OS-CFAR with the intensity gate of feature_extraction.py:224 goes through cfar_u8_os_gated (only the pixels above
+    the gate are looked at: at least k + 1 training cells <= L[x]); same masks as the oracle and as the histogram kernel,
+    for shipped and odd windows, gates from 0 (nearly every pixel a candidate) to 250, tiles that end inside the image,
+    all-255 and all-0 frames, k at both ends"""
+    rows, cols = shape
+    monkeypatch.setenv("SFE_CFAR_OS_GATED_MIN", "0")      # every gate through the candidates-only kernel
+    rng = np.random.default_rng(rows * 7 + cols)
+    first = (synth.sonar_frame(seed=rows + cols, rows=rows, cols=cols, n_blobs=12) if rows > 61 and cols > 11
+             else rng.integers(40, 256, (rows, cols)).astype(np.uint8))
+    imgs = [first, rng.integers(0, 256, (rows, cols)).astype(np.uint8), np.full((rows, cols), 255, np.uint8),
+            np.zeros((rows, cols), np.uint8)]
+    for (th, gh, k, tau) in ((20, 5, 10, 9.137608674642355), (6, 2, 0, 1.3), (6, 2, 11, 0.9), (3, 0, 5, 2.0)):
+        for gate in (0, 20, 65, 250):   # (0 and 20 take the histogram kernel by default, the others the candidates-only one)
+            for img in imgs:
+                want = oracle.gate(img, oracle.cfar(img, "OS", th, gh, tau, k), gate)
+                got = cfar.detect_gated(img, "OS", (th, gh, k, tau), gate)
+                assert np.array_equal(got, want), (shape, th, gh, k, gate)
+    monkeypatch.setenv("SFE_CFAR_NO_OS_GATED", "1")     # A/B: the histogram kernel gives the same
+    img = imgs[0]
+    assert np.array_equal(cfar.detect_gated(img, "OS", (20, 5, 10, 9.137608674642355), 65),
+                          oracle.gate(img, oracle.cfar(img, "OS", 20, 5, 9.137608674642355, 10), 65))
+
+
 def test_fused_intensity_gate(shipped_cfar):
     img = synth.sonar_frame(seed=2)
     for alg in ALGS:
