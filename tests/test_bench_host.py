@@ -85,3 +85,33 @@ def test_parity_check_accepts_correct_outputs_and_raises_on_wrong_ones():
     kb.p[0] = kb.p[0][::-1].copy()          # right points, wrong order
     with pytest.raises(AssertionError):
         bench.parity_check(kb, res, frames, srcs, tgts, guesses, det, fe, "reference", True, 2)
+
+
+def test_leg_checker_accepts_the_oracle_and_raises_on_a_wrong_pose_status_or_iteration_count():
+    """tools/bench_legs.check_against_oracle guards every ICP leg of the bench line: status and iteration count equal to
+    the oracle with fp64 sums, pose within the tolerance, else AssertionError; the float-oracle statistic rides along."""
+    import pytest
+
+    import oracle
+    sys.path.insert(0, os.path.join(bench.ROOT, "tools"))
+    import bench_legs
+    from sonar_slam_amd import synth
+    jobs = [synth.scan_pair(seed=60 + i, n_src=300, n_tgt=280)[:3] for i in range(4)]
+    ref = [oracle.icp(s, t, g, oracle.shipped_icp_params(precision=1)) for s, t, g in jobs]
+    T = np.stack([r[1] for r in ref])
+    st = np.array([r[0] for r in ref])
+    it = np.array([r[2] for r in ref])
+    ok = bench_legs.check_against_oracle("t", jobs, (T, st, it), {}, threads=2)
+    assert ok["jobs"] == 4 and ok["max_pose_diff_vs_f64_oracle"] == 0.0 and ok["float_oracle_beyond_1e-4"].endswith("/ 4")
+    bad = T.copy()
+    bad[2, 1, 2] += 5e-6
+    with pytest.raises(AssertionError, match="pose"):
+        bench_legs.check_against_oracle("t", jobs, (bad, st, it), {}, threads=2)
+    with pytest.raises(AssertionError, match="status/iterations"):
+        bench_legs.check_against_oracle("t", jobs, (T, st, it + 1), {}, threads=2)
+    with pytest.raises(AssertionError, match="status/iterations"):
+        bench_legs.check_against_oracle("t", jobs, (T, st + 1, it), {}, threads=2)
+    # the oracle is reentrant: the same jobs on several threads give the same answers (kd-tree on)
+    again = bench_legs.oracle_many(jobs * 4, {}, threads=8)
+    for j, (r64, r32) in enumerate(again):
+        assert r64[0] == ref[j % 4][0] and r64[2] == ref[j % 4][2] and np.array_equal(r64[1], ref[j % 4][1])
