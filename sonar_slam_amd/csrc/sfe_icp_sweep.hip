@@ -217,7 +217,7 @@ template <int NT, int TCAP>
 struct PrepShared {
     // first the sort keys, then (same bytes) the sorted cloud with its sentinels
     unsigned long long buf[TCAP + SW_PAD + 4];
-    double red[(NT / 64) * 2 + 2];
+    double red[16 * 2 + 2]; // (sized for the 16 waves whose order every build reproduces, see the mean below)
     float mean[2];
     unsigned ykey[2], xkey[2]; // min / max order keys of the finite centred coordinates
     int cnt[SW_NS_MAX];
@@ -560,15 +560,42 @@ __global__ __launch_bounds__(NT, 4) void icp_sweep_prep_kernel(sfe_icp_params P,
     int *__restrict__ perm = perm_all + J.off;
     const float qnan = __uint_as_float(0x7FC00000u);
 
-    // reference mean (fp64 accumulation, rounded to float), as the brute-force kernel
+    // reference mean (fp64 accumulation, rounded to float), as the brute-force kernel -- and in ITS order whatever NT is:
+    // point i belongs to thread i mod 1024 of a 1024-thread workgroup, 64 consecutive threads are a wave (fixed tree), the
+    // 16 wave totals are added left to right.  A smaller workgroup plays those waves one after the other (a target of a
+    // few points makes the ICP sums rank-deficient, and then the last bit of the mean decides the outcome).
     {
         double m[2] = {0, 0};
-        for (int i = tid; i < nt; i += NT) {
-            const float2 t = tgt[i];
-            m[0] += t.x;
-            m[1] += t.y;
+        if constexpr (NT == 1024) {
+            for (int i = tid; i < nt; i += NT) {
+                const float2 t = tgt[i];
+                m[0] += t.x;
+                m[1] += t.y;
+            }
+            block_sum<2, NT>(m, S.red);
+        } else {
+            const int wave = tid >> 6;
+            for (int w0 = wave; w0 < 16; w0 += NT / 64) {
+                double a0 = 0, a1 = 0;
+                for (int i = 64 * w0 + lane; i < nt; i += 1024) {
+                    const float2 t = tgt[i];
+                    a0 += t.x;
+                    a1 += t.y;
+                }
+                a0 = wave_sum(a0);
+                a1 = wave_sum(a1);
+                if (lane == 0) {
+                    S.red[2 * w0] = a0;
+                    S.red[2 * w0 + 1] = a1;
+                }
+            }
+            __syncthreads();
+            for (int w = 0; w < 16; ++w) { // (every thread: the same sixteen additions)
+                m[0] += S.red[2 * w];
+                m[1] += S.red[2 * w + 1];
+            }
+            __syncthreads();
         }
-        block_sum<2, NT>(m, S.red);
         if (tid == 0) {
             S.mean[0] = (float)(m[0] / nt);
             S.mean[1] = (float)(m[1] / nt);
@@ -849,7 +876,7 @@ __device__ __forceinline__ long long sw_uniform_ll(long long v)
 // run many workgroups per CU: every KB of control block is a job less per CU).
 template <int NT, bool PROF, bool REC>
 struct SweepShared {
-    double red[(NT / 64) * 10 + 10];
+    double red[(NT / 64) * 10 + 10 > 16 * 5 ? (NT / 64) * 10 + 10 : 16 * 5]; // (16 x 5: the canonical order of the sums, below)
     double acc[10];  // the reduced error-minimiser sums (read by the solving lane)
     unsigned hist[256], hist0[256];
     unsigned sel_prefix, sel_k;
@@ -1943,8 +1970,119 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
                     }
                 }
                 };
+                // The fresh pass of an iteration in triage mode (most queries are settled by their clearance records): the same
+                // decisions as walk_pass(fresh) takes when it does not search -- transform, witness, record / clearance
+                // test, classification, the misses handed to the second pass -- as a loop of its own.  walk_pass carries
+                // the whole search state through its body (the 64-VGPR builds spill ~85 registers there); here a lane holds
+                // a dozen values.  A late iteration of the 5000 x 5000 job spent 55 k of its 134 k cycles in this pass.
+                auto triage_pass = [&]() {
+                    const float sC = f_mul(sqrtf(C), 1.00001f);
+                    int *wl_next = Q.wl[cur ^ 1];
+                    // (query index, source point, record) of the next slice are requested a slice ahead: three words from HBM
+                    // scratch whose latency would otherwise stand in front of every slice
+                    int q_n = 0;
+                    float2 sp_n = make_float2(0, 0);
+                    unsigned rec_n = 0u;
+                    if (tid < ns) {
+                        q_n = Q.order[tid];
+                        sp_n = Q.ssrc[tid];
+                        rec_n = Q.rec[tid];
+                    }
+                    for (int k0 = 0; k0 < ns; k0 += NT) {
+                        const int slot = k0 + tid;
+                        const bool valid = slot < ns;
+                        int q = 0, bpos = 0;
+                        float px = 0, py = 0, best = W2;
+                        bool skip = false, rec_hit = false;
+                        const int q_c = q_n;
+                        const float2 sp = sp_n;
+                        const unsigned rec = rec_n;
+                        if (slot + NT < ns) {
+                            q_n = Q.order[slot + NT];
+                            sp_n = Q.ssrc[slot + NT];
+                            rec_n = Q.rec[slot + NT];
+                        }
+                        if (valid) {
+                            q = q_c;
+                            const int prev = Pz(q);
+                            const float2 p = xform(Ti, sp);
+                            px = p.x;
+                            py = p.y;
+                            const int w = prev >= 0 ? prev + 1 : (prev <= -3 ? -2 - prev : 0);
+                            if (w) {
+                                const float2 t = T[w];
+                                const float dxw = f_add(px, -t.x), dyw = f_add(py, -t.y);
+                                const float dw = f_add(f_mul(dxw, dxw), f_mul(dyw, dyw));
+                                if (dw < best) {
+                                    best = dw;
+                                    bpos = w;
+                                    if (rec != 0u && (int)(rec & 63u) >= rec_epoch && dw < r2m_up) {
+                                        const float ux = f_add(px, -Ti[2]), uy = f_add(py, -Ti[5]);
+                                        const float xr = f_mul(sqrtf(f_add(f_mul(ux, ux), f_mul(uy, uy))), 1.0001f);
+                                        const float mv = f_add(f_mul(S.mva[rec & 63u], xr), S.mvt[rec & 63u]);
+                                        const float Ro = f_add(__uint_as_float(rec & ~63u), -mv);
+                                        rec_hit = f_mul(sqrtf(dw), 1.00001f) < Ro || (dw > C && sC < Ro);
+                                    }
+                                }
+                            } else if (prev == SW_NONE) {
+                                const int4 r = Q.st[q];
+                                const float mx0 = f_add(px, -__int_as_float(r.x)), my0 = f_add(py, -__int_as_float(r.y));
+                                const float mv = sqrtf(f_add(f_mul(mx0, mx0), f_mul(my0, my0)));
+                                skip = f_mul(mv, 1.00001f) < __int_as_float(r.z); // NaN -> search
+                            }
+                        }
+                        {
+                            const unsigned long long mh = __ballot(rec_hit);
+                            if (mh && lane == 0)
+                                atomicAdd(&S.n_rechit[it & 1], (unsigned)__popcll(mh));
+                        }
+                        const bool lane_done = !valid || skip || rec_hit || !(px == px && py == py);
+                        const bool is_long = valid && !lane_done; // a miss: the second pass searches it
+                        const bool settled = valid && lane_done;
+                        const bool found = best < r2m_up;
+                        const bool is_none = settled && !found;
+                        const bool is_exact = settled && found && best <= C;
+                        const bool is_susp = settled && found && !(best <= C);
+                        if (is_none) {
+                            setQ(q, INFINITY, SW_NONE);
+                            if (!skip)
+                                Q.st[q] = make_int4(__float_as_int(px), __float_as_int(py),
+                                                    __float_as_int(f_add(f_mul(sqrtf(best), 0.99999f), -md_hi)), 0);
+                        }
+                        if (is_exact)
+                            setQ(q, best, bpos - 1);
+                        if (is_susp || is_long)
+                            setQ(q, best, SW_INEXACT_OF(bpos));
+                        if (is_long) { // (nothing visited yet: no runner-up, no record meanwhile)
+                            Q.st[q].z = __float_as_int(INFINITY);
+                            Q.rec[slot] = 0u;
+                        }
+                        tally_settled(is_none, is_exact, best);
+                        const unsigned long long ms = __ballot(is_susp), ml = __ballot(is_long);
+                        const unsigned long long below = (1ull << lane) - 1ull;
+                        if (ms) {
+                            int base = 0;
+                            if (lane == 0)
+                                base = atomicAdd(&S.wl_n[cur ^ 1], __popcll(ms));
+                            base = __builtin_amdgcn_readfirstlane(base);
+                            if (is_susp)
+                                wl_next[base + __popcll(ms & below)] = q;
+                        }
+                        if (ml) {
+                            int base = 0;
+                            if (lane == 0)
+                                base = atomicAdd(&S.mid_n, __popcll(ml));
+                            base = __builtin_amdgcn_readfirstlane(base);
+                            if (is_long)
+                                Q.mid[base + __popcll(ml & below)] = (int)((unsigned)q | SW_PARTIAL);
+                        }
+                    }
+                };
                 if (round == 0) {
-                    walk_pass(wl, nwork, true, sw_budget_a, false);
+                    if (REC && triage && (sw_cache & (1 << 25)) != 0)
+                        triage_pass();
+                    else
+                        walk_pass(wl, nwork, true, sw_budget_a, false);
                     __syncthreads();
                     SW_PROF(1);
                     if (PROF && tid == 0)
@@ -2219,16 +2357,20 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
 
         // ---- D: error minimiser sums over the kept pairs, in two halves of five accumulators: ten fp64
         // accumulators per lane do not fit the 64-VGPR budget next to the loop state (they spilled) ----
+        // The order of these sums is that of a 1024-thread workgroup whatever NT is: query i belongs to thread i mod 1024,
+        // 64 consecutive threads are a wave (its fixed tree), the 16 wave totals are added left to right.  The smaller
+        // builds play those waves one after the other.  (On a rank-deficient problem -- a target of three points -- the
+        // sums are rounding noise that the solve amplifies without bound: only the same order gives the same result
+        // as the other kernels; tools/icp_soak.py found such jobs at 6 in 100 000 before.)
         auto sums = [&](auto lo_tag) {
             constexpr int LO = decltype(lo_tag)::value;
-            double a5[5] = {0, 0, 0, 0, 0};
-            for (int i = tid; i < ns; i += NT) {
+            auto terms = [&](int i, double (&a5)[5]) {
                 const int id = Pz(i);
                 const float d = Dz(i);
                 const bool ok = id >= 0 && (!P.use_max_dist_filter || d <= r2_filter) &&
                                 (!P.use_trimmed_filter || d <= limit);
                 if (!ok)
-                    continue;
+                    return;
                 const float2 p = xform(Ti, src[i]);
                 const double px = p.x, py = p.y;
                 const float2 q = T[id + 1];
@@ -2263,12 +2405,39 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
 #pragma unroll
                 for (int k = 0; k < 5; ++k)
                     a5[k] += t[LO + k];
-            }
-            block_sum<5, NT>(a5, S.red);
-            if (tid == 0) {
+            };
+            if constexpr (NT == 1024) {
+                double a5[5] = {0, 0, 0, 0, 0};
+                for (int i = tid; i < ns; i += NT)
+                    terms(i, a5);
+                block_sum<5, NT>(a5, S.red);
+                if (tid == 0) {
 #pragma unroll
-                for (int k = 0; k < 5; ++k)
-                    S.acc[LO + k] = a5[k];
+                    for (int k = 0; k < 5; ++k)
+                        S.acc[LO + k] = a5[k];
+                }
+            } else {
+                const int wave = tid >> 6;
+                const int roles = min(16, (ns + 63) >> 6); // (the waves beyond hold no query: their totals are 0.0)
+                for (int w0 = wave; w0 < roles; w0 += NT / 64) {
+                    double a5[5] = {0, 0, 0, 0, 0};
+                    for (int i = 64 * w0 + lane; i < ns; i += 1024)
+                        terms(i, a5);
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) {
+                        const double sk = wave_sum(a5[k]);
+                        if (lane == 0)
+                            S.red[5 * w0 + k] = sk;
+                    }
+                }
+                __syncthreads();
+                if (tid < 5) {
+                    double sk = 0;
+                    for (int w = 0; w < roles; ++w)
+                        sk += S.red[5 * w + tid];
+                    S.acc[LO + tid] = sk;
+                }
+                __syncthreads();
             }
         };
         sums(std::integral_constant<int, 0>());
@@ -2813,6 +2982,7 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
                          (env_int("SFE_SW_TRIAGE", 1) ? 32 : 0) |   // bit 5: ... with triage passes
                          (env_int("SFE_SW_GRID_DEFER", 1) ? 64 : 0) | // bit 6: first iteration: queries without a witness wait for round 1
                          (env_int("SFE_SW_UNBOUNDED_COOP", 1) ? 128 : 0) | // bit 7: later passes: unbounded queries -> cooperative tier
+                         (env_int("SFE_SW_LEAN_TRIAGE", 1) ? (1 << 25) : 0) |  // bit 25: the triage pass as a loop of its own
                          (env_int("SFE_SW_JUMP", 1) ? 2 : 0) |
                          // bits 16..23: margin (percent) of the next iteration's cap over this iteration's limit
                          (std::max(0, std::min(255, env_int("SFE_SW_MARGIN", SW_CAP_MARGIN))) << 16) |

@@ -62,14 +62,14 @@ __global__ __launch_bounds__(SW_TINY_NT, 4) void icp_tiny_kernel(
     // mean is taken here, in the summation order of a one-wave preparation (block_sum<2, 64>).
     float mx, my;
     if (P.minimizer == 0) {
+        // (64 consecutive points = one wave of the 1024-thread kernels: their tree, then the waves in order)
         double m0 = 0, m1 = 0;
-        for (int i = lane; i < nt; i += SW_TINY_NT) {
-            const float2 t = tgt[i];
-            m0 += t.x;
-            m1 += t.y;
+        for (int i0 = 0; i0 < nt; i0 += SW_TINY_NT) {
+            const int i = i0 + lane;
+            const float2 t = i < nt ? tgt[i] : make_float2(0.0f, 0.0f);
+            m0 += wave_sum(i < nt ? (double)t.x : 0.0);
+            m1 += wave_sum(i < nt ? (double)t.y : 0.0);
         }
-        m0 = 0.0 + wave_sum(m0);
-        m1 = 0.0 + wave_sum(m1);
         mx = sw_uniform((float)(m0 / nt));
         my = sw_uniform((float)(m1 / nt));
     } else {
@@ -245,50 +245,60 @@ __global__ __launch_bounds__(SW_TINY_NT, 4) void icp_tiny_kernel(
             }
             limit = sw_uniform(__uint_as_float(prefix));
         }
-        // ---- error minimiser: sums over the kept pairs, per lane in query order, fp64 ----
+        // ---- error minimiser: sums over the kept pairs, fp64, in the order of the 1024-thread kernels (query i = their
+        // thread i, 64 consecutive queries = one of their waves: the wave's fixed tree, then the waves left to right).
+        // The sums of a rank-deficient problem (a target of three points) are rounding noise that the solve amplifies
+        // without bound: with any other order such jobs would come out differently from the other kernels. ----
         double acc[10];
 #pragma unroll
         for (int k = 0; k < 10; ++k)
             acc[k] = 0.0;
-        for (int i = lane; i < ns; i += SW_TINY_NT) {
-            const int id = (int)s_idx[i];
-            const float d = s_d2[i];
-            const bool ok = id >= 0 && (!P.use_max_dist_filter || d <= r2_filter) && (!P.use_trimmed_filter || d <= limit);
-            if (!ok)
-                continue;
-            const float2 p = xform(Ti, src[i]);
-            const double px = p.x, py = p.y;
-            const float2 q = s_tgt[id];
-            const double qx = q.x, qy = q.y;
-            acc[0] += 1.0;
-            if (P.minimizer == 0) {
-                acc[1] += px;
-                acc[2] += py;
-                acc[3] += qx;
-                acc[4] += qy;
-                acc[5] += qx * px;
-                acc[6] += qx * py;
-                acc[7] += qy * px;
-                acc[8] += qy * py;
-            } else {
-                const float2 n = s_nrm[id];
-                const double nx = n.x, ny = n.y;
-                const double a0 = px * ny - py * nx;
-                const double e = nx * (px - qx) + ny * (py - qy);
-                acc[1] += a0 * a0;
-                acc[2] += a0 * nx;
-                acc[3] += a0 * ny;
-                acc[4] += nx * nx;
-                acc[5] += nx * ny;
-                acc[6] += ny * ny;
-                acc[7] += -(a0 * e);
-                acc[8] += -(nx * e);
-                acc[9] += -(ny * e);
-            }
-        }
+        for (int i0 = 0; i0 < ns; i0 += SW_TINY_NT) {
+            const int i = i0 + lane;
+            double t[10];
 #pragma unroll
-        for (int k = 0; k < 10; ++k)
-            acc[k] = wave_sum(acc[k]);
+            for (int k = 0; k < 10; ++k)
+                t[k] = 0.0;
+            const int id = i < ns ? (int)s_idx[i] : -1;
+            const float d = i < ns ? s_d2[i] : INFINITY;
+            const bool ok = id >= 0 && (!P.use_max_dist_filter || d <= r2_filter) && (!P.use_trimmed_filter || d <= limit);
+            if (ok) {
+                const float2 p = xform(Ti, src[i]);
+                const double px = p.x, py = p.y;
+                const float2 q = s_tgt[id];
+                const double qx = q.x, qy = q.y;
+                t[0] = 1.0;
+                if (P.minimizer == 0) {
+                    t[1] = px;
+                    t[2] = py;
+                    t[3] = qx;
+                    t[4] = qy;
+                    t[5] = qx * px;
+                    t[6] = qx * py;
+                    t[7] = qy * px;
+                    t[8] = qy * py;
+                } else {
+                    const float2 n = s_nrm[id];
+                    const double nx = n.x, ny = n.y;
+                    const double a0 = px * ny - py * nx;
+                    const double e = nx * (px - qx) + ny * (py - qy);
+                    t[1] = a0 * a0;
+                    t[2] = a0 * nx;
+                    t[3] = a0 * ny;
+                    t[4] = nx * nx;
+                    t[5] = nx * ny;
+                    t[6] = ny * ny;
+                    t[7] = -(a0 * e);
+                    t[8] = -(nx * e);
+                    t[9] = -(ny * e);
+                }
+            }
+            const int nk = P.minimizer == 0 ? 9 : 10;
+#pragma unroll
+            for (int k = 0; k < 10; ++k)
+                if (k < nk)
+                    acc[k] += wave_sum(0.0 + t[k]);
+        }
         // ---- solve, compose, check (one lane) ----
         if (lane == 0) {
             int status, iterate;

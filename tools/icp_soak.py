@@ -13,6 +13,9 @@ from sonar_slam_amd import _lib, icp_config, pcl, synth  # noqa: E402
 from sonar_slam_amd._lib import IcpParams  # noqa: E402
 
 
+LAST = {}
+
+
 def both(ctx, p, srcs, tgts, gs):
     out = []
     for v in (0, 4):
@@ -22,6 +25,7 @@ def both(ctx, p, srcs, tgts, gs):
         out.append(icp.compute_pairs(srcs, tgts, gs))
     ctx._check(ctx.lib.sfe_icp_set_tuning(ctx.handle, 0))
     a, b = out
+    LAST.update(a=a, b=b)
     return a[0] == b[0] and np.array_equal(a[1], b[1], equal_nan=True) and np.array_equal(a[2], b[2])
 
 
@@ -68,6 +72,15 @@ def main():
         if not ok:
             bad += 1
             print("MISMATCH small", p.as_dict(), flush=True)
+            a_, b_ = LAST["a"], LAST["b"]
+            for j in range(len(srcs)):       # which jobs, and by how much
+                if a_[0][j] != b_[0][j] or a_[2][j] != b_[2][j] or not np.array_equal(a_[1][j], b_[1][j], equal_nan=True):
+                    print("   job %d: %d x %d points, messages %r / %r, iterations %d / %d, max |dT| %.3e"
+                          % (j, len(srcs[j]), len(tgts[j]), a_[0][j], b_[0][j], a_[2][j], b_[2][j],
+                             float(np.nanmax(np.abs(a_[1][j] - b_[1][j])))), flush=True)
+            os.makedirs("gpurun_out", exist_ok=True)
+            np.savez("gpurun_out/icp_soak_mismatch_%d.npz" % bad, params=np.array(list(p.as_dict().items()), dtype=object),
+                     srcs=np.array(srcs, dtype=object), tgts=np.array(tgts, dtype=object), gs=np.stack(gs), allow_pickle=True)
     print("soak: %d bench-size and %d small scan matches compared in %.0f s, %d mismatching batches"
           % (n_big, n_small, time.time() - t0, bad))
     sys.exit(1 if bad else 0)
