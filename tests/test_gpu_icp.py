@@ -423,6 +423,38 @@ def test_sweep_vs_brute_force_fuzz(ctx):
     assert 0 < n_fail < 200      # the fuzz reaches both the success and the failure paths
 
 
+def test_rank_deficient_jobs_come_out_the_same_from_every_kernel(ctx):
+    """A few hundred source points on a target of 2..7 points (duplicates among them): every inlier is matched to one or
+    two points, the point-to-point system is rank-deficient, its sums are rounding noise and the closed-form solve amplifies
+    them without bound -- the last bit of an fp64 sum decides the pose.  Every build adds the mean and the minimiser's
+    sums in the order of a 1024-thread workgroup, so the one-wave kernels still equal the brute-force kernel bit for bit
+    (tools/icp_soak.py found 7 such batches in 113 000 scan matches before that)."""
+    from sonar_slam_amd._lib import IcpParams
+    rng = np.random.default_rng(4711)
+    for rep in range(6):
+        srcs, tgts, gs = [], [], []
+        for _ in range(48):
+            ns, nt = int(rng.integers(150, 320)), int(rng.integers(2, 8))
+            tgt = rng.uniform(-8, 8, (nt, 2)).astype(np.float32)
+            if rng.random() < 0.5:
+                tgt[:, 0] = np.round(tgt[:, 0] * 2) / 2
+            if nt > 3 and rng.random() < 0.6:
+                tgt[nt // 2:] = tgt[:nt - nt // 2]
+            src = (tgt[rng.integers(0, nt, ns)] + rng.normal(0, 0.1, (ns, 2))).astype(np.float32)
+            srcs.append(src)
+            tgts.append(tgt)
+            gs.append(synth.pose_matrix(*rng.normal(0, [0.3, 0.3, 0.05])).astype(np.float32))
+        p = IcpParams(matcher_max_dist=float(rng.choice([0.5, 3.0, 10.0])), use_max_dist_filter=int(rng.integers(0, 2)),
+                      max_dist_filter=float(rng.choice([0.3, 3.0])), use_trimmed_filter=int(rng.integers(0, 2)),
+                      trim_ratio=float(rng.choice([0.3, 1.0])), minimizer=0, max_iter=int(rng.integers(3, 14)),
+                      use_diff_checker=int(rng.integers(0, 2)), min_diff_rot=0.001, min_diff_trans=0.01,
+                      smooth_len=int(rng.integers(1, 4)), normals_knn=10)
+        a = _with_variant(ctx, 0, lambda: _icp(p, ctx).compute_pairs(srcs, tgts, gs))
+        b = _with_variant(ctx, 4, lambda: _icp(p, ctx).compute_pairs(srcs, tgts, gs))
+        assert a[0] == b[0] and np.array_equal(a[2], b[2]), rep
+        assert np.array_equal(a[1], b[1], equal_nan=True), rep
+
+
 def _sweep_vs_brute(ctx, p, src, tgt, guesses):
     a = _with_variant(ctx, 0, lambda: _icp(p, ctx).compute_batch(src, tgt, guesses))
     b = _with_variant(ctx, 4, lambda: _icp(p, ctx).compute_batch(src, tgt, guesses))
