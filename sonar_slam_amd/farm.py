@@ -278,32 +278,52 @@ class IcpFarm(object):
             packed.append((mine, pack_jobs(mine)))
         self._seq += 1
         seq = self._seq
-        sent = []
-        try:
-            # 2. fill the shared-memory blocks and start the workers one after the other
-            for w, (mine, (src_pool, tgt_pool, ns_pts, nt_pts, rows, guesses)) in zip(self._workers, packed):
-                lay = _layout(ns_pts, nt_pts, len(rows))
-                v = _views(w.block(lay["bytes"]).buf, lay)
-                o = 0
-                for c in src_pool:                      # one copy (and the float32 cast) per DISTINCT cloud
-                    v["src"][o:o + len(c)] = c
-                    o += len(c)
-                o = 0
-                for c in tgt_pool:
-                    v["tgt"][o:o + len(c)] = c
-                    o += len(c)
-                if rows:
-                    v["jobs4"][:] = np.asarray(rows, np.int32)
-                    v["guess"][:] = np.stack(guesses)
-                del v
-                w.conn.send(("run", w.shm.name, lay, self.chunk, seq))   # the worker starts while the next block is packed
-                sent.append((w, lay, [len(gs) for _, _, gs in mine]))
-        except BaseException:
-            # something failed between the first send and the last: every request already out is answered before the
-            # error leaves, so no worker is still reading a block (or owes a reply) when the caller tries again
+
+        def fill_and_send(w, mine, pk):
+            """one rank's block: fill the shared memory, start the worker; -> what the collection below needs"""
+            src_pool, tgt_pool, ns_pts, nt_pts, rows, guesses = pk
+            lay = _layout(ns_pts, nt_pts, len(rows))
+            v = _views(w.block(lay["bytes"]).buf, lay)
+            o = 0
+            for c in src_pool:                      # one copy (and the float32 cast) per DISTINCT cloud
+                v["src"][o:o + len(c)] = c
+                o += len(c)
+            o = 0
+            for c in tgt_pool:
+                v["tgt"][o:o + len(c)] = c
+                o += len(c)
+            if rows:
+                v["jobs4"][:] = np.asarray(rows, np.int32)
+                v["guess"][:] = np.stack(guesses)
+            del v
+            w.conn.send(("run", w.shm.name, lay, self.chunk, seq))
+            return w, lay, [len(gs) for _, _, gs in mine]
+
+        # 2. fill the shared-memory blocks and start the workers: one packing thread per rank (the copies into shared
+        #    memory are plain numpy slice assignments, which release the GIL) -- with G devices the parent would
+        #    otherwise pack G blocks one after the other while G - 1 workers wait for theirs.  A rank's worker starts
+        #    as soon as its own block is complete.
+        sent, errors = [], []
+        if world == 1:
+            try:
+                sent.append(fill_and_send(self._workers[0], *packed[0]))
+            except BaseException as e:   # noqa: B902 (re-raised below, after the replies are drained)
+                errors.append(e)
+        else:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=min(world, 16)) as pool:
+                futs = [pool.submit(fill_and_send, w, mine, pk) for w, (mine, pk) in zip(self._workers, packed)]
+                for f in futs:
+                    try:
+                        sent.append(f.result())
+                    except BaseException as e:   # noqa: B902
+                        errors.append(e)
+        if errors:
+            # something failed after some requests went out: every request already out is answered before the error
+            # leaves, so no worker is still reading a block (or owes a reply) when the caller tries again
             for w, _, _ in sent:
                 self._recv_reply(w, seq)
-            raise
+            raise errors[0]
         per_rank, failure = [], None
         for w, lay, ks in sent:
             tag, payload = self._recv_reply(w, seq)
