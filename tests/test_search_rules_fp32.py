@@ -10,7 +10,9 @@ the brute-force kernel; these fuzz each rule on its own, on inputs built to sit 
   3. clearance: a query that stood at p0 with every target at d2 >= best0 > maxDist^2 and has moved to p with
      fl(|p - p0| * 1.00001) < fl(fl(sqrt(best0) * 0.99999) - fl(maxDist * 1.00001)) still has no target within
      maxDist: d2(p, t) > maxDist^2 for every t;
-  4. clearance records of matched queries (stated in front of its test below).
+  4. clearance records of matched queries (stated in front of its test below);
+  5. the union window of a wave's queries covers every lane's own window (round 3, stated at its test);
+  6. the two-level arg-min of the exhaustive one-wave kernel (sfe_icp_tiny.h) picks the index a plain scan picks.
 """
 import numpy as np
 
@@ -202,3 +204,81 @@ def test_clearance_record_rule_never_keeps_a_wrong_neighbour():
                 hits_b += 1
                 assert (dn > C).all(), (case, frac)
     assert hits_a > 1500 and hits_b > 50                        # both rules do fire on these inputs
+
+
+def _strip_of(y, ylo, inv_g, ns):
+    v = F(F(F(y) - F(ylo)) * F(inv_g))
+    v = min(max(v, F(0.0)), F(ns - 1)) if v == v else F(0.0)
+    return int(v)
+
+
+def test_union_window_covers_every_lanes_own_window():
+    """5. union scan (round 3): a wave of neighbouring queries, each holding a bound sb (squared), searches the points whose
+    strip lies between strip_of(min py - r) and strip_of(max py + r) and whose x lies in [min px - r, max px + r], with
+    r = fl(fl(sqrt(max sb) * 1.0001) + 1e-6).  Every target with d2(p, t) <= sb of ANY of its lanes must be inside:
+    strips are assigned by the same strip_of (monotone in y), x by plain comparisons."""
+    rng = np.random.default_rng(5)
+    for case in range(300):
+        scale = float(rng.choice([0.05, 1.0, 30.0]))
+        t = _clouds(rng, int(rng.integers(20, 400)), scale)
+        ns = int(rng.integers(1, 12))
+        ylo, yhi = F(t[:, 1].min()), F(t[:, 1].max())
+        inv_g = F(ns) / F(yhi - ylo) if yhi > ylo else F(0.0)
+        if not np.isfinite(inv_g):
+            inv_g = F(0.0)
+        strip = np.array([_strip_of(y, ylo, inv_g, ns) for y in t[:, 1]])
+        nq = int(rng.integers(1, 65))
+        c = t[rng.integers(0, len(t))]
+        q = (c + rng.normal(0, scale * 0.05, (nq, 2))).astype(F)
+        d_all = np.stack([d2(q[i, 0], q[i, 1], t[:, 0], t[:, 1]) for i in range(nq)])
+        # bounds on the decision boundary: exactly the distance of some target, one ulp above / below it, tiny, zero
+        sb = np.array([rng.choice([np.sort(d_all[i])[min(len(t) - 1, int(rng.integers(0, 8)))],
+                                   np.nextafter(d_all[i].min(), F(np.inf)), F(d_all[i].min()), F(1e-12), F(0.0)])
+                       for i in range(nq)], F)
+        r = F(F(np.sqrt(F(sb.max()))) * F(1.0001)) + F(1e-6)
+        ux0, ux1 = F(q[:, 0].min()) - r, F(q[:, 0].max()) + r
+        uy0, uy1 = F(q[:, 1].min()) - r, F(q[:, 1].max()) + r
+        s_lo, s_hi = _strip_of(uy0, ylo, inv_g, ns), _strip_of(uy1, ylo, inv_g, ns)
+        inside = (strip >= s_lo) & (strip <= s_hi) & ~(t[:, 0] < ux0) & (t[:, 0] <= ux1)
+        for i in range(nq):
+            need = d_all[i] <= sb[i]
+            assert not (need & ~inside).any(), (case, i)
+
+
+def test_two_level_arg_min_equals_the_plain_scan():
+    """6. exhaustive one-wave kernel (sfe_icp_tiny.h): chunk minima (fminf over 16 points, strict '<' between chunks), then
+    the first point of the winning chunk that attains the minimum -- the same index as a plain scan with a strict '<'
+    in index order (lowest index on ties), NaN / inf points and padded chunks included."""
+    rng = np.random.default_rng(6)
+    for case in range(400):
+        n = int(rng.integers(1, 200))
+        t = _clouds(rng, n, 8.0)
+        if case % 3 == 0 and n > 4:
+            t[n // 2:] = t[:n - n // 2]                       # exact duplicates: ties
+        if case % 5 == 0:
+            t[rng.integers(0, n), rng.integers(0, 2)] = np.nan
+        if case % 7 == 0:
+            t[rng.integers(0, n)] = np.inf
+        q = (t[rng.integers(0, n)] + rng.normal(0, 0.2, 2)).astype(F) if case % 11 else np.array([np.nan, 0.0], F)
+        with np.errstate(invalid="ignore"):
+            d = d2(q[0], q[1], t[:, 0], t[:, 1])
+        best, bid = F(np.inf), -1
+        for j in range(n):                                     # the reference scan
+            if d[j] < best:
+                best, bid = d[j], j
+        npad = (n + 15) // 16 * 16
+        dp = np.full(npad, np.inf, F)
+        dp[:n] = d
+        b2, bch = F(np.inf), -1
+        for c0 in range(0, npad, 16):
+            cmin = F(np.inf)
+            for v in dp[c0:c0 + 16]:
+                cmin = v if (v < cmin) else cmin               # fminf: a NaN never replaces the minimum
+            if cmin < b2:
+                b2, bch = cmin, c0
+        id2 = -1
+        if bch >= 0:
+            for jj in range(15, -1, -1):
+                if dp[bch + jj] == b2:
+                    id2 = bch + jj
+        assert id2 == bid and (bid < 0 or b2 == best), (case, bid, id2)
