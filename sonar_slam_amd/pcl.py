@@ -94,11 +94,12 @@ def downsample(points, *args, **kw):
     if len(pts) == 0:  # pcl.cpp:130-131,145-146
         return pts if desc is None else (pts, desc)
     out = _np.zeros_like(pts)
-    idx = _np.zeros(len(pts), _np.int32)
+    idx = _np.zeros(len(pts), _np.int32) if desc is not None else None   # (only the descriptor overload needs the indices)
     n = _C.c_int(0)
     with ctx.lock:
         ctx._check(ctx.lib.sfe_downsample(ctx.handle, _L.ptr(pts, _C.c_float), len(pts), float(resolution),
-                                          _L.ptr(out, _C.c_float), _L.ptr(idx, _C.c_int32), _C.byref(n)))
+                                          _L.ptr(out, _C.c_float), _L.ptr(idx, _C.c_int32) if idx is not None else None,
+                                          _C.byref(n)))
     out = out[:n.value].copy()
     return out if desc is None else (out, desc[idx[:n.value]].copy())
 

@@ -207,6 +207,26 @@ def test_downsample_matches_oracle_octree():
     assert pcl.downsample(np.zeros((0, 2), np.float32), 0.5).shape == (0, 2)
 
 
+def test_downsample_without_indices_large_and_deep_clouds():
+    """pcl.downsample(points, resolution) runs the resident batch path as a batch of one (sort in LDS up to 16 384
+    points, in global memory up to 65 536, the rank-counting path above that and for trees deeper than 24 levels);
+    the descriptor overload keeps the rank-counting path.  All of them against the oracle's octree."""
+    rng = np.random.default_rng(55)
+    cases = [(rng.uniform(-30, 30, (11000, 2)), 0.5), (rng.uniform(-30, 30, (16384, 2)), 0.5),
+             (rng.uniform(-30, 30, (16385, 2)), 0.3), (rng.uniform(-60, 60, (40000, 2)), 0.5),
+             (rng.uniform(-60, 60, (70000, 2)), 1.0),
+             (rng.uniform(-30, 30, (600, 2)), 1e-6),     # a tree deeper than 24 levels: falls back
+             (np.r_[rng.uniform(-30, 30, (900, 2)), rng.uniform(0, 1e-4, (100, 2))], 1e-5)]
+    for pts, res in cases:
+        pts = pts.astype(np.float32)
+        want, widx = oracle.downsample(pts, res, return_index=True)
+        got = pcl.downsample(pts, res)
+        assert np.array_equal(got, want), (len(pts), res)
+        desc = np.arange(len(pts), dtype=np.float32)[:, None]
+        g2, d2 = pcl.downsample(pts, desc, res)
+        assert np.array_equal(g2, want) and np.array_equal(d2[:, 0].astype(np.int64), widx), (len(pts), res)
+
+
 def test_feature_extraction_callback_end_to_end(shipped_cfar):
     """FeatureExtraction.callback (feature_extraction.py:196-252 without ROS) vs the oracle chain
     CFAR -> gate -> remap -> nonzero -> px2m -> downsample -> remove_outlier."""
