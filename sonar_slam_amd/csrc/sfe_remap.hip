@@ -663,6 +663,202 @@ __global__ __launch_bounds__(256) void extract_scatter_kernel(const uint32_t *__
     flush();
 }
 
+// The same pass, round 3: list first, then one lane per set pixel.  The kernel above gives a workgroup a block of polar
+// rows; a sonar frame's ~5 000 detections sit in a few range bands, so most waves find a handful of set pixels and pay
+// ~900 instructions of staging, scanning and prefix searches around them.  Here a workgroup takes every
+// `slices`-th 64-word piece of the frame's bit stream (interleaved: every workgroup sees every band), collects the
+// set pixels of its pieces in ONE LDS list (unordered: the canvas bits are OR-ed), and then all 256 threads draw from
+// that list: a lane owns one set pixel, reads the 3 x 3 mask bits around it once from the frame's bit stream (rows
+// y-1 .. y+1: every tap of every candidate of this pixel lies there) and walks the pixel's inverse-map range itself --
+// neighbouring polar pixels have ranges of about the same length, so the lanes of a wave finish together and no
+// search maps candidates to lanes.  No staging of mask rows in LDS.
+// The canvas bits: a frame's ~10 000 canvas points lie in ~2 300 bitmap words, and with everything else out of the way
+// the global atomics were what the kernel waited for (0.31 -> 0.13 ms per 512 frames without them).  A lane first joins
+// the consecutive entries of its pixel that fall into one bitmap word (the entries are sorted by canvas pixel), then
+// ORs the word into a direct-mapped LDS table (tag = bitmap word of the frame); a word that finds its slot taken by
+// another goes to memory directly, the table is written out once at the end.
+// Identical canvas bitmap (same candidates, same blend, same first-tap rule).
+#define SG_LIST 1536  // set pixels a workgroup collects before it expands them (list + table: 18 KB, eight workgroups per CU)
+#define SG_BLOCK 1024 // mask words looked at per collection step (4 per thread)
+#define SG_TAB 1024   // slots of the canvas-word table
+__global__ __launch_bounds__(256, 8) void extract_gather_kernel(const uint32_t *__restrict__ bits,
+                                                                const int32_t *__restrict__ nonbinary,
+                                                                const int32_t *__restrict__ inv_off,
+                                                                const uint2 *__restrict__ inv_ent,
+                                                                unsigned long long *__restrict__ bitmap, int prows,
+                                                                int pcols, unsigned rcp, int crows, int wpr,
+                                                                long long words_per_frame, int piece_shift)
+{
+    __shared__ uint32_t s_list[SG_LIST]; // (row << 16 | column) of a set pixel
+    __shared__ int s_n, s_want[2]; // (s_want: by step parity -- the other one is cleared while this one is read)
+    __shared__ unsigned s_tag[SG_TAB];
+    __shared__ unsigned long long s_acc[SG_TAB];
+    const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    if (nonbinary[f] != 0)
+        return;
+    for (int i = tid; i < SG_TAB; i += 256) {
+        s_tag[i] = 0xFFFFFFFFu;
+        s_acc[i] = 0ull;
+    }
+    if (tid == 0) {
+        s_n = 0;
+        s_want[0] = s_want[1] = 0;
+    }
+    __syncthreads();
+    const int pw = pcols >> 5, nwords = prows * pw;
+    const int slices = gridDim.x;
+    // rotate the pieces from frame to frame: workgroups are dealt to the 8 XCDs in launch order, and every XCD should
+    // see every range band (cf. mode 2 of the kernel above)
+    const int sl = (int)((blockIdx.x + 5u * blockIdx.y) % (unsigned)slices);
+    const uint32_t *__restrict__ src = bits + (long long)f * words_per_frame;
+    unsigned long long *__restrict__ bm = bitmap + (long long)f * crows * wpr;
+    // pieces of 64 << piece_shift words (64 words = 4 polar rows of 512 beams); piece p belongs to slice p % slices.  The
+    // workgroup's words, piece after piece, are looked at `blk` at a time: thread t takes words t, t + 256, ...
+    const int pwords = 64 << piece_shift;
+    const int npieces = (nwords + pwords - 1) >> (6 + piece_shift);
+    const int my_pieces = (npieces - sl + slices - 1) / slices; // pieces sl, sl + slices, ...
+    const int my_words = my_pieces * pwords;
+    int v0 = 0, blk = SG_BLOCK, par = 0;
+    while (true) {
+        // ---- collect: steps of `blk` words while their set pixels fit the list
+        while (v0 < my_words) {
+            uint32_t w[4];
+            int gw[4], pc = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int v = v0 + u * 256 + tid;
+                gw[u] = (sl + (v >> (6 + piece_shift)) * slices) * pwords + (v & (pwords - 1));
+                w[u] = (u * 256 + tid < blk && v < my_words && gw[u] < nwords) ? src[gw[u]] : 0u;
+                pc += __popc(w[u]);
+            }
+            const int incl = scan_wave_incl(pc);
+            const int wtotal = __builtin_amdgcn_readlane(incl, 63);
+            int base = 0;
+            if (wtotal != 0 && lane == 63)
+                base = atomicAdd(&s_want[par], wtotal); // (one LDS atomic per wave that has any)
+            base = __builtin_amdgcn_readlane(base, 63);
+            __syncthreads();
+            const int want = s_want[par], at = s_n; // set pixels of this step, set pixels already listed
+            if (tid == 0)
+                s_want[par ^ 1] = 0;
+            __syncthreads();
+            par ^= 1;
+            if (at + want > SG_LIST) {
+                // this step waits for the list to be expanded.  Alone it does not fit either (more than SG_LIST set pixels
+                // in 1024 words: no sonar mask): 32 words per step from here on, whose 1024 pixels always fit
+                if (at == 0)
+                    blk = 32;
+                break;
+            }
+            if (want != 0) {
+                int pos = at + base + incl - pc;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    uint32_t word = w[u];
+                    if (word) {
+                        const int row = gw[u] / pw, c0 = (gw[u] - row * pw) * 32;
+                        do {
+                            const int bb = __ffs((int)word) - 1;
+                            s_list[pos++] = ((uint32_t)row << 16) | (uint32_t)(c0 + bb);
+                            word &= word - 1u;
+                        } while (word);
+                    }
+                }
+                __syncthreads();
+                if (tid == 0)
+                    s_n = at + want;
+            }
+            v0 += blk;
+        }
+        __syncthreads();
+        // ---- expand the list: one lane per set pixel
+        const int n = s_n;
+        for (int j = tid; j < n; j += 256) {
+            const uint32_t ent = s_list[j];
+            const int py = (int)(ent >> 16), px = (int)(ent & 0xFFFFu);
+            const int wc = px >> 5, b = px & 31;
+            auto bits3 = [&](int yy) -> unsigned { // mask bits of pixels (yy, px - 1 .. px + 1), 0 outside the image
+                if (yy < 0 || yy >= prows)
+                    return 0u;
+                const uint32_t *rowp = src + (long long)yy * pw;
+                unsigned long long ww = (unsigned long long)rowp[wc] << 1; // bit k + 1 = pixel 32 * wc + k
+                if (b == 0 && wc > 0)
+                    ww |= rowp[wc - 1] >> 31;
+                if (b == 31 && wc + 1 < pw)
+                    ww |= (unsigned long long)(rowp[wc + 1] & 1u) << 33;
+                return (unsigned)(ww >> b) & 7u;
+            };
+            const int pi = py * pcols + px;
+            const int off0 = inv_off[pi], cnt = inv_off[pi + 1] - off0;
+            const unsigned nb = bits3(py - 1) | (bits3(py) << 3) | (bits3(py + 1) << 6); // bit 3 * dy + dx, dy, dx = 0..2 <-> -1..+1
+            unsigned run_w = 0xFFFFFFFFu;
+            unsigned long long run_m = 0ull;
+            auto emit = [&](unsigned wd, unsigned long long m) {
+                const unsigned slot = (wd * 0x9E3779B1u) >> (32 - 10);
+                static_assert(SG_TAB == 1 << 10, "slot bits");
+                const unsigned old = atomicCAS(&s_tag[slot], 0xFFFFFFFFu, wd);
+                if (old == 0xFFFFFFFFu || old == wd)
+                    atomicOr(&s_acc[slot], m);
+                else
+                    atomicOr(&bm[wd], m);
+            };
+            auto candidate = [&](const uint2 e) {
+                    if (e.y == SFE_CODE_NONE)
+                        return;
+                    const unsigned lin = e.y >> 10;
+                    const int fy = (int)((e.y >> 5) & 31u), fx = (int)(e.y & 31u);
+                    const unsigned q = __umulhi(lin, rcp);
+                    const int iy = (int)q - 1, ix = (int)(lin - q * (unsigned)(pcols + 1)) - 1;
+                    const int ry = iy - py + 1, rx = ix - px + 1; // 0 or 1: the set pixel is one of the four taps
+                    const unsigned sh = nb >> (ry * 3 + rx);
+                    const int v00 = (int)(sh & 1u), v01 = (int)((sh >> 1) & 1u), v10 = (int)((sh >> 3) & 1u), v11 = (int)((sh >> 4) & 1u);
+                    int w00 = (32 - fy) * (32 - fx) * 32, w01 = (32 - fy) * fx * 32;
+                    int w10 = fy * (32 - fx) * 32, w11 = fy * fx * 32;
+                    if ((fx | fy) == 0) {
+                        w00 = 32767;
+                        w11 = 1;
+                    }
+                    const int acc = w00 * v00 + w01 * v01 + w10 * v10 + w11 * v11;
+                    // only the visit through the canvas pixel's FIRST set tap with a non-zero weight writes
+                    const int t_src = (1 - ry) * 2 + (1 - rx);
+                    const int first = (v00 && w00) ? 0 : (v01 && w01) ? 1 : (v10 && w10) ? 2 : 3;
+                    if (((acc + 16384) >> 15) != 0 && t_src == first) {
+                        const unsigned wd = e.x >> 6;
+                        if (wd != run_w) {
+                            if (run_m)
+                                emit(run_w, run_m);
+                            run_w = wd;
+                            run_m = 0ull;
+                        }
+                        run_m |= 1ull << (e.x & 63u);
+                    }
+            };
+            const uint2 none = make_uint2(0u, SFE_CODE_NONE);
+            for (int k = 0; k < cnt; k += 4) { // the loads are what a lane waits for: four entries in flight
+                const uint2 e0 = inv_ent[off0 + k];
+                const uint2 e1 = (k + 1 < cnt) ? inv_ent[off0 + k + 1] : none;
+                const uint2 e2 = (k + 2 < cnt) ? inv_ent[off0 + k + 2] : none;
+                const uint2 e3 = (k + 3 < cnt) ? inv_ent[off0 + k + 3] : none;
+                candidate(e0);
+                candidate(e1);
+                candidate(e2);
+                candidate(e3);
+            }
+            if (run_m)
+                emit(run_w, run_m);
+        }
+        __syncthreads();
+        if (v0 >= my_words)
+            break;
+        if (tid == 0)
+            s_n = 0;
+        __syncthreads();
+    }
+    for (int i = tid; i < SG_TAB; i += 256)
+        if (s_tag[i] != 0xFFFFFFFFu)
+            atomicOr(&bm[s_tag[i]], s_acc[i]);
+}
+
 // ---------------------------------------------------------------------------------------------
 // byte mask -> bit stream (mask_pack_kernel) for n_frames frames of px pixels; d_nonbin (optional, n_frames ints,
 // zeroed by the caller) is set for frames holding a byte > 1
@@ -733,8 +929,22 @@ static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_f
         if (!d_bits_in)
             hipLaunchKernelGGL(mask_pack_kernel, dim3((unsigned)((wpf + 255) / 256), nf), dim3(256), 0, ctx->stream, m,
                                d_bits_own, d_nonbin, px, wpf);
-        const bool scatter = g->d_inv_off != nullptr && (g->polar_cols & 31) == 0 && ctx->extract_variant == 0;
-        if (scatter) {
+        const bool scatter = g->d_inv_off != nullptr && (g->polar_cols & 31) == 0 && ctx->extract_variant != 1;
+        // (row << 16 | column) list entries: images up to 65 535 x 65 535; variant 2 = the row-block kernel of round 2
+        const bool gather = scatter && ctx->extract_variant == 0 && g->polar_rows < 65536 && g->polar_cols < 65536;
+        if (gather) {
+            SFE_HIP(ctx, hipMemsetAsync(d_bm, 0, (size_t)nf * crows * wpr * sizeof(unsigned long long), ctx->stream));
+            // workgroups per frame: enough of them to fill the device with a few frames, few enough that a
+            // workgroup's list holds several rounds of 256 set pixels when there are many
+            static const int sg_slices = getenv("SFE_SG_SLICES") ? atoi(getenv("SFE_SG_SLICES")) : 0;
+            static const int sg_piece = getenv("SFE_SG_PIECE") ? std::min(8, std::max(0, atoi(getenv("SFE_SG_PIECE")))) : 0;
+            const int npieces = (int)((((long long)g->polar_rows * (g->polar_cols >> 5) + 63) / 64) >> sg_piece) + 1;
+            int slices = sg_slices > 0 ? sg_slices : std::max(2, std::min(16, 4096 / std::max(nf, 1)));
+            slices = std::max(1, std::min(slices, npieces));
+            hipLaunchKernelGGL(extract_gather_kernel, dim3((unsigned)slices, nf), dim3(256), 0, ctx->stream, d_bits, d_nonbin,
+                               g->d_inv_off, g->d_inv_ent, d_bm, g->polar_rows, g->polar_cols, g->rcp, crows, wpr, wpf,
+                               sg_piece);
+        } else if (scatter) {
             // sparse binary masks: inverse map (binary frames), dense pass only for frames with other values
             SFE_HIP(ctx, hipMemsetAsync(d_bm, 0, (size_t)nf * crows * wpr * sizeof(unsigned long long), ctx->stream));
             const int pw = g->polar_cols >> 5;
@@ -793,7 +1003,7 @@ int sfe_extract_set_tuning(sfe_ctx *ctx, int variant)
 {
     if (!ctx)
         return SFE_ERR_ARG;
-    SFE_ARG(ctx, variant == 0 || variant == 1);
+    SFE_ARG(ctx, variant >= 0 && variant <= 2);
     ctx->extract_variant = variant;
     return 0;
 }

@@ -172,13 +172,14 @@ def test_inverse_map_extraction_equals_dense_pass_and_oracle(ctx, density):
             mask[:, 0] = 1
             mask[:, -1] = 1                                # image borders: out-of-image taps
         out = {}
-        for variant in (0, 1):
+        for variant in (0, 1, 2):   # list + lane per set pixel (default), dense pass, row-block scatter of round 2
             ctx._check(ctx.lib.sfe_extract_set_tuning(ctx.handle, variant))
             try:
                 out[variant] = fe.geometry.extract(mask)
             finally:
                 ctx._check(ctx.lib.sfe_extract_set_tuning(ctx.handle, 0))
-        assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+        for v in (1, 2):
+            assert np.array_equal(out[0][0], out[v][0]) and np.array_equal(out[0][1], out[v][1]), v
         rc = oracle.nonzero(oracle.remap_u8(mask, fe.map_x, fe.map_y))
         assert np.array_equal(out[0][0], rc)
 
@@ -228,7 +229,7 @@ def test_fused_ping_call_equals_the_per_stage_chain_and_the_oracle(ctx, shipped_
     assert fe.callback(dark).shape == (0, 2)
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_bit_stream_extraction_equals_the_byte_mask_path(ctx, shipped_cfar, variant):
     """KeyframeBatch hands the detections to the extraction as bit streams (sfe_cfar_u8_bits_batch_dev ->
     sfe_extract_points_bits_batch_dev): same masks and the same points as the 0/1 byte path and the oracle,
