@@ -70,6 +70,7 @@ struct sfe_geom {
     // non-zero weight (CSR: offsets [polar_rows * polar_cols + 1], entries = linear canvas indices)
     int32_t *d_inv_off = nullptr;
     uint2 *d_inv_ent = nullptr;     // {canvas index, its remap code}
+    uint2 *d_inv_lut = nullptr;     // {canvas index, decision table of the entry} (extract_gather_kernel)
     // px -> m of feature_extraction.py:236-237 per canvas row / column (fp64, the reference's operation order,
     // evaluated once on the host: extract_expand_words_kernel looks the metres up instead of dividing per point)
     double *d_ytab = nullptr, *d_xtab = nullptr;

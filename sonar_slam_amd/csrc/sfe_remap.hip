@@ -677,6 +677,9 @@ __global__ __launch_bounds__(256) void extract_scatter_kernel(const uint32_t *__
 // the consecutive entries of its pixel that fall into one bitmap word (the entries are sorted by canvas pixel), then
 // ORs the word into a direct-mapped LDS table (tag = bitmap word of the frame); a word that finds its slot taken by
 // another goes to memory directly, the table is written out once at the end.
+// The blend itself is decided when the geometry is built: whether a candidate is a detection and whether this tap reports
+// it depends on the entry and the four tap bits only, so the entry carries the 16 answers (sfe_geom_create) and a
+// candidate costs a shift, a mask and a bit test instead of the ~50 instructions of the fixed-point blend.
 // Identical canvas bitmap (same candidates, same blend, same first-tap rule).
 #define SG_LIST 1536  // set pixels a workgroup collects before it expands them (list + table: 18 KB, eight workgroups per CU)
 #define SG_BLOCK 1024 // mask words looked at per collection step (4 per thread)
@@ -686,8 +689,8 @@ __global__ __launch_bounds__(256, 8) void extract_gather_kernel(const uint32_t *
                                                                 const int32_t *__restrict__ inv_off,
                                                                 const uint2 *__restrict__ inv_ent,
                                                                 unsigned long long *__restrict__ bitmap, int prows,
-                                                                int pcols, unsigned rcp, int crows, int wpr,
-                                                                long long words_per_frame, int piece_shift)
+                                                                int pcols, int crows, int wpr, long long words_per_frame,
+                                                                int piece_shift)
 {
     __shared__ uint32_t s_list[SG_LIST]; // (row << 16 | column) of a set pixel
     __shared__ int s_n, s_want[2]; // (s_want: by step parity -- the other one is cleared while this one is read)
@@ -776,21 +779,30 @@ __global__ __launch_bounds__(256, 8) void extract_gather_kernel(const uint32_t *
         for (int j = tid; j < n; j += 256) {
             const uint32_t ent = s_list[j];
             const int py = (int)(ent >> 16), px = (int)(ent & 0xFFFFu);
-            const int wc = px >> 5, b = px & 31;
-            auto bits3 = [&](int yy) -> unsigned { // mask bits of pixels (yy, px - 1 .. px + 1), 0 outside the image
-                if (yy < 0 || yy >= prows)
-                    return 0u;
-                const uint32_t *rowp = src + (long long)yy * pw;
-                unsigned long long ww = (unsigned long long)rowp[wc] << 1; // bit k + 1 = pixel 32 * wc + k
-                if (b == 0 && wc > 0)
-                    ww |= rowp[wc - 1] >> 31;
-                if (b == 31 && wc + 1 < pw)
-                    ww |= (unsigned long long)(rowp[wc + 1] & 1u) << 33;
-                return (unsigned)(ww >> b) & 7u;
-            };
             const int pi = py * pcols + px;
             const int off0 = inv_off[pi], cnt = inv_off[pi + 1] - off0;
-            const unsigned nb = bits3(py - 1) | (bits3(py) << 3) | (bits3(py + 1) << 6); // bit 3 * dy + dx, dy, dx = 0..2 <-> -1..+1
+            // the 3 x 3 mask bits around the pixel: bit 3 * (dy + 1) + dx + 1; 0 outside the image.  Per row ONE 8-byte read
+            // of two neighbouring words of the bit stream that hold columns px - 1 .. px + 1 (4-byte aligned)
+            unsigned nb;
+            if (pw >= 2) {
+                const int wb = min(max((px >> 5) - ((px & 31) < 16 ? 1 : 0), 0), pw - 2);
+                const int rel = px - 1 - 32 * wb; // -1 .. 62: where column px - 1 sits in the pair
+                auto bits3 = [&](int yy) -> unsigned {
+                    const bool in = yy >= 0 && yy < prows;
+                    unsigned long long ww;
+                    __builtin_memcpy(&ww, src + (long long)(in ? yy : py) * pw + wb, 8);
+                    ww = rel >= 0 ? ww >> rel : ww << 1; // (column -1 and column pcols fall off the ends: 0)
+                    return in ? (unsigned)ww & 7u : 0u;
+                };
+                nb = bits3(py - 1) | (bits3(py) << 3) | (bits3(py + 1) << 6);
+            } else { // a 32-beam image: one word per row
+                auto bits3 = [&](int yy) -> unsigned {
+                    if (yy < 0 || yy >= prows)
+                        return 0u;
+                    return (unsigned)(((unsigned long long)src[yy] << 1) >> px) & 7u;
+                };
+                nb = bits3(py - 1) | (bits3(py) << 3) | (bits3(py + 1) << 6);
+            }
             unsigned run_w = 0xFFFFFFFFu;
             unsigned long long run_m = 0ull;
             auto emit = [&](unsigned wd, unsigned long long m) {
@@ -802,43 +814,29 @@ __global__ __launch_bounds__(256, 8) void extract_gather_kernel(const uint32_t *
                 else
                     atomicOr(&bm[wd], m);
             };
-            auto candidate = [&](const uint2 e) {
-                    if (e.y == SFE_CODE_NONE)
-                        return;
-                    const unsigned lin = e.y >> 10;
-                    const int fy = (int)((e.y >> 5) & 31u), fx = (int)(e.y & 31u);
-                    const unsigned q = __umulhi(lin, rcp);
-                    const int iy = (int)q - 1, ix = (int)(lin - q * (unsigned)(pcols + 1)) - 1;
-                    const int ry = iy - py + 1, rx = ix - px + 1; // 0 or 1: the set pixel is one of the four taps
-                    const unsigned sh = nb >> (ry * 3 + rx);
-                    const int v00 = (int)(sh & 1u), v01 = (int)((sh >> 1) & 1u), v10 = (int)((sh >> 3) & 1u), v11 = (int)((sh >> 4) & 1u);
-                    int w00 = (32 - fy) * (32 - fx) * 32, w01 = (32 - fy) * fx * 32;
-                    int w10 = fy * (32 - fx) * 32, w11 = fy * fx * 32;
-                    if ((fx | fy) == 0) {
-                        w00 = 32767;
-                        w11 = 1;
+            auto candidate = [&](const uint2 e) { // e.y = 0 (no case reports): the padding of the last round
+                const unsigned sh = nb >> (e.y >> 16);
+                const unsigned pat = (sh & 3u) | ((sh >> 1) & 12u); // taps 00 01 10 11 of the canvas pixel
+                if ((e.y >> pat) & 1u) {
+                    const unsigned wd = e.x >> 6;
+                    if (wd != run_w) {
+                        if (run_m)
+                            emit(run_w, run_m);
+                        run_w = wd;
+                        run_m = 0ull;
                     }
-                    const int acc = w00 * v00 + w01 * v01 + w10 * v10 + w11 * v11;
-                    // only the visit through the canvas pixel's FIRST set tap with a non-zero weight writes
-                    const int t_src = (1 - ry) * 2 + (1 - rx);
-                    const int first = (v00 && w00) ? 0 : (v01 && w01) ? 1 : (v10 && w10) ? 2 : 3;
-                    if (((acc + 16384) >> 15) != 0 && t_src == first) {
-                        const unsigned wd = e.x >> 6;
-                        if (wd != run_w) {
-                            if (run_m)
-                                emit(run_w, run_m);
-                            run_w = wd;
-                            run_m = 0ull;
-                        }
-                        run_m |= 1ull << (e.x & 63u);
-                    }
+                    run_m |= 1ull << (e.x & 63u);
+                }
             };
-            const uint2 none = make_uint2(0u, SFE_CODE_NONE);
             for (int k = 0; k < cnt; k += 4) { // the loads are what a lane waits for: four entries in flight
-                const uint2 e0 = inv_ent[off0 + k];
-                const uint2 e1 = (k + 1 < cnt) ? inv_ent[off0 + k + 1] : none;
-                const uint2 e2 = (k + 2 < cnt) ? inv_ent[off0 + k + 2] : none;
-                const uint2 e3 = (k + 3 < cnt) ? inv_ent[off0 + k + 3] : none;
+                // (past the end: the last entry again, with an empty table)
+                uint2 e0 = inv_ent[off0 + k];
+                uint2 e1 = inv_ent[off0 + min(k + 1, cnt - 1)];
+                uint2 e2 = inv_ent[off0 + min(k + 2, cnt - 1)];
+                uint2 e3 = inv_ent[off0 + min(k + 3, cnt - 1)];
+                e1.y = (k + 1 < cnt) ? e1.y : 0u;
+                e2.y = (k + 2 < cnt) ? e2.y : 0u;
+                e3.y = (k + 3 < cnt) ? e3.y : 0u;
                 candidate(e0);
                 candidate(e1);
                 candidate(e2);
@@ -937,13 +935,19 @@ static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_f
             // workgroups per frame: enough of them to fill the device with a few frames, few enough that a
             // workgroup's list holds several rounds of 256 set pixels when there are many
             static const int sg_slices = getenv("SFE_SG_SLICES") ? atoi(getenv("SFE_SG_SLICES")) : 0;
-            static const int sg_piece = getenv("SFE_SG_PIECE") ? std::min(8, std::max(0, atoi(getenv("SFE_SG_PIECE")))) : 0;
-            const int npieces = (int)((((long long)g->polar_rows * (g->polar_cols >> 5) + 63) / 64) >> sg_piece) + 1;
-            int slices = sg_slices > 0 ? sg_slices : std::max(2, std::min(16, 4096 / std::max(nf, 1)));
-            slices = std::max(1, std::min(slices, npieces));
+            static const int sg_piece_env = getenv("SFE_SG_PIECE") ? std::min(8, std::max(0, atoi(getenv("SFE_SG_PIECE")))) : -1;
+            // 8192 workgroups per 512 frames measured best (16: 0.259 ms per 512 frames, 8: 0.274, 4: 0.36 -- a workgroup's
+            // rounds of 256 set pixels wait for their loads one after the other), in pieces of 1024 words when the frame
+            // has that many per workgroup (64 rows of 512 beams: a canvas word collects its bits from neighbouring rows,
+            // so whole bands keep the table's words to one workgroup; 0.280 -> 0.259)
+            const long long nwords = (long long)g->polar_rows * (g->polar_cols >> 5);
+            int slices = sg_slices > 0 ? sg_slices : std::max(2, std::min(64, 8192 / std::max(nf, 1)));
+            slices = (int)std::max<long long>(1, std::min<long long>(slices, (nwords + 63) / 64));
+            int sg_piece = sg_piece_env >= 0 ? sg_piece_env : 4;
+            while (sg_piece_env < 0 && sg_piece > 0 && (nwords >> (6 + sg_piece)) < slices)
+                --sg_piece;
             hipLaunchKernelGGL(extract_gather_kernel, dim3((unsigned)slices, nf), dim3(256), 0, ctx->stream, d_bits, d_nonbin,
-                               g->d_inv_off, g->d_inv_ent, d_bm, g->polar_rows, g->polar_cols, g->rcp, crows, wpr, wpf,
-                               sg_piece);
+                               g->d_inv_off, g->d_inv_lut, d_bm, g->polar_rows, g->polar_cols, crows, wpr, wpf, sg_piece);
         } else if (scatter) {
             // sparse binary masks: inverse map (binary frames), dense pass only for frames with other values
             SFE_HIP(ctx, hipMemsetAsync(d_bm, 0, (size_t)nf * crows * wpr * sizeof(unsigned long long), ctx->stream));
@@ -1132,6 +1136,42 @@ int sfe_geom_create(sfe_ctx *ctx, const float *map_x, const float *map_y, int ca
                 const size_t row = o / (size_t)cart_cols, col = o - row * (size_t)cart_cols;
                 inv_ent[(size_t)cur[pi]++] = make_uint2((uint32_t)(row * (size_t)g->words_per_row * 64 + col), code[o]);
             });
+        // The same entries with the blend decided in advance (extract_gather_kernel).  Whether a canvas pixel reached from
+        // one of its set taps is a detection -- and whether THIS tap is the one that reports it -- depends on the entry
+        // (the tap's place among the four, the two 5-bit fractions) and on the four mask bits of the taps only: 16 cases,
+        // evaluated here with the kernels' arithmetic.  y = table (bit p: taps v00 v01 v10 v11 = bits 0..3 of p) |
+        // shift << 16, shift = position of tap 00 inside the 3 x 3 neighbourhood of the set pixel (bit 3 * (dy + 1) + dx + 1).
+        std::vector<uint2> inv_lut(inv_ent.size());
+        for (size_t pi = 0; pi + 1 < inv_off.size(); ++pi) {
+            const int py = (int)(pi / (size_t)polar_cols), px = (int)(pi - (size_t)py * polar_cols);
+            for (int32_t j = inv_off[pi]; j < inv_off[pi + 1]; ++j) {
+                const uint32_t cd = inv_ent[(size_t)j].y, lin = cd >> 10;
+                const int fy = (int)((cd >> 5) & 31u), fx = (int)(cd & 31u);
+                const int iy = (int)(lin / (uint32_t)(polar_cols + 1)) - 1, ix = (int)(lin % (uint32_t)(polar_cols + 1)) - 1;
+                const int ry = iy - py + 1, rx = ix - px + 1; // 0 or 1
+                int w00 = (32 - fy) * (32 - fx) * 32, w01 = (32 - fy) * fx * 32, w10 = fy * (32 - fx) * 32, w11 = fy * fx * 32;
+                if ((fx | fy) == 0) {
+                    w00 = 32767;
+                    w11 = 1;
+                }
+                const int t_src = (1 - ry) * 2 + (1 - rx);
+                uint32_t lut = 0;
+                for (int p = 0; p < 16; ++p) {
+                    const int v00 = p & 1, v01 = (p >> 1) & 1, v10 = (p >> 2) & 1, v11 = (p >> 3) & 1;
+                    const int acc = w00 * v00 + w01 * v01 + w10 * v10 + w11 * v11;
+                    const int first = (v00 && w00) ? 0 : (v01 && w01) ? 1 : (v10 && w10) ? 2 : 3;
+                    if (((acc + 16384) >> 15) != 0 && t_src == first)
+                        lut |= 1u << p;
+                }
+                inv_lut[(size_t)j] = make_uint2(inv_ent[(size_t)j].x, lut | ((uint32_t)(ry * 3 + rx) << 16));
+            }
+        }
+        if (hipMalloc((void **)&g->d_inv_lut, std::max<size_t>(inv_lut.size(), 1) * sizeof(uint2)) != hipSuccess ||
+            (!inv_lut.empty() &&
+             hipMemcpy(g->d_inv_lut, inv_lut.data(), inv_lut.size() * sizeof(uint2), hipMemcpyHostToDevice) != hipSuccess)) {
+            sfe_geom_destroy(g);
+            return sfe_set_err(ctx, SFE_ERR_HIP, "inverse remap table upload failed");
+        }
         if (hipMalloc((void **)&g->d_inv_off, inv_off.size() * 4) != hipSuccess ||
             hipMalloc((void **)&g->d_inv_ent, std::max<size_t>(inv_ent.size(), 1) * sizeof(uint2)) != hipSuccess ||
             hipMemcpy(g->d_inv_off, inv_off.data(), inv_off.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
@@ -1192,6 +1232,8 @@ void sfe_geom_destroy(sfe_geom *g)
         (void)hipFree(g->d_inv_off);
     if (g->d_inv_ent)
         (void)hipFree(g->d_inv_ent);
+    if (g->d_inv_lut)
+        (void)hipFree(g->d_inv_lut);
     if (g->d_ytab)
         (void)hipFree(g->d_ytab);
     if (g->d_xtab)
