@@ -42,6 +42,8 @@ struct sfe_ctx {
         bool pending = false;
     } pin[2];
     int pin_next = 0;
+    void *bm_clean_ptr = nullptr; // extract_dev: the canvas bitmap scratch is known to be zero up to bm_clean_bytes
+    size_t bm_clean_bytes = 0;
     Pin pin_io[4]; // grow-only pinned buffers of the synchronous single-item entry points (no events: the call syncs)
     // float threshold table of the sliding-sum CFAR kernel currently on the device (scratch slot 37)
     int thr_tab_alg = -1, thr_tab_T = -1;

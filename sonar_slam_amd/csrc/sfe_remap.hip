@@ -375,54 +375,108 @@ __global__ __launch_bounds__(SCAN_THREADS) void extract_scan_kernel(const unsign
 // 8 lanes of a word write one contiguous run.  ~25 instructions per point against ~150 of the lane-per-point form
 // below (row search, k-th set bit of the row, divisions).  The kernel is a chain of dependent accesses (list length
 // -> entry -> tables -> store), so the next entry is fetched while the current one is expanded.
-#define EXPAND_WG 8 // workgroups per frame (a sonar frame has 2-3 thousand non-empty words, 8 lanes each)
+#define EXPAND_WG 8 // workgroups per frame (a sonar frame has 2-3 thousand non-empty words)
+// Round 3: a lane per POINT of a batch of words.  A wave takes 64 list entries (a lane each: popcount, wave prefix sum ->
+// T points in the batch, ~240), parks them in LDS, and then lane j of every round of 64 finds the entry its point
+// belongs to (binary search in the 64 prefix values), clears the lower set bits of the word up to the point's rank and
+// stores {y(row), x(col)} at the entry's offset + rank.  The entries of one 64-word chunk of the bitmap follow each other
+// in the list with consecutive offsets, so a round's 64 stores of 16 bytes are one or two contiguous kilobytes (the
+// lane-per-byte form above left 17 % of the store lanes busy and ran at the line rate of its partial stores: 61 us per
+// 512 frames).  The words it has expanded are cleared in the canvas bitmap on the way (clean_bm != nullptr): the next
+// batch finds the bitmap zero without a 128 MB memset (extract_dev).
 __global__ __launch_bounds__(256) void extract_expand_words_kernel(const int4 *__restrict__ wlist,
                                                                    const int32_t *__restrict__ wlist_n, int list_cap,
                                                                    long long *__restrict__ rc_out,
                                                                    double *__restrict__ pts_out, long long cap, int crows,
                                                                    int ccols, const double *__restrict__ ytab,
-                                                                   const double *__restrict__ xtab)
+                                                                   const double *__restrict__ xtab,
+                                                                   unsigned long long *__restrict__ clean_bm, int wpr)
 {
     extern __shared__ double s_tab[]; // crows y values, ccols x values
+    __shared__ int4 s_ent[4][64];
+    __shared__ int s_ex[4][64];
     double *s_y = s_tab, *s_x = s_tab + crows;
     const int f = blockIdx.y;
     const int n = wlist_n[f];
     const int4 *__restrict__ wl = wlist + (long long)f * list_cap;
-    const int sub = threadIdx.x & 7;
-    const int e0 = blockIdx.x * 32 + (threadIdx.x >> 3), stride = gridDim.x * 32;
-    if (blockIdx.x * 32 >= n)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (blockIdx.x * 256 >= n)
         return; // nothing for this workgroup (the list is short): skip the tables too
-    int4 nxt = e0 < n ? wl[e0] : make_int4(0, 0, 0, 0);
     if (pts_out) {
         for (int i = threadIdx.x; i < crows; i += 256)
             s_y[i] = ytab[i];
         for (int i = threadIdx.x; i < ccols; i += 256)
             s_x[i] = xtab[i];
     }
-    __syncthreads();
-    for (int e = e0; e < n; e += stride) {
-        const int4 ent = nxt;
-        if (e + stride < n)
-            nxt = wl[e + stride];
-        const unsigned long long word = ((unsigned long long)(unsigned)ent.w << 32) | (unsigned)ent.z;
-        unsigned bits = (unsigned)(word >> (8 * sub)) & 0xffu;
-        const int row = ent.x >> 16, c0 = (ent.x & 0xFFFF) * 64 + 8 * sub;
-        long long t = (long long)f * cap + ent.y + __popcll(word & ((1ull << (8 * sub)) - 1ull));
-        const double y = pts_out ? s_y[row] : 0.0;
+    for (int eb = blockIdx.x * 256; eb < n; eb += gridDim.x * 256) { // (workgroup-uniform)
+        const int e = eb + wave * 64 + lane;
+        const int4 ent = e < n ? wl[e] : make_int4(0, 0, 0, 0);
+        const int pc = __popc((unsigned)ent.z) + __popc((unsigned)ent.w); // (0 past the end of the list)
+        if (clean_bm && e < n)
+            clean_bm[((long long)f * crows + (ent.x >> 16)) * wpr + (ent.x & 0xFFFF)] = 0ull;
+        const int incl = scan_wave_incl(pc);
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        s_ent[wave][lane] = ent;
+        s_ex[wave][lane] = e < n ? incl - pc : 0x7FFFFFFF;
+        __syncthreads();
+        for (int j = lane; j < total; j += 64) {
+            int lo = 0, hi = 63; // the last entry whose first point is <= j
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (bits) {
-                const int col = c0 + __ffs((int)bits) - 1;
-                bits &= bits - 1;
-                if (rc_out)
-                    reinterpret_cast<longlong2 *>(rc_out)[t] = make_longlong2(row, col);
-                if (pts_out)
-                    reinterpret_cast<double2 *>(pts_out)[t] = make_double2(y, s_x[col]);
-                ++t;
+            for (int step = 0; step < 6; ++step) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (s_ex[wave][mid] <= j)
+                    lo = mid;
+                else
+                    hi = mid - 1;
             }
+            const int4 en = s_ent[wave][lo];
+            const int r = j - s_ex[wave][lo];
+            // the r-th set bit of the word, by halving (a loop that clears r bits costs the wave its densest word: 63 steps)
+            int rr = r, bit = 0;
+            unsigned w32 = (unsigned)en.z;
+            {
+                const int c = __popc(w32);
+                if (rr >= c) {
+                    rr -= c;
+                    w32 = (unsigned)en.w;
+                    bit = 32;
+                }
+            }
+#pragma unroll
+            for (int h = 16; h >= 1; h >>= 1) {
+                const int c = __popc(w32 & ((1u << h) - 1u));
+                if (rr >= c) {
+                    rr -= c;
+                    w32 >>= h;
+                    bit += h;
+                }
+            }
+            const int row = en.x >> 16, col = (en.x & 0xFFFF) * 64 + bit;
+            const long long t = (long long)f * cap + en.y + r;
+            if (rc_out)
+                reinterpret_cast<longlong2 *>(rc_out)[t] = make_longlong2(row, col);
+            if (pts_out)
+                reinterpret_cast<double2 *>(pts_out)[t] = make_double2(s_y[row], s_x[col]);
         }
+        __syncthreads();
     }
 }
+
+// the canvas bitmaps of the frames that got no word list (above the point capacity; queued by the scan kernel): cleared
+// whole, after the per-point kernel has read them.  Normally no frame is queued and the workgroups leave at once.
+__global__ __launch_bounds__(256) void extract_clean_queued_kernel(unsigned long long *__restrict__ bitmap,
+                                                                   long long words_per_frame,
+                                                                   const int32_t *__restrict__ ovf_n,
+                                                                   const int32_t *__restrict__ ovf_list)
+{
+    const int nq = *ovf_n;
+    for (int q = 0; q < nq; ++q) {
+        unsigned long long *bm = bitmap + (long long)ovf_list[q] * words_per_frame;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < words_per_frame; i += (long long)gridDim.x * 256)
+            bm[i] = 0ull;
+    }
+}
+
 
 // pass 3, point form: one lane per POINT: point t of a frame lies in the last row whose offset is <= t (binary
 // search in the row offsets; empty rows share their successor's offset, so the last such row is the occupied one) and
@@ -828,19 +882,17 @@ __global__ __launch_bounds__(256, 8) void extract_gather_kernel(const uint32_t *
                     run_m |= 1ull << (e.x & 63u);
                 }
             };
-            for (int k = 0; k < cnt; k += 4) { // the loads are what a lane waits for: four entries in flight
-                // (past the end: the last entry again, with an empty table)
-                uint2 e0 = inv_ent[off0 + k];
-                uint2 e1 = inv_ent[off0 + min(k + 1, cnt - 1)];
-                uint2 e2 = inv_ent[off0 + min(k + 2, cnt - 1)];
-                uint2 e3 = inv_ent[off0 + min(k + 3, cnt - 1)];
-                e1.y = (k + 1 < cnt) ? e1.y : 0u;
-                e2.y = (k + 2 < cnt) ? e2.y : 0u;
-                e3.y = (k + 3 < cnt) ? e3.y : 0u;
-                candidate(e0);
-                candidate(e1);
-                candidate(e2);
-                candidate(e3);
+            for (int k = 0; k < cnt; k += 4) { // the loads are what a lane waits for: four entries in flight, two per 16-byte read
+                // (past the end of the range: whatever follows in the table -- it ends with two spare entries -- with an empty
+                // decision table)
+                uint4 a, b2;
+                __builtin_memcpy(&a, inv_ent + off0 + k, 16);
+                __builtin_memcpy(&b2, inv_ent + off0 + min(k + 2, cnt - 1), 16);
+                const bool two = k + 2 < cnt; // (else b2 holds entries cnt - 1, cnt: both done or out of range)
+                candidate(make_uint2(a.x, a.y));
+                candidate(make_uint2(a.z, (k + 1 < cnt) ? a.w : 0u));
+                candidate(make_uint2(b2.x, two ? b2.y : 0u));
+                candidate(make_uint2(b2.z, (k + 3 < cnt) ? b2.w : 0u));
             }
             if (run_m)
                 emit(run_w, run_m);
@@ -885,7 +937,7 @@ static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_f
     const int crows = g->cart_rows, wpr = g->words_per_row;
     static const int chunk = getenv("SFE_EXTRACT_CHUNK") ? std::max(1, atoi(getenv("SFE_EXTRACT_CHUNK"))) : 1024; // frames per pass: bounds the bitmap scratch (0.25 MB per frame), fewer passes = fewer launches
     const size_t bm_bytes = (size_t)chunk * crows * wpr * sizeof(unsigned long long);
-    unsigned long long *d_bm = (unsigned long long *)sfe_scratch(ctx, 4, bm_bytes);
+    unsigned long long *d_bm = (unsigned long long *)sfe_scratch(ctx, 39, bm_bytes); // (a slot of its own: its contents outlive the call, see self_clean)
     int32_t *d_rcnt = (int32_t *)sfe_scratch(ctx, 5, (size_t)chunk * crows * 4);
     int32_t *d_roff = (int32_t *)sfe_scratch(ctx, 6, (size_t)chunk * crows * 4);
     if (!d_bm || !d_rcnt || !d_roff)
@@ -900,6 +952,7 @@ static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_f
                                      g->lds_bytes));
     // word form of the expansion: a list of the non-empty bitmap words per frame (at most one per stored point)
     static const bool points_form = getenv("SFE_EXPAND_POINTS") != nullptr; // A/B: lane-per-point expansion
+    static const bool nosc = getenv("SFE_NO_SELF_CLEAN") != nullptr;         // A/B: memset of the bitmap per batch
     const long long words_pf = (long long)crows * wpr;
     const size_t tab_bytes = ((size_t)crows + g->cart_cols) * sizeof(double);
     const bool use_words = !points_form && cap > 0 && std::min(words_pf, cap) <= (1ll << 24) && cap < (1ll << 31) &&
@@ -917,6 +970,11 @@ static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_f
         SFE_HIP(ctx, hipFuncSetAttribute((const void *)extract_expand_words_kernel,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)tab_bytes));
     }
+    // bytes of the bitmap scratch known to be zero (the state is dropped for the duration of the call: an error return
+    // leaves it unknown)
+    size_t clean_bytes = ctx->bm_clean_ptr == (void *)d_bm ? ctx->bm_clean_bytes : 0;
+    ctx->bm_clean_ptr = nullptr;
+    ctx->bm_clean_bytes = 0;
     for (int f0 = 0; f0 < n_frames; f0 += chunk) {
         const int nf = std::min(chunk, n_frames - f0);
         const uint8_t *m = d_bits_in ? nullptr : d_mask + (size_t)f0 * g->polar_rows * g->polar_cols;
@@ -930,8 +988,19 @@ static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_f
         const bool scatter = g->d_inv_off != nullptr && (g->polar_cols & 31) == 0 && ctx->extract_variant != 1;
         // (row << 16 | column) list entries: images up to 65 535 x 65 535; variant 2 = the row-block kernel of round 2
         const bool gather = scatter && ctx->extract_variant == 0 && g->polar_rows < 65536 && g->polar_cols < 65536;
+        // The bitmap cleans up after itself on this path (binary frames through the list kernel, word-list expansion
+        // with a capacity: extract_expand_words_kernel clears the words it expands, extract_clean_queued_kernel the
+        // frames without a list): the memset is only needed when the scratch is new or another path (or a failed
+        // call) has left bits behind.
+        const bool self_clean = gather && d_bits_in && use_words && cap > 0 && !nosc;
+        const size_t bm_need = (size_t)nf * crows * wpr * sizeof(unsigned long long);
+        if (!self_clean)
+            clean_bytes = 0; // (this pass leaves its bits in the bitmap)
         if (gather) {
-            SFE_HIP(ctx, hipMemsetAsync(d_bm, 0, (size_t)nf * crows * wpr * sizeof(unsigned long long), ctx->stream));
+            if (!(self_clean && clean_bytes >= bm_need))
+                SFE_HIP(ctx, hipMemsetAsync(d_bm, 0, bm_need, ctx->stream));
+            if (self_clean)
+                clean_bytes = std::max(clean_bytes, bm_need);
             // workgroups per frame: enough of them to fill the device with a few frames, few enough that a
             // workgroup's list holds several rounds of 256 set pixels when there are many
             static const int sg_slices = getenv("SFE_SG_SLICES") ? atoi(getenv("SFE_SG_SLICES")) : 0;
@@ -977,13 +1046,20 @@ static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_f
             long long *rc_f = d_rc ? d_rc + (size_t)f0 * cap * 2 : nullptr;
             double *pts_f = d_pts ? d_pts + (size_t)f0 * cap * 2 : nullptr;
             if (use_words) {
-                static const int expand_wg = getenv("SFE_EXPAND_WG") ? std::max(1, atoi(getenv("SFE_EXPAND_WG"))) : EXPAND_WG;
+                static const int expand_wg_env = getenv("SFE_EXPAND_WG") ? std::max(1, atoi(getenv("SFE_EXPAND_WG"))) : 0;
+                // a workgroup first fetches the two metre tables (23 KB for config A): about a thousand workgroups
+                // per launch, all resident at once (8 per frame measured 69 us per 512 frames, 2 per frame 53)
+                const int expand_wg = expand_wg_env ? expand_wg_env : std::max(1, std::min(EXPAND_WG, 1024 / std::max(nf, 1)));
                 hipLaunchKernelGGL(extract_expand_words_kernel, dim3(expand_wg, nf), dim3(256), tab_bytes, ctx->stream,
-                                   d_wlist, d_wlist_n, list_cap, rc_f, pts_f, cap, crows, g->cart_cols, g->d_ytab, g->d_xtab);
+                                   d_wlist, d_wlist_n, list_cap, rc_f, pts_f, cap, crows, g->cart_cols, g->d_ytab, g->d_xtab,
+                                   self_clean ? d_bm : nullptr, wpr);
                 // frames above the capacity (queued by the scan kernel; normally none): their first cap points
                 hipLaunchKernelGGL(extract_expand_kernel, dim3((unsigned)((cap + 255) / 256), 1), dim3(256),
                                    sizeof(int32_t) * (size_t)crows, ctx->stream, d_bm, d_roff, d_counts + f0, rc_f, pts_f, cap,
                                    crows, g->cart_cols, wpr, g->width, g->height, d_ovf, d_ovf + 1);
+                if (self_clean)
+                    hipLaunchKernelGGL(extract_clean_queued_kernel, dim3(64), dim3(256), 0, ctx->stream, d_bm,
+                                       (long long)crows * wpr, d_ovf, d_ovf + 1);
             } else {
                 hipLaunchKernelGGL(extract_expand_kernel, dim3((unsigned)((cap + 255) / 256), nf), dim3(256),
                                    sizeof(int32_t) * (size_t)crows, ctx->stream, d_bm, d_roff, d_counts + f0, rc_f, pts_f, cap,
@@ -993,6 +1069,8 @@ static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_f
         }
     }
     SFE_LAUNCH_CHECK(ctx);
+    ctx->bm_clean_ptr = (void *)d_bm; // every launch went through: that much of the bitmap is zero again when they have run
+    ctx->bm_clean_bytes = clean_bytes;
     return 0;
 }
 
@@ -1166,6 +1244,7 @@ int sfe_geom_create(sfe_ctx *ctx, const float *map_x, const float *map_y, int ca
                 inv_lut[(size_t)j] = make_uint2(inv_ent[(size_t)j].x, lut | ((uint32_t)(ry * 3 + rx) << 16));
             }
         }
+        inv_lut.resize(inv_lut.size() + 2, make_uint2(0u, 0u)); // (the kernel reads entries in pairs)
         if (hipMalloc((void **)&g->d_inv_lut, std::max<size_t>(inv_lut.size(), 1) * sizeof(uint2)) != hipSuccess ||
             (!inv_lut.empty() &&
              hipMemcpy(g->d_inv_lut, inv_lut.data(), inv_lut.size() * sizeof(uint2), hipMemcpyHostToDevice) != hipSuccess)) {

@@ -229,6 +229,52 @@ def test_fused_ping_call_equals_the_per_stage_chain_and_the_oracle(ctx, shipped_
     assert fe.callback(dark).shape == (0, 2)
 
 
+def test_bit_stream_batches_leave_the_canvas_bitmap_clean(ctx, shipped_cfar):
+    """The resident path clears the canvas bitmap as it expands it instead of a memset per batch (words with a list entry:
+    extract_expand_words_kernel; frames above the point capacity, which get no list: extract_clean_queued_kernel).
+    A batch with frames above the capacity, then other frames through the same scratch, a larger batch (the scratch
+    grows), the dense pass in between (which leaves its bits behind) -- every batch equal to the oracle."""
+    from sonar_slam_amd.pipeline import KeyframeBatch
+    th, gh, tau = shipped_cfar.params["SOCA"]
+    fe = FeatureExtraction(ctx)
+    fe.Ntc, fe.Ngc, fe.Pfa, fe.rank, fe.alg, fe.threshold = 40, 10, 0.1, 10, "SOCA", 65
+    fe.configure()
+    frames = np.stack([synth.sonar_frame(seed=700 + s, n_blobs=(4 if s % 2 else 40)) for s in range(6)])
+    fe.generate_map_xy(SonarPing(frames[0], oculus_bearings(512), 30.0 / 1024))
+    want = []
+    for f in frames:
+        m = oracle.gate(f, oracle.cfar(f, "SOCA", th, gh, tau), 65)
+        want.append(oracle.nonzero(oracle.remap_u8(m, fe.map_x, fe.map_y)))
+    sizes = sorted(len(w) for w in want)
+    small = (sizes[2] + sizes[3]) // 2                    # half of the frames are above it
+
+    def batch(idx, cap, variant=0):
+        kb = KeyframeBatch(ctx, fe.geometry, (th, gh, tau), "SOCA", 65, None, len(idx), max_points=cap, bit_masks=True)
+        try:
+            ctx._check(ctx.lib.sfe_extract_set_tuning(ctx.handle, variant))
+            kb.upload_frames(frames[idx])
+            kb.run_cfar()
+            kb.run_extract()
+            ctx.sync()
+            counts = kb.d_cnt.download(np.int32, len(idx))
+            for k, j in enumerate(idx):
+                assert counts[k] == len(want[j]), (idx, cap, j)
+                if counts[k] <= cap:
+                    assert np.array_equal(kb.points(k), oracle.px_to_m(want[j], fe.rows, fe.cols, fe.width, fe.height)), j
+        finally:
+            ctx._check(ctx.lib.sfe_extract_set_tuning(ctx.handle, 0))
+            kb.free()
+
+    big = sizes[-1] + 8
+    batch([0, 1, 2, 3], big)            # (whatever ran before this test: the scratch may be new or dirty)
+    batch([0, 1, 2, 3, 4, 5], small)    # three frames above the capacity: no list, cleared whole
+    batch([5, 4, 3], big)               # the same scratch, other frames
+    batch([1, 0], big, variant=1)       # dense pass: leaves its bits in the bitmap
+    batch([2, 3, 4], big)
+    batch(list(range(6)) * 3, big)      # more frames than before: the scratch grows
+    batch([4, 1], big)
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2])
 def test_bit_stream_extraction_equals_the_byte_mask_path(ctx, shipped_cfar, variant):
     """KeyframeBatch hands the detections to the extraction as bit streams (sfe_cfar_u8_bits_batch_dev ->
