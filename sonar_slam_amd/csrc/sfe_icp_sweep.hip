@@ -236,6 +236,10 @@ __device__ __forceinline__ void sweep_knn_normals(const sfe_icp_params &P, const
                                                   const float2 *__restrict__ s_tgt, const int *__restrict__ perm,
                                                   float2 *__restrict__ snrm, int nt, int c_begin = 0, int c_stride = NT)
 { // (c_begin, c_stride: the positions this workgroup takes when several share a target, icp_sweep_normals_kernel)
+    // (Tried in round 3 and dropped: a first pass that gives up on a point after 16 / 24 / 32 steps of its walk and a
+    // second pass over the listed points packed into whole waves -- a point walks 16 steps on average on a sonar
+    // cloud, the longest of 64 neighbours 41 -- 5.5 -> 5.9 ms per 4096 targets: the restarts and the second pass's own
+    // longest walks cost more than the waiting lanes of the first.)
     const int tid = threadIdx.x;
     const int K = min(min(P.normals_knn, KM), nt);
     const int ns = tab.ns, len = tab.len;
@@ -246,12 +250,13 @@ __device__ __forceinline__ void sweep_knn_normals(const sfe_icp_params &P, const
                       // nothing can ever match it)
         float bd[KM];
         int bj[KM];
-        // The search runs twice at most.  First without the tie rule: equal distances are only NOTED (one compare per
-        // exchange step), the list orders by distance alone.  Two equal distances among a point's candidates are
+        // The search runs twice at most.  First without the tie rule: equal distances are only NOTED (where they could
+        // change the outcome: at the end of the list when an entry leaves, and in the finished list), the list orders by
+        // distance alone.  Two equal distances among a point's candidates are
         // rare (exactly equal fp32 sums of squares); only then the point is searched again with the full rule
         // (equal distances order by original index, which costs a compare, a branch and -- when taken -- two reads
         // of the permutation per exchange step: about half of the instructions of an insertion).
-        auto search = [&](auto exact_tag) -> bool {
+        auto search = [&](auto exact_tag) -> int { // 0: done, 1: a tie the distance-only order cannot settle
         constexpr bool EXACT = decltype(exact_tag)::value;
         bool tie_seen = false;
 #pragma unroll
@@ -275,6 +280,10 @@ __device__ __forceinline__ void sweep_knn_normals(const sfe_icp_params &P, const
                     if (!(perm[j - 1] < perm[bj[KM - 1] - 1]))
                         return;
                 }
+                // (distance-only mode: the entry that leaves must not tie with the one that becomes last -- which of the two
+                // stays is the tie rule's call; ties inside the list are looked for once, at the end of the search)
+                if (!EXACT && KM >= 2)
+                    tie_seen |= bd[KM - 2] == bd[KM - 1] && bd[KM - 1] < INFINITY;
                 bd[KM - 1] = d;
                 bj[KM - 1] = j;
 #pragma unroll
@@ -283,8 +292,6 @@ __device__ __forceinline__ void sweep_knn_normals(const sfe_icp_params &P, const
                     if (EXACT) {
                         if (bd[k] == bd[k - 1] && bj[k - 1] != 0)
                             up = perm[bj[k] - 1] < perm[bj[k - 1] - 1];
-                    } else {
-                        tie_seen |= bd[k] == bd[k - 1] && bd[k] < INFINITY;
                     }
                     const float td = up ? bd[k - 1] : bd[k];
                     const int tj = up ? bj[k - 1] : bj[k];
@@ -353,9 +360,14 @@ __device__ __forceinline__ void sweep_knn_normals(const sfe_icp_params &P, const
                 iR += okr ? 1 : 0;
             }
         }
-        return tie_seen;
+        if (!EXACT && K == KM) {
+#pragma unroll
+            for (int k = 1; k < KM; ++k)
+                tie_seen |= bd[k] == bd[k - 1] && bd[k] < INFINITY;
+        }
+        return tie_seen ? 1 : 0;
         };
-        if (K != KM || search(std::false_type{}))
+        if (K != KM || search(std::false_type{}) == 1)
             search(std::true_type{});
         double sx = 0, sy = 0;
 #pragma unroll
@@ -536,8 +548,14 @@ __device__ __forceinline__ void bitonic_sort_global(unsigned long long *keys, un
 
 // NT threads; targets of up to TCAP points are sorted (and their normals / witness grid built) in LDS; GM = most cells
 // of the witness grid.  prep_ids[blockIdx.x] = the target this workgroup prepares (one launch per tier).
-template <int NT, int TCAP, int GM>
-__global__ __launch_bounds__(NT, 4) void icp_sweep_prep_kernel(sfe_icp_params P,
+// GTAIL (the 1024-thread build): no LDS of its own for the witness grid -- it is built last, in the part of the key
+// buffer the sorted cloud leaves free (a 5 000-point cloud: 5 067 of 8 264 slots; its grid has ~4 300 cells of 4
+// bytes), or in place in the output array when that is too small.  66 KB per workgroup instead of 100: two
+// workgroups per CU, so that one's k-NN walks fill the other's barriers and LDS waits.
+// KMF: capacity of the k-NN list when the launch knows normals_knn (0: all four capacities in one kernel, chosen at run
+// time -- whose registers are then those of the largest; the 64-register GTAIL build spilled 705 of them that way).
+template <int NT, int TCAP, int GM, bool GTAIL = false, int KMF = 0>
+__global__ __launch_bounds__(NT, GTAIL ? 8 : 4) void icp_sweep_prep_kernel(sfe_icp_params P,
                                                                         const SweepPrep *__restrict__ preps,
                                                                         const int *__restrict__ prep_ids,
                                                                         const float2 *__restrict__ tgt_all,
@@ -551,7 +569,7 @@ __global__ __launch_bounds__(NT, 4) void icp_sweep_prep_kernel(sfe_icp_params P,
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     PrepShared<NT, TCAP> &S = *reinterpret_cast<PrepShared<NT, TCAP> *>(smem_raw);
-    int *s_grid = reinterpret_cast<int *>(smem_raw + ((sizeof(PrepShared<NT, TCAP>) + 15) & ~(size_t)15)); // witness grid + distances
+    int *s_grid = reinterpret_cast<int *>(smem_raw + ((sizeof(PrepShared<NT, TCAP>) + 15) & ~(size_t)15)); // witness grid + distances (not GTAIL)
     const int pid = __builtin_amdgcn_readfirstlane(prep_ids[blockIdx.x]);
     const SweepPrep J = preps[pid];
     const int nt = J.n_tgt, ns = J.ns, tid = threadIdx.x, lane = threadIdx.x & 63;
@@ -735,6 +753,16 @@ __global__ __launch_bounds__(NT, 4) void icp_sweep_prep_kernel(sfe_icp_params P,
     if (tid < 2)
         stgt[len + tid] = make_float2(qnan, qnan);
 
+    auto grid_witness = [&](const float2 *cloud, int used_slots) { // used_slots: 8-byte slots of S.buf the cloud occupies
+        int *out = grid_all + J.grid_off;
+        if constexpr (GTAIL) {
+            const int room = (TCAP + SW_PAD + 4 - used_slots) * 2, ncell = S.tab.gnx * S.tab.gny;
+            unsigned *tail = reinterpret_cast<unsigned *>(S.buf + used_slots);
+            sweep_grid_witness<NT>(S.tab, cloud, out, ncell <= room ? tail : reinterpret_cast<unsigned *>(out));
+        } else {
+            sweep_grid_witness<NT>(S.tab, cloud, out, reinterpret_cast<unsigned *>(s_grid));
+        }
+    };
     float2 *nrm = snrm_all ? snrm_all + J.off : nullptr;
     if (in_lds) {
         bitonic_sort_lds<NT>(S.buf, n2);
@@ -771,7 +799,9 @@ __global__ __launch_bounds__(NT, 4) void icp_sweep_prep_kernel(sfe_icp_params P,
             s_tgt[len + tid] = make_float2(qnan, qnan);
         __syncthreads();
         if (P.minimizer == 1) {
-            if (P.normals_knn <= 8)
+            if constexpr (KMF != 0)
+                sweep_knn_normals<KMF, NT>(P, S.tab, s_tgt, perm, nrm, nt);
+            else if (P.normals_knn <= 8)
                 sweep_knn_normals<8, NT>(P, S.tab, s_tgt, perm, nrm, nt);
             else if (P.normals_knn <= 10)
                 sweep_knn_normals<10, NT>(P, S.tab, s_tgt, perm, nrm, nt);
@@ -781,7 +811,7 @@ __global__ __launch_bounds__(NT, 4) void icp_sweep_prep_kernel(sfe_icp_params P,
                 sweep_knn_normals<ICP_KMAX, NT>(P, S.tab, s_tgt, perm, nrm, nt);
         }
         if (grid_all)
-            sweep_grid_witness<NT>(S.tab, s_tgt, grid_all + J.grid_off, reinterpret_cast<unsigned *>(s_grid));
+            grid_witness(s_tgt, len + 2);
     } else {
         bitonic_sort_global<NT, TCAP>(keys, n2, S.buf); // (n2 > TCAP here; S.buf holds TCAP + SW_PAD + 4 keys)
         for (int r = tid; r < nt; r += NT) {
@@ -792,7 +822,9 @@ __global__ __launch_bounds__(NT, 4) void icp_sweep_prep_kernel(sfe_icp_params P,
         }
         __syncthreads();
         if (P.minimizer == 1 && J.pad_ == 0) { // (pad_ = 1: icp_sweep_normals_kernel computes them, many workgroups per target)
-            if (P.normals_knn <= 8)
+            if constexpr (KMF != 0)
+                sweep_knn_normals<KMF, NT>(P, S.tab, stgt, perm, nrm, nt);
+            else if (P.normals_knn <= 8)
                 sweep_knn_normals<8, NT>(P, S.tab, stgt, perm, nrm, nt);
             else if (P.normals_knn <= 10)
                 sweep_knn_normals<10, NT>(P, S.tab, stgt, perm, nrm, nt);
@@ -802,7 +834,7 @@ __global__ __launch_bounds__(NT, 4) void icp_sweep_prep_kernel(sfe_icp_params P,
                 sweep_knn_normals<ICP_KMAX, NT>(P, S.tab, stgt, perm, nrm, nt);
         }
         if (grid_all)
-            sweep_grid_witness<NT>(S.tab, stgt, grid_all + J.grid_off, reinterpret_cast<unsigned *>(s_grid));
+            grid_witness(stgt, 0); // (the key buffer was the sort's staging chunk: free now)
     }
 }
 
@@ -2664,13 +2696,20 @@ int sweep_launch_loop(const SweepLaunchArgs &a, int n, const int *d_ids, size_t 
     return 0;
 }
 
-template <int NT, int TCAP, int GM>
+int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+template <int NT, int TCAP, int GM, bool GTAIL = false, int KMF = 0>
 int sweep_launch_prep(sfe_ctx *ctx, hipStream_t ps, const sfe_icp_params *p, int n, const SweepPrep *d_preps, const int *d_pids,
                       const float2 *d_tgt, float2 *d_stgt, int *d_perm, float2 *d_snrm, float *d_mean,
                       unsigned long long *d_gkeys, StripTab *d_tab, int *d_grid)
 {
-    auto kernel = icp_sweep_prep_kernel<NT, TCAP, GM>;
-    const size_t smem = ((sizeof(PrepShared<NT, TCAP>) + 15) & ~(size_t)15) + 4 * (size_t)GM;
+    auto kernel = icp_sweep_prep_kernel<NT, TCAP, GM, GTAIL, KMF>;
+    const size_t smem = ((sizeof(PrepShared<NT, TCAP>) + 15) & ~(size_t)15) + (GTAIL ? 0 : 4 * (size_t)GM);
+    static_assert(!GTAIL || 8 * (size_t)(TCAP + SW_PAD + 4) >= 4 * (size_t)GM, "the key buffer holds a whole witness grid");
     SFE_HIP(ctx, hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(kernel, dim3(n), dim3(NT), smem, ps, *p, d_preps, d_pids, d_tgt, d_stgt, d_perm, d_snrm, d_mean, d_gkeys,
                        d_tab, d_grid);
@@ -2678,11 +2717,6 @@ int sweep_launch_prep(sfe_ctx *ctx, hipStream_t ps, const sfe_icp_params *p, int
     return 0;
 }
 
-int env_int(const char *name, int dflt)
-{
-    const char *v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
 } // namespace
 
 int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_src, const float *d_tgt,
@@ -2945,11 +2979,22 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
             if (int rc = sweep_launch_prep<SW_T1_NT, SW_T1_TCAP, SW_T1_GRID>(ctx, ps, p, np1, d_preps, d_pids + np0, (const float2 *)d_tgt,
                                                                           d_stgt, d_perm, d_snrm, d_mean, d_gkeys, d_tab, d_grid))
                 return rc;
-        if (np2)
-            if (int rc = sweep_launch_prep<ICP_THREADS, SW_TCAP, SW_GRID_MAX>(ctx, ps, p, np2, d_preps, d_pids + np0 + np1,
-                                                                           (const float2 *)d_tgt, d_stgt, d_perm, d_snrm, d_mean, d_gkeys,
-                                                                           d_tab, d_grid))
+        if (np2) {
+            const bool gtail = env_int("SFE_SW_PREP_GTAIL", 1) != 0; // (0: the witness grid in LDS of its own, one workgroup per CU: A/B)
+            // (the list capacity the kernel is built for: the smallest of 8 / 10 / 12 / 16 that holds normals_knn)
+            const int km = p->minimizer != 1 ? 8 : p->normals_knn <= 8 ? 8 : p->normals_knn <= 10 ? 10 : p->normals_knn <= 12 ? 12 : ICP_KMAX;
+            auto go = [&](auto gt, auto kmf) {
+                return sweep_launch_prep<ICP_THREADS, SW_TCAP, SW_GRID_MAX, decltype(gt)::value, decltype(kmf)::value>(
+                    ctx, ps, p, np2, d_preps, d_pids + np0 + np1, (const float2 *)d_tgt, d_stgt, d_perm, d_snrm, d_mean, d_gkeys, d_tab,
+                    d_grid);
+            };
+            using std::integral_constant;
+            // (lists of 12 / 16 neighbours do not fit 64 registers: 184 / 541 spills; those keep one workgroup per CU)
+            if (int rc = !gtail || km > 10 ? go(std::false_type{}, integral_constant<int, 0>{})
+                         : km == 8          ? go(std::true_type{}, integral_constant<int, 8>{})
+                                            : go(std::true_type{}, integral_constant<int, 10>{}))
                 return rc;
+        }
     }
     if (!pids_nrm.empty()) { // behind the prep (sorted cloud, strip table), 1024 points per workgroup and pass
         int tmax = 0;
