@@ -557,6 +557,7 @@ struct CfarOsGateTab {
     int xc;         // smallest x with L[x] >= 0 (L grows with x: "can fire at all" is one threshold); 257: none
 };
 
+template <bool V16> // V16: rows and pointers are 16-byte aligned -- the tile streams through in 16-byte pieces
 __global__ __launch_bounds__(256) void cfar_u8_os_gated(const uint8_t *__restrict__ img, uint8_t *__restrict__ mask, int rows,
                                                         int cols, int n_frames, int T, int G, int k, int tiles_y, int tiles_x,
                                                         CfarOsGateTab tab)
@@ -581,16 +582,38 @@ __global__ __launch_bounds__(256) void cfar_u8_os_gated(const uint8_t *__restric
     // stage rows r0 - H .. r0 + tr + H - 1 (clamped into the image: rows that need a clamped cell are border rows,
     // whose output is 0 anyway, cfar.cpp:82), 4 bytes per thread and load
     const int wpr = OSG_TC / 4; // dwords per staged row
-    for (int i = tid; i < (tr + 2 * H) * wpr; i += 256) {
-        const int rr = i / wpr, cw = i - rr * wpr;
-        const int gr = min(max(r0 - H + rr, 0), rows - 1);
-        uint32_t v = 0u;
-        if (4 * cw < tc)
-            v = *reinterpret_cast<const uint32_t *>(in + (size_t)gr * cols + c0 + 4 * cw);
-        reinterpret_cast<uint32_t *>(s_in)[rr * wpr + cw] = v;
+    if constexpr (V16) {
+        constexpr int QPR = OSG_TC / 16; // 16-byte pieces per staged row
+        const int n16 = (tr + 2 * H) * QPR;
+        for (int i0 = tid; i0 < n16; i0 += 4 * 256) { // four loads in flight per thread
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 256, rr = i / QPR, cw = i - rr * QPR;
+                const int gr = min(max(r0 - H + rr, 0), rows - 1);
+                v[u] = make_uint4(0u, 0u, 0u, 0u);
+                if (i < n16 && 16 * cw < tc)
+                    v[u] = *reinterpret_cast<const uint4 *>(in + (size_t)gr * cols + c0 + 16 * cw);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + u * 256 < n16)
+                    reinterpret_cast<uint4 *>(s_in)[i0 + u * 256] = v[u];
+        }
+        for (int i = tid; i < OSG_TR * QPR; i += 256)
+            reinterpret_cast<uint4 *>(s_out)[i] = make_uint4(0u, 0u, 0u, 0u);
+    } else {
+        for (int i = tid; i < (tr + 2 * H) * wpr; i += 256) {
+            const int rr = i / wpr, cw = i - rr * wpr;
+            const int gr = min(max(r0 - H + rr, 0), rows - 1);
+            uint32_t v = 0u;
+            if (4 * cw < tc)
+                v = *reinterpret_cast<const uint32_t *>(in + (size_t)gr * cols + c0 + 4 * cw);
+            reinterpret_cast<uint32_t *>(s_in)[rr * wpr + cw] = v;
+        }
+        for (int i = tid; i < OSG_TR * wpr; i += 256)
+            reinterpret_cast<uint32_t *>(s_out)[i] = 0u;
     }
-    for (int i = tid; i < OSG_TR * wpr; i += 256)
-        reinterpret_cast<uint32_t *>(s_out)[i] = 0u;
     __syncthreads();
     unsigned short *wl = s_list + wave * (OSG_LIST + 256);
     int nl = 0; // candidates in this wave's list (wave-uniform)
@@ -644,10 +667,19 @@ __global__ __launch_bounds__(256) void cfar_u8_os_gated(const uint8_t *__restric
     if (nl > 0)
         take(nl);
     __syncthreads();
-    for (int i = tid; i < tr * wpr; i += 256) {
-        const int rr = i / wpr, cw = i - rr * wpr;
-        if (4 * cw < tc)
-            *reinterpret_cast<uint32_t *>(out + (size_t)(r0 + rr) * cols + c0 + 4 * cw) = reinterpret_cast<const uint32_t *>(s_out)[rr * wpr + cw];
+    if constexpr (V16) {
+        constexpr int QPR = OSG_TC / 16;
+        for (int i = tid; i < tr * QPR; i += 256) {
+            const int rr = i / QPR, cw = i - rr * QPR;
+            if (16 * cw < tc)
+                *reinterpret_cast<uint4 *>(out + (size_t)(r0 + rr) * cols + c0 + 16 * cw) = reinterpret_cast<const uint4 *>(s_out)[i];
+        }
+    } else {
+        for (int i = tid; i < tr * wpr; i += 256) {
+            const int rr = i / wpr, cw = i - rr * wpr;
+            if (4 * cw < tc)
+                *reinterpret_cast<uint32_t *>(out + (size_t)(r0 + rr) * cols + c0 + 4 * cw) = reinterpret_cast<const uint32_t *>(s_out)[rr * wpr + cw];
+        }
     }
 }
 
@@ -894,8 +926,10 @@ static int launch_os_gated(sfe_ctx *ctx, const uint8_t *d_img, int n_frames, int
             tab.xc = x;
     const int tiles_y = (rows + OSG_TR - 1) / OSG_TR, tiles_x = (cols + OSG_TC - 1) / OSG_TC;
     const size_t smem = (size_t)(OSG_TR + 2 * (T + G)) * OSG_TC + (size_t)OSG_TR * OSG_TC + sizeof(unsigned short) * 4 * (OSG_LIST + 256);
-    SFE_HIP(ctx, hipFuncSetAttribute((const void *)cfar_u8_os_gated, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL(cfar_u8_os_gated, dim3((unsigned)((long long)n_frames * tiles_y * tiles_x)), dim3(256), smem, ctx->stream,
+    const bool v16 = cols % 16 == 0 && (((uintptr_t)d_img | (uintptr_t)d_mask) & 15) == 0 && !getenv("SFE_CFAR_OSG_V4");
+    auto kernel = v16 ? cfar_u8_os_gated<true> : cfar_u8_os_gated<false>;
+    SFE_HIP(ctx, hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)((long long)n_frames * tiles_y * tiles_x)), dim3(256), smem, ctx->stream,
                        d_img, d_mask, rows, cols, n_frames, T, G, k, tiles_y, tiles_x, tab);
     return 0;
 }
