@@ -72,6 +72,28 @@ __device__ __forceinline__ uint32_t pk_sub_opaque(uint32_t a, uint32_t b)
 
 typedef __amdgpu_buffer_rsrc_t sfe_rsrc_t; // 128-bit buffer resource (SGPRs)
 
+// The threshold map's value for a window sum s, thr = (float)(tau * (double)(float)s / D) with D = T or 2T (cfar.cpp:27,46,67
+// as the host table below restates it), computed instead of fetched: one table gather per pixel is one L1 tag look-up
+// per pixel, and that rate -- not HBM -- bounded the map kernels (0.47-0.60 ms per 512 frames whatever the window).
+// The quotient is formed with the reciprocal of D and two residual corrections (fma), which is the correctly rounded
+// quotient for every operand the host has tried: cfar_u8_dev evaluates this very sequence for every possible sum of the
+// launch and compares it with the table bit by bit -- a single difference and the kernel keeps the table (ta.on = 0).
+struct CfarThrArith {
+    double tau, rinv, d;
+    int on;
+};
+__host__ __device__ __forceinline__ float cfar_thr_arith(const CfarThrArith &ta, uint32_t sv)
+{
+    const double p = ta.tau * (double)(float)sv;
+    double q = p * ta.rinv;
+    double e = fma(-ta.d, q, p);
+    q = fma(e, ta.rinv, q);
+    e = fma(-ta.d, q, p);
+    q = fma(e, ta.rinv, q);
+    return (float)q;
+}
+
+
 // Tiles and column chunks OVERLAP instead of being predicated: a tile is always a whole number
 // of R-row groups (the last tile is shifted up so it ends at the last row) and the last 64-lane
 // chunk is shifted left so it ends at the last beam.  Overlapped outputs are recomputed with
@@ -82,13 +104,17 @@ typedef __amdgpu_buffer_rsrc_t sfe_rsrc_t; // 128-bit buffer resource (SGPRs)
 // into a nibble (one v_dot4), 8 lanes OR their nibbles into a 32-bit word over three DPP steps and one lane
 // of the 8 stores it -- the other 56 lanes aim past the end of the buffer, where the hardware drops the
 // store.  Needs cols % 32 == 0 (a row is a whole number of words and every 64-lane chunk starts on one).
-template <int T, int G, int ALG, int D, bool BITS>
+// THR (the *2 variants, cfar.cpp:98-192): the float threshold map next to the byte mask, from the window sums this
+// kernel holds in registers anyway -- thr = (float)(tau * s / T) computed per pixel (cfar_thr_arith), one float4 per lane and row.
+template <int T, int G, int ALG, int D, bool BITS, bool THR = false>
 __global__ __launch_bounds__(256, 3) void cfar_u8_ring(const uint8_t *__restrict__ img,
                                                     uint8_t *__restrict__ mask, int rows, int cols,
                                                     int n_frames, int groups_per_tile,
                                                     int tiles_per_frame, int chunks_per_row,
-                                                    long long out_frame_bytes, CfarLut lut)
+                                                    long long out_frame_bytes, CfarLut lut, float *__restrict__ thr = nullptr,
+                                                    CfarThrArith ta = CfarThrArith{0.0, 0.0, 1.0, 0})
 {
+    static_assert(!(THR && BITS), "the threshold map goes with the byte mask");
     constexpr int H = T + G;
     constexpr int R = 2 * H + 2;
     static_assert(R % D == 0, "prefetch depth must divide the ring length");
@@ -205,6 +231,13 @@ __global__ __launch_bounds__(256, 3) void cfar_u8_ring(const uint8_t *__restrict
             } else {
                 __builtin_amdgcn_raw_buffer_store_b32(o, dst, voff, pr * cols, 0);
             }
+            if (THR) {
+                float4 tv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (keep)
+                    tv = make_float4(cfar_thr_arith(ta, sL & 0xffffu), cfar_thr_arith(ta, sL >> 16),
+                                     cfar_thr_arith(ta, sH & 0xffffu), cfar_thr_arith(ta, sH >> 16));
+                *reinterpret_cast<float4 *>(thr + (size_t)f * frame_bytes + (size_t)pr * cols + voff) = tv;
+            }
 
             const uint32_t x = pre[(j + R - 1) % D]; // row r+H+1
             pre[(j + R - 1) % D] = ld(r + H + 1 + D);
@@ -235,7 +268,7 @@ template <int ALG, bool THR>
 __global__ __launch_bounds__(256) void cfar_u8_slide(const uint8_t *__restrict__ img, uint8_t *__restrict__ mask,
                                                      float *__restrict__ thr, const float *__restrict__ thr_tab,
                                                      int rows, int cols, int n_frames, int T, int G, int tile_rows,
-                                                     int tiles_per_frame, int chunks_per_row, CfarLut lut)
+                                                     int tiles_per_frame, int chunks_per_row, CfarLut lut, CfarThrArith ta)
 {
     __shared__ uint16_t s_lut[256];
     s_lut[threadIdx.x] = lut.v[threadIdx.x];
@@ -305,7 +338,8 @@ __global__ __launch_bounds__(256) void cfar_u8_slide(const uint8_t *__restrict__
         if (THR) {
             float4 tv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (inside)
-                tv = make_float4(thr_tab[s0], thr_tab[s1], thr_tab[s2], thr_tab[s3]);
+                tv = ta.on ? make_float4(cfar_thr_arith(ta, s0), cfar_thr_arith(ta, s1), cfar_thr_arith(ta, s2), cfar_thr_arith(ta, s3))
+                           : make_float4(thr_tab[s0], thr_tab[s1], thr_tab[s2], thr_tab[s3]);
             *reinterpret_cast<float4 *>(thr + (size_t)f * frame_bytes + (size_t)r * cols + voff) = tv;
         }
         leadL = pk_sub(pk_add(leadL, unpack_lo(a)), unpack_lo(b));
@@ -334,7 +368,7 @@ template <int ALG, bool THR>
 __global__ __launch_bounds__(256) void cfar_u8_slide_lds(const uint8_t *__restrict__ img, uint8_t *__restrict__ mask,
                                                          float *__restrict__ thr, const float *__restrict__ thr_tab,
                                                          int rows, int cols, int n_frames, int T, int G, int tile_rows,
-                                                         int tiles_per_frame, int chunks_per_row, CfarLut lut)
+                                                         int tiles_per_frame, int chunks_per_row, CfarLut lut, CfarThrArith ta)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_ring_all[]; // [4 waves][R][64]
     __shared__ uint16_t s_lut[256];
@@ -429,7 +463,8 @@ __global__ __launch_bounds__(256) void cfar_u8_slide_lds(const uint8_t *__restri
                 if (THR) {
                     float4 tv = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (inside)
-                        tv = make_float4(thr_tab[s0], thr_tab[s1], thr_tab[s2], thr_tab[s3]);
+                        tv = ta.on ? make_float4(cfar_thr_arith(ta, s0), cfar_thr_arith(ta, s1), cfar_thr_arith(ta, s2), cfar_thr_arith(ta, s3))
+                           : make_float4(thr_tab[s0], thr_tab[s1], thr_tab[s2], thr_tab[s3]);
                     *reinterpret_cast<float4 *>(thr + (size_t)f * frame_bytes + (size_t)r * cols + voff) = tv;
                 }
                 leadL = pk_sub(pk_add(leadL, unpack_lo(a)), unpack_lo(b));
@@ -855,22 +890,50 @@ static bool build_lut(int alg, int T, double tau, int intensity_thr, CfarLut *lu
     return true;
 }
 
-template <int T, int G, int D, bool BITS>
+template <int T, int G, int D, bool BITS, bool THR = false>
 static void launch_ring(sfe_ctx *ctx, int alg, const uint8_t *d_img, uint8_t *d_mask, int rows, int cols,
-                        int n_frames, int groups, int tiles, long long out_frame_bytes, const CfarLut &lut)
+                        int n_frames, int groups, int tiles, long long out_frame_bytes, const CfarLut &lut,
+                        float *d_thr = nullptr, CfarThrArith ta = CfarThrArith{0.0, 0.0, 1.0, 0})
 {
     const int chunks = ((cols >> 2) + 63) / 64;
     const long long bpf = ((long long)tiles * chunks + 3) / 4;             // workgroups per frame
     const unsigned blocks = (unsigned)((((long long)n_frames + 7) / 8) * 8 * bpf); // frames padded to the 8 XCDs
     if (alg == SFE_CFAR_SOCA)
-        hipLaunchKernelGGL((cfar_u8_ring<T, G, SFE_CFAR_SOCA, D, BITS>), dim3(blocks), dim3(256), 0, ctx->stream,
-                           d_img, d_mask, rows, cols, n_frames, groups, tiles, chunks, out_frame_bytes, lut);
+        hipLaunchKernelGGL((cfar_u8_ring<T, G, SFE_CFAR_SOCA, D, BITS, THR>), dim3(blocks), dim3(256), 0, ctx->stream,
+                           d_img, d_mask, rows, cols, n_frames, groups, tiles, chunks, out_frame_bytes, lut, d_thr, ta);
     else if (alg == SFE_CFAR_GOCA)
-        hipLaunchKernelGGL((cfar_u8_ring<T, G, SFE_CFAR_GOCA, D, BITS>), dim3(blocks), dim3(256), 0, ctx->stream,
-                           d_img, d_mask, rows, cols, n_frames, groups, tiles, chunks, out_frame_bytes, lut);
+        hipLaunchKernelGGL((cfar_u8_ring<T, G, SFE_CFAR_GOCA, D, BITS, THR>), dim3(blocks), dim3(256), 0, ctx->stream,
+                           d_img, d_mask, rows, cols, n_frames, groups, tiles, chunks, out_frame_bytes, lut, d_thr, ta);
     else
-        hipLaunchKernelGGL((cfar_u8_ring<T, G, SFE_CFAR_CA, D, BITS>), dim3(blocks), dim3(256), 0, ctx->stream,
-                           d_img, d_mask, rows, cols, n_frames, groups, tiles, chunks, out_frame_bytes, lut);
+        hipLaunchKernelGGL((cfar_u8_ring<T, G, SFE_CFAR_CA, D, BITS, THR>), dim3(blocks), dim3(256), 0, ctx->stream,
+                           d_img, d_mask, rows, cols, n_frames, groups, tiles, chunks, out_frame_bytes, lut, d_thr, ta);
+}
+
+// cfar_thr_arith checked against the reference expression for every window sum of (alg, T, tau): on = 1 when each of them
+// agrees bit by bit (cached per context)
+static CfarThrArith thr_arith_checked(sfe_ctx *ctx, int alg, int T, double tau)
+{
+    const double d = (alg == SFE_CFAR_CA) ? 2.0 * T : (double)T;
+    CfarThrArith ta{tau, 1.0 / d, d, 1};
+    if (ctx->tha_alg == alg && ctx->tha_T == T && ctx->tha_tau == tau) {
+        ta.on = ctx->tha_on;
+        return ta;
+    }
+    const int smax = (alg == SFE_CFAR_CA) ? 255 * 2 * T : 255 * T;
+    for (int sv = 0; sv <= smax && ta.on; ++sv) {
+        const float sf = (float)sv;
+        const float want = (float)((alg == SFE_CFAR_CA) ? tau * (double)sf / (2.0 * T) : tau * (double)sf / T);
+        const float got = cfar_thr_arith(ta, (uint32_t)sv);
+        if (__builtin_memcmp(&want, &got, sizeof want) != 0)
+            ta.on = 0; // (never seen: the kernels then read the table)
+    }
+    if (getenv("SFE_CFAR_THR_TABLE"))
+        ta.on = 0; // A/B
+    ctx->tha_alg = alg;
+    ctx->tha_T = T;
+    ctx->tha_tau = tau;
+    ctx->tha_on = ta.on;
+    return ta;
 }
 
 // R-row groups per tile.  Measured on MI355X (tools/cfar_sweep.py, 1024 frames of 1024x512, XCD-aware
@@ -955,7 +1018,10 @@ static int cfar_u8_dev(sfe_ctx *ctx, const uint8_t *d_img, int n_frames, int row
     // the reference's feature.yaml comments and tests go through: (32, 8), (20, 4), (16, 2)
     const bool ring_window = (T == 20 && G == 5) || (T == 16 && G == 4) || (T == 10 && G == 2) || (T == 8 && G == 1);
     const int ringR = 2 * (T + G) + 2;
-    bool ring = (alg != SFE_CFAR_OS) && !d_thr && (cols % 4 == 0) && cols >= 256 && rows >= ringR && (size_t)rows * cols < (1u << 30) &&
+    // (with a threshold map: when it can be computed, cfar_thr_arith, and not next to the bit-stream output)
+    const CfarThrArith thr_ta = (d_thr && alg != SFE_CFAR_OS) ? thr_arith_checked(ctx, alg, T, tau) : CfarThrArith{0.0, 0.0, 1.0, 0};
+    static const bool no_ring_thr = getenv("SFE_CFAR_NO_RING_THR") != nullptr; // A/B
+    bool ring = (alg != SFE_CFAR_OS) && (!d_thr || (thr_ta.on && !d_bits && !no_ring_thr && reinterpret_cast<uintptr_t>(d_thr) % 16 == 0)) && (cols % 4 == 0) && cols >= 256 && rows >= ringR && (size_t)rows * cols < (1u << 30) &&
                 ctx->cfar_variant != 1 &&
                 ((reinterpret_cast<uintptr_t>(d_img) | reinterpret_cast<uintptr_t>(d_mask)) % 4 == 0) &&
                 ring_window && build_lut(alg, T, tau, intensity_thr, &lut);
@@ -988,6 +1054,15 @@ static int cfar_u8_dev(sfe_ctx *ctx, const uint8_t *d_img, int n_frames, int row
                 launch_ring<10, 2, 13, true>(ctx, alg, d_img, d_mask, rows, cols, n_frames, groups, tiles, bb, lut);
             else
                 launch_ring<8, 1, 5, true>(ctx, alg, d_img, d_mask, rows, cols, n_frames, groups, tiles, bb, lut);
+        } else if (d_thr) {
+            if (T == 20)
+                launch_ring<20, 5, 4, false, true>(ctx, alg, d_img, d_mask, rows, cols, n_frames, groups, tiles, fb, lut, d_thr, thr_ta);
+            else if (T == 16)
+                launch_ring<16, 4, 6, false, true>(ctx, alg, d_img, d_mask, rows, cols, n_frames, groups, tiles, fb, lut, d_thr, thr_ta);
+            else if (T == 10)
+                launch_ring<10, 2, 13, false, true>(ctx, alg, d_img, d_mask, rows, cols, n_frames, groups, tiles, fb, lut, d_thr, thr_ta);
+            else
+                launch_ring<8, 1, 5, false, true>(ctx, alg, d_img, d_mask, rows, cols, n_frames, groups, tiles, fb, lut, d_thr, thr_ta);
         } else if (T == 20 && ctx->cfar_variant == 3)
             launch_ring<20, 5, 13, false>(ctx, alg, d_img, d_mask, rows, cols, n_frames, groups, tiles, fb, lut);
         else if (T == 20)
@@ -1044,10 +1119,10 @@ static int cfar_u8_dev(sfe_ctx *ctx, const uint8_t *d_img, int n_frames, int row
             SFE_HIP(ctx, hipFuncSetAttribute((const void *)cfar_u8_slide_lds<A, THRB>,                                 \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_bytes));            \
             hipLaunchKernelGGL((cfar_u8_slide_lds<A, THRB>), dim3(blocks), dim3(256), ring_bytes, ctx->stream, d_img,  \
-                               d_mask, d_thr, d_tab, rows, cols, n_frames, T, G, tile_rows, tiles, chunks, lut);       \
+                               d_mask, d_thr, d_tab, rows, cols, n_frames, T, G, tile_rows, tiles, chunks, lut, thr_ta); \
         } else {                                                                                                       \
             hipLaunchKernelGGL((cfar_u8_slide<A, THRB>), dim3(blocks), dim3(256), 0, ctx->stream, d_img, d_mask,       \
-                               d_thr, d_tab, rows, cols, n_frames, T, G, tile_rows, tiles, chunks, lut);               \
+                               d_thr, d_tab, rows, cols, n_frames, T, G, tile_rows, tiles, chunks, lut, thr_ta);       \
         }                                                                                                              \
     } while (0)
         if (alg == SFE_CFAR_SOCA) {

@@ -49,6 +49,8 @@ struct sfe_ctx {
     int thr_tab_alg = -1, thr_tab_T = -1;
     double thr_tab_tau = 0.0;
     const void *thr_tab_ptr = nullptr;
+    int tha_alg = -1, tha_T = -1, tha_on = 0; // cfar_thr_arith checked against the reference expression for these
+    double tha_tau = 0.0;
     int cfar_tile_rows = 0;
     int cfar_variant = 0;
     int icp_variant = 0;
