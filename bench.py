@@ -560,6 +560,9 @@ def main():
             # cpu_baseline.sample
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import live_latency
+            # (a live node uses the context as it comes: without the batch pipeline's side-stream preparation, whose event
+            # hand-over between two streams costs a single small call ~20 us)
+            ctx._check(ctx.lib.sfe_icp_set_tuning(ctx.handle, 0))
             out["live_latency"] = live_latency.measure(ctx)
             out["live_latency"]["note"] = ("median host wall time per call: FeatureExtraction.callback on a 1024x512 ping "
                                            "(fused = sfe_feature_extract_ping, per_stage = the four per-stage calls), "
