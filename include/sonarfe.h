@@ -37,6 +37,14 @@
  *     workgroup, row-block -> XCD map, frames per pass, per-point instead of word-list expansion, its workgroups per
  *     frame), SFE_CFAR_NO_BITS, SFE_CFAR_NO_LDS_RING (CFAR: byte kernel + pack instead of the bit-stream kernel, sliding
  *     sums without the LDS ring), SFE_CF_BITONIC (resident downsample by bitonic sort), SFE_ICP_DEBUG (watchdog report).
+ *     Round 3: SFE_SW_TIERS, SFE_SW_TINY, SFE_SW_TINY_PAIRS, SFE_SW_MULTI, SFE_SW_MULTI_G, SFE_SW_T0_SRC, SFE_SW_T1_SRC,
+ *     SFE_SW_T0_MIN_JOBS, SFE_SW_T1_MIN_JOBS, SFE_SW_WIN, SFE_SW_UNION_ITERS, SFE_SW_UNION_MAX, SFE_SW_LEAN_TRIAGE,
+ *     SFE_SW_GRID_DEFER, SFE_SW_UNBOUNDED_COOP, SFE_SW_NORMALS_SPLIT, SFE_SW_PREP_GTAIL (ICP job classes and their
+ *     limits, jobs shared by several workgroups, search variants, the prep kernel's two-workgroups-per-CU build),
+ *     SFE_SG_SLICES, SFE_SG_PIECE, SFE_NO_SELF_CLEAN (list-driven extraction: workgroups per frame, rows per piece,
+ *     a memset of the canvas bitmap per batch), SFE_DS_RANK (per-cloud downsample by rank counting), SFE_CFAR_NO_OS_GATED,
+ *     SFE_CFAR_OS_GATED_MIN, SFE_CFAR_OSG_V4, SFE_CFAR_THR_TABLE, SFE_CFAR_NO_RING_THR (CFAR: OS behind the gate,
+ *     threshold maps from a table / from the sliding-sum kernel).
  *   - one sfe_ctx = one device + one HIP stream + its scratch; a ctx is not
  *     re-entrant (the reference's pybind calls hold the GIL and its ICP object is
  *     stateful, SURVEY 8b "Threading"); use one ctx per worker thread/process.
@@ -165,8 +173,9 @@ int sfe_remap_u8_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_src, uint8_t *d
 int sfe_extract_points(sfe_ctx *ctx, sfe_geom *g, const uint8_t *mask, int64_t cap,
                        int64_t *rc_out, double *pts_out, int64_t *n_out);
 /* A-B knob of the extraction: 0 = binary masks go through the inverse map (walk the set polar pixels,
- * evaluate only the canvas pixels that tap them; default), 1 = dense pass over the whole canvas for
- * every frame.  Identical results. */
+ * evaluate only the canvas pixels that tap them; default: the list-driven kernel of round 3), 1 = dense pass
+ * over the whole canvas for every frame, 2 = the inverse map through the row-block kernel of round 2.
+ * Identical results. */
 int sfe_extract_set_tuning(sfe_ctx *ctx, int variant);
 /* device-resident batch: per frame f, points go to d_pts + f*cap*2 (float64), count to d_counts[f]
  * (count is the true number even if it exceeds cap; only the first cap points are stored) */
