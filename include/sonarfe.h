@@ -81,7 +81,7 @@ typedef struct sfe_geom sfe_geom;
 #define SFE_ICP_NAN_ROT 3    /* "abs rotation norm not a number" */
 #define SFE_ICP_NAN_TRANS 4  /* "abs translation norm not a number" */
 #define SFE_ICP_SINGULAR 5   /* point-to-plane normal system not positive definite */
-#define SFE_ICP_SPLIT_TIMEOUT 6 /* internal: the workgroups sharing one large job lost each other (never seen in practice) */
+#define SFE_ICP_SPLIT_TIMEOUT 6 /* *_dev entry points only: the workgroups sharing one large job were not resident together (sfe_icp_set_tuning bit 4) */
 
 /* ---- library / context ------------------------------------------------- */
 const char *sfe_version(void);
@@ -251,6 +251,12 @@ int sfe_icp_compute_jobs(sfe_ctx *ctx, const sfe_icp_params *p, const float *src
  * entry points are final, i.e. no work enqueued earlier on this context still writes them; the preparation of
  * the targets (sort, strip table, normals) then runs on a side stream next to that earlier work and only the
  * iteration kernel waits for both.  Leave it clear when a preceding call on the context produces the clouds.
+ * bit 4: never share one large job between several workgroups.  Sharing (jobs of >= 8192 queries on a target beyond
+ * 8192 points, when the call holds nothing else and shares x jobs <= CUs) needs every share resident at the same
+ * time, which only a device this context has to itself can promise; a share that waits 0.5 s for the others gives up
+ * and the job reports SFE_ICP_SPLIT_TIMEOUT.  The host-pointer entry points (sfe_icp_compute*) then run the call again
+ * with this bit set, so their callers never see that status; callers of the enqueue-only *_dev entry points that
+ * share the device set the bit themselves or repeat the call with it when they read status 6.
  * All variants return identical results. */
 int sfe_icp_set_tuning(sfe_ctx *ctx, int variant);
 /* profile mode of the strip-sweep ICP kernel: enable/disable, and read the 96 values of the last profiled launch

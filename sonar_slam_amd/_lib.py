@@ -25,7 +25,7 @@ ICP_STATUS_MESSAGES = {
     3: "abs rotation norm not a number",
     4: "abs translation norm not a number",
     5: "point-to-plane system not positive definite",
-    6: "internal: split job timed out",
+    6: "internal: the workgroups sharing one job were not resident together (sfe_icp_set_tuning bit 4)",
 }
 
 
@@ -265,6 +265,11 @@ class Context(object):
 
     def close(self):
         if self.handle is not None:
+            # pinned blocks handed out by host_alloc die with the context (sfe_host_free waits for the copy stream);
+            # numpy views of them must not be used afterwards
+            for p in list(getattr(self, "_pinned", {}).values()):
+                self.lib.sfe_host_free(self.handle, p)
+            self._pinned = {}
             self.lib.sfe_ctx_destroy(self.handle)
             self.handle = None
 

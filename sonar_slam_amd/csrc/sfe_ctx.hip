@@ -28,6 +28,14 @@ void *sfe_scratch(sfe_ctx *ctx, int slot, size_t bytes)
         (void)hipStreamSynchronize(ctx->stream);
         if (ctx->stream2)
             (void)hipStreamSynchronize(ctx->stream2); // the ICP target preparation may run there
+        if (ctx->stream_copy)
+            (void)hipStreamSynchronize(ctx->stream_copy); // an upload into the old block may still be in flight
+        // a "known to be zero" note about this buffer dies with it: hipMalloc commonly hands the same address out
+        // again, with whatever the allocation holds (extract_dev trusted the pointer alone)
+        if (ctx->bm_clean_ptr == b.p) {
+            ctx->bm_clean_ptr = nullptr;
+            ctx->bm_clean_bytes = 0;
+        }
         (void)hipFree(b.p);
         b.p = nullptr;
         b.cap = 0;
@@ -205,7 +213,11 @@ int sfe_free(sfe_ctx *ctx, void *dptr)
 {
     if (int rc = sfe_use(ctx))
         return rc;
+    // nothing this context has enqueued may still touch the block: kernels, the ICP preparation on the side stream,
+    // uploads on the copy stream (sfe_memcpy_h2d_async)
     SFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SFE_HIP(ctx, hipStreamSynchronize(ctx->stream2));
+    SFE_HIP(ctx, hipStreamSynchronize(ctx->stream_copy));
     if (dptr)
         SFE_HIP(ctx, hipFree(dptr));
     return 0;

@@ -216,7 +216,9 @@ int sfe_downsample(sfe_ctx *ctx, const float *pts, int n, float resolution, floa
     // cloud against ~0.1 ms).  Same octree restatement, same medoids (both are checked against the oracle).  The
     // float32 points are widened to float64 on the way up, which sfe_cloud_filter_batch_dev casts back unchanged.
     static const bool no_fast = getenv("SFE_DS_RANK") != nullptr; // A/B
-    if (!out_idx && !no_fast && n <= 65536) {
+    // (resolution <= 0 / NaN means "no downsample" to the batch entry point -- feature_extraction.py:241 -- but to
+    // pcl.downsample it is maxSizeByNode = 0: split down to single points.  Those calls keep the rank-counting path.)
+    if (!out_idx && !no_fast && n <= 65536 && resolution > 0.0f) {
         const size_t b_in = sizeof(double) * 2 * (size_t)n + 16;
         double *h64 = (double *)sfe_pinned_io(ctx, 0, b_in);
         char *d_in = (char *)sfe_scratch(ctx, 13, b_in);

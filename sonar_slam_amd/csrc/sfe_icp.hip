@@ -782,13 +782,33 @@ static int icp_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_src,
     return 0;
 }
 
+// A job that was shared by several workgroups reports SFE_ICP_SPLIT_TIMEOUT when its shares were not resident
+// together (the device is shared with another context or process; sfe_icp_sweep.hip "split jobs").  The host-pointer
+// entry points see the statuses and run the call once more with splitting off, so the caller never meets status 6.
+static bool icp_any_split_timeout(const int32_t *status, int n)
+{
+    for (int j = 0; j < n; ++j)
+        if (status[j] == SFE_ICP_SPLIT_TIMEOUT)
+            return true;
+    return false;
+}
+#define ICP_RETRY_UNSPLIT(call)                                                                  \
+    do {                                                                                         \
+        if (!(ctx->icp_variant & 16) && icp_any_split_timeout(status, n_retry_)) {               \
+            ctx->icp_variant |= 16;                                                              \
+            const int rc_ = (call);                                                              \
+            ctx->icp_variant &= ~16;                                                             \
+            return rc_;                                                                          \
+        }                                                                                        \
+    } while (0)
+
 extern "C" {
 
 int sfe_icp_set_tuning(sfe_ctx *ctx, int variant)
 {
     if (!ctx)
         return SFE_ERR_ARG;
-    SFE_ARG(ctx, variant >= 0 && variant <= 15);
+    SFE_ARG(ctx, variant >= 0 && variant <= 31);
     ctx->icp_variant = variant;
     return 0;
 }
@@ -867,6 +887,8 @@ int sfe_icp_compute_guesses(sfe_ctx *ctx, const sfe_icp_params *p, const float *
     memcpy(status, h_out + sizeof(float) * 9 * (size_t)n_guesses, sizeof(int32_t) * (size_t)n_guesses);
     if (iters)
         memcpy(iters, h_out + (sizeof(float) * 9 + sizeof(int32_t)) * (size_t)n_guesses, sizeof(int32_t) * (size_t)n_guesses);
+    const int n_retry_ = n_guesses;
+    ICP_RETRY_UNSPLIT(sfe_icp_compute_guesses(ctx, p, src, n_src, tgt, n_tgt, guesses9, n_guesses, T_out9, status, iters));
     return 0;
 }
 
@@ -898,6 +920,8 @@ int sfe_icp_compute_pairs(sfe_ctx *ctx, const sfe_icp_params *p, const float *sr
         SFE_HIP(ctx, hipMemcpyAsync(iters, d_st + n_jobs, sizeof(int32_t) * (size_t)n_jobs, hipMemcpyDeviceToHost,
                                     ctx->stream));
     SFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int n_retry_ = n_jobs;
+    ICP_RETRY_UNSPLIT(sfe_icp_compute_pairs(ctx, p, src, src_off, tgt, tgt_off, guesses9, n_jobs, T_out9, status, iters));
     return 0;
 }
 
@@ -936,6 +960,9 @@ int sfe_icp_compute_jobs(sfe_ctx *ctx, const sfe_icp_params *p, const float *src
         SFE_HIP(ctx, hipMemcpyAsync(iters, d_st + n_jobs, sizeof(int32_t) * (size_t)n_jobs, hipMemcpyDeviceToHost,
                                     ctx->stream));
     SFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int n_retry_ = n_jobs;
+    ICP_RETRY_UNSPLIT(sfe_icp_compute_jobs(ctx, p, src, n_src_pts, tgt, n_tgt_pts, jobs4, guesses9, n_jobs, T_out9, status,
+                                           iters));
     return 0;
 }
 

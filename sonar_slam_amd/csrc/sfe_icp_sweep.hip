@@ -1164,7 +1164,7 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
     // two banks: a share can be one exchange ahead of the slowest one, never two (it needs everybody's words of the
     // exchange in between).  Every share adds the rows up in share order, so all of them hold the same totals, take
     // the same decisions and run the same number of rounds and iterations.  The area is zeroed before every launch
-    // (tag 0 = nothing yet).  A wait of more than ~2 s (a share that never became resident: the launcher only splits
+    // (tag 0 = nothing yet).  A wait of more than ~0.5 s (a share that never became resident: the launcher only splits
     // jobs when all shares fit the device at once) gives up and the job reports SFE_ICP_SPLIT_TIMEOUT.
     typedef __attribute__((address_space(1))) unsigned long long gu64;
     unsigned xepoch = 0;
@@ -1178,7 +1178,7 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
                 x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((unsigned)(x >> 32) == epoch)
                     break;
-                if (wall_clock64() - t0 > 200000000ull) {
+                if (wall_clock64() - t0 > 50000000ull) { // 0.5 s
                     S.xabort = 1;
                     break;
                 }
@@ -2748,7 +2748,9 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
     const int force_wide = env_int("SFE_SW_WIDE", -1); // A/B: 1 = one 128-VGPR workgroup per CU
     const int force_share = env_int("SFE_SW_SHARE_KB", 0); // A/B: LDS per workgroup
     const bool no_ldsq = getenv("SFE_SW_NO_LDSQ") != nullptr; // A/B
-    const int multi_on = env_int("SFE_SW_MULTI", 1);           // A/B: 0 = never split a job
+    // A/B: 0 = never split a job; sfe_icp_set_tuning bit 4 = the same per context (a device shared with another
+    // context / process cannot promise that all shares of a job are resident together: ADVICE r3)
+    const int multi_on = (ctx->icp_variant & 16) ? 0 : env_int("SFE_SW_MULTI", 1);
     const int multi_min_src = env_int("SFE_SW_MULTI_MIN_SRC", 8192);
     const int multi_share_min = env_int("SFE_SW_MULTI_SHARE_MIN", 1024); // fewest queries worth a workgroup
     const int multi_force = env_int("SFE_SW_MULTI_G", 0);     // A/B: shares per job

@@ -9,7 +9,7 @@
 
 #include "../../include/sonarfe.h"
 
-#define SFE_NSCRATCH 48
+#define SFE_NSCRATCH 64
 #define SFE_ICP_PROF_N 96 // values sfe_icp_get_profile hands back
 
 struct sfe_ctx {

@@ -15,6 +15,7 @@ Extension (not in the reference): ``ICP.compute_batch(source, target, guesses)``
 many-guesses-one-pair loop of SLAM.compute_icp_with_cov (slam.py:346-358) in one launch.
 """
 import ctypes as _C
+import os as _os
 
 import numpy as _np
 
@@ -222,19 +223,32 @@ class ICP(object):
         # PM::ICP() starts without a chain (pcl.cpp:185); the SLAM node always calls loadFromYaml next (slam.py:99)
         self.params = None
 
-    def loadFromYaml(self, filename):
+    def loadFromYaml(self, filename, strict=None):
         """pcl.cpp:187-197.  A file that cannot be opened makes the reference print a message and fall back to
         PM::ICP::setDefault(): random sub-sampling of the reading, surface-normal sampling of the reference and a
-        3-D point-to-plane chain -- not reproducible and not what any bruce_slam launch file intends, so here it is
-        an error instead of a silently different chain (deviations)."""
+        3-D point-to-plane chain -- not reproducible and not what any bruce_slam launch file intends.  Default
+        (``strict`` True): an error instead of a silently different chain (deviations).
+
+        ``strict=False``, or ``SONARFE_YAML_FALLBACK=shipped`` in the environment when ``strict`` is not given: behave
+        like the reference AT THE CALL SITE (slam_ros.py:124-125 sees no exception) -- print the reference's exact
+        line (pcl.cpp:192) and carry on with a default chain; the default installed here is the chain of the shipped
+        ``config/icp.yaml`` (``icp_config.shipped_params``), since libpointmatcher's ``setDefault`` chain is 3-D and
+        random and has no counterpart on this path."""
+        if strict is None:
+            strict = _os.environ.get("SONARFE_YAML_FALLBACK", "").strip().lower() != "shipped"
         try:
             with open(filename, "r") as fh:
                 text = fh.read()
         except (IOError, OSError) as e:
+            if not strict:
+                print("Failed to load %s. Use default configuration." % filename)      # pcl.cpp:192, verbatim
+                self.params = _cfg.shipped_params()
+                return
             raise RuntimeError("ICP.loadFromYaml: cannot open %s (%s).  The reference would print 'Failed to load ... Use "
                                "default configuration.' and run libpointmatcher's setDefault() chain (random sampling + "
-                               "surface normals), which this front end does not provide: fix the path, or install a "
-                               "chain with setParams()" % (filename, e))
+                               "surface normals), which this front end does not provide: fix the path, install a "
+                               "chain with setParams(), or pass strict=False / set SONARFE_YAML_FALLBACK=shipped to "
+                               "carry on with the chain of the shipped config/icp.yaml" % (filename, e))
         self.params = _cfg.parse_icp_yaml(text)
 
     def setParams(self, params):

@@ -227,6 +227,18 @@ def test_downsample_without_indices_large_and_deep_clouds():
         assert np.array_equal(g2, want) and np.array_equal(d2[:, 0].astype(np.int64), widx), (len(pts), res)
 
 
+def test_downsample_with_a_non_positive_resolution_splits_down_to_single_points():
+    """maxSizeByNode = 0 has no size limit in libpointmatcher's octree: one point per leaf, in path order
+    (not "skip the filter", which is what resolution <= 0 means to the batched FeatureExtraction tail)."""
+    rng = np.random.default_rng(56)
+    pts = rng.uniform(-10, 10, (300, 2)).astype(np.float32)
+    for res in (0.0, -1.0):
+        want = oracle.downsample(pts, res)
+        got = pcl.downsample(pts, res)
+        assert len(want) == 300 and not np.array_equal(want, pts)
+        assert np.array_equal(got, want), res
+
+
 def test_feature_extraction_callback_end_to_end(shipped_cfar):
     """FeatureExtraction.callback (feature_extraction.py:196-252 without ROS) vs the oracle chain
     CFAR -> gate -> remap -> nonzero -> px2m -> downsample -> remove_outlier."""

@@ -244,6 +244,32 @@ def test_icp_object_has_no_silent_default_chain(tmp_path):
         pcl.match(np.zeros((2, 2), np.float32), np.zeros((5, 2), np.float32), 3, 1.0, ctx=object())
 
 
+def test_load_from_yaml_can_behave_like_the_reference_at_the_call_site(tmp_path, capsys, monkeypatch):
+    """pcl.cpp:190-194: a launch file with a wrong icp_config path prints one line and carries on (slam_ros.py:124-125
+    sees no exception).  Opt-in here (strict=False or SONARFE_YAML_FALLBACK=shipped): the reference's exact line, then
+    the chain of the shipped config/icp.yaml; the default stays loud."""
+    from sonar_slam_amd import pcl
+    missing = str(tmp_path / "no_such_icp.yaml")
+    icp = pcl.ICP()
+    icp.loadFromYaml(missing, strict=False)
+    assert capsys.readouterr().out == "Failed to load %s. Use default configuration.\n" % missing
+    assert icp.params.as_dict() == icp_config.shipped_params().as_dict()
+    icp2 = pcl.ICP()
+    monkeypatch.setenv("SONARFE_YAML_FALLBACK", "shipped")
+    icp2.loadFromYaml(missing)                       # the reference's one-argument call
+    assert "Failed to load" in capsys.readouterr().out and icp2.params is not None
+    with pytest.raises(RuntimeError, match="cannot open"):
+        pcl.ICP().loadFromYaml(missing, strict=True)     # an explicit strict wins over the environment
+    monkeypatch.delenv("SONARFE_YAML_FALLBACK")
+    with pytest.raises(RuntimeError, match="cannot open"):
+        pcl.ICP().loadFromYaml(missing)
+    # a file that opens but does not parse is an error either way (the reference's loadFromYaml throws on it too)
+    bad = tmp_path / "bad.yaml"
+    bad.write_text("matcher:\n  NoSuchMatcher:\n    knn: 1\n")
+    with pytest.raises(Exception):
+        pcl.ICP().loadFromYaml(str(bad), strict=False)
+
+
 def test_shims_bind_every_name_the_reference_modules_define():
     """cfar.cpp:194-204 and pcl.cpp:176-213 by name and arity: every m.def / .def of the two pybind modules exists in
     the shims and accepts the reference's positional arguments (overloads included)."""
