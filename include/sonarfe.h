@@ -311,6 +311,70 @@ int sfe_feature_extract_ping(sfe_ctx *ctx, sfe_geom *g, const uint8_t *img, int 
                              int k, double tau, int intensity_thr, float resolution, double radius, int min_points,
                              int64_t cap, float *cloud_out, int32_t *n_out, int32_t *n_raw_out, uint8_t *vis_out);
 
+/* ---- device-resident keyframe clouds: the hand-off feature node -> SLAM node without PCIe ------------------
+ * Reference flow (every cloud crosses the process boundary and is rebuilt in numpy):
+ *   feature_extraction.py:175-193  publish_features           cloud -> PointCloud2 xyz32
+ *   slam_ros.py:169-170            SLAM_callback              xyz -> [x, -z] (float64 array of float32 values:
+ *                                                             ros_numpy pointcloud2_to_xyz_array)
+ *   slam_objects.py:178-198        Keyframe.transform_points  points.dot(T[:2,:2].T) + T[:2,2], T float32
+ *   slam.py:229-292                SLAM.get_points            transform, concatenate, pcl.downsample
+ *   slam.py:294-323                SLAM.compute_icp           pcl.ICP.compute(source, target, guess)
+ *   slam.py:389-424                SLAM.get_overlap           transform, pcl.match, count ids != -1
+ * A store keeps the clouds in HBM: one pool of float2 points and a slot table (offset, count) per cloud.  A cloud is
+ * named by its handle (slot index, handed out in order); slots are released in stack order (sfe_cloud_store_truncate):
+ * keyframe clouds stay for the session, the target clouds get_points builds are dropped after their scan match.
+ * Clouds are appended by kernels that read their sizes from device memory, so the sizes reach the host lazily: the
+ * entry points that need them (meta, read, get_points, the scan match) copy the new slot-table entries down once
+ * (a few bytes per cloud, one stream synchronisation) -- never the points.  A cloud's count is < 0 when its producer
+ * failed: -1 the resident downsample refused it (octree deeper than 24 levels), -3 the pool was full. */
+typedef struct sfe_cloud_store sfe_cloud_store;
+#define SFE_STORE_NEGATE_Y 1   /* put: store (x, -y), what slam_ros.py:170 makes of the feature message */
+#define SFE_STORE_F32_POINTS 2 /* get_points / overlap: the caller's keyframe clouds are float32 numpy arrays (sgemm
+                                  rounding: fma(p1, r1, p0 * r0) + t in float) instead of the SLAM node's float64 ones
+                                  (products and sums in double, rounded to float32 at the pybind boundary) */
+int sfe_cloud_store_create(sfe_ctx *ctx, int64_t capacity_points, int32_t max_clouds, sfe_cloud_store **out);
+void sfe_cloud_store_destroy(sfe_cloud_store *s);
+int sfe_cloud_store_count(sfe_cloud_store *s); /* slots in use = the next handle */
+/* one cloud from the host (a feature message that arrived over the wire), enqueue only */
+int sfe_cloud_store_put(sfe_ctx *ctx, sfe_cloud_store *s, int64_t stamp, const float *pts, int n, int32_t *handle_out);
+/* n_frames clouds straight from sfe_cloud_filter_batch_dev's outputs (d_clouds [n_frames][cap][2] float32, d_counts),
+ * device to device, enqueue only; stamps (host, nullable) are kept with the slots; handles_out (host, nullable) */
+int sfe_cloud_store_put_batch_dev(sfe_ctx *ctx, sfe_cloud_store *s, const int64_t *stamps, const float *d_clouds,
+                                  const int32_t *d_counts, int n_frames, int64_t cap, int flags, int32_t *handles_out);
+/* slot table of clouds first .. first + n - 1 (each output nullable); synchronises if entries are new */
+int sfe_cloud_store_meta(sfe_ctx *ctx, sfe_cloud_store *s, int32_t first, int32_t n, int64_t *stamps, int64_t *offsets,
+                         int32_t *counts);
+/* the points of one cloud, for whoever needs them on the host (the PointCloud2 of publish_features, rviz, mapping) */
+int sfe_cloud_store_read(sfe_ctx *ctx, sfe_cloud_store *s, int32_t handle, float *out, int cap, int *n_out);
+/* release every slot >= n_slots */
+int sfe_cloud_store_truncate(sfe_ctx *ctx, sfe_cloud_store *s, int32_t n_slots);
+/* SLAM.get_points(frames, ref_frame) for n_jobs target clouds at once (slam.py:229-292): job j takes the clouds
+ * handles[j*m .. j*m+m) (-1 = unused), moves cloud k by T6[(j*m+k)*6 ..] = {T00 T01 T02 T10 T11 T12} of
+ * ref_pose.between(pose).matrix().astype(float32) like Keyframe.transform_points, concatenates them in that order and
+ * runs pcl.downsample(resolution) (resolution <= 0: no downsample); the results become new slots (handles_out, host). */
+int sfe_cloud_store_get_points(sfe_ctx *ctx, sfe_cloud_store *s, const int32_t *handles, const float *T6, int n_jobs, int m,
+                               float resolution, int flags, const int64_t *stamps, int32_t *handles_out);
+/* SLAM.compute_icp over handles (slam.py:294-323): pairs = n_jobs x (source handle, target handle); otherwise like
+ * sfe_icp_jobs_dev (device guesses / results, enqueue only once the sizes are known) and sfe_icp_compute_jobs (host
+ * guesses / results, one synchronisation).  Empty or failed clouds are refused (SFE_ERR_ARG): the caller tests
+ * ssm_min_points first like slam.py:745. */
+int sfe_icp_store_jobs_dev(sfe_ctx *ctx, const sfe_icp_params *p, sfe_cloud_store *s, const int32_t *pairs,
+                           const float *d_guess9, int n_jobs, float *d_T9, int32_t *d_status, int32_t *d_iters);
+int sfe_icp_store_compute(sfe_ctx *ctx, const sfe_icp_params *p, sfe_cloud_store *s, const int32_t *pairs,
+                          const float *guesses9, int n_jobs, float *T_out9, int32_t *status, int32_t *iters);
+/* SLAM.get_overlap (slam.py:389-424) for n_jobs (source, target) pairs: the source moved by T6[j*6 ..] (the estimated
+ * pose's matrix as float32), pcl.match(target, source, 1, max_dist), counts_out[j] = matched points (host) */
+int sfe_cloud_store_overlap(sfe_ctx *ctx, sfe_cloud_store *s, const int32_t *pairs, const float *T6, int n_jobs,
+                            float max_dist, int flags, int32_t *counts_out);
+/* sfe_feature_extract_ping with the cloud left in the store instead of copied to the host: the
+ * filtered cloud becomes a new slot (with SFE_STORE_NEGATE_Y in flags: as the SLAM node holds it), *handle_out its
+ * handle, *n_out its size; cloud_out (nullable, host [cap x 2], (forward, lateral) as published) receives the points
+ * only when the caller wants to publish them.  On SFE_ERR_CAP / *n_out = -1 no slot is kept (*handle_out = -1). */
+int sfe_feature_extract_ping_store(sfe_ctx *ctx, sfe_geom *g, sfe_cloud_store *s, int64_t stamp, const uint8_t *img, int alg,
+                                   int train_hs, int guard_hs, int k, double tau, int intensity_thr, float resolution,
+                                   double radius, int min_points, int64_t cap, int flags, int32_t *handle_out,
+                                   int32_t *n_out, int32_t *n_raw_out, float *cloud_out, uint8_t *vis_out);
+
 /* ---- global-initialisation matching cost: slam.py:461-570 ---------------- */
 /*
  * get_matching_cost_subroutine1 builds a dilated occupancy grid of the target cloud and hands

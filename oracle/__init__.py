@@ -101,6 +101,7 @@ def lib():
         L.orc_cost_grid.argtypes = [i32p, i32p, C.c_int, C.c_int, C.c_int, C.c_int, u8p]
         L.orc_matching_cost.argtypes = [u8p, C.c_int, C.c_int, f32p, C.c_int, f32p, C.c_int, C.c_float,
                                         C.c_float, C.c_float, i32p]
+        L.orc_transform_points.argtypes = [f32p, C.c_int, f32p, C.c_int, f32p]
         _lib = L
     return _lib
 
@@ -240,6 +241,33 @@ def downsample(pts, resolution, return_index=False):
     res = np.float32(float("%f" % np.float32(resolution)))
     m = lib().orc_downsample(_p(pts, C.c_float), len(pts), float(res), _p(out, C.c_float), _p(idx, C.c_int32))
     return (out[:m].copy(), idx[:m].copy()) if return_index else out[:m].copy()
+
+
+def transform_points(points, T, f64_points=True):
+    """Keyframe.transform_points (slam_objects.py:178-198) as the scan matcher sees its result: float32 at the pybind
+    boundary.  T: 3 x 3 (or 2 x 3) pose matrix, rounded to float32 like `pose.matrix().astype(np.float32)`;
+    f64_points: the keyframe cloud is a float64 array of float32 values (the SLAM node, slam_ros.py:169-170 through
+    ros_numpy) -- else float32 (sgemm).  -> N x 2 float32"""
+    pts = np.ascontiguousarray(points, np.float32).reshape(-1, 2)
+    T6 = np.ascontiguousarray(np.asarray(T)[:2, :3], np.float32)
+    out = np.zeros_like(pts)
+    lib().orc_transform_points(_p(pts, C.c_float), len(pts), _p(T6, C.c_float), 1 if f64_points else 0, _p(out, C.c_float))
+    return out
+
+
+def get_points(clouds, transforms, resolution, f64_points=True):
+    """SLAM.get_points with a reference frame (slam.py:229-292): every keyframe cloud moved by its transform
+    (ref_pose.between(pose).matrix()), concatenated in frame order, pcl.downsample -> N x 2 float32"""
+    parts = [transform_points(c, T, f64_points) for c, T in zip(clouds, transforms)]
+    allp = np.concatenate(parts) if parts else np.zeros((0, 2), np.float32)
+    return downsample(allp, resolution) if len(allp) else allp
+
+
+def overlap(source, target, T, max_dist, f64_points=True):
+    """SLAM.get_overlap (slam.py:389-424): transform the source, pcl.match(target, source, 1, max_dist), count the
+    matched points"""
+    ids, _ = match(target, transform_points(source, T, f64_points), max_dist)
+    return int(np.sum(ids != -1))
 
 
 def ellipse_kernel(hs):

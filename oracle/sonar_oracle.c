@@ -1149,3 +1149,38 @@ void orc_matching_cost(const uint8_t *grid, int rows, int cols, const float *src
         cost_out[p] = -hits;
     }
 }
+
+/* ------------------------------------------------------------------------- */
+/* Keyframe.transform_points (slam_objects.py:178-198):                       */
+/*     T = pose.matrix().astype(np.float32)                                   */
+/*     return points.dot(T[:2, :2].T) + T[:2, 2]                              */
+/* T6 = {T00, T01, T02, T10, T11, T12} (float32).  What numpy computes depends */
+/* on the dtype of `points`:                                                  */
+/*   f64_points != 0: the SLAM node's keyframe clouds are float64 arrays       */
+/*     holding float32 values (ros_numpy.point_cloud2.pointcloud2_to_xyz_array */
+/*     -> get_xyz_points(dtype=np.float), slam_ros.py:169-170; ros_numpy is    */
+/*     un-vendored), so the product is promoted to float64: both products are  */
+/*     exact in double (24 x 24 bits), their sum is rounded once (with or      */
+/*     without FMA in dgemm: the same), the translation is added in double;    */
+/*     the cloud reaches float32 at the pybind boundary of pcl.downsample /    */
+/*     ICP.compute / match (Matrix = fp32, pcl.cpp:10-16).                     */
+/*   f64_points == 0: float32 points go through sgemm, whose x86 kernels        */
+/*     accumulate over k with FMA: fma(p1, r1, fl(p0 * r0)), then a float add. */
+/* Both pinned by tests/golden/transform_points.npz (the reference's own       */
+/* function run on this image's numpy).                                        */
+/* ------------------------------------------------------------------------- */
+void orc_transform_points(const float *pts, int n, const float *T6, int f64_points, float *out)
+{
+    for (int i = 0; i < n; ++i) {
+        const float p0 = pts[2 * i], p1 = pts[2 * i + 1];
+        if (f64_points) {
+            const double x = ((double)p0 * (double)T6[0] + (double)p1 * (double)T6[1]) + (double)T6[2];
+            const double y = ((double)p0 * (double)T6[3] + (double)p1 * (double)T6[4]) + (double)T6[5];
+            out[2 * i] = (float)x;
+            out[2 * i + 1] = (float)y;
+        } else {
+            out[2 * i] = fmaf(p1, T6[1], p0 * T6[0]) + T6[2];
+            out[2 * i + 1] = fmaf(p1, T6[4], p0 * T6[3]) + T6[5];
+        }
+    }
+}

@@ -124,6 +124,21 @@ SIGNATURES = {
     "sfe_icp_jobs_dev": (C.c_int, [_vp, C.POINTER(IcpParams), _vp, _vp, _i32p, _vp, C.c_int, _vp, _vp, _vp]),
     "sfe_cloud_filter_batch_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_int,
                                              _vp, _vp]),
+    "sfe_cloud_store_create": (C.c_int, [_vp, C.c_int64, C.c_int32, C.POINTER(_vp)]),
+    "sfe_cloud_store_destroy": (None, [_vp]),
+    "sfe_cloud_store_count": (C.c_int, [_vp]),
+    "sfe_cloud_store_put": (C.c_int, [_vp, _vp, C.c_int64, _f32p, C.c_int, _i32p]),
+    "sfe_cloud_store_put_batch_dev": (C.c_int, [_vp, _vp, _i64p, _vp, _vp, C.c_int, C.c_int64, C.c_int, _i32p]),
+    "sfe_cloud_store_meta": (C.c_int, [_vp, _vp, C.c_int32, C.c_int32, _i64p, _i64p, _i32p]),
+    "sfe_cloud_store_read": (C.c_int, [_vp, _vp, C.c_int32, _f32p, C.c_int, C.POINTER(C.c_int)]),
+    "sfe_cloud_store_truncate": (C.c_int, [_vp, _vp, C.c_int32]),
+    "sfe_cloud_store_get_points": (C.c_int, [_vp, _vp, _i32p, _f32p, C.c_int, C.c_int, C.c_float, C.c_int, _i64p, _i32p]),
+    "sfe_icp_store_jobs_dev": (C.c_int, [_vp, C.POINTER(IcpParams), _vp, _i32p, _vp, C.c_int, _vp, _vp, _vp]),
+    "sfe_icp_store_compute": (C.c_int, [_vp, C.POINTER(IcpParams), _vp, _i32p, _f32p, C.c_int, _f32p, _i32p, _i32p]),
+    "sfe_cloud_store_overlap": (C.c_int, [_vp, _vp, _i32p, _f32p, C.c_int, C.c_float, C.c_int, _i32p]),
+    "sfe_feature_extract_ping_store": (C.c_int, [_vp, _vp, _vp, C.c_int64, _u8p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                 C.c_double, C.c_int, C.c_float, C.c_double, C.c_int, C.c_int64, C.c_int,
+                                                 _i32p, _i32p, _i32p, _f32p, _u8p]),
     "sfe_costgrid_create": (C.c_int, [_vp, _i32p, _i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     "sfe_costgrid_destroy": (None, [_vp]),
     "sfe_costgrid_download": (C.c_int, [_vp, _vp, _u8p]),

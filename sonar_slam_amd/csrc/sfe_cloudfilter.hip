@@ -14,24 +14,11 @@
 // equal keys, medoid per leaf.  Here the stable sort is an in-LDS bitonic sort of (key << 16 | index)
 // per frame (<= 16384 points, key <= 48 bits); clouds or trees beyond that take the rank-counting
 // sort of sfe_downsample.hip.
-#include "sfe_internal.h"
+#include "sfe_cloudfilter.h"
 
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
-
-#define CF_MAX_LEVELS 31
-#define CF_SORT_CAP 16384 // points per frame the LDS sort holds (128 KiB of 64-bit keys)
-#define CF_MAX_CAP 65536  // 16 index bits in the sort key
-
-struct CfHeader {
-    float cx, cy, radius;
-    int levels;
-    int n;      // points of this frame (clamped to cap)
-    int n_seg;  // leaves = points after the downsample
-    int n_out;  // points after the outlier filter
-    int zlev;   // >= 0: the downsampled cloud is in octree path order and its leaf keys (2 * zlev bits) were kept
-};
 
 // one workgroup per frame: float64 -> float32 (what pybind does at pcl.cpp's boundary), bounding box,
 // octree root and depth
@@ -75,27 +62,7 @@ __global__ __launch_bounds__(1024) void cf_cast_bbox_kernel(const double *__rest
             mxx = fmaxf(mxx, s_mx[0][w]);
             mxy = fmaxf(mxy, s_mx[1][w]);
         }
-        CfHeader h;
-        // Octree::build: centre = min + radii*0.5, radius = max(radii)*0.5
-        const float rx = mxx - mnx, ry = mxy - mny;
-        h.cx = mnx + rx * 0.5f;
-        h.cy = mny + ry * 0.5f;
-        float radius = rx;
-        if (radius < ry)
-            radius = ry;
-        radius *= 0.5f;
-        h.radius = radius;
-        int L = 0;
-        float r = radius;
-        while (!((double)r * 2.0 <= (double)max_size) && L < CF_MAX_LEVELS) {
-            r *= 0.5f;
-            ++L;
-        }
-        h.levels = L;
-        h.n = n;
-        h.n_seg = n; // if the downsample is skipped the cloud passes through
-        h.n_out = n;
-        h.zlev = -1;
+        const CfHeader h = cf_make_header(mnx, mny, mxx, mxy, max_size, n);
         hdrs[f] = h;
     }
 }
@@ -629,6 +596,13 @@ __global__ __launch_bounds__(1024) void cf_radius_filter_kernel(const float2 *__
     }
 }
 
+float sfe_cf_max_size(float resolution)
+{
+    char buf[64];
+    snprintf(buf, sizeof buf, "%f", (double)resolution);
+    return strtof(buf, nullptr);
+}
+
 extern "C" int sfe_cloud_filter_batch_dev(sfe_ctx *ctx, const double *d_pts, const int32_t *d_counts, int n_frames,
                                           int64_t cap, float resolution, double radius, int min_points, float *d_out,
                                           int32_t *d_out_counts)
@@ -638,24 +612,33 @@ extern "C" int sfe_cloud_filter_batch_dev(sfe_ctx *ctx, const double *d_pts, con
     SFE_ARG(ctx, n_frames >= 0 && cap >= 0 && (n_frames == 0 || cap == 0 || (d_pts && d_counts && d_out && d_out_counts)));
     if (n_frames == 0)
         return 0;
+    if (resolution > 0.0f && cap > CF_MAX_CAP)
+        return sfe_set_err(ctx, SFE_ERR_ARG, "sfe_cloud_filter_batch_dev: cap %lld exceeds %d points per frame",
+                           (long long)cap, CF_MAX_CAP);
+    const size_t per = (size_t)std::max<int64_t>(cap, 1);
+    float2 *d_p32 = (float2 *)sfe_scratch(ctx, CF_SLOT_P32, sizeof(float2) * per * (size_t)n_frames);
+    CfHeader *d_hdr = (CfHeader *)sfe_scratch(ctx, CF_SLOT_HDR, sizeof(CfHeader) * (size_t)n_frames);
+    if (!d_p32 || !d_hdr)
+        return SFE_ERR_HIP;
+    hipLaunchKernelGGL(cf_cast_bbox_kernel, dim3(n_frames), dim3(1024), 0, ctx->stream, d_pts, d_counts, (long long)cap,
+                       sfe_cf_max_size(resolution), d_p32, d_hdr);
+    return sfe_cf_run_staged(ctx, n_frames, cap, resolution, radius, min_points, d_out, d_out_counts);
+}
+
+int sfe_cf_run_staged(sfe_ctx *ctx, int n_frames, int64_t cap, float resolution, double radius, int min_points,
+                      float *d_out, int32_t *d_out_counts)
+{
     const bool do_ds = resolution > 0.0f;            // feature_extraction.py:241
     const bool do_filter = min_points > 1;           // feature_extraction.py:245
     if (do_ds && cap > CF_MAX_CAP)
-        return sfe_set_err(ctx, SFE_ERR_ARG, "sfe_cloud_filter_batch_dev: cap %lld exceeds %d points per frame",
+        return sfe_set_err(ctx, SFE_ERR_ARG, "resident cloud filter: cap %lld exceeds %d points per frame",
                            (long long)cap, CF_MAX_CAP);
-    // pcl.cpp:134 hands the resolution over as std::to_string(float): six decimals survive
-    char buf[64];
-    snprintf(buf, sizeof buf, "%f", (double)resolution);
-    const float max_size = strtof(buf, nullptr);
-
     const size_t per = (size_t)std::max<int64_t>(cap, 1);
-    float2 *d_p32 = (float2 *)sfe_scratch(ctx, 25, sizeof(float2) * per * (size_t)n_frames);
+    float2 *d_p32 = (float2 *)sfe_scratch(ctx, CF_SLOT_P32, sizeof(float2) * per * (size_t)n_frames);
     float2 *d_ds = (float2 *)sfe_scratch(ctx, 26, sizeof(float2) * per * (size_t)n_frames);
-    CfHeader *d_hdr = (CfHeader *)sfe_scratch(ctx, 27, sizeof(CfHeader) * (size_t)n_frames);
+    CfHeader *d_hdr = (CfHeader *)sfe_scratch(ctx, CF_SLOT_HDR, sizeof(CfHeader) * (size_t)n_frames);
     if (!d_p32 || !d_ds || !d_hdr)
         return SFE_ERR_HIP;
-    hipLaunchKernelGGL(cf_cast_bbox_kernel, dim3(n_frames), dim3(1024), 0, ctx->stream, d_pts, d_counts, (long long)cap,
-                       max_size, d_p32, d_hdr);
     const float2 *stage = d_p32;
     unsigned *d_lkeys = nullptr; // leaf keys of the downsampled clouds (radius filter fast path)
     if (do_ds) {

@@ -114,6 +114,11 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
                          const int32_t *jobs4, const float *d_guess9, int n_jobs, float *d_T9, int32_t *d_status,
                          int32_t *d_iters);
 
+// sfe_store.hip: append n_frames clouds ([f][cap] float2 + counts[f], device) to a store; enqueue only
+struct sfe_cloud_store;
+int sfe_store_append_dev(sfe_cloud_store *s, const int64_t *stamps, const float *d_clouds, const int32_t *d_counts,
+                         int n_frames, int64_t cap, int flags, int32_t *handles_out);
+
 static inline int sfe_use(sfe_ctx *ctx)
 {
     if (!ctx)

@@ -36,14 +36,13 @@ static void *pinned_io(sfe_ctx *ctx, int slot, size_t bytes)
 
 void *sfe_pinned_io(sfe_ctx *ctx, int slot, size_t bytes) { return pinned_io(ctx, slot, bytes); }
 
-extern "C" int sfe_feature_extract_ping(sfe_ctx *ctx, sfe_geom *g, const uint8_t *img, int alg, int train_hs,
-                                        int guard_hs, int k, double tau, int intensity_thr, float resolution,
-                                        double radius, int min_points, int64_t cap, float *cloud_out, int32_t *n_out,
-                                        int32_t *n_raw_out, uint8_t *vis_out)
+// store != nullptr: the filtered cloud is appended to the store (device to device) and only the two counts come down,
+// plus the points when cloud_out is given
+static int ping_impl(sfe_ctx *ctx, sfe_geom *g, sfe_cloud_store *store, int64_t stamp, int store_flags, const uint8_t *img,
+                     int alg, int train_hs, int guard_hs, int k, double tau, int intensity_thr, float resolution,
+                     double radius, int min_points, int64_t cap, float *cloud_out, int32_t *n_out, int32_t *n_raw_out,
+                     uint8_t *vis_out, int32_t *handle_out)
 {
-    if (int rc = sfe_use(ctx))
-        return rc;
-    SFE_ARG(ctx, g && img && cloud_out && n_out && g->ctx == ctx && cap > 0 && cap <= 65536);
     const size_t np = (size_t)g->polar_rows * g->polar_cols, nc = (size_t)g->cart_rows * g->cart_cols;
     uint8_t *d_img = (uint8_t *)sfe_scratch(ctx, 32, np);
     // detections: a bit stream when the rows are whole words (SFE_BITS_WORDS(np) words fit into np bytes for
@@ -75,7 +74,13 @@ extern "C" int sfe_feature_extract_ping(sfe_ctx *ctx, sfe_geom *g, const uint8_t
     float *d_cloud = reinterpret_cast<float *>(d_res + 4);
     if (int rc = sfe_cloud_filter_batch_dev(ctx, d_pts, d_res, 1, cap, resolution, radius, min_points, d_cloud, d_res + 1))
         return rc;
-    SFE_HIP(ctx, hipMemcpyAsync(h_res, d_res, 16 + (size_t)cap * 8, hipMemcpyDeviceToHost, ctx->stream));
+    int32_t handle = -1;
+    if (store)
+        if (int rc = sfe_store_append_dev(store, &stamp, d_cloud, d_res + 1, 1, cap, store_flags, &handle))
+            return rc;
+    // the points come down only when somebody wants them on the host
+    const size_t b_down = 16 + ((!store || cloud_out) ? (size_t)cap * 8 : 0);
+    SFE_HIP(ctx, hipMemcpyAsync(h_res, d_res, b_down, hipMemcpyDeviceToHost, ctx->stream));
     if (vis_out)
         SFE_HIP(ctx, hipMemcpyAsync(h_res + 16 + (size_t)cap * 8, d_vis, nc, hipMemcpyDeviceToHost, ctx->stream));
     SFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -84,15 +89,49 @@ extern "C" int sfe_feature_extract_ping(sfe_ctx *ctx, sfe_geom *g, const uint8_t
         *n_raw_out = n_raw;
     if (vis_out)
         memcpy(vis_out, h_res + 16 + (size_t)cap * 8, nc);
-    if (n_raw > cap) {
-        *n_out = 0;
-        return sfe_set_err(ctx, SFE_ERR_CAP, "feature_extract_ping: %d points exceed capacity %lld", n_raw, (long long)cap);
-    }
-    if (n < 0) { // octree deeper than 24 levels (sfe_cloud_filter_batch_dev): the caller takes the per-cloud path
-        *n_out = -1;
+    if (handle_out)
+        *handle_out = handle;
+    if (n_raw > cap || n < 0) {
+        if (store) { // no slot for a cloud that is truncated or was refused
+            if (int rc = sfe_cloud_store_truncate(ctx, store, handle))
+                return rc;
+            if (handle_out)
+                *handle_out = -1;
+        }
+        if (n_raw > cap) {
+            *n_out = 0;
+            return sfe_set_err(ctx, SFE_ERR_CAP, "feature_extract_ping: %d points exceed capacity %lld", n_raw, (long long)cap);
+        }
+        *n_out = -1; // octree deeper than 24 levels (sfe_cloud_filter_batch_dev): the caller takes the per-cloud path
         return 0;
     }
     *n_out = n;
-    memcpy(cloud_out, h_res + 16, (size_t)n * 8);
+    if (cloud_out)
+        memcpy(cloud_out, h_res + 16, (size_t)n * 8);
     return 0;
+}
+
+extern "C" int sfe_feature_extract_ping(sfe_ctx *ctx, sfe_geom *g, const uint8_t *img, int alg, int train_hs,
+                                        int guard_hs, int k, double tau, int intensity_thr, float resolution,
+                                        double radius, int min_points, int64_t cap, float *cloud_out, int32_t *n_out,
+                                        int32_t *n_raw_out, uint8_t *vis_out)
+{
+    if (int rc = sfe_use(ctx))
+        return rc;
+    SFE_ARG(ctx, g && img && cloud_out && n_out && g->ctx == ctx && cap > 0 && cap <= 65536);
+    return ping_impl(ctx, g, nullptr, 0, 0, img, alg, train_hs, guard_hs, k, tau, intensity_thr, resolution, radius,
+                     min_points, cap, cloud_out, n_out, n_raw_out, vis_out, nullptr);
+}
+
+extern "C" int sfe_feature_extract_ping_store(sfe_ctx *ctx, sfe_geom *g, sfe_cloud_store *s, int64_t stamp,
+                                              const uint8_t *img, int alg, int train_hs, int guard_hs, int k, double tau,
+                                              int intensity_thr, float resolution, double radius, int min_points,
+                                              int64_t cap, int flags, int32_t *handle_out, int32_t *n_out,
+                                              int32_t *n_raw_out, float *cloud_out, uint8_t *vis_out)
+{
+    if (int rc = sfe_use(ctx))
+        return rc;
+    SFE_ARG(ctx, g && s && img && handle_out && n_out && g->ctx == ctx && cap > 0 && cap <= 65536);
+    return ping_impl(ctx, g, s, stamp, flags, img, alg, train_hs, guard_hs, k, tau, intensity_thr, resolution, radius,
+                     min_points, cap, cloud_out, n_out, n_raw_out, vis_out, handle_out);
 }

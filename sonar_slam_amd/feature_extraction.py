@@ -133,6 +133,42 @@ class Geometry(object):
                 return None
             return cloud[:n.value].copy(), vis
 
+    def feature_extract_store(self, img, alg, cfar_params, threshold, resolution, radius, min_points, store, stamp=0,
+                              flags=1, want_cloud=False, want_vis=False, cap=16384):
+        """``feature_extract`` with the cloud left in a ``store.CloudStore`` (sfe_feature_extract_ping_store): the
+        filtered cloud never crosses PCIe unless ``want_cloud`` asks for the publishable copy.  flags: store.NEGATE_Y
+        (default) keeps it as the SLAM node holds it (slam_ros.py:170).
+        -> (handle, n, cloud or None, vis or None), or None when the resident filter cannot take the ping."""
+        from .cfar import _gate_u8
+        img = np.ascontiguousarray(img, np.uint8)
+        if img.shape != (self.polar_rows, self.polar_cols):
+            raise ValueError("feature_extract: image shape %r does not match the geometry" % (img.shape,))
+        code = _L.ALG[alg]
+        if code == 3:
+            train_hs, guard_hs, k, tau = cfar_params
+        else:
+            (train_hs, guard_hs, tau), k = cfar_params, 0
+        vis = np.zeros((self.cart_rows, self.cart_cols), np.uint8) if want_vis else None
+        cap = int(cap)
+        while True:
+            cloud = np.zeros((cap, 2), np.float32) if want_cloud else None
+            n, n_raw, h = _C.c_int32(0), _C.c_int32(0), _C.c_int32(-1)
+            with self.ctx.lock:
+                ret = self.ctx.lib.sfe_feature_extract_ping_store(
+                    self.ctx.handle, self.handle, store.handle, int(stamp), _L.ptr(img, _C.c_uint8), code, int(train_hs),
+                    int(guard_hs), int(k), float(tau), _gate_u8(threshold), float(resolution), float(radius),
+                    int(min_points), cap, int(flags), _C.byref(h), _C.byref(n), _C.byref(n_raw),
+                    _L.ptr(cloud, _C.c_float) if want_cloud else None, _L.ptr(vis, _C.c_uint8) if want_vis else None)
+            if ret == _L.SFE_ERR_CAP and n_raw.value > cap and n_raw.value <= 65536:
+                cap = int(n_raw.value)
+                continue
+            if ret == _L.SFE_ERR_CAP:
+                return None
+            self.ctx._check(ret)
+            if n.value < 0:
+                return None
+            return h.value, n.value, (cloud[:n.value].copy() if want_cloud else None), vis
+
     def close(self):
         if self.handle is not None:
             self.ctx.lib.sfe_geom_destroy(self.handle)
@@ -260,6 +296,37 @@ class FeatureExtraction(object):
                 if self.make_vis_image:
                     self.feature_img = vis
                 return points
+        return self._callback_stages(img)
+
+    def callback_store(self, ping, store, stamp=0, publish=False):
+        """``callback`` for a SLAM front end that lives in the same process (replay.FrontEnd with a store): the cloud
+        stays on the device as a new slot of ``store`` in the SLAM node's convention (forward, -lateral;
+        slam_ros.py:170).  -> (handle, n_points, cloud): ``cloud`` is the publishable N x 2 copy
+        (feature_extraction.py:175-193) when ``publish`` is set, else None -- the wire bytes exist only on request.
+        Skipped frames (:201-207) -> (-1, 0, [[nan, nan]])."""
+        if ping.ping_id % self.skip != 0:
+            self.feature_img = None
+            return -1, 0, np.array([[np.nan, np.nan]])
+        img = ping.image
+        self.generate_map_xy(ping)
+        if np.asarray(img).dtype == np.uint8:
+            out = self.geometry.feature_extract_store(img, self.alg, self.detector.params[self.alg], self.threshold,
+                                                      self.resolution, self.outlier_filter_radius,
+                                                      self.outlier_filter_min_points, store, stamp=stamp,
+                                                      want_cloud=publish, want_vis=self.make_vis_image)
+            if out is not None:
+                h, n, cloud, vis = out
+                if self.make_vis_image:
+                    self.feature_img = vis
+                return h, n, cloud
+        # pings the one-call path cannot take (non-uint8 images, clouds beyond the resident filter): the per-stage
+        # chain on the host API, then one upload of the finished cloud
+        points = self._callback_stages(img)
+        pts32 = np.ascontiguousarray(points, np.float32).reshape(-1, 2)
+        h = store.put(np.c_[pts32[:, 0], -1 * pts32[:, 1]], stamp)
+        return h, len(pts32), (points if publish else None)
+
+    def _callback_stages(self, img):
         peaks = self.detect(img)
         if self.make_vis_image:
             self.feature_img = self.geometry.remap(img)  # :226 (colour map is applied by the node)

@@ -100,6 +100,14 @@ class KeyframeBatch(object):
                                                   float(resolution), float(radius), int(min_points),
                                                   self.d_cloud.ptr, self.d_cloud_cnt.ptr))
 
+    def store_clouds(self, store, stamps=None, flags=1):
+        """The filtered clouds of this batch (after run_filter) appended to a ``store.CloudStore``, device to device
+        (sfe_cloud_store_put_batch_dev; enqueue only).  flags: store.NEGATE_Y = the SLAM node's convention
+        (slam_ros.py:170).  -> handles [n]"""
+        if self.d_cloud is None:
+            raise _L.SonarFEError("store_clouds before run_filter")
+        return store.put_batch_dev(self.d_cloud, self.d_cloud_cnt, self.n, self.cap, stamps=stamps, flags=flags)
+
     def cloud(self, j):
         """the filtered float32 feature cloud of frame j (after run_filter)"""
         self._check_frame(j)

@@ -14,6 +14,12 @@ order of operations, and leaves the graph optimiser pluggable:
          -> sanity checks, overlap               slam.py:786-811 -> pcl.match              (GPU)
          -> BetweenFactorPose2(target, source)   slam.py:813-832  -> ``backend.add_between``
 
+With ``FrontEnd(store=CloudStore)`` the same flow runs on device-resident clouds: the feature
+extractor leaves each cloud in the store (``FeatureExtraction.callback_store``), a keyframe holds a handle,
+``get_points`` / ``compute_icp`` / ``get_overlap`` run on handles (sfe_cloud_store_get_points, sfe_icp_store_compute,
+sfe_cloud_store_overlap); the host sees point COUNTS and results only, and the wire bytes are produced on request.
+Results are identical to the host-mediated flow (tests/test_gpu_store.py).
+
 ``ChainBackend`` composes the accepted between-transforms, which is what ISAM2 returns for a
 graph that only holds a prior and sequential between factors.  A gtsam-backed backend can be
 dropped in where gtsam exists.  Loop closures (NSSM + PCM) need the real
@@ -23,8 +29,22 @@ import time as _time
 
 import numpy as np
 
+from . import _lib as _L
 from . import icp_config, pcl, wire
+from . import store as _store
 from .pose2 import Pose2
+
+
+class CloudRef(object):
+    """A keyframe cloud that lives in a ``store.CloudStore``: handle + size (what ``len(points)`` tests read)."""
+
+    __slots__ = ("handle", "n")
+
+    def __init__(self, handle, n):
+        self.handle, self.n = int(handle), int(n)
+
+    def __len__(self):
+        return self.n
 
 
 class Keyframe(object):
@@ -40,7 +60,10 @@ class Keyframe(object):
 
     def update(self, new_pose):
         self.pose = new_pose
-        self.transf_points = Keyframe.transform_points(self.points, self.pose)
+        if isinstance(self.points, np.ndarray):     # (a device-resident cloud is transformed where it is used)
+            self.transf_points = Keyframe.transform_points(self.points, self.pose)
+
+    update_pose = update
 
     @staticmethod
     def transform_points(points, pose):
@@ -69,8 +92,9 @@ class FrontEnd(object):
 
     def __init__(self, ctx=None, icp_params=None, backend=None, keyframe_duration=1.0, keyframe_translation=3.0,
                  keyframe_rotation=np.deg2rad(30), point_resolution=0.5, point_noise=0.5, ssm_min_points=50,
-                 ssm_max_translation=3.0, ssm_max_rotation=np.deg2rad(30), ssm_target_frames=3):
+                 ssm_max_translation=3.0, ssm_max_rotation=np.deg2rad(30), ssm_target_frames=3, store=None):
         self.ctx = ctx
+        self.store = store          # CloudStore: keyframe clouds stay on the device (feed_handle)
         self.icp = pcl.ICP(ctx)
         self.icp.setParams(icp_params if icp_params is not None else icp_config.shipped_params())
         self.backend = backend or ChainBackend()
@@ -111,6 +135,12 @@ class FrontEnd(object):
     def get_points(self, frames, ref_frame):
         """slam.py:229-292 (no keys): accumulate, move to the reference keyframe, downsample"""
         ref_pose = self.keyframes[ref_frame].pose
+        if self.store is not None:
+            frames = list(frames)
+            T6 = [_store.pose_T6(ref_pose.between(self.keyframes[key].pose)) for key in frames]
+            h = self.store.get_points([[self.keyframes[key].points.handle for key in frames]], [T6],
+                                      self.point_resolution)[0]
+            return CloudRef(h, self.store.counts([h])[0])
         all_points = [np.zeros((0, 2), np.float32)]
         for key in frames:
             transf = ref_pose.between(self.keyframes[key].pose)
@@ -119,6 +149,12 @@ class FrontEnd(object):
 
     def compute_icp(self, source_points, target_points, guess):
         """slam.py:294-323"""
+        if self.store is not None:
+            T, st, _ = self.store.icp(self.icp._chain(), [(source_points.handle, target_points.handle)],
+                                      [pcl.ICP._guess(guess.matrix())])
+            message, T = _L.ICP_STATUS_MESSAGES.get(int(st[0]), "ICP failure %d" % st[0]), T[0]
+            x, y = T[:2, 2]
+            return message, Pose2(x, y, np.arctan2(T[1, 0], T[0, 0]))
         source_points = np.array(source_points, np.float32)
         target_points = np.array(target_points, np.float32)
         message, T = self.icp.compute(source_points, target_points, guess.matrix())
@@ -158,6 +194,9 @@ class FrontEnd(object):
 
     def get_overlap(self, source_points, target_points, source_pose):
         """slam.py:389-424"""
+        if self.store is not None:
+            return int(self.store.overlap([(source_points.handle, target_points.handle)], [_store.pose_T6(source_pose)],
+                                          self.point_noise)[0])
         source_points = Keyframe.transform_points(source_points, source_pose)
         indices, _ = pcl.match(target_points, source_points, 1, self.point_noise)
         return int(np.sum(indices != -1))
@@ -175,8 +214,17 @@ class FrontEnd(object):
         if len(source_points) < self.ssm_min_points or len(target_points) < self.ssm_min_points:
             rec["status"] = "NOT_ENOUGH_POINTS"
             self.backend.add_between(target_key, source_key, dr_between, "odometry")
+            self._release(target_points)
             return rec
         initial_transform = target_pose.between(keyframe.pose)
+        try:
+            return self._scan_match(keyframe, rec, source_key, target_key, target_pose, source_points, target_points,
+                                    initial_transform, dr_between)
+        finally:
+            self._release(target_points)    # the target cloud get_points built is dropped (it was the newest slot)
+
+    def _scan_match(self, keyframe, rec, source_key, target_key, target_pose, source_points, target_points,
+                    initial_transform, dr_between):
         message, estimated = self.compute_icp(source_points, target_points, initial_transform)
         rec["icp"] = message
         status = "SUCCESS"
@@ -201,22 +249,39 @@ class FrontEnd(object):
         rec["transform"] = (estimated.x(), estimated.y(), estimated.theta())
         return rec
 
+    def _release(self, ref):
+        """a cloud that nothing refers to any more and that is the newest slot of the store (stack order)"""
+        if self.store is not None and isinstance(ref, CloudRef) and ref.handle >= 0:
+            self.store.truncate(ref.handle)
+
     def feed(self, cloud_bytes, time, dr_pose):
         """``SLAMNode.SLAM_callback`` (slam_ros.py:157-213): one feature message + its odometry."""
-        frame = Keyframe(False, time, dr_pose)
         points = wire.unpack_features(cloud_bytes)
-        if wire.is_skipped(points):
+        if self.store is not None:      # a message that did arrive over the wire: one upload, then as below
+            skipped = wire.is_skipped(points)
+            ref = CloudRef(-1, 0) if skipped else CloudRef(self.store.put(points, int(time)), len(points))
+            return self._feed(ref, skipped, time, dr_pose)
+        return self._feed(points, wire.is_skipped(points), time, dr_pose)
+
+    def feed_handle(self, handle, n_points, time, dr_pose):
+        """The same for a cloud ``FeatureExtraction.callback_store`` left in the store (handle < 0: a skipped
+        frame).  A frame that does not become a keyframe gives its slot back (it is the newest one)."""
+        return self._feed(CloudRef(handle, n_points), handle < 0, time, dr_pose)
+
+    def _feed(self, points, skipped, time, dr_pose):
+        frame = Keyframe(False, time, dr_pose)
+        if skipped:
             frame.status = False
         else:
             frame.status = self.is_keyframe(frame)
         if self.keyframes:
             dr_odom = self.current_keyframe.dr_pose.between(frame.dr_pose)
-            frame.update(self.current_keyframe.pose.compose(dr_odom))
+            frame.update_pose(self.current_keyframe.pose.compose(dr_odom))
         else:
-            frame.update(dr_pose)
+            frame.update_pose(dr_pose)
         rec = None
         if frame.status:
-            frame.points = np.ascontiguousarray(points, np.float32)
+            frame.points = points                       # slam_ros.py:190 (float64 array of float32 values, or a handle)
             frame.update(frame.pose)
             if not self.keyframes:
                 self.backend.add_prior(0, frame.pose)
@@ -227,6 +292,8 @@ class FrontEnd(object):
             rec["pose"] = (frame.pose.x(), frame.pose.y(), frame.pose.theta())
             rec["time"] = time
             self.log.append(rec)
+        else:
+            self._release(points)
         self.current_frame = frame
         return rec
 
@@ -238,6 +305,15 @@ def replay(pings, stamps, dr_poses, feature_extraction, front_end):
     t_fe = t_slam = 0.0
     for ping, stamp, dr in zip(pings, stamps, dr_poses):
         t0 = _time.perf_counter()
+        if front_end.store is not None:
+            # same process, same device: the cloud stays in the store; nothing is packed unless somebody subscribes
+            h, n, _ = feature_extraction.callback_store(ping, front_end.store, stamp=int(stamp))
+            t1 = _time.perf_counter()
+            front_end.feed_handle(h, n, stamp, Pose2(*dr))
+            t2 = _time.perf_counter()
+            t_fe += t1 - t0
+            t_slam += t2 - t1
+            continue
         pts = feature_extraction.callback(ping)
         data = wire.pack_features(pts)
         t1 = _time.perf_counter()

@@ -21,9 +21,17 @@ def pack_features(points):
     return np.ascontiguousarray(xyz, "<f4").tobytes()
 
 
-def unpack_features(data):
-    """PointCloud2.data bytes -> the N x 2 cloud the SLAM node works with (slam_ros.py:169-170)."""
-    xyz = np.frombuffer(data, "<f4").reshape(-1, 3)
+def unpack_features(data, remove_nans=False):
+    """PointCloud2.data bytes -> the N x 2 cloud the SLAM node works with (slam_ros.py:169-170):
+    ``ros_numpy.point_cloud2.pointcloud2_to_xyz_array(msg)`` then ``np.c_[x, -1 * z]``.  ros_numpy (un-vendored)
+    builds that array with ``get_xyz_points(..., dtype=np.float)``: a FLOAT64 array holding the float32 values of the
+    message -- which is why ``Keyframe.transform_points`` computes in double on the SLAM side -- so this returns float64
+    too.  ``remove_nans=True`` additionally drops non-finite points like ros_numpy's default does (then the one-NaN
+    message of a skipped frame arrives EMPTY and slam_ros.py:173 never fires: the reference's own quirk); the default
+    keeps them so that ``is_skipped`` can do what slam_ros.py:173 intends."""
+    xyz = np.frombuffer(data, "<f4").reshape(-1, 3).astype(np.float64)
+    if remove_nans:
+        xyz = xyz[np.isfinite(xyz).all(axis=1)]
     return np.c_[xyz[:, 0], -1 * xyz[:, 2]]
 
 

@@ -195,6 +195,41 @@ def main():
     pts7 = Keyframe.transform_points(src, types.SimpleNamespace(matrix=lambda: T))
     np.savez_compressed(os.path.join(HERE, "matching_cost.npz"), src=src, tgt=tgt, source_pose=np.array(synth.pose_of(truth)),
                         X=X, costs=costs, samples=np.array(samples), points_pose7=pts7, point_noise=0.5)
+    # ---- Keyframe.transform_points / SLAM.get_points: the scan matcher's inputs ----
+    # transform_points on float64 keyframe clouds holding float32 values (what ros_numpy hands the SLAM node,
+    # slam_ros.py:169-170) and on float32 ones (sgemm); get_points (slam.py:229-292) cut by AST with
+    # pcl.downsample = the oracle's octree (that one stays unpinned) -- the transform, the frame order of the
+    # concatenation and the float32 rounding at the pybind boundary are the reference's own code on this numpy.
+    from typing import Any
+    gp_src = _cut("slam.py", "get_points")
+    ns_gp = {"np": np, "gtsam": types.SimpleNamespace(Pose2=Pose2), "Keyframe": Keyframe, "Any": Any,
+             "pcl": types.SimpleNamespace(downsample=lambda pts, res: oracle_downsample(pts, res))}
+    import oracle as _orc
+
+    def oracle_downsample(pts, res):
+        return _orc.downsample(np.asarray(pts, np.float32), res)      # (pybind: Matrix = fp32)
+    exec(compile(gp_src, "reference:slam.py", "exec"), ns_gp)
+    rng = np.random.default_rng(77)
+    clouds32 = [np.c_[rng.uniform(1, 29, n), rng.uniform(-20, 20, n)].astype(np.float32) for n in (700, 1, 1300, 0, 450)]
+    poses = [(0.0, 0.0, 0.0), (1.7, -0.2, 0.05), (3.1, 0.4, 0.13), (4.9, 0.1, 0.2), (6.2, -0.7, 0.31)]
+    out_tp = {}
+    for name, clouds in (("f64", [c.astype(np.float64) for c in clouds32]), ("f32", clouds32)):
+        kfs = [types.SimpleNamespace(points=c, pose=Pose2(*q)) for c, q in zip(clouds, poses)]
+        slam = types.SimpleNamespace(keyframes=kfs, current_key=len(kfs), point_resolution=0.5)
+        for ref in (4, 2):
+            frames = [1, 2, 3] if ref == 4 else [0, 1]
+            Ts = [kfs[ref].pose.between(kfs[k].pose).matrix().astype(np.float32) for k in frames]
+            moved = [Keyframe.transform_points(kfs[k].points, kfs[ref].pose.between(kfs[k].pose)) for k in frames]
+            tgt_cloud = ns_gp["get_points"](slam, frames, ref)
+            out_tp["%s_ref%d_T" % (name, ref)] = np.array(Ts)
+            out_tp["%s_ref%d_frames" % (name, ref)] = np.array(frames)
+            for k, mv in zip(frames, moved):
+                out_tp["%s_ref%d_moved%d" % (name, ref, k)] = np.asarray(mv, np.float32)   # the pybind boundary
+                out_tp["%s_ref%d_moved%d_dtype" % (name, ref, k)] = np.array(str(np.asarray(mv).dtype))
+            out_tp["%s_ref%d_target" % (name, ref)] = np.asarray(tgt_cloud, np.float32)
+    for i, c in enumerate(clouds32):
+        out_tp["cloud%d" % i] = c
+    np.savez_compressed(os.path.join(HERE, "transform_points.npz"), **out_tp)
     # ---- CFAR masks / threshold maps from the reference's own cfar.cpp (oracle/_ref, compiled unmodified) ----
     import oracle
     if not oracle.have_ref_cfar():
@@ -219,7 +254,7 @@ def main():
                 index.append([key, name, alg, th, gh, taus[alg], k])
     out["index"] = np.array(json.dumps(index))
     np.savez_compressed(os.path.join(HERE, "cfar_ref.npz"), **out)
-    print("wrote cfar_tau.json, maps_small.npz, maps_digest.json, matching_cost.npz, cfar_ref.npz")
+    print("wrote cfar_tau.json, maps_small.npz, maps_digest.json, matching_cost.npz, transform_points.npz, cfar_ref.npz")
 
 
 if __name__ == "__main__":

@@ -76,3 +76,28 @@ def test_oracle_cfar_equals_the_reference_fixture():
         assert np.array_equal(got_thr, thr), key
         n += 1
     assert n == 48
+
+
+def test_transform_points_and_get_points_match_the_reference_functions():
+    """Keyframe.transform_points (slam_objects.py:178-198) and SLAM.get_points (slam.py:229-292), executed from the
+    reference sources by make_golden.py on float64 keyframe clouds (what ros_numpy hands the SLAM node) and on
+    float32 ones: the oracle's restatement of the transform (products and sums in double, float32 at the pybind
+    boundary / sgemm with FMA) and of the frame-order concatenation equals them bit for bit."""
+    import oracle
+    z = np.load(os.path.join(G, "transform_points.npz"))
+    clouds = [z["cloud%d" % i] for i in range(5)]
+    for name, f64 in (("f64", True), ("f32", False)):
+        for ref in (4, 2):
+            frames, Ts = z["%s_ref%d_frames" % (name, ref)], z["%s_ref%d_T" % (name, ref)]
+            for k, T in zip(frames, Ts):
+                want = z["%s_ref%d_moved%d" % (name, ref, k)]
+                if len(want):        # numpy's own result type: double for the SLAM node's float64 clouds
+                    assert str(z["%s_ref%d_moved%d_dtype" % (name, ref, k)]) == ("float64" if f64 else "float32")
+                got = oracle.transform_points(clouds[k], T, f64_points=f64)
+                assert got.dtype == np.float32 and np.array_equal(got, want), (name, ref, k)
+            tgt = oracle.get_points([clouds[k] for k in frames], Ts, 0.5, f64_points=f64)
+            assert np.array_equal(tgt, z["%s_ref%d_target" % (name, ref)]), (name, ref)
+    # the two dtypes really do round differently somewhere (else the flag would be untested)
+    a = np.concatenate([z["f64_ref4_moved%d" % k] for k in (1, 2, 3)])
+    b = np.concatenate([z["f32_ref4_moved%d" % k] for k in (1, 2, 3)])
+    assert a.shape == b.shape and not np.array_equal(a, b)
