@@ -1,0 +1,241 @@
+"""Many independent SLAM sessions advanced in lock-step, every cloud device-resident.
+
+One session is what ``replay.FrontEnd`` runs: ping -> FeatureExtraction.callback -> keyframe test -> target cloud
+= get_points(last 3 keyframes) -> ICP(source, target, odometry guess) -> sanity checks + overlap -> pose
+(slam_ros.py:157-213, slam.py:716-832).  Inside a session the keyframes are strictly sequential -- keyframe k's
+target cloud needs the poses the scan matches of k-1, k-2, k-3 produced -- so the batch axis is the SESSION: S
+trajectories (robots, bags, replays) step together, step k = keyframe k of every session:
+
+    CFAR + gate -> remap + nonzero + px->m -> downsample -> outlier filter      sfe_*_batch_dev, S pings
+    -> append to the keyframe store (slam_ros.py:170 convention)                 sfe_cloud_store_put_batch_dev
+    -> S target clouds: transform + concatenate + pcl.downsample                 sfe_cloud_store_get_points
+    -> S scan matches over handles                                               sfe_icp_store_compute
+    -> S overlap counts                                                          sfe_cloud_store_overlap
+
+The host does what the SLAM node's Python does between those calls -- gtsam.Pose2 algebra in double, the
+ssm_min_points / max translation / max rotation / overlap tests, the factor list -- on S sessions at a time, with
+exactly the arithmetic of ``pose2.Pose2`` (so a session's records equal those of ``replay.FrontEnd`` on the same
+pings bit for bit: tests/test_gpu_store.py).  Per step three small synchronisations (cloud sizes; scan-match
+results; overlap counts); no cloud crosses PCIe.
+"""
+import math
+
+import numpy as np
+
+from . import _lib as _L
+from . import store as _store
+
+
+class Pose2Batch(object):
+    """``pose2.Pose2`` for n poses at once: the same double-precision expressions, element by element (cos / sin /
+    atan2 through ``math`` per element, so that no vector math library rounds differently from the scalar class)."""
+
+    __slots__ = ("x", "y", "c", "s")
+
+    def __init__(self, x, y, theta=None, cs=None):
+        self.x, self.y = np.array(x, np.float64), np.array(y, np.float64)
+        if cs is None:
+            th = np.asarray(theta, np.float64)
+            self.c = np.array([math.cos(t) for t in th])
+            self.s = np.array([math.sin(t) for t in th])
+        else:
+            c, s = np.array(cs[0], np.float64), np.array(cs[1], np.float64)
+            scale = c * c + s * s
+            fix = np.abs(scale - 1.0) > 1e-10
+            if fix.any():
+                with np.errstate(invalid="ignore", divide="ignore"):
+                    k = 1.0 / np.sqrt(scale)
+                c, s = np.where(fix, c * k, c), np.where(fix, s * k, s)
+            self.c, self.s = c, s
+
+    def __len__(self):
+        return len(self.x)
+
+    def theta(self):
+        return np.array([math.atan2(s, c) for s, c in zip(self.s, self.c)])
+
+    def compose(self, o):
+        return Pose2Batch(self.x + self.c * o.x - self.s * o.y, self.y + self.s * o.x + self.c * o.y,
+                          cs=(self.c * o.c - self.s * o.s, self.s * o.c + self.c * o.s))
+
+    def inverse(self):
+        return Pose2Batch(-(self.c * self.x + self.s * self.y), -(-self.s * self.x + self.c * self.y),
+                          cs=(self.c, -self.s))
+
+    def between(self, o):
+        return self.inverse().compose(o)
+
+    def T6(self):
+        """[n x 6] float32: T00 T01 T02 T10 T11 T12 of ``matrix().astype(np.float32)``"""
+        return np.stack([self.c, -self.s, self.x, self.s, self.c, self.y], axis=1).astype(np.float32)
+
+    def matrix32(self):
+        """[n x 3 x 3] float32 = ``matrix()`` handed to pybind (the ICP guess, slam.py:316)"""
+        M = np.zeros((len(self), 3, 3), np.float64)
+        M[:, 0, 0], M[:, 0, 1], M[:, 0, 2] = self.c, -self.s, self.x
+        M[:, 1, 0], M[:, 1, 1], M[:, 1, 2] = self.s, self.c, self.y
+        M[:, 2, 2] = 1.0
+        return M.astype(np.float32)
+
+    def take(self, idx):
+        return Pose2Batch(self.x[idx], self.y[idx], cs=(self.c[idx], self.s[idx]))
+
+    def put(self, idx, o):
+        self.x[idx], self.y[idx], self.c[idx], self.s[idx] = o.x, o.y, o.c, o.s
+
+    def xytheta(self):
+        return np.stack([self.x, self.y, self.theta()], axis=1)
+
+
+class _View(object):
+    """a window into a DeviceBuffer (what KeyframeBatch reads as .ptr)"""
+
+    def __init__(self, buf, offset):
+        import ctypes as _C
+        self.ptr = _C.c_void_p(buf.ptr.value + int(offset))
+
+
+class SessionBatch(object):
+    """S sessions x K pings, all pings resident in HBM.  ``step(k)`` advances every session by its k-th ping."""
+
+    def __init__(self, ctx, geometry, cfar_params, alg, intensity_thr, icp_params, n_sessions, n_steps, dr_poses,
+                 max_points=16384, resolution=0.5, outlier_radius=1.0, outlier_min_points=5, point_resolution=0.5,
+                 point_noise=0.5, ssm_min_points=50, ssm_max_translation=3.0, ssm_max_rotation=np.deg2rad(30),
+                 ssm_target_frames=3, store_points=None):
+        from .pipeline import KeyframeBatch
+        self.ctx, self.S, self.K = ctx, int(n_sessions), int(n_steps)
+        self.icp_params = icp_params
+        self.kb = KeyframeBatch(ctx, geometry, cfar_params, alg, intensity_thr, icp_params, self.S, max_points=max_points)
+        self.frame_bytes = self.kb.rows * self.kb.cols
+        self._kb_img = self.kb.d_img                     # (kept for free(): the batch's own frame buffer is unused)
+        self.d_frames = ctx.alloc(self.K * self.S * self.frame_bytes)
+        self.resolution, self.outlier_radius, self.outlier_min_points = resolution, outlier_radius, outlier_min_points
+        self.point_resolution, self.point_noise = point_resolution, point_noise
+        self.ssm_min_points, self.ssm_max_translation = ssm_min_points, ssm_max_translation
+        self.ssm_max_rotation, self.ssm_target_frames = ssm_max_rotation, ssm_target_frames
+        # keyframe clouds of K steps + the targets of one step (3 keyframes each before the downsample shrinks them)
+        pts = store_points or int(self.S * (self.K + 4) * 2048)
+        self.store = _store.CloudStore(ctx, capacity_points=pts, max_clouds=self.S * (self.K + 2))
+        dr = np.asarray(dr_poses, np.float64).reshape(self.S, self.K, 3)
+        self.dr = [Pose2Batch(dr[:, k, 0], dr[:, k, 1], dr[:, k, 2]) for k in range(self.K)]
+        self.reset()
+
+    def upload_frames(self, k, frames):
+        """pings of step k: [S x rows x cols] uint8"""
+        frames = np.ascontiguousarray(frames, np.uint8)
+        assert frames.shape == (self.S, self.kb.rows, self.kb.cols)
+        self.d_frames.upload(frames, offset=k * self.S * self.frame_bytes)
+
+    def reset(self):
+        self.store.truncate(0)
+        self.handles = np.full((self.S, self.K), -1, np.int32)      # keyframe k of session s -> store handle
+        self.poses = [None] * self.K                                # Pose2Batch per step (every ping is a keyframe)
+        self.records = []
+
+    def step(self, k):
+        """-> dict of per-session arrays: status codes, sizes, transforms, overlaps, poses"""
+        S, kb, store = self.S, self.kb, self.store
+        kb.d_img = _View(self.d_frames, k * S * self.frame_bytes)
+        kb.run_cfar()
+        kb.run_extract()
+        kb.run_filter(self.resolution, self.outlier_radius, self.outlier_min_points)
+        src_h = kb.store_clouds(store, stamps=np.arange(S) * self.K + k)
+        self.handles[:, k] = src_h
+        rec = {"k": k, "status": np.full(S, PRIOR if k == 0 else SUCCESS, np.int8)}
+        if k == 0:
+            self.poses[0] = self.dr[0]                                      # add_prior (slam.py:426-442)
+            rec["n_source"] = store.counts(src_h)
+            self._check_raw(k)
+            self._check_counts(rec["n_source"], k)
+            rec["pose"] = self.poses[0].xytheta()
+            self.records.append(rec)
+            return rec
+        # frame.update(current_keyframe.pose.compose(dr_odom))              slam_ros.py:181-184
+        prev = self.poses[k - 1]
+        dr_odom = self.dr[k - 1].between(self.dr[k])
+        pose = prev.compose(dr_odom)
+        # target = get_points(last ssm_target_frames keyframes, target_key = k - 1)   slam.py:740-741
+        frames = list(range(k))[-self.ssm_target_frames:]
+        m = self.ssm_target_frames
+        th = np.full((S, m), -1, np.int32)
+        T6 = np.zeros((S, m, 6), np.float32)
+        for j, key in enumerate(frames):
+            th[:, j] = self.handles[:, key]
+            T6[:, j] = prev.between(self.poses[key]).T6()
+        n_keep = len(store)
+        tgt_h = store.get_points(th, T6, self.point_resolution)
+        counts = store.counts(np.concatenate([src_h, tgt_h]))
+        n_src, n_tgt = counts[:S], counts[S:]
+        self._check_raw(k)
+        self._check_counts(n_src, k)
+        self._check_counts(n_tgt, k)
+        rec["n_source"], rec["n_target"] = n_src, n_tgt
+        enough = (n_src >= self.ssm_min_points) & (n_tgt >= self.ssm_min_points)
+        rec["status"][~enough] = NOT_ENOUGH_POINTS
+        dr_between = prev.between(pose)
+        initial = prev.between(pose)                                        # target_pose.between(keyframe.pose) slam.py:757
+        idx = np.nonzero(enough)[0]
+        T = np.zeros((S, 3, 3), np.float32)
+        icp_status = np.full(S, -1, np.int32)
+        iters = np.zeros(S, np.int32)
+        overlap = np.full(S, -1, np.int32)
+        est = Pose2Batch(dr_between.x.copy(), dr_between.y.copy(), cs=(dr_between.c.copy(), dr_between.s.copy()))
+        if len(idx):
+            pairs = np.stack([src_h[idx], tgt_h[idx]], axis=1)
+            Ti, sti, iti = store.icp(self.icp_params, pairs, initial.take(idx).matrix32())
+            T[idx], icp_status[idx], iters[idx] = Ti, sti, iti
+            # x, y = T[:2, 2]; theta = np.arctan2(T[1, 0], T[0, 0]); gtsam.Pose2(x, y, theta)     slam.py:319-323
+            theta32 = np.arctan2(Ti[:, 1, 0], Ti[:, 0, 0])
+            e = Pose2Batch(Ti[:, 0, 2].astype(np.float64), Ti[:, 1, 2].astype(np.float64), theta32.astype(np.float64))
+            est.put(idx, e)
+            rec["status"][idx[sti != 0]] = NOT_CONVERGED
+            delta = initial.take(idx).between(e)
+            large = (np.hypot(delta.x, delta.y) > self.ssm_max_translation) | (np.abs(delta.theta()) > self.ssm_max_rotation)
+            rec["status"][idx[(sti == 0) & large]] = LARGE_TRANSFORMATION
+            ok = idx[(sti == 0) & ~large]
+            if len(ok):
+                ov = store.overlap(np.stack([src_h[ok], tgt_h[ok]], axis=1), est.take(ok).T6(), self.point_noise)
+                overlap[ok] = ov
+                rec["status"][ok[ov < self.ssm_min_points]] = NOT_ENOUGH_OVERLAP
+        good = rec["status"] == SUCCESS
+        # keyframe.update(target_pose.compose(estimated))   slam.py:825-827; otherwise the dead-reckoned pose stays
+        new_pose = Pose2Batch(pose.x.copy(), pose.y.copy(), cs=(pose.c.copy(), pose.s.copy()))
+        gi = np.nonzero(good)[0]
+        if len(gi):
+            new_pose.put(gi, prev.take(gi).compose(est.take(gi)))
+        self.poses[k] = new_pose
+        store.truncate(n_keep)                                              # the targets are dropped, the keyframes stay
+        rec.update(T=T, icp_status=icp_status, iters=iters, overlap=overlap, transform=est.xytheta(),
+                   pose=new_pose.xytheta())
+        self.records.append(rec)
+        return rec
+
+    def _check_raw(self, k):
+        """a ping with more detections than the batch's point capacity would be truncated silently"""
+        raw = self.kb.d_cnt.download(np.int32, self.S)
+        if int(raw.max()) > self.kb.cap:
+            f = int(raw.argmax())
+            raise _L.SonarFEError("step %d, session %d: %d points extracted, more than the batch capacity %d "
+                                  "(max_points)" % (k, f, raw[f], self.kb.cap))
+
+    def _check_counts(self, counts, k):
+        bad = np.nonzero(counts < 0)[0]
+        if len(bad):
+            raise _L.SonarFEError("step %d, session %d: cloud not stored (count %d: -1 octree deeper than 24 levels, "
+                                  "-3 store full)" % (k, int(bad[0]), int(counts[bad[0]])))
+
+    def run(self):
+        self.reset()
+        for k in range(self.K):
+            self.step(k)
+        return self.records
+
+    def free(self):
+        self.kb.d_img = self._kb_img
+        self.kb.free()
+        self.d_frames.free()
+        self.store.close()
+
+
+PRIOR, SUCCESS, NOT_ENOUGH_POINTS, NOT_CONVERGED, LARGE_TRANSFORMATION, NOT_ENOUGH_OVERLAP = range(6)
+STATUS_NAMES = ("PRIOR", "SUCCESS", "NOT_ENOUGH_POINTS", "NOT_CONVERGED", "LARGE_TRANSFORMATION", "NOT_ENOUGH_OVERLAP")
