@@ -554,6 +554,9 @@ def main():
                                 else bench_legs.real_size(ctx, threads))
             out["configs4_hires"] = (bench_legs.configs4_hires(ctx, det, threads, n_pairs=2, n_frames=8, parity_pairs=1) if small
                                      else bench_legs.configs4_hires(ctx, det, threads))
+            # the path end to end on the device: every scan match consumes the cloud its own CFAR produced
+            out["chained"] = (bench_legs.chained(ctx, det, threads, n_sessions=8, n_steps=4, n_distinct=4, parity_sessions=2, reps=1)
+                              if small else bench_legs.chained(ctx, det, threads))
         if not args.no_latency:
             # the live single-item path of the ROS nodes (one ping / one scan match per call, host wall clock incl.
             # PCIe copies and the one synchronisation); the oracle's per-ping / per-match milliseconds are in

@@ -364,3 +364,128 @@ def stream_frames(ctx, kb, filters, steps=4, distinct=512, seed0=20000):
             "pcie_gb_per_s_upload_alone": n * frame_b / t_copy / 1e9, "pcie_gb_per_s_while_streaming": n * frame_b / t_stream / 1e9,
             "overlap_fraction": max(0.0, min(1.0, hidden)), "converged": int((res["status"] == 0).sum()),
             "note": "overlap_fraction = (upload alone + kernels alone - streamed) / min(upload alone, kernels alone)"}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def chained_inputs(n_distinct, n_steps, rows=1024, beams=512, world_seed=2, scatterers=3000):
+    """`n_distinct` trajectories through ONE synthetic scene (SURVEY 8d Config 2, first option): pings rendered from the
+    scene under the true poses, dead-reckoned poses with drifting odometry noise.  Pure numpy: call it before any HIP
+    call if it is to fork."""
+    from sonar_slam_amd import synth
+    from sonar_slam_amd.feature_extraction import oculus_bearings
+    # 3000 scatterers: 5-8 k raw detections and 200-300 points per filtered cloud at 1024 x 512 -- the cloud sizes
+    # bruce_slam itself produces (SURVEY D8: 10^2..10^3 points)
+    world = synth.world_structure(seed=world_seed, n=scatterers)
+    bearings = oculus_bearings(beams)
+    frames = np.zeros((n_steps, n_distinct, rows, beams), np.uint8)
+    dr = np.zeros((n_distinct, n_steps, 3))
+    true = np.zeros((n_distinct, n_steps, 3))
+    for s in range(n_distinct):
+        start = (2.0 + 0.37 * (s % 16), 0.9 * (s // 16) - 2.0 + 0.11 * (s % 5), 0.015 * (s % 9) - 0.06)
+        t, d = synth.trajectory(n=n_steps, step=1.7, turn=0.02 + 0.008 * (s % 5), start=start, seed=300 + s)
+        true[s], dr[s] = t, d
+        for k in range(n_steps):
+            frames[k, s] = synth.render_ping(world, t[k], bearings, rows=rows, seed=5000 * s + k)
+    return frames, dr, true, bearings
+
+
+def chained(ctx, det, threads, n_sessions=256, n_steps=8, n_distinct=64, parity_sessions=4, reps=3):
+    """the path end to end on the device, every scan match consuming the cloud its own CFAR produced.
+    `n_sessions` independent SLAM sessions advance in lock-step (chained.SessionBatch): step k = ping k of every session
+    through CFAR + gate -> remap + nonzero + px->m -> downsample -> outlier filter -> keyframe store -> target cloud =
+    get_points(previous <= 3 keyframes under the poses their own scan matches gave them, slam.py:740-741) -> ICP(source,
+    target, odometry guess) -> overlap; pings resident in HBM, no cloud crosses PCIe, the host does the SLAM node's
+    pose bookkeeping between the calls.  Timed with the host clock around whole runs (the loop has host work in it).
+    Parity: `parity_sessions` sessions through the oracle's chain (oracle/chain.py) on the same pings."""
+    import oracle
+    from oracle import chain
+    from sonar_slam_amd import chained as ch
+    from sonar_slam_amd import icp_config
+    from sonar_slam_amd.feature_extraction import FeatureExtraction, SonarPing
+    rows, beams = 1024, 512
+    t0 = time.perf_counter()
+    frames, dr, true, bearings = chained_inputs(n_distinct, n_steps, rows, beams)
+    t_render = time.perf_counter() - t0
+    fe = FeatureExtraction(ctx)
+    fe.Ntc, fe.Ngc, fe.Pfa, fe.rank, fe.alg, fe.threshold = 40, 10, 0.1, 10, "SOCA", 65
+    fe.configure()
+    fe.generate_map_xy(SonarPing(frames[0, 0], bearings, 30.0 / rows))
+    sel = np.arange(n_sessions) % n_distinct
+    out = {"workload": "%d sessions x %d keyframes (%d distinct trajectories through one synthetic scene, 1024x512 pings, "
+                       "1.7 m apart, drifting odometry): CFAR -> cloud -> store -> get_points(last 3) -> ICP -> overlap, "
+                       "device-resident" % (n_sessions, n_steps, n_distinct),
+           "sessions": n_sessions, "keyframes_per_session": n_steps, "distinct_sessions": n_distinct,
+           "render_s": t_render}
+    for name, params in (("shipped_chain", icp_config.shipped_params()),
+                         ("p2plane30", icp_config.shipped_params(minimizer=1, use_diff_checker=0, max_iter=30))):
+        sb = ch.SessionBatch(ctx, fe.geometry, det.params["SOCA"], "SOCA", 65, params, n_sessions, n_steps, dr[sel])
+        for k in range(n_steps):
+            sb.upload_frames(k, frames[k][sel])
+        sb.run()                                # untimed: scratch and store allocations
+        ctx.sync()
+        best = None
+        for _ in range(reps):
+            ctx.sync()
+            t0 = time.perf_counter()
+            recs = sb.run()
+            ctx.sync()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        status = np.stack([r["status"] for r in recs[1:]], axis=1)           # [S x (K-1)]
+        n_src = np.stack([r["n_source"] for r in recs], axis=1)
+        n_tgt = np.stack([r["n_target"] for r in recs[1:]], axis=1)
+        iters = np.stack([r["iters"] for r in recs[1:]], axis=1)
+        est = np.stack([r["pose"] for r in recs], axis=1)                    # [S x K x 3]
+
+        def end_error(p):       # relative motion first -> last keyframe against ground truth (the frames differ by a
+            e = []              # constant: sensor frame vs world frame)
+            for s in range(n_distinct):
+                a, b, ta, tb = chain.pose(*p[s, 0]), chain.pose(*p[s, -1]), chain.pose(*true[s, 0]), chain.pose(*true[s, -1])
+                got, want = chain.between(a, b), chain.between(ta, tb)
+                e.append(np.hypot(got[0] - want[0], got[1] - want[1]))
+            return float(np.mean(e)), float(np.max(e))
+        leg = {"seconds_per_run": best, "keyframes_per_s": n_sessions * n_steps / best,
+               "scan_matches_per_s": n_sessions * (n_steps - 1) / best, "ms_per_step": 1e3 * best / n_steps,
+               "status_counts": {ch.STATUS_NAMES[c]: int((status == c).sum()) for c in range(1, 6) if (status == c).any()},
+               "mean_source_points": float(n_src.mean()), "mean_target_points": float(n_tgt.mean()),
+               "mean_icp_iters": float(iters[status != ch.NOT_ENOUGH_POINTS].mean()),
+               "end_position_error_m": dict(zip(("icp_chain_mean", "icp_chain_max"), end_error(est[:n_distinct]))),
+               "odometry_end_position_error_m": dict(zip(("mean", "max"), end_error(dr)))}
+        # ---- parity: whole sessions through the oracle's chain (feature cloud, target cloud, ICP, overlap, pose) ----
+        picks = sorted(set(int(round(i * (n_distinct - 1) / max(1, parity_sessions - 1))) for i in range(parity_sessions)))
+        oprm = oracle.IcpParams(precision=1, **params.as_dict())
+        oracle.set_kdtree(1)
+        try:
+            def one(s):
+                clouds = [chain.slam_cloud(chain.feature_cloud(frames[k, s], det.params["SOCA"], "SOCA", 65, fe)[1])
+                          for k in range(n_steps)]
+                return clouds, chain.run_session(clouds, dr[s], oprm)
+            with ThreadPool(max(1, threads)) as tp:
+                ref = tp.map(one, picks, chunksize=1)
+        finally:
+            oracle.set_kdtree(0)
+        worst = 0.0
+        for s, (clouds, orc) in zip(picks, ref):
+            if not np.array_equal(sb.store.read(sb.handles[s, n_steps - 1]), clouds[-1]):
+                raise AssertionError("chained/%s: session %d, the stored cloud of the last keyframe differs from the oracle's" % (name, s))
+            for k, o in enumerate(orc):
+                r = recs[k]
+                if ch.STATUS_NAMES[r["status"][s]] != o["status"] or r["n_source"][s] != o["n_source"]:
+                    raise AssertionError("chained/%s: session %d keyframe %d: %s / %d points vs the oracle's %s / %d"
+                                         % (name, s, k, ch.STATUS_NAMES[r["status"][s]], r["n_source"][s], o["status"], o["n_source"]))
+                if k and (r["n_target"][s] != o["n_target"] or ("icp_status" in o and (r["icp_status"][s] != o["icp_status"]
+                                                                                        or r["iters"][s] != o["iters"]))
+                          or ("overlap" in o and r["overlap"][s] != o["overlap"])):
+                    raise AssertionError("chained/%s: session %d keyframe %d differs from the oracle chain" % (name, s, k))
+                d = max(abs(a - b) for a, b in zip(r["pose"][s], o["pose"]))
+                if not d <= 1e-6:
+                    raise AssertionError("chained/%s: session %d keyframe %d pose is %.3e from the oracle chain" % (name, s, k, d))
+                worst = max(worst, d)
+        leg["parity"] = {"sessions": picks, "keyframes": len(picks) * n_steps, "max_pose_diff_vs_oracle_chain": worst,
+                         "checked": "per keyframe: status, source / target cloud sizes, ICP status and iteration count, "
+                                    "overlap (equal), pose <= 1e-6 vs oracle/chain.py (fp64-sum ICP, exact kd-tree); last "
+                                    "keyframe's stored cloud bit-exact"}
+        out[name] = leg
+        sb.free()
+    out["keyframes_per_s"] = out["shipped_chain"]["keyframes_per_s"]
+    return out
