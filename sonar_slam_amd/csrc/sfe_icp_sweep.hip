@@ -1124,6 +1124,8 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
     if (PROF && tid == 0) {
         for (int i = 0; i < 16; ++i)
             S.prof[i] = 0;
+        for (int i = 0; i < 64; ++i) // (LDS is not zeroed: words no iteration / round writes used to come out as garbage)
+            S.prof_it[i] = 0;
         S.prof_t = clock64();
     }
     // wave-uniform work counters (PROF only): candidate distance evaluations of the lane-per-query tiers, of the

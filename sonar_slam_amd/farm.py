@@ -206,6 +206,7 @@ class _Worker(object):
         self.proc, self.conn, self.device = proc, conn, device
         self.shm = None
         self.name = None
+        self.pending = None     # sequence number of a request this worker has not answered yet
 
     def block(self, nbytes):
         """this worker's shared-memory block, grown (never shrunk) to hold nbytes"""
@@ -282,6 +283,11 @@ class IcpFarm(object):
         def fill_and_send(w, mine, pk):
             """one rank's block: fill the shared memory, start the worker; -> what the collection below needs"""
             src_pool, tgt_pool, ns_pts, nt_pts, rows, guesses = pk
+            if w.pending is not None:
+                # a request abandoned by an interrupted run (KeyboardInterrupt between send and reply) may still be
+                # executing: its worker reads -- and writes results into -- the block about to be refilled (ADVICE r3).
+                # Its reply is awaited (and dropped) before the block is touched.
+                self._recv_reply(w, w.pending)
             lay = _layout(ns_pts, nt_pts, len(rows))
             v = _views(w.block(lay["bytes"]).buf, lay)
             o = 0
@@ -297,6 +303,7 @@ class IcpFarm(object):
                 v["guess"][:] = np.stack(guesses)
             del v
             w.conn.send(("run", w.shm.name, lay, self.chunk, seq))
+            w.pending = seq
             return w, lay, [len(gs) for _, _, gs in mine]
 
         # 2. fill the shared-memory blocks and start the workers: one packing thread per rank (the copies into shared
@@ -349,8 +356,10 @@ class IcpFarm(object):
         while True:
             msg = self._recv(w)
             if msg[0] == "error" and len(msg) == 2:       # worker died / start-up failure: no sequence number
+                w.pending = None
                 return msg
             if msg[2] == seq:
+                w.pending = None
                 return msg[0], msg[1]
 
     def close(self):

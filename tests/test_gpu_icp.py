@@ -702,3 +702,61 @@ def test_clearance_records_with_results_in_hbm_scratch(ctx):
                np.asarray(guess, np.float32)]
     same, a, b = _sweep_vs_brute(ctx, p, src, tgt, guesses)
     assert same, (a[0], b[0], a[2], b[2])
+
+
+@pytest.mark.parametrize("offset", [300.0, 3000.0])
+def test_clearance_records_far_from_the_origin(ctx, offset):
+    """VERDICT r3 5a / ADVICE r2: pcl.ICP.compute is a general API (mapping.py and any caller in a global frame hand it
+    clouds hundreds of metres from the origin).  The clearance-record test allows for the rounding of the two
+    transformed positions with a slack that scales with the extent (sfe_icp_sweep.hip, `max(3e-5, 6e-7 (rmax + |t|))`):
+    with both clouds offset by +300 m / +3000 m the records build (>= 12 fixed iterations) must still equal the
+    brute-force kernel bit for bit and the oracle (fp64 sums) in status, iteration count and pose."""
+    src, tgt, guess, _ = synth.scan_pair(seed=35, n_src=2500, n_tgt=2600)
+    shift = np.array([offset, -0.7 * offset], np.float32)
+    # the guess maps source into target coordinates: T' = S T S^-1 for a common translation S of both clouds
+    S = synth.pose_matrix(float(shift[0]), float(shift[1]), 0.0)
+    g64 = S @ np.asarray(guess, np.float64) @ np.linalg.inv(S)
+    src_o, tgt_o = (src + shift).astype(np.float32), (tgt + shift).astype(np.float32)
+    for mz in (0, 1):
+        p = icp_config.shipped_params(minimizer=mz, max_iter=24, use_diff_checker=0)
+        guesses = [g64.astype(np.float32), (g64 @ synth.pose_matrix(0.05, -0.04, 0.004)).astype(np.float32)]
+        same, a, b = _sweep_vs_brute(ctx, p, src_o, tgt_o, guesses)
+        assert same, (offset, mz, a[0], b[0], a[2], b[2])
+        assert list(a[2]) == [24, 24]
+        for g, msg, T, it in zip(guesses, a[0], a[1], a[2]):
+            st, To, ito = oracle.icp(src_o, tgt_o, g, oracle.IcpParams(precision=1, **p.as_dict()))
+            assert msg == oracle.ICP_STATUS_MESSAGES[st] and it == ito
+            # float32 transforms at |t| ~ 3000 m resolve 2.4e-4 m: compare in units of the translation's ulp
+            tol = max(TOL_TIGHT, 2.0 * float(np.spacing(np.float32(offset))))
+            assert _pose_diff(T, To) <= tol, (offset, mz, _pose_diff(T, To))
+
+
+def test_two_real_farm_workers_on_one_device(ctx):
+    """IcpFarm with two REAL HIP worker processes (two contexts on the one GPU, devices=[0, 0]): two
+    batches on the same workers, a bad job between them (ADVICE r2's scenario: nothing may stay in flight), results
+    equal to single calls in this process."""
+    from sonar_slam_amd.farm import IcpFarm
+    p = icp_config.shipped_params()
+    pairs = [synth.scan_pair(seed=400 + i, n_src=300 + 41 * i, n_tgt=420 + 13 * i) for i in range(9)]
+    icp = _icp(p, ctx)
+
+    def jobs_of(sel):
+        return [(pairs[i][0], pairs[i][1], [pairs[i][2], pairs[i][2] @ synth.pose_matrix(0.08, 0.0, 0.01).astype(np.float32)])
+                for i in sel]
+    with IcpFarm(p, devices=[ctx.device, ctx.device], chunk=3) as f:
+        pids = None
+        for sel in (range(5), range(9)):
+            jobs = jobs_of(sel)
+            out = f.run(jobs)
+            assert len(out) == len(jobs)
+            for (s, t, gs), (m, Tf, itf) in zip(jobs, out):
+                mb, Tb, itb = icp.compute_batch(s, t, gs)
+                assert list(m) == list(mb) and np.array_equal(Tf, Tb) and np.array_equal(itf, itb)
+            now = [w.proc.pid for w in f._workers]
+            assert len(now) == 2 and len(set(now)) == 2 and (pids is None or pids == now)
+            pids = now
+            if sel == range(5):
+                bad = jobs_of(range(4))
+                bad[1] = (np.zeros((0, 2), np.float32), pairs[1][1], [pairs[1][2]])      # job 1 -> worker 1
+                with pytest.raises(RuntimeError, match="empty source"):
+                    f.run(bad)

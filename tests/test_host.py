@@ -221,6 +221,36 @@ def test_farm_bad_job_leaves_no_request_in_flight():
         assert np.array_equal(out[0][1][0], To)
 
 
+def test_farm_run_after_an_interrupted_run_waits_for_the_abandoned_request():
+    """a run() interrupted between send and reply (Ctrl-C) leaves its request executing in the workers; the
+    next run() must not refill a worker's shared-memory block under it.  The interrupted request is awaited (and its
+    reply dropped) per worker before that worker's block is touched."""
+    import oracle
+    from sonar_slam_amd import farm, icp_config, synth
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    p = icp_config.shipped_params()
+    pairs = [synth.scan_pair(seed=20 + s, n_src=130, n_tgt=120) for s in range(6)]
+    first = [(s, t, [g]) for s, t, g, _ in pairs[:4]]
+    second = [(s, t, [g]) for s, t, g, _ in pairs[2:]]          # other clouds, same layout: the blocks are reused as they are
+    with farm.IcpFarm(p, devices=[0, 1], _backend="farm_backend:slow_oracle_compute") as f:
+        real = f._recv_reply
+        calls = []
+
+        def interrupted(w, seq):
+            calls.append(seq)
+            raise KeyboardInterrupt()
+        f._recv_reply = interrupted
+        with pytest.raises(KeyboardInterrupt):
+            f.run(first)
+        f._recv_reply = real
+        assert [w.pending for w in f._workers] == [1, 1]        # both requests are still out
+        out = f.run(second)
+        assert [w.pending for w in f._workers] == [None, None]
+        for (s, t, gs), (msgs, T, it) in zip(second, out):
+            st, To, ito = oracle.icp(s, t, gs[0], oracle.IcpParams(precision=1, **p.as_dict()))
+            assert msgs[0] == oracle.ICP_STATUS_MESSAGES[st] and it[0] == ito and np.array_equal(T[0], To)
+
+
 def test_icp_object_has_no_silent_default_chain(tmp_path):
     """PM::ICP() has no chain until loadFromYaml (pcl.cpp:185-197); a missing YAML is an error here, not
     libpointmatcher's setDefault() chain."""

@@ -18,6 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--icp-variants", default="0,4")  # 0 = sweep, 4 = brute force
+    ap.add_argument("--p2plane-only", action="store_true", help="skip the shipped chain (counter passes)")
     a = ap.parse_args()
     ctx = _lib.default_context()
     det = CFAR(40, 10, 0.1, 10)
@@ -36,6 +37,8 @@ def main():
         return ctx.timer_stop() / reps
     for mode, p in (("p2plane30", icp_config.shipped_params(minimizer=1, use_diff_checker=0, max_iter=30)),
                     ("reference", icp_config.shipped_params())):
+        if a.p2plane_only and mode != "p2plane30":
+            continue
         kb = KeyframeBatch(ctx, fe.geometry, det.params["SOCA"], "SOCA", 65, p, a.batch)
         kb.upload_frames(frames)
         kb.upload_scan_pairs(srcs, tgts, guesses)
