@@ -164,6 +164,14 @@ void sfe_geom_destroy(sfe_geom *g);
 int sfe_remap_u8(sfe_ctx *ctx, sfe_geom *g, const uint8_t *src, uint8_t *dst);
 /* the same on device pointers (enqueue only): d_src polar_rows x polar_cols, d_dst cart_rows x cart_cols */
 int sfe_remap_u8_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_src, uint8_t *d_dst);
+/* cv2.applyColorMap(cv2.remap(src, map_x, map_y, cv2.INTER_LINEAR), colormap) in one pass: the publishable bgr8 feature
+ * image of feature_extraction.py:226-228 (dst_bgr: cart_rows x cart_cols x 3, B G R per pixel; the _dev form needs it
+ * 4-byte aligned).  Only cv2.COLORMAP_JET (2), the one the node uses.  sfe_colormap_lut: the 256 x 3 BGR table itself
+ * (applyColorMap(x, 2)[..] == lut[x]).  OpenCV's table restated, parity unpinned. */
+#define SFE_COLORMAP_JET 2
+int sfe_colormap_lut(int colormap, uint8_t *lut_bgr);
+int sfe_remap_u8_colormap(sfe_ctx *ctx, sfe_geom *g, const uint8_t *src, int colormap, uint8_t *dst_bgr);
+int sfe_remap_u8_colormap_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_src, int colormap, uint8_t *d_dst_bgr);
 /*
  * remap(mask) -> np.nonzero -> px->m in one call (feature_extraction.py:231-238).
  * mask: polar_rows x polar_cols uint8 0/1 (host).  Outputs (host, nullable):
@@ -329,6 +337,8 @@ int sfe_feature_extract_ping(sfe_ctx *ctx, sfe_geom *g, const uint8_t *img, int 
  * failed: -1 the resident downsample refused it (octree deeper than 24 levels), -3 the pool was full. */
 typedef struct sfe_cloud_store sfe_cloud_store;
 #define SFE_STORE_NEGATE_Y 1   /* put: store (x, -y), what slam_ros.py:170 makes of the feature message */
+#define SFE_PING_VIS_JET 4     /* sfe_feature_extract_ping_store: vis_out is the bgr8 image applyColorMap(remap(img), JET)
+                                  (cart_rows x cart_cols x 3, feature_extraction.py:226-228) instead of the grey remap */
 #define SFE_STORE_F32_POINTS 2 /* get_points / overlap: the caller's keyframe clouds are float32 numpy arrays (sgemm
                                   rounding: fma(p1, r1, p0 * r0) + t in float) instead of the SLAM node's float64 ones
                                   (products and sums in double, rounded to float32 at the pybind boundary) */
@@ -369,7 +379,9 @@ int sfe_cloud_store_overlap(sfe_ctx *ctx, sfe_cloud_store *s, const int32_t *pai
 /* sfe_feature_extract_ping with the cloud left in the store instead of copied to the host: the
  * filtered cloud becomes a new slot (with SFE_STORE_NEGATE_Y in flags: as the SLAM node holds it), *handle_out its
  * handle, *n_out its size; cloud_out (nullable, host [cap x 2], (forward, lateral) as published) receives the points
- * only when the caller wants to publish them.  On SFE_ERR_CAP / *n_out = -1 no slot is kept (*handle_out = -1). */
+ * only when the caller wants to publish them.  On SFE_ERR_CAP / *n_out = -1 no slot is kept (*handle_out = -1).
+ * s may be NULL (then cloud_out is required and handle_out may be NULL): the same call without a store, for the flags
+ * sfe_feature_extract_ping has no argument for (SFE_PING_VIS_JET). */
 int sfe_feature_extract_ping_store(sfe_ctx *ctx, sfe_geom *g, sfe_cloud_store *s, int64_t stamp, const uint8_t *img, int alg,
                                    int train_hs, int guard_hs, int k, double tau, int intensity_thr, float resolution,
                                    double radius, int min_points, int64_t cap, int flags, int32_t *handle_out,

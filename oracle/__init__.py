@@ -270,6 +270,56 @@ def overlap(source, target, T, max_dist, f64_points=True):
     return int(np.sum(ids != -1))
 
 
+def colormap_jet_lut():
+    """cv2.applyColorMap(x, cv2.COLORMAP_JET)'s table, 256 x 3 uint8 BGR (feature_extraction.py:227).  OpenCV's
+    colormap.cpp (class Jet, "equals the GNU Octave colormap jet") samples the ramps r = 4x - 3/2 on [3/8, 5/8), 1 on
+    [5/8, 7/8), -4x + 9/2 above; g = 4x - 1/2 on [1/8, 3/8), 1 on [3/8, 5/8), -4x + 7/2 on [5/8, 7/8); b = 4x + 1/2
+    below 1/8, 1 on [1/8, 3/8), -4x + 5/2 on [3/8, 5/8) at x = i / 255, scales by 255 and rounds to uint8 (half to
+    even).  Here: exact rational arithmetic.  Un-vendored third party, PARITY UNPINNED."""
+    from fractions import Fraction as F
+    lut = np.zeros((256, 3), np.uint8)
+    for i in range(256):
+        x = F(i, 255)
+        r = (4 * x - F(3, 2)) if F(3, 8) <= x < F(5, 8) else (1 if F(5, 8) <= x < F(7, 8) else ((-4 * x + F(9, 2)) if x >= F(7, 8) else 0))
+        g = (4 * x - F(1, 2)) if F(1, 8) <= x < F(3, 8) else (1 if F(3, 8) <= x < F(5, 8) else ((-4 * x + F(7, 2)) if F(5, 8) <= x < F(7, 8) else 0))
+        b = (4 * x + F(1, 2)) if x < F(1, 8) else (1 if F(1, 8) <= x < F(3, 8) else ((-4 * x + F(5, 2)) if F(3, 8) <= x < F(5, 8) else 0))
+        for c, v in enumerate((b, g, r)):
+            v = v * 255
+            fl = v.numerator // v.denominator
+            rem = v - fl
+            q = fl + (1 if (rem > F(1, 2) or (rem == F(1, 2) and fl % 2 == 1)) else 0)
+            lut[i, c] = min(max(q, 0), 255)
+    return lut
+
+
+def colormap_jet_lut_float_emulation():
+    """The same table through the float32 steps OpenCV takes (as far as its published source is remembered: linspace in
+    float, the literal per-channel tables as float, interp1 AT the sample points -- y0 + (x - x0) * (y1 - y0) / (x1 - x0)
+    in float -- and convertTo(CV_8U, 255)): where float rounding noise could move a tie."""
+    f32 = np.float32
+    x = np.arange(256) / 255.0
+    r = ((x >= 3 / 8) & (x < 5 / 8)) * (4 * x - 3 / 2) + ((x >= 5 / 8) & (x < 7 / 8)) * 1.0 + (x >= 7 / 8) * (-4 * x + 9 / 2)
+    g = ((x >= 1 / 8) & (x < 3 / 8)) * (4 * x - 1 / 2) + ((x >= 3 / 8) & (x < 5 / 8)) * 1.0 + ((x >= 5 / 8) & (x < 7 / 8)) * (-4 * x + 7 / 2)
+    b = (x < 1 / 8) * (4 * x + 1 / 2) + ((x >= 1 / 8) & (x < 3 / 8)) * 1.0 + ((x >= 3 / 8) & (x < 5 / 8)) * (-4 * x + 5 / 2)
+    step = f32(1.0) / f32(255)
+    X = np.array([f32(0) + f32(i) * step for i in range(256)], f32)
+    out = np.zeros((256, 3), np.uint8)
+    for c, ch in enumerate((b, g, r)):
+        Y = ch.astype(f32)
+        yi = np.zeros(256, f32)
+        for i in range(256):
+            xi, low, high = X[i], 0, 255
+            while high - low > 1:
+                cc = low + ((high - low) >> 1)
+                if xi > X[cc]:
+                    low = cc
+                else:
+                    high = cc
+            yi[i] = Y[low] + (xi - X[low]) * (Y[high] - Y[low]) / (X[high] - X[low])
+        out[:, c] = np.clip(np.rint(yi * f32(255)), 0, 255).astype(np.uint8)
+    return out
+
+
 def ellipse_kernel(hs):
     """cv2.getStructuringElement(cv2.MORPH_ELLIPSE, (2hs+1, 2hs+1), (hs, hs)) as a 0/1 array."""
     size = 2 * hs + 1

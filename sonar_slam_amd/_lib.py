@@ -97,6 +97,9 @@ SIGNATURES = {
     "sfe_geom_destroy": (None, [_vp]),
     "sfe_remap_u8": (C.c_int, [_vp, _vp, _u8p, _u8p]),
     "sfe_remap_u8_dev": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "sfe_colormap_lut": (C.c_int, [C.c_int, _u8p]),
+    "sfe_remap_u8_colormap": (C.c_int, [_vp, _vp, _u8p, C.c_int, _u8p]),
+    "sfe_remap_u8_colormap_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
     "sfe_feature_extract_ping": (C.c_int, [_vp, _vp, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_float,
                                            C.c_double, C.c_int, C.c_int64, _f32p, _i32p, _i32p, _u8p]),
     "sfe_extract_points": (C.c_int, [_vp, _vp, _u8p, C.c_int64, _i64p, _f64p, _i64p]),

@@ -52,9 +52,11 @@ static int ping_impl(sfe_ctx *ctx, sfe_geom *g, sfe_cloud_store *store, int64_t 
     double *d_pts = (double *)sfe_scratch(ctx, 34, (size_t)cap * 16);
     // [0] raw point count, [1] filtered count, then the filtered float32 cloud: one block, one copy back
     int32_t *d_res = (int32_t *)sfe_scratch(ctx, 35, 16 + (size_t)cap * 8);
-    uint8_t *d_vis = vis_out ? (uint8_t *)sfe_scratch(ctx, 36, nc) : nullptr;
+    const bool jet = (store_flags & SFE_PING_VIS_JET) != 0;
+    const size_t nvis = jet ? 3 * nc : nc;
+    uint8_t *d_vis = vis_out ? (uint8_t *)sfe_scratch(ctx, 36, nvis + 4) : nullptr;
     uint8_t *h_img = (uint8_t *)pinned_io(ctx, 0, np);
-    char *h_res = (char *)pinned_io(ctx, 1, 16 + (size_t)cap * 8 + (vis_out ? nc : 0));
+    char *h_res = (char *)pinned_io(ctx, 1, 16 + (size_t)cap * 8 + (vis_out ? nvis : 0));
     if (!d_img || !d_mask || !d_pts || !d_res || (vis_out && !d_vis) || !h_img || !h_res)
         return SFE_ERR_HIP;
     memcpy(h_img, img, np);
@@ -65,7 +67,7 @@ static int ping_impl(sfe_ctx *ctx, sfe_geom *g, sfe_cloud_store *store, int64_t 
                                               tau, intensity_thr, d_mask, nullptr))
         return rc;
     if (vis_out)
-        if (int rc = sfe_remap_u8_dev(ctx, g, d_img, d_vis))
+        if (int rc = jet ? sfe_remap_u8_colormap_dev(ctx, g, d_img, SFE_COLORMAP_JET, d_vis) : sfe_remap_u8_dev(ctx, g, d_img, d_vis))
             return rc;
     if (int rc = bits ? sfe_extract_points_bits_batch_dev(ctx, g, reinterpret_cast<const uint32_t *>(d_mask), 1, cap,
                                                           d_pts, d_res)
@@ -82,13 +84,13 @@ static int ping_impl(sfe_ctx *ctx, sfe_geom *g, sfe_cloud_store *store, int64_t 
     const size_t b_down = 16 + ((!store || cloud_out) ? (size_t)cap * 8 : 0);
     SFE_HIP(ctx, hipMemcpyAsync(h_res, d_res, b_down, hipMemcpyDeviceToHost, ctx->stream));
     if (vis_out)
-        SFE_HIP(ctx, hipMemcpyAsync(h_res + 16 + (size_t)cap * 8, d_vis, nc, hipMemcpyDeviceToHost, ctx->stream));
+        SFE_HIP(ctx, hipMemcpyAsync(h_res + 16 + (size_t)cap * 8, d_vis, nvis, hipMemcpyDeviceToHost, ctx->stream));
     SFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const int32_t n_raw = reinterpret_cast<int32_t *>(h_res)[0], n = reinterpret_cast<int32_t *>(h_res)[1];
     if (n_raw_out)
         *n_raw_out = n_raw;
     if (vis_out)
-        memcpy(vis_out, h_res + 16 + (size_t)cap * 8, nc);
+        memcpy(vis_out, h_res + 16 + (size_t)cap * 8, nvis);
     if (handle_out)
         *handle_out = handle;
     if (n_raw > cap || n < 0) {
@@ -131,7 +133,7 @@ extern "C" int sfe_feature_extract_ping_store(sfe_ctx *ctx, sfe_geom *g, sfe_clo
 {
     if (int rc = sfe_use(ctx))
         return rc;
-    SFE_ARG(ctx, g && s && img && handle_out && n_out && g->ctx == ctx && cap > 0 && cap <= 65536);
+    SFE_ARG(ctx, g && img && n_out && g->ctx == ctx && cap > 0 && cap <= 65536 && (s ? handle_out != nullptr : cloud_out != nullptr));
     return ping_impl(ctx, g, s, stamp, flags, img, alg, train_hs, guard_hs, k, tau, intensity_thr, resolution, radius,
                      min_points, cap, cloud_out, n_out, n_raw_out, vis_out, handle_out);
 }

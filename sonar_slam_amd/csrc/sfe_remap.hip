@@ -66,6 +66,46 @@ __global__ __launch_bounds__(256) void remap_u8_kernel(const uint8_t *__restrict
     dst[i] = (c == SFE_CODE_NONE) ? 0 : (uint8_t)remap_value(src + f * (long long)prows * pcols, prows, pcols, rcp, c);
 }
 
+// cv2.applyColorMap(cv2.remap(img, ...), cv2.COLORMAP_JET) in one pass (feature_extraction.py:226-228): the remapped grey
+// value goes through a 256-entry BGR table on its way out, so the publishable bgr8 image is written once and the grey
+// canvas never exists.  A thread owns 4 consecutive canvas pixels = 12 output bytes = three aligned dword stores.
+// lut: 256 x (B | G << 8 | R << 16), staged in LDS.
+__global__ __launch_bounds__(256) void remap_u8_lut_kernel(const uint8_t *__restrict__ src,
+                                                           const uint32_t *__restrict__ code,
+                                                           const uint32_t *__restrict__ lut, uint32_t *__restrict__ dst3,
+                                                           int prows, int pcols, unsigned rcp, long long n_cart)
+{
+    __shared__ uint32_t s_lut[256];
+    s_lut[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x; // group of 4 pixels
+    const long long o = q * 4;
+    if (o >= n_cart)
+        return;
+    uint32_t px[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t v = 0;
+        if (o + k < n_cart) {
+            const uint32_t c = code[o + k];
+            v = (c == SFE_CODE_NONE) ? 0u : (uint32_t)remap_value(src, prows, pcols, rcp, c);
+        }
+        px[k] = s_lut[v];
+    }
+    if (o + 4 <= n_cart) { // b0 g0 r0 b1 | g1 r1 b2 g2 | r2 b3 g3 r3
+        dst3[q * 3] = px[0] | (px[1] << 24);
+        dst3[q * 3 + 1] = (px[1] >> 8) | (px[2] << 16);
+        dst3[q * 3 + 2] = (px[2] >> 16) | (px[3] << 8);
+    } else {
+        uint8_t *d = reinterpret_cast<uint8_t *>(dst3) + o * 3;
+        for (int k = 0; o + k < n_cart; ++k) {
+            d[3 * k] = (uint8_t)px[k];
+            d[3 * k + 1] = (uint8_t)(px[k] >> 8);
+            d[3 * k + 2] = (uint8_t)(px[k] >> 16);
+        }
+    }
+}
+
 // pass 0: pack the uint8 detection mask into bits (bit iy*pcols+ix of the frame's bit stream,
 // LSB first) and note whether any byte is > 1 (then the binary shortcut of pass 1 is not valid).
 __global__ __launch_bounds__(256) void mask_pack_kernel(const uint8_t *__restrict__ mask,
@@ -1348,6 +1388,90 @@ int sfe_remap_u8_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_src, uint8_t *d
     hipLaunchKernelGGL(remap_u8_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, ctx->stream, d_src,
                        (const uint32_t *)g->d_code, d_dst, g->polar_rows, g->polar_cols, g->rcp, (long long)nc, 1);
     SFE_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+// OpenCV's COLORMAP_JET (imgproc colormap.cpp, class Jet: "equals the GNU Octave colormap jet"): 256 control values per
+// channel sampled from the piecewise-linear ramps
+//     r = 4x - 3/2 on [3/8, 5/8), 1 on [5/8, 7/8), -4x + 9/2 from 7/8;   g = 4x - 1/2 on [1/8, 3/8), 1, -4x + 7/2 on [5/8, 7/8);
+//     b = 4x + 1/2 below 1/8, 1 on [1/8, 3/8), -4x + 5/2 on [3/8, 5/8);   x = i / 255,
+// scaled by 255 and rounded to uint8 (cvRound: half to even).  Every ramp value is k + 1/2 exactly, so here the table is
+// evaluated in exact integer arithmetic (twice the value) with the tie rule; OpenCV goes through float32 (a literal table,
+// an interp1 at the sample points, convertTo(CV_8U, 255)) whose rounding noise may move an entry by one grey level: a
+// float32 emulation of that pipeline differs from this table in 1 of 768 entries (tests/test_oracle_pipeline.py).
+// OpenCV is un-vendored and absent: PARITY UNPINNED.
+static void jet_lut(uint32_t *lut)
+{
+    auto q = [](int twice) { // round(twice / 2) half to even, clamped to uint8
+        int v = twice >> 1;
+        if (twice & 1)
+            v += v & 1;
+        return (uint32_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+    };
+    for (int i = 0; i < 256; ++i) {
+        // 8i vs 255 k: x >= k/8  <=>  8 i >= 255 k
+        const int e = 8 * i;
+        const int r2 = (e >= 765 && e < 1275) ? 8 * i - 765 : (e >= 1275 && e < 1785) ? 510 : (e >= 1785) ? -8 * i + 2295 : 0;
+        const int g2 = (e >= 255 && e < 765) ? 8 * i - 255 : (e >= 765 && e < 1275) ? 510 : (e >= 1275 && e < 1785) ? -8 * i + 1785 : 0;
+        const int b2 = (e < 255) ? 8 * i + 255 : (e >= 255 && e < 765) ? 510 : (e >= 765 && e < 1275) ? -8 * i + 1275 : 0;
+        lut[i] = q(b2) | (q(g2) << 8) | (q(r2) << 16);
+    }
+}
+
+int sfe_colormap_lut(int colormap, uint8_t *lut_bgr)
+{
+    if (colormap != SFE_COLORMAP_JET || !lut_bgr)
+        return SFE_ERR_ARG;
+    uint32_t lut[256];
+    jet_lut(lut);
+    for (int i = 0; i < 256; ++i) {
+        lut_bgr[3 * i] = (uint8_t)lut[i];
+        lut_bgr[3 * i + 1] = (uint8_t)(lut[i] >> 8);
+        lut_bgr[3 * i + 2] = (uint8_t)(lut[i] >> 16);
+    }
+    return 0;
+}
+
+int sfe_remap_u8_colormap_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_src, int colormap, uint8_t *d_dst_bgr)
+{
+    if (int rc = sfe_use(ctx))
+        return rc;
+    SFE_ARG(ctx, g && d_src && d_dst_bgr && g->ctx == ctx && (reinterpret_cast<uintptr_t>(d_dst_bgr) & 3) == 0);
+    if (colormap != SFE_COLORMAP_JET)
+        return sfe_set_err(ctx, SFE_ERR_ARG, "colour map %d: only cv2.COLORMAP_JET (2) is built (feature_extraction.py:227)", colormap);
+    uint32_t *d_lut = (uint32_t *)sfe_scratch(ctx, 51, 1024);
+    if (!d_lut)
+        return SFE_ERR_HIP;
+    uint32_t *h_lut = (uint32_t *)sfe_pinned_begin(ctx, 1024);
+    if (!h_lut)
+        return SFE_ERR_HIP;
+    jet_lut(h_lut);
+    SFE_HIP(ctx, hipMemcpyAsync(d_lut, h_lut, 1024, hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = sfe_pinned_end(ctx, ctx->stream))
+        return rc;
+    const long long nc = (long long)g->cart_rows * g->cart_cols;
+    hipLaunchKernelGGL(remap_u8_lut_kernel, dim3((unsigned)(((nc + 3) / 4 + 255) / 256)), dim3(256), 0, ctx->stream, d_src,
+                       (const uint32_t *)g->d_code, (const uint32_t *)d_lut, reinterpret_cast<uint32_t *>(d_dst_bgr),
+                       g->polar_rows, g->polar_cols, g->rcp, nc);
+    SFE_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+int sfe_remap_u8_colormap(sfe_ctx *ctx, sfe_geom *g, const uint8_t *src, int colormap, uint8_t *dst_bgr)
+{
+    if (int rc = sfe_use(ctx))
+        return rc;
+    SFE_ARG(ctx, g && src && dst_bgr && g->ctx == ctx);
+    const size_t np = (size_t)g->polar_rows * g->polar_cols, nc = (size_t)g->cart_rows * g->cart_cols;
+    uint8_t *d_src = (uint8_t *)sfe_scratch(ctx, 0, np);
+    uint8_t *d_dst = (uint8_t *)sfe_scratch(ctx, 3, 3 * nc + 4);
+    if (!d_src || !d_dst)
+        return SFE_ERR_HIP;
+    SFE_HIP(ctx, hipMemcpyAsync(d_src, src, np, hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = sfe_remap_u8_colormap_dev(ctx, g, d_src, colormap, d_dst))
+        return rc;
+    SFE_HIP(ctx, hipMemcpyAsync(dst_bgr, d_dst, 3 * nc, hipMemcpyDeviceToHost, ctx->stream));
+    SFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
 

@@ -28,6 +28,18 @@ from . import pcl
 from .CFAR import CFAR
 
 
+COLORMAP_JET = 2        # cv2.COLORMAP_JET, the map of feature_extraction.py:227
+PING_VIS_JET = 4        # SFE_PING_VIS_JET
+
+
+def colormap_lut(colormap=COLORMAP_JET):
+    """the 256 x 3 BGR table: cv2.applyColorMap(img, colormap) == lut[img] (sfe_colormap_lut; host only)"""
+    lut = np.zeros((256, 3), np.uint8)
+    if _L.load_library().sfe_colormap_lut(int(colormap), _L.ptr(lut, _C.c_uint8)) != 0:
+        raise ValueError("only cv2.COLORMAP_JET (2) is built (feature_extraction.py:227)")
+    return lut
+
+
 class SonarPing(object):
     """Minimal stand-in for sonar_oculus/OculusPing(Uncompressed) (last row)."""
 
@@ -64,11 +76,18 @@ class Geometry(object):
                 self.height, _C.byref(h)))
         self.handle = h
 
-    def remap(self, img):
-        """cv2.remap(img, map_x, map_y, cv2.INTER_LINEAR) for a uint8 polar image."""
+    def remap(self, img, colormap=None):
+        """cv2.remap(img, map_x, map_y, cv2.INTER_LINEAR) for a uint8 polar image; with ``colormap=COLORMAP_JET`` the
+        bgr8 image cv2.applyColorMap(remap, 2) of feature_extraction.py:226-228 in the same pass."""
         img = np.ascontiguousarray(img, np.uint8)
         if img.shape != (self.polar_rows, self.polar_cols):
             raise ValueError("remap: image shape %r does not match the geometry" % (img.shape,))
+        if colormap is not None:
+            dst = np.zeros((self.cart_rows, self.cart_cols, 3), np.uint8)
+            with self.ctx.lock:
+                self.ctx._check(self.ctx.lib.sfe_remap_u8_colormap(self.ctx.handle, self.handle, _L.ptr(img, _C.c_uint8),
+                                                                   int(colormap), _L.ptr(dst, _C.c_uint8)))
+            return dst
         dst = np.zeros((self.cart_rows, self.cart_cols), np.uint8)
         with self.ctx.lock:
             self.ctx._check(self.ctx.lib.sfe_remap_u8(self.ctx.handle, self.handle,
@@ -98,7 +117,7 @@ class Geometry(object):
             return rc[:n.value].copy(), pts[:n.value].copy()
 
     def feature_extract(self, img, alg, cfar_params, threshold, resolution, radius, min_points, want_vis=False,
-                        cap=16384):
+                        cap=16384, colormap=None):
         """One ping through CFAR + gate -> remap + nonzero + px->m -> pcl.downsample -> pcl.remove_outlier in ONE
         library call (sfe_feature_extract_ping: one pinned upload, one download, one synchronisation).
         -> (cloud float32 [N x 2], vis image or None), or None when the cloud's octree is too deep for the
@@ -112,17 +131,26 @@ class Geometry(object):
             train_hs, guard_hs, k, tau = cfar_params
         else:
             (train_hs, guard_hs, tau), k = cfar_params, 0
-        vis = np.zeros((self.cart_rows, self.cart_cols), np.uint8) if want_vis else None
+        jet = want_vis and colormap is not None
+        if jet and int(colormap) != COLORMAP_JET:
+            raise ValueError("only cv2.COLORMAP_JET (2) is built (feature_extraction.py:227)")
+        vis = np.zeros((self.cart_rows, self.cart_cols) + ((3,) if jet else ()), np.uint8) if want_vis else None
         cap = int(cap)
         while True:
             cloud = np.zeros((cap, 2), np.float32)
             n, n_raw = _C.c_int32(0), _C.c_int32(0)
             with self.ctx.lock:
-                ret = self.ctx.lib.sfe_feature_extract_ping(
-                    self.ctx.handle, self.handle, _L.ptr(img, _C.c_uint8), code, int(train_hs), int(guard_hs), int(k),
-                    float(tau), _gate_u8(threshold), float(resolution), float(radius), int(min_points), cap,
-                    _L.ptr(cloud, _C.c_float), _C.byref(n), _C.byref(n_raw),
-                    _L.ptr(vis, _C.c_uint8) if want_vis else None)
+                if jet:     # (the entry point with a flags argument, without a store)
+                    ret = self.ctx.lib.sfe_feature_extract_ping_store(
+                        self.ctx.handle, self.handle, None, 0, _L.ptr(img, _C.c_uint8), code, int(train_hs), int(guard_hs),
+                        int(k), float(tau), _gate_u8(threshold), float(resolution), float(radius), int(min_points), cap,
+                        PING_VIS_JET, None, _C.byref(n), _C.byref(n_raw), _L.ptr(cloud, _C.c_float), _L.ptr(vis, _C.c_uint8))
+                else:
+                    ret = self.ctx.lib.sfe_feature_extract_ping(
+                        self.ctx.handle, self.handle, _L.ptr(img, _C.c_uint8), code, int(train_hs), int(guard_hs), int(k),
+                        float(tau), _gate_u8(threshold), float(resolution), float(radius), int(min_points), cap,
+                        _L.ptr(cloud, _C.c_float), _C.byref(n), _C.byref(n_raw),
+                        _L.ptr(vis, _C.c_uint8) if want_vis else None)
             if ret == _L.SFE_ERR_CAP and n_raw.value > cap and n_raw.value <= 65536:
                 cap = int(n_raw.value)
                 continue
@@ -134,7 +162,7 @@ class Geometry(object):
             return cloud[:n.value].copy(), vis
 
     def feature_extract_store(self, img, alg, cfar_params, threshold, resolution, radius, min_points, store, stamp=0,
-                              flags=1, want_cloud=False, want_vis=False, cap=16384):
+                              flags=1, want_cloud=False, want_vis=False, cap=16384, colormap=None):
         """``feature_extract`` with the cloud left in a ``store.CloudStore`` (sfe_feature_extract_ping_store): the
         filtered cloud never crosses PCIe unless ``want_cloud`` asks for the publishable copy.  flags: store.NEGATE_Y
         (default) keeps it as the SLAM node holds it (slam_ros.py:170).
@@ -148,7 +176,11 @@ class Geometry(object):
             train_hs, guard_hs, k, tau = cfar_params
         else:
             (train_hs, guard_hs, tau), k = cfar_params, 0
-        vis = np.zeros((self.cart_rows, self.cart_cols), np.uint8) if want_vis else None
+        jet = want_vis and colormap is not None
+        if jet and int(colormap) != COLORMAP_JET:
+            raise ValueError("only cv2.COLORMAP_JET (2) is built (feature_extraction.py:227)")
+        vis = np.zeros((self.cart_rows, self.cart_cols) + ((3,) if jet else ()), np.uint8) if want_vis else None
+        flags = int(flags) | (PING_VIS_JET if jet else 0)
         cap = int(cap)
         while True:
             cloud = np.zeros((cap, 2), np.float32) if want_cloud else None
@@ -227,6 +259,7 @@ class FeatureExtraction(object):
         self.geometry = None
         self.feature_img = None
         self.make_vis_image = False
+        self.vis_colormap = None   # COLORMAP_JET: feature_img is the bgr8 image the node publishes (:226-228), one pass
         self.fused = True          # callback() = one sfe_feature_extract_ping call (False: the per-stage calls)
 
     # ---- configuration: the rosparam keys of init_node (feature_extraction.py:83-110) ----
@@ -290,7 +323,8 @@ class FeatureExtraction(object):
             # the live path: the whole chain below in one library call (bit-identical to it)
             out = self.geometry.feature_extract(img, self.alg, self.detector.params[self.alg], self.threshold,
                                                 self.resolution, self.outlier_filter_radius,
-                                                self.outlier_filter_min_points, want_vis=self.make_vis_image)
+                                                self.outlier_filter_min_points, want_vis=self.make_vis_image,
+                                                colormap=self.vis_colormap)
             if out is not None:
                 points, vis = out
                 if self.make_vis_image:
@@ -313,7 +347,8 @@ class FeatureExtraction(object):
             out = self.geometry.feature_extract_store(img, self.alg, self.detector.params[self.alg], self.threshold,
                                                       self.resolution, self.outlier_filter_radius,
                                                       self.outlier_filter_min_points, store, stamp=stamp,
-                                                      want_cloud=publish, want_vis=self.make_vis_image)
+                                                      want_cloud=publish, want_vis=self.make_vis_image,
+                                                      colormap=self.vis_colormap)
             if out is not None:
                 h, n, cloud, vis = out
                 if self.make_vis_image:
@@ -329,7 +364,7 @@ class FeatureExtraction(object):
     def _callback_stages(self, img):
         peaks = self.detect(img)
         if self.make_vis_image:
-            self.feature_img = self.geometry.remap(img)  # :226 (colour map is applied by the node)
+            self.feature_img = self.geometry.remap(img, self.vis_colormap)  # :226-227
         _, points = self.extract(peaks)
         if len(points) and self.resolution > 0:
             points = pcl.downsample(points, self.resolution)  # :241-242

@@ -350,3 +350,32 @@ def test_batch_extraction_above_the_capacity_keeps_the_first_points(ctx, shipped
         k = min(cap, len(want[f]))
         assert np.array_equal(pts[f, :k], want[f][:k]), f
         assert np.all(pts[f, k:] == -7.0)                 # nothing is written behind a frame's points
+
+
+def test_vis_image_with_the_jet_colour_map_in_one_pass(ctx):
+    """feature_extraction.py:226-228: vis_img = cv2.applyColorMap(cv2.remap(img, ...), 2) published as bgr8.  The fused
+    kernel (remap value -> BGR table -> packed 3-byte pixels) against table[oracle remap], per-stage call and the
+    one-call ping path (with and without a store); odd canvas sizes exercise the tail of the 4-pixel groups."""
+    from sonar_slam_amd import store as st
+    from sonar_slam_amd.feature_extraction import COLORMAP_JET, FeatureExtraction, SonarPing, oculus_bearings
+    lut = oracle.colormap_jet_lut()
+    for rows, beams in ((256, 96), (300, 128), (512, 256)):
+        fe = FeatureExtraction(ctx)
+        fe.Ntc, fe.Ngc, fe.Pfa, fe.rank, fe.alg, fe.threshold, fe.skip = 40, 10, 0.1, 10, "SOCA", 65, 1
+        fe.configure()
+        img = synth.sonar_frame(seed=rows, rows=rows, cols=beams, n_blobs=10)
+        ping = SonarPing(img, oculus_bearings(beams), 30.0 / rows)
+        fe.generate_map_xy(ping)
+        want = lut[oracle.remap_u8(img, fe.map_x, fe.map_y)]
+        got = fe.geometry.remap(img, COLORMAP_JET)
+        assert got.shape == want.shape and got.dtype == np.uint8 and np.array_equal(got, want)
+        fe.make_vis_image, fe.vis_colormap = True, COLORMAP_JET
+        pts = fe.callback(ping)
+        assert np.array_equal(fe.feature_img, want)
+        s = st.CloudStore(ctx, capacity_points=1 << 16, max_clouds=4)
+        h, n, cloud = fe.callback_store(ping, s, publish=True)
+        assert np.array_equal(fe.feature_img, want) and np.array_equal(cloud, np.asarray(pts, np.float32))
+        fe.fused = False
+        fe.callback(ping)
+        assert np.array_equal(fe.feature_img, want)
+        s.close()

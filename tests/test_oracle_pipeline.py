@@ -181,3 +181,21 @@ def test_kdtree_backend_returns_the_same_neighbours_and_poses():
     for (sa, Ta, ia), (sb, Tb, ib) in zip(a[3], b[3]):
         assert sa == sb and ia == ib and np.array_equal(Ta, Tb)
     assert b[4] < a[4]
+
+
+def test_jet_colour_map_table():
+    """cv2.applyColorMap(img, cv2.COLORMAP_JET) (feature_extraction.py:227) as a 256 x 3 BGR table: the library's
+    integer evaluation equals the oracle's rational one; anchor values everybody knows from OpenCV's JET
+    (0 -> (128, 0, 0), 255 -> (0, 0, 128), mid-grey green-ish with full G); a float32 emulation of OpenCV's own pipeline
+    moves ONE of the 768 entries by one grey level (the table's ramp values are all exact ties): parity unpinned."""
+    from sonar_slam_amd.feature_extraction import colormap_lut
+    lut = colormap_lut()
+    want = oracle.colormap_jet_lut()
+    assert lut.shape == (256, 3) and np.array_equal(lut, want)
+    assert lut[0].tolist() == [128, 0, 0] and lut[255].tolist() == [0, 0, 128]
+    assert lut[1].tolist() == [132, 0, 0] and lut[128, 1] == 255 and lut[64].tolist() == [255, 128, 0]
+    emu = oracle.colormap_jet_lut_float_emulation()
+    diff = np.argwhere(want != emu)
+    assert len(diff) <= 1 and np.abs(want.astype(int) - emu.astype(int)).max() <= 1
+    with pytest.raises(ValueError):
+        colormap_lut(4)
