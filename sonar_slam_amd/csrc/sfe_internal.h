@@ -75,6 +75,8 @@ struct sfe_geom {
     int32_t *d_inv_off = nullptr;
     uint2 *d_inv_ent = nullptr;     // {canvas index, its remap code}
     uint2 *d_inv_lut = nullptr;     // {canvas index, decision table of the entry} (extract_gather_kernel)
+    uint2 *d_inv_ob = nullptr;      // compact form (round 4): per polar pixel {offset into d_inv_c4, base bit index}
+    uint32_t *d_inv_c4 = nullptr;   //   4-byte entries {table, tap place, dx, dy}, dead entries dropped
     // px -> m of feature_extraction.py:236-237 per canvas row / column (fp64, the reference's operation order,
     // evaluated once on the host: extract_expand_words_kernel looks the metres up instead of dividing per point)
     double *d_ytab = nullptr, *d_xtab = nullptr;

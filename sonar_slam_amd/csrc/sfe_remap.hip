@@ -407,6 +407,175 @@ __global__ __launch_bounds__(SCAN_THREADS) void extract_scan_kernel(const unsign
     }
 }
 
+
+// pass 2 from the second level (round 4): the frame's non-empty canvas words are enumerated from the flag bytes
+// extract_gather_kernel sets (one per canvas word; 64 of them make an l2 word: bit w = word w is not empty) instead of
+// found by streaming the whole canvas bitmap.  One workgroup
+// per frame: the l2 words (480 for config A) are read and cleared; a thread's l2 word gives up to 64 word indices in
+// ascending order = row-major order = np.nonzero order, so the exclusive prefix of the popcounts in LIST order is the
+// number of the frame's points in front of a word: no row bookkeeping for the list at all.  Rounds of L2_ROUND entries:
+// indices -> LDS, then every thread gathers its words' 64 bits (8-byte reads of lines the gather kernel has just
+// written: L2 hits), block scan of the popcounts, entries {row << 16 | word of the row, points in front, 64 bits}
+// straight to the list.  Row counts / offsets (needed by the per-point fallback of frames above the capacity) from LDS
+// counters as in extract_scan_kernel.  Same outputs as extract_scan_kernel.
+#define L2_THREADS 256
+#define L2_ROUND 2048
+__device__ __forceinline__ int l2_block_excl_scan(int v, int *s_w, int *total) // 256 threads; s_w: >= 5 ints
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int incl = scan_wave_incl(v);
+    __syncthreads(); // (s_w may still be read from a previous call)
+    if (lane == 63)
+        s_w[wave] = incl;
+    __syncthreads();
+    int pre = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < L2_THREADS / 64; ++w) {
+        const int x = s_w[w];
+        pre += w < wave ? x : 0;
+        tot += x;
+    }
+    *total = tot;
+    return pre + incl - v;
+}
+
+__global__ __launch_bounds__(L2_THREADS) void extract_scan_l2_kernel(unsigned long long *__restrict__ l2_all, int l2_words,
+                                                                     const unsigned long long *__restrict__ bitmap,
+                                                                     int32_t *__restrict__ row_count,
+                                                                     int32_t *__restrict__ row_off,
+                                                                     int32_t *__restrict__ frame_count, int crows, int wpr,
+                                                                     int4 *__restrict__ wlist, int32_t *__restrict__ wlist_n,
+                                                                     int list_cap, long long cap, int32_t *__restrict__ ovf_n,
+                                                                     int32_t *__restrict__ ovf_list)
+{
+    extern __shared__ __attribute__((aligned(16))) int s_dyn[]; // crows row counts | l2 bases | l2 words (8 B each)
+    __shared__ int s_idx[L2_ROUND];
+    __shared__ int s_w[8];
+    int *s_cntp = s_dyn, *s_base = s_dyn + crows;
+    unsigned long long *s_l2 = reinterpret_cast<unsigned long long *>(s_dyn + crows + ((l2_words + 1) & ~1));
+    const int f = blockIdx.x, tid = threadIdx.x;
+    // flag bytes of the frame's canvas words (extract_gather_kernel), 64 per l2 word
+    uint4 *__restrict__ flags = reinterpret_cast<uint4 *>(reinterpret_cast<uint8_t *>(l2_all) + (long long)f * l2_words * 64);
+    const unsigned long long *__restrict__ bm = bitmap + (long long)f * crows * wpr;
+    int4 *__restrict__ wl = wlist + (long long)f * list_cap;
+    for (int i = tid; i < crows; i += L2_THREADS)
+        s_cntp[i] = 0;
+    // ---- 64 flag bytes -> one l2 word (bit b = canvas word 64 i + b is not empty); the flags that were set are cleared
+    //      (the next batch finds them zero, like the canvas words the expansion clears); exclusive prefix of the
+    //      popcounts = list position of a word's first entry
+    int n_ent = 0;
+    {
+        int carry = 0;
+        for (int b = 0; b < l2_words; b += L2_THREADS) {
+            const int i = b + tid;
+            unsigned long long w = 0ull;
+            if (i < l2_words) {
+                uint4 q[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    q[k] = flags[4 * i + k];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned n16 = __builtin_amdgcn_udot4(q[k].x, 0x08040201u, 0u, false) |
+                                         (__builtin_amdgcn_udot4(q[k].y, 0x08040201u, 0u, false) << 4) |
+                                         (__builtin_amdgcn_udot4(q[k].z, 0x08040201u, 0u, false) << 8) |
+                                         (__builtin_amdgcn_udot4(q[k].w, 0x08040201u, 0u, false) << 12);
+                    w |= (unsigned long long)n16 << (16 * k);
+                    if (n16)
+                        flags[4 * i + k] = make_uint4(0u, 0u, 0u, 0u);
+                }
+                s_l2[i] = w;
+            }
+            int tot;
+            const int ex = l2_block_excl_scan(__popcll(w), s_w, &tot);
+            if (i < l2_words)
+                s_base[i] = carry + ex;
+            carry += tot;
+        }
+        n_ent = carry;
+    }
+    __syncthreads();
+    // ---- rounds of L2_ROUND list entries
+    int pts_before = 0; // points of the frame in front of this round's first entry (the same in every thread)
+    for (int r0 = 0; r0 < n_ent; r0 += L2_ROUND) {
+        const int r1 = min(r0 + L2_ROUND, n_ent);
+        for (int i = tid; i < l2_words; i += L2_THREADS) { // (few l2 words intersect a round: the loop is short)
+            const int b = s_base[i];
+            unsigned long long w = s_l2[i];
+            const int pc = __popcll(w);
+            if (pc == 0 || b >= r1 || b + pc <= r0)
+                continue;
+            int e = b;
+            while (w) {
+                const int bit = __ffsll((long long)w) - 1;
+                w &= w - 1ull;
+                if (e >= r0 && e < r1)
+                    s_idx[e - r0] = i * 64 + bit;
+                ++e;
+            }
+        }
+        __syncthreads();
+        // a thread owns L2_ROUND / L2_THREADS consecutive entries of the round: their words are requested together (one
+        // exposed round trip per round; one entry per thread and scan step waited for eight of them, one after the other)
+        constexpr int EPT = L2_ROUND / L2_THREADS;
+        int wi[EPT], pc[EPT], sum = 0;
+        unsigned long long wv[EPT];
+#pragma unroll
+        for (int u = 0; u < EPT; ++u) {
+            const int e = r0 + tid * EPT + u;
+            wi[u] = e < r1 ? s_idx[e - r0] : 0;
+            wv[u] = e < r1 ? bm[wi[u]] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < EPT; ++u) {
+            pc[u] = __popcll(wv[u]);
+            sum += pc[u];
+        }
+        int tot;
+        int run = pts_before + l2_block_excl_scan(sum, s_w, &tot);
+#pragma unroll
+        for (int u = 0; u < EPT; ++u) {
+            const int e = r0 + tid * EPT + u;
+            if (e < r1) {
+                const int row = wi[u] / wpr;
+                if (pc[u])
+                    atomicAdd(&s_cntp[row], pc[u]);
+                if (e < list_cap)
+                    wl[e] = make_int4((row << 16) | (wi[u] - row * wpr), run, (int)(unsigned)(wv[u] & 0xFFFFFFFFull),
+                                      (int)(unsigned)(wv[u] >> 32));
+                run += pc[u];
+            }
+        }
+        const int carry = pts_before + tot;
+        pts_before = carry;
+        __syncthreads(); // s_idx is rewritten by the next round
+    }
+    __syncthreads();
+    // ---- row counts -> offsets
+    int32_t *__restrict__ cnt = row_count + (long long)f * crows;
+    int32_t *__restrict__ off = row_off + (long long)f * crows;
+    int carry = 0;
+    for (int b = 0; b < crows; b += L2_THREADS) {
+        const int i = b + tid;
+        const int c = i < crows ? s_cntp[i] : 0;
+        int tot;
+        const int ex = l2_block_excl_scan(c, s_w, &tot);
+        if (i < crows) {
+            cnt[i] = c;
+            off[i] = carry + ex;
+        }
+        carry += tot;
+    }
+    const int total = carry;
+    const bool listed = total <= cap && n_ent <= list_cap; // (total <= cap implies the second: a word holds a point)
+    if (tid == 0) {
+        frame_count[f] = total;
+        wlist_n[f] = listed ? n_ent : 0;
+        if (!listed)
+            ovf_list[atomicAdd(ovf_n, 1)] = f;
+    }
+}
+
 // pass 3, word form: one lane per BYTE of a non-empty bitmap word (extract_scan_kernel's list; 8 lanes share a word):
 // the set bits of a word are consecutive points of the frame (np.nonzero order: row-major), the byte's first one
 // comes after the word's offset + the set bits of the lower bytes.  A lane walks its <= 8 bits -- next set bit,
@@ -448,9 +617,20 @@ __global__ __launch_bounds__(256) void extract_expand_words_kernel(const int4 *_
         for (int i = threadIdx.x; i < ccols; i += 256)
             s_x[i] = xtab[i];
     }
+    int4 ent_next = make_int4(0, 0, 0, 0);
+    {
+        const int e0 = blockIdx.x * 256 + wave * 64 + lane;
+        if (e0 < n)
+            ent_next = wl[e0];
+    }
     for (int eb = blockIdx.x * 256; eb < n; eb += gridDim.x * 256) { // (workgroup-uniform)
         const int e = eb + wave * 64 + lane;
-        const int4 ent = e < n ? wl[e] : make_int4(0, 0, 0, 0);
+        const int4 ent = ent_next;
+        {   // the next batch's entry is requested before this one is expanded (the list read was an exposed round trip
+            // per batch)
+            const int en = e + gridDim.x * 256;
+            ent_next = en < n ? wl[en] : make_int4(0, 0, 0, 0);
+        }
         const int pc = __popc((unsigned)ent.z) + __popc((unsigned)ent.w); // (0 past the end of the list)
         if (clean_bm && e < n)
             clean_bm[((long long)f * crows + (ent.x >> 16)) * wpr + (ent.x & 0xFFFF)] = 0ull;
@@ -778,13 +958,20 @@ __global__ __launch_bounds__(256) void extract_scatter_kernel(const uint32_t *__
 #define SG_LIST 1536  // set pixels a workgroup collects before it expands them (list + table: 18 KB, eight workgroups per CU)
 #define SG_BLOCK 1024 // mask words looked at per collection step (4 per thread)
 #define SG_TAB 1024   // slots of the canvas-word table
+// COMPACT (round 4): 4-byte entries {decision table [15:0], tap place [17:16], dx [24:18], dy [31:25]} relative to a
+// per-pixel base bit index that travels with the pixel's offset ({offset, base} pairs: ONE 16-byte read brings the
+// pixel's offset, its base and the next offset), four entries per 16-byte read; entries that can never report (their
+// table is 0: a last tap below half weight, ...) are not stored at all.  Half the bytes and fewer reads per set pixel
+// than the 8-byte {bit index, table} entries (inv_off / inv_ent of the other instantiation).
+template <bool COMPACT>
 __global__ __launch_bounds__(256, 8) void extract_gather_kernel(const uint32_t *__restrict__ bits,
                                                                 const int32_t *__restrict__ nonbinary,
                                                                 const int32_t *__restrict__ inv_off,
                                                                 const uint2 *__restrict__ inv_ent,
                                                                 unsigned long long *__restrict__ bitmap, int prows,
                                                                 int pcols, int crows, int wpr, long long words_per_frame,
-                                                                int piece_shift)
+                                                                int piece_shift, unsigned long long *__restrict__ l2_all,
+                                                                int l2_words)
 {
     __shared__ uint32_t s_list[SG_LIST]; // (row << 16 | column) of a set pixel
     __shared__ int s_n, s_want[2]; // (s_want: by step parity -- the other one is cleared while this one is read)
@@ -809,6 +996,17 @@ __global__ __launch_bounds__(256, 8) void extract_gather_kernel(const uint32_t *
     const int sl = (int)((blockIdx.x + 5u * blockIdx.y) % (unsigned)slices);
     const uint32_t *__restrict__ src = bits + (long long)f * words_per_frame;
     unsigned long long *__restrict__ bm = bitmap + (long long)f * crows * wpr;
+    // second level (round 4): one FLAG BYTE per canvas word of the frame, set by a plain store next to the OR into the
+    // word, so the scan kernel visits the ~2 300 non-empty words of a frame instead of streaming all 30 720 (0.24 MB per
+    // frame: the largest single stream the stage had).  Measured on the way: a second-level BIT map needs an atomic per
+    // flushed word -- returning ("was the word empty?") or not, the gather kernel went from 113 to 140 us per 512 frames:
+    // it is bound by its ~1.3 M global atomics per launch.  A byte store is idempotent and needs no atomic.
+    uint8_t *__restrict__ l2 = l2_all ? reinterpret_cast<uint8_t *>(l2_all) + (long long)f * l2_words * 64 : nullptr;
+    auto or_word = [&](unsigned wd, unsigned long long m) {
+        atomicOr(&bm[wd], m);
+        if (l2)
+            l2[wd] = 1;
+    };
     // pieces of 64 << piece_shift words (64 words = 4 polar rows of 512 beams); piece p belongs to slice p % slices.  The
     // workgroup's words, piece after piece, are looked at `blk` at a time: thread t takes words t, t + 256, ...
     const int pwords = 64 << piece_shift;
@@ -874,7 +1072,18 @@ __global__ __launch_bounds__(256, 8) void extract_gather_kernel(const uint32_t *
             const uint32_t ent = s_list[j];
             const int py = (int)(ent >> 16), px = (int)(ent & 0xFFFFu);
             const int pi = py * pcols + px;
-            const int off0 = inv_off[pi], cnt = inv_off[pi + 1] - off0;
+            int off0, cnt;
+            unsigned base_bit = 0;
+            if (COMPACT) {
+                uint4 ob; // {offset, base} of this pixel, offset of the next one
+                __builtin_memcpy(&ob, reinterpret_cast<const uint2 *>(inv_off) + pi, 16);
+                off0 = (int)ob.x;
+                base_bit = ob.y;
+                cnt = (int)ob.z - off0;
+            } else {
+                off0 = inv_off[pi];
+                cnt = inv_off[pi + 1] - off0;
+            }
             // the 3 x 3 mask bits around the pixel: bit 3 * (dy + 1) + dx + 1; 0 outside the image.  Per row ONE 8-byte read
             // of two neighbouring words of the bit stream that hold columns px - 1 .. px + 1 (4-byte aligned)
             unsigned nb;
@@ -906,7 +1115,7 @@ __global__ __launch_bounds__(256, 8) void extract_gather_kernel(const uint32_t *
                 if (old == 0xFFFFFFFFu || old == wd)
                     atomicOr(&s_acc[slot], m);
                 else
-                    atomicOr(&bm[wd], m);
+                    or_word(wd, m);
             };
             auto candidate = [&](const uint2 e) { // e.y = 0 (no case reports): the padding of the last round
                 const unsigned sh = nb >> (e.y >> 16);
@@ -922,6 +1131,29 @@ __global__ __launch_bounds__(256, 8) void extract_gather_kernel(const uint32_t *
                     run_m |= 1ull << (e.x & 63u);
                 }
             };
+            if (COMPACT) {
+                const unsigned rowbits = (unsigned)wpr * 64u;
+                const uint32_t *__restrict__ ent4 = reinterpret_cast<const uint32_t *>(inv_ent);
+                auto cand4 = [&](uint32_t e, bool live) {
+                    const unsigned sc = (e >> 16) & 3u; // tap place: ry * 2 + rx -> shift ry * 3 + rx
+                    const unsigned x = base_bit + (e >> 25) * rowbits + ((e >> 18) & 127u);
+                    candidate(make_uint2(x, live ? ((e & 0xFFFFu) | ((sc + (sc >> 1)) << 16)) : 0u));
+                };
+                for (int k = 0; k < cnt; k += 8) { // eight entries in flight: two 16-byte reads
+                    uint4 a, b2;
+                    __builtin_memcpy(&a, ent4 + off0 + k, 16);
+                    __builtin_memcpy(&b2, ent4 + off0 + min(k + 4, cnt - 1), 16);
+                    const bool two = k + 4 < cnt;
+                    cand4(a.x, true);
+                    cand4(a.y, k + 1 < cnt);
+                    cand4(a.z, k + 2 < cnt);
+                    cand4(a.w, k + 3 < cnt);
+                    cand4(b2.x, two);
+                    cand4(b2.y, k + 5 < cnt);
+                    cand4(b2.z, k + 6 < cnt);
+                    cand4(b2.w, k + 7 < cnt);
+                }
+            } else
             for (int k = 0; k < cnt; k += 4) { // the loads are what a lane waits for: four entries in flight, two per 16-byte read
                 // (past the end of the range: whatever follows in the table -- it ends with two spare entries -- with an empty
                 // decision table)
@@ -946,7 +1178,7 @@ __global__ __launch_bounds__(256, 8) void extract_gather_kernel(const uint32_t *
     }
     for (int i = tid; i < SG_TAB; i += 256)
         if (s_tag[i] != 0xFFFFFFFFu)
-            atomicOr(&bm[s_tag[i]], s_acc[i]);
+            or_word(s_tag[i], s_acc[i]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -977,7 +1209,17 @@ static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_f
     const int crows = g->cart_rows, wpr = g->words_per_row;
     static const int chunk = getenv("SFE_EXTRACT_CHUNK") ? std::max(1, atoi(getenv("SFE_EXTRACT_CHUNK"))) : 1024; // frames per pass: bounds the bitmap scratch (0.25 MB per frame), fewer passes = fewer launches
     const size_t bm_bytes = (size_t)chunk * crows * wpr * sizeof(unsigned long long);
-    unsigned long long *d_bm = (unsigned long long *)sfe_scratch(ctx, 39, bm_bytes); // (a slot of its own: its contents outlive the call, see self_clean)
+    // second-level bitmap: one bit per canvas word, behind the canvas bitmaps in the same slot (they are clean together)
+    const int l2_words = (int)(((long long)crows * wpr + 63) / 64);
+    const size_t l2_bytes = (size_t)chunk * l2_words * 64; // one flag byte per canvas word, 64 per l2 word
+    unsigned long long *d_bm = (unsigned long long *)sfe_scratch(ctx, 39, bm_bytes + l2_bytes); // (a slot of its own: its contents outlive the call, see self_clean)
+    unsigned long long *d_l2 = d_bm ? d_bm + (size_t)chunk * crows * wpr : nullptr;
+    // The second level is OFF by default (SFE_EXTRACT_L2=1 switches it on; read per call so that the tests cover both):
+    // measured on MI355X it saves the scan kernel's stream over the canvas bitmap (0.24 MB per frame) but its own kernel
+    // gathers the ~2 300 non-empty words of a frame one 64-byte line each -- 150 MB per 1024 frames against a 256 MB
+    // sequential stream at 6 TB/s -- and came out level at 512 frames per launch (0.182 vs 0.184 ms) and 9 % slower at
+    // the bench's 4096 (1.62 vs 1.48 ms): DESIGN 5.2.
+    const bool no_l2 = !(getenv("SFE_EXTRACT_L2") && atoi(getenv("SFE_EXTRACT_L2")) != 0);
     int32_t *d_rcnt = (int32_t *)sfe_scratch(ctx, 5, (size_t)chunk * crows * 4);
     int32_t *d_roff = (int32_t *)sfe_scratch(ctx, 6, (size_t)chunk * crows * 4);
     if (!d_bm || !d_rcnt || !d_roff)
@@ -1037,8 +1279,10 @@ static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_f
         if (!self_clean)
             clean_bytes = 0; // (this pass leaves its bits in the bitmap)
         if (gather) {
-            if (!(self_clean && clean_bytes >= bm_need))
+            if (!(self_clean && clean_bytes >= bm_need)) {
                 SFE_HIP(ctx, hipMemsetAsync(d_bm, 0, bm_need, ctx->stream));
+                SFE_HIP(ctx, hipMemsetAsync(d_l2, 0, (size_t)nf * l2_words * 64, ctx->stream));
+            }
             if (self_clean)
                 clean_bytes = std::max(clean_bytes, bm_need);
             // workgroups per frame: enough of them to fill the device with a few frames, few enough that a
@@ -1055,8 +1299,16 @@ static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_f
             int sg_piece = sg_piece_env >= 0 ? sg_piece_env : 4;
             while (sg_piece_env < 0 && sg_piece > 0 && (nwords >> (6 + sg_piece)) < slices)
                 --sg_piece;
-            hipLaunchKernelGGL(extract_gather_kernel, dim3((unsigned)slices, nf), dim3(256), 0, ctx->stream, d_bits, d_nonbin,
-                               g->d_inv_off, g->d_inv_lut, d_bm, g->polar_rows, g->polar_cols, crows, wpr, wpf, sg_piece);
+            const bool no_compact = getenv("SFE_EXTRACT_NO_COMPACT") != nullptr; // A/B: the 8-byte entries of round 3 (read per call)
+            if (g->d_inv_c4 && !no_compact)
+                hipLaunchKernelGGL(extract_gather_kernel<true>, dim3((unsigned)slices, nf), dim3(256), 0, ctx->stream, d_bits,
+                                   d_nonbin, reinterpret_cast<const int32_t *>(g->d_inv_ob),
+                                   reinterpret_cast<const uint2 *>(g->d_inv_c4), d_bm, g->polar_rows, g->polar_cols, crows, wpr,
+                                   wpf, sg_piece, (self_clean && !no_l2) ? d_l2 : (unsigned long long *)nullptr, l2_words);
+            else
+            hipLaunchKernelGGL(extract_gather_kernel<false>, dim3((unsigned)slices, nf), dim3(256), 0, ctx->stream, d_bits, d_nonbin,
+                               g->d_inv_off, g->d_inv_lut, d_bm, g->polar_rows, g->polar_cols, crows, wpr, wpf, sg_piece,
+                               (self_clean && !no_l2) ? d_l2 : (unsigned long long *)nullptr, l2_words);
         } else if (scatter) {
             // sparse binary masks: inverse map (binary frames), dense pass only for frames with other values
             SFE_HIP(ctx, hipMemsetAsync(d_bm, 0, (size_t)nf * crows * wpr * sizeof(unsigned long long), ctx->stream));
@@ -1079,6 +1331,16 @@ static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_f
         if (scan_lds > 48 * 1024)
             SFE_HIP(ctx, hipFuncSetAttribute((const void *)extract_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)scan_lds));
+        if (gather && self_clean && !no_l2) {
+            // (self_clean: binary frames only, every bit of the canvas bitmap came through the gather kernel's or_word)
+            const size_t l2_lds = sizeof(int) * ((size_t)crows + ((l2_words + 1) & ~1) + 2 * (size_t)l2_words);
+            if (l2_lds > 32 * 1024)
+                SFE_HIP(ctx, hipFuncSetAttribute((const void *)extract_scan_l2_kernel,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2_lds));
+            hipLaunchKernelGGL(extract_scan_l2_kernel, dim3(nf), dim3(L2_THREADS), l2_lds, ctx->stream, d_l2, l2_words,
+                               (const unsigned long long *)d_bm, d_rcnt, d_roff, d_counts + f0, crows, wpr, d_wlist, d_wlist_n,
+                               list_cap, cap, d_ovf, d_ovf + 1);
+        } else
         hipLaunchKernelGGL(extract_scan_kernel, dim3(nf), dim3(SCAN_THREADS), scan_lds,
                            ctx->stream, d_bm, d_rcnt, d_roff, d_counts + f0, crows, wpr, d_wlist, d_wlist_n,
                            use_words ? list_cap : 0, cap, d_ovf, d_ovf ? d_ovf + 1 : nullptr);
@@ -1284,6 +1546,52 @@ int sfe_geom_create(sfe_ctx *ctx, const float *map_x, const float *map_y, int ca
                 inv_lut[(size_t)j] = make_uint2(inv_ent[(size_t)j].x, lut | ((uint32_t)(ry * 3 + rx) << 16));
             }
         }
+        // Round 4: the same table in 4 bytes per entry, relative to a base bit index per polar pixel, without the entries
+        // whose table is 0 (extract_gather_kernel<true>).  Falls back to the 8-byte entries when a pixel's candidates span
+        // more than 127 canvas rows / columns (no sonar fan does).
+        {
+            const size_t npix = inv_off.size() - 1;
+            std::vector<uint2> ob(npix + 1);
+            std::vector<uint32_t> c4;
+            c4.reserve(inv_lut.size());
+            const unsigned long long rowbits = (unsigned long long)g->words_per_row * 64ull;
+            bool fits = true;
+            for (size_t pi = 0; pi < npix && fits; ++pi) {
+                unsigned long long rmin = ~0ull, cmin = ~0ull;
+                for (int32_t j = inv_off[pi]; j < inv_off[pi + 1]; ++j)
+                    if (inv_lut[(size_t)j].y & 0xFFFFu) {
+                        rmin = std::min<unsigned long long>(rmin, inv_lut[(size_t)j].x / rowbits);
+                        cmin = std::min<unsigned long long>(cmin, inv_lut[(size_t)j].x % rowbits);
+                    }
+                if (rmin == ~0ull)
+                    rmin = cmin = 0;
+                ob[pi] = make_uint2((uint32_t)c4.size(), (uint32_t)(rmin * rowbits + cmin));
+                for (int32_t j = inv_off[pi]; j < inv_off[pi + 1]; ++j) {
+                    const uint2 e = inv_lut[(size_t)j];
+                    if (!(e.y & 0xFFFFu))
+                        continue;
+                    const unsigned long long dy = e.x / rowbits - rmin, dx = e.x % rowbits - cmin;
+                    const unsigned shift = e.y >> 16, sc = shift >= 3 ? shift - 1 : shift; // ry * 3 + rx -> ry * 2 + rx
+                    if (dy > 127 || dx > 127 || c4.size() >= 0xFFFFFFF0ull) {
+                        fits = false;
+                        break;
+                    }
+                    c4.push_back((e.y & 0xFFFFu) | (sc << 16) | ((uint32_t)dx << 18) | ((uint32_t)dy << 25));
+                }
+            }
+            if (fits) {
+                ob[npix] = make_uint2((uint32_t)c4.size(), 0u);
+                c4.resize(c4.size() + 8, 0u); // (the kernel reads entries in fours, two reads ahead)
+                ob.resize(ob.size() + 1, make_uint2((uint32_t)c4.size(), 0u)); // (16-byte reads of {offset, base} pairs)
+                if (hipMalloc((void **)&g->d_inv_ob, ob.size() * sizeof(uint2)) != hipSuccess ||
+                    hipMalloc((void **)&g->d_inv_c4, c4.size() * 4) != hipSuccess ||
+                    hipMemcpy(g->d_inv_ob, ob.data(), ob.size() * sizeof(uint2), hipMemcpyHostToDevice) != hipSuccess ||
+                    hipMemcpy(g->d_inv_c4, c4.data(), c4.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+                    sfe_geom_destroy(g);
+                    return sfe_set_err(ctx, SFE_ERR_HIP, "compact inverse remap table upload failed");
+                }
+            }
+        }
         inv_lut.resize(inv_lut.size() + 2, make_uint2(0u, 0u)); // (the kernel reads entries in pairs)
         if (hipMalloc((void **)&g->d_inv_lut, std::max<size_t>(inv_lut.size(), 1) * sizeof(uint2)) != hipSuccess ||
             (!inv_lut.empty() &&
@@ -1353,6 +1661,10 @@ void sfe_geom_destroy(sfe_geom *g)
         (void)hipFree(g->d_inv_ent);
     if (g->d_inv_lut)
         (void)hipFree(g->d_inv_lut);
+    if (g->d_inv_ob)
+        (void)hipFree(g->d_inv_ob);
+    if (g->d_inv_c4)
+        (void)hipFree(g->d_inv_c4);
     if (g->d_ytab)
         (void)hipFree(g->d_ytab);
     if (g->d_xtab)

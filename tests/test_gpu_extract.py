@@ -9,6 +9,18 @@ from sonar_slam_amd.feature_extraction import FeatureExtraction, Geometry, Sonar
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["default", "second-level", "entries8"])
+def extraction_build(request, monkeypatch):
+    """Every test of this module runs three times: the default (4-byte inverse-map entries, streaming scan of the
+    canvas bitmap), with the second-level flags + extract_scan_l2_kernel (round 4, off by default: DESIGN 5.2), and with
+    round 3's 8-byte entries.  The knobs are read per call (extract_dev)."""
+    if request.param == "second-level":
+        monkeypatch.setenv("SFE_EXTRACT_L2", "1")
+    elif request.param == "entries8":
+        monkeypatch.setenv("SFE_EXTRACT_NO_COMPACT", "1")
+    return request.param
+
+
 def _geom(ctx, beams, ranges, res):
     r, height, rows, width, cols, mx, my = build_maps(oculus_bearings(beams), res, ranges)
     return Geometry(ctx, mx, my, (ranges, beams), width, height), mx, my, width, height
