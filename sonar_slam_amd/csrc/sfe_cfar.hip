@@ -72,6 +72,46 @@ __device__ __forceinline__ uint32_t pk_sub_opaque(uint32_t a, uint32_t b)
 
 typedef __amdgpu_buffer_rsrc_t sfe_rsrc_t; // 128-bit buffer resource (SGPRs)
 
+typedef __amdgpu_buffer_rsrc_t sfe_rsrc_t; // 128-bit buffer resource (SGPRs)
+
+// the same, pinned in program order between other volatile asm statements (the bit-stream kernel puts the window sums
+// between the issue of its table reads and the wait for them)
+__device__ __forceinline__ uint32_t pk_sub_opaque_ordered(uint32_t a, uint32_t b)
+{
+    uint32_t d;
+    asm volatile("v_pk_sub_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
+typedef __amdgpu_buffer_rsrc_t sfe_rsrc_t; // 128-bit buffer resource (SGPRs)
+
+// Two 16-bit table entries into the two halves of ONE register: ds_read_u16_d16 / _d16_hi write a half and keep the
+// other, so the pair needs no v_perm to be joined (round 4: 2 of the ~29 VALU instructions per row of the bit-stream
+// kernel).  a_lo / a_hi: LDS byte addresses.  The compiler does not count inline-asm LDS reads, so the value may only be
+// used behind lut_wait().
+__device__ __forceinline__ uint32_t lut_pair_issue(uint32_t a_lo, uint32_t a_hi)
+{
+    uint32_t r;
+    asm volatile("ds_read_u16_d16 %0, %1\n\tds_read_u16_d16_hi %0, %2" : "=&v"(r) : "v"(a_lo), "v"(a_hi));
+    return r;
+}
+// (the window sums ride along: they are formed between the issue and the wait, not behind it)
+__device__ __forceinline__ void lut_wait(uint32_t &a, uint32_t &b, uint32_t &s0, uint32_t &s1)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(s0), "+v"(s1));
+}
+// 2 * (16-bit half w of x): the byte offset of a uint16 table entry, one SDWA shift
+template <int W>
+__device__ __forceinline__ uint32_t half_x2(uint32_t x)
+{
+    uint32_t r;
+    if (W == 0)
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(1u), "v"(x));
+    else
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(1u), "v"(x));
+    return r;
+}
+
 // The threshold map's value for a window sum s, thr = (float)(tau * (double)(float)s / D) with D = T or 2T (cfar.cpp:27,46,67
 // as the host table below restates it), computed instead of fetched: one table gather per pixel is one L1 tag look-up
 // per pixel, and that rate -- not HBM -- bounded the map kernels (0.47-0.60 ms per 512 frames whatever the window).
@@ -154,6 +194,8 @@ __global__ __launch_bounds__(256, 3) void cfar_u8_ring(const uint8_t *__restrict
     // BITS: byte offset of this lane's word inside its row (lanes 0, 8, .. store), shift of its nibble
     const uint32_t boff = (lane & 7) == 0 ? (uint32_t)(cx0 + lane) >> 1 : 0x80000000u;
     const uint32_t nsh = (uint32_t)(lane & 7) * 4u;
+    const uint32_t nrot = (7u - nsh) & 31u; // BITS: the nibble comes out of the dot product at bits 7..10
+    (void)nsh;
     if (BITS && wvf == wpf - 1 && lane == 0) // the pad word behind the last row (read by the extraction's taps)
         __builtin_amdgcn_raw_buffer_store_b32(0u, dst, (uint32_t)(frame_bytes >> 3), 0, 0);
 
@@ -195,6 +237,8 @@ __global__ __launch_bounds__(256, 3) void cfar_u8_ring(const uint8_t *__restrict
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             const int r = rb + j;
+            const uint32_t xL = pk_sub(lo[(j + H + 1) % R], lo[(j + H) % R]);
+            const uint32_t xH = pk_sub(hi[(j + H + 1) % R], hi[(j + H) % R]);
             const uint32_t leadL = pk_sub_opaque(lo[(j + T) % R], lo[j]);
             const uint32_t leadH = pk_sub_opaque(hi[(j + T) % R], hi[j]);
             const uint32_t lagL = pk_sub(lo[(j + R - 1) % R], lo[(j + H + G + 1) % R]);
@@ -210,25 +254,37 @@ __global__ __launch_bounds__(256, 3) void cfar_u8_ring(const uint8_t *__restrict
                 sL = pk_add(leadL, lagL);
                 sH = pk_add(leadH, lagH);
             }
-            const uint32_t xL = pk_sub(lo[(j + H + 1) % R], lo[(j + H) % R]);
-            const uint32_t xH = pk_sub(hi[(j + H + 1) % R], hi[(j + H) % R]);
-            const uint32_t l0 = s_lut[xL & 0xffffu], l1 = s_lut[xL >> 16];
-            const uint32_t l2 = s_lut[xH & 0xffffu], l3 = s_lut[xH >> 16];
-            // s < lut[x]  <=>  bit 15 of the 16-bit difference s - lut[x] (both < 2^15)
-            const uint32_t dL = pk_sub(sL, l0 | (l1 << 16));
-            const uint32_t dH = pk_sub(sH, l2 | (l3 << 16));
-            // sign bits sit in bit 7 of bytes 1 and 3: gather the 4 bytes, shift to bit 0
-            uint32_t o = (__builtin_amdgcn_perm(dH, dL, 0x07050301u) >> 7) & 0x01010101u;
             const int pr = rbase + rs * r; // image row of this output
-            const uint32_t keep = (pr >= H && pr < rows - H) ? 0xffffffffu : 0u; // cfar.cpp:16,36
-            o &= keep;
+            const bool in_rows = pr >= H && pr < rows - H; // cfar.cpp:16,36
+            const uint32_t keep = in_rows ? 0xffffffffu : 0u;
             if (BITS) {
-                uint32_t v = __builtin_amdgcn_udot4(o, 0x08040201u, 0u, false) << nsh;
+                // s < lut[x]  <=>  bit 15 of the 16-bit difference s - lut[x] (both < 2^15).  (Joining the two 16-bit
+                // entries with ds_read_u16_d16 / _d16_hi instead of a v_perm was tried in round 4: with SRAM ECC on, as on
+                // MI300 / MI355X, a d16 load zeroes the other half instead of keeping it.)
+                const uint32_t l0 = s_lut[xL & 0xffffu], l1 = s_lut[xL >> 16];
+                const uint32_t l2 = s_lut[xH & 0xffffu], l3 = s_lut[xH >> 16];
+                const uint32_t dL = pk_sub(sL, l0 | (l1 << 16));
+                const uint32_t dH = pk_sub(sH, l2 | (l3 << 16));
+                // the sign bits sit in bit 7 of bytes 1 and 3: gather the 4 bytes; ONE mask keeps the sign bits and
+                // zeroes the rows outside cfar.cpp's loop; the dot product with (1, 2, 4, 8) of bytes that are 0 or 0x80
+                // is the nibble << 7, which a rotate puts in its place in the word
+                const uint32_t km = in_rows ? 0x80808080u : 0u;
+                const uint32_t o = __builtin_amdgcn_perm(dH, dL, 0x07050301u) & km;
+                uint32_t v = __builtin_amdgcn_udot4(o, 0x08040201u, 0u, false);
+                v = __builtin_amdgcn_alignbit(v, v, nrot);
                 v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
                 v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
                 v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false); // row_half_mirror
                 __builtin_amdgcn_raw_buffer_store_b32(v, dst, boff, pr * (cols >> 3), 0);
             } else {
+                const uint32_t l0 = s_lut[xL & 0xffffu], l1 = s_lut[xL >> 16];
+                const uint32_t l2 = s_lut[xH & 0xffffu], l3 = s_lut[xH >> 16];
+                // s < lut[x]  <=>  bit 15 of the 16-bit difference s - lut[x] (both < 2^15)
+                const uint32_t dL = pk_sub(sL, l0 | (l1 << 16));
+                const uint32_t dH = pk_sub(sH, l2 | (l3 << 16));
+                // sign bits sit in bit 7 of bytes 1 and 3: gather the 4 bytes, shift to bit 0
+                uint32_t o = (__builtin_amdgcn_perm(dH, dL, 0x07050301u) >> 7) & 0x01010101u;
+                o &= keep;
                 __builtin_amdgcn_raw_buffer_store_b32(o, dst, voff, pr * cols, 0);
             }
             if (THR) {

@@ -389,7 +389,7 @@ def chained_inputs(n_distinct, n_steps, rows=1024, beams=512, world_seed=2, scat
     return frames, dr, true, bearings
 
 
-def chained(ctx, det, threads, n_sessions=256, n_steps=8, n_distinct=64, parity_sessions=4, reps=3):
+def chained(ctx, det, threads, n_sessions=1024, n_steps=8, n_distinct=64, parity_sessions=4, reps=3):
     """the path end to end on the device, every scan match consuming the cloud its own CFAR produced.
     `n_sessions` independent SLAM sessions advance in lock-step (chained.SessionBatch): step k = ping k of every session
     through CFAR + gate -> remap + nonzero + px->m -> downsample -> outlier filter -> keyframe store -> target cloud =
