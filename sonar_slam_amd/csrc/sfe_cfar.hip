@@ -72,46 +72,6 @@ __device__ __forceinline__ uint32_t pk_sub_opaque(uint32_t a, uint32_t b)
 
 typedef __amdgpu_buffer_rsrc_t sfe_rsrc_t; // 128-bit buffer resource (SGPRs)
 
-typedef __amdgpu_buffer_rsrc_t sfe_rsrc_t; // 128-bit buffer resource (SGPRs)
-
-// the same, pinned in program order between other volatile asm statements (the bit-stream kernel puts the window sums
-// between the issue of its table reads and the wait for them)
-__device__ __forceinline__ uint32_t pk_sub_opaque_ordered(uint32_t a, uint32_t b)
-{
-    uint32_t d;
-    asm volatile("v_pk_sub_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-
-typedef __amdgpu_buffer_rsrc_t sfe_rsrc_t; // 128-bit buffer resource (SGPRs)
-
-// Two 16-bit table entries into the two halves of ONE register: ds_read_u16_d16 / _d16_hi write a half and keep the
-// other, so the pair needs no v_perm to be joined (round 4: 2 of the ~29 VALU instructions per row of the bit-stream
-// kernel).  a_lo / a_hi: LDS byte addresses.  The compiler does not count inline-asm LDS reads, so the value may only be
-// used behind lut_wait().
-__device__ __forceinline__ uint32_t lut_pair_issue(uint32_t a_lo, uint32_t a_hi)
-{
-    uint32_t r;
-    asm volatile("ds_read_u16_d16 %0, %1\n\tds_read_u16_d16_hi %0, %2" : "=&v"(r) : "v"(a_lo), "v"(a_hi));
-    return r;
-}
-// (the window sums ride along: they are formed between the issue and the wait, not behind it)
-__device__ __forceinline__ void lut_wait(uint32_t &a, uint32_t &b, uint32_t &s0, uint32_t &s1)
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(s0), "+v"(s1));
-}
-// 2 * (16-bit half w of x): the byte offset of a uint16 table entry, one SDWA shift
-template <int W>
-__device__ __forceinline__ uint32_t half_x2(uint32_t x)
-{
-    uint32_t r;
-    if (W == 0)
-        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(1u), "v"(x));
-    else
-        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(1u), "v"(x));
-    return r;
-}
-
 // The threshold map's value for a window sum s, thr = (float)(tau * (double)(float)s / D) with D = T or 2T (cfar.cpp:27,46,67
 // as the host table below restates it), computed instead of fetched: one table gather per pixel is one L1 tag look-up
 // per pixel, and that rate -- not HBM -- bounded the map kernels (0.47-0.60 ms per 512 frames whatever the window).
