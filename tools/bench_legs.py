@@ -389,7 +389,7 @@ def chained_inputs(n_distinct, n_steps, rows=1024, beams=512, world_seed=2, scat
     return frames, dr, true, bearings
 
 
-def chained(ctx, det, threads, n_sessions=1024, n_steps=8, n_distinct=64, parity_sessions=4, reps=3):
+def chained(ctx, det, threads, n_sessions=4096, n_steps=8, n_distinct=64, parity_sessions=4, reps=3):
     """the path end to end on the device, every scan match consuming the cloud its own CFAR produced.
     `n_sessions` independent SLAM sessions advance in lock-step (chained.SessionBatch): step k = ping k of every session
     through CFAR + gate -> remap + nonzero + px->m -> downsample -> outlier filter -> keyframe store -> target cloud =
@@ -416,11 +416,14 @@ def chained(ctx, det, threads, n_sessions=1024, n_steps=8, n_distinct=64, parity
                        "device-resident" % (n_sessions, n_steps, n_distinct),
            "sessions": n_sessions, "keyframes_per_session": n_steps, "distinct_sessions": n_distinct,
            "render_s": t_render}
+    # the pings go up once (n_sessions x n_steps x 512 KB resident: 16 GB at the default size) and serve both chains
+    sb = ch.SessionBatch(ctx, fe.geometry, det.params["SOCA"], "SOCA", 65, icp_config.shipped_params(), n_sessions, n_steps,
+                         dr[sel])
+    for k in range(n_steps):
+        sb.upload_frames(k, frames[k][sel])
     for name, params in (("shipped_chain", icp_config.shipped_params()),
                          ("p2plane30", icp_config.shipped_params(minimizer=1, use_diff_checker=0, max_iter=30))):
-        sb = ch.SessionBatch(ctx, fe.geometry, det.params["SOCA"], "SOCA", 65, params, n_sessions, n_steps, dr[sel])
-        for k in range(n_steps):
-            sb.upload_frames(k, frames[k][sel])
+        sb.icp_params = params
         sb.run()                                # untimed: scratch and store allocations
         ctx.sync()
         best = None
@@ -486,6 +489,6 @@ def chained(ctx, det, threads, n_sessions=1024, n_steps=8, n_distinct=64, parity
                                     "overlap (equal), pose <= 1e-6 vs oracle/chain.py (fp64-sum ICP, exact kd-tree); last "
                                     "keyframe's stored cloud bit-exact"}
         out[name] = leg
-        sb.free()
+    sb.free()
     out["keyframes_per_s"] = out["shipped_chain"]["keyframes_per_s"]
     return out
