@@ -118,6 +118,7 @@ class SessionBatch(object):
         self.store = _store.CloudStore(ctx, capacity_points=pts, max_clouds=self.S * (self.K + 2))
         dr = np.asarray(dr_poses, np.float64).reshape(self.S, self.K, 3)
         self.dr = [Pose2Batch(dr[:, k, 0], dr[:, k, 1], dr[:, k, 2]) for k in range(self.K)]
+        self.max_raw = 0
         self.reset()
 
     def upload_frames(self, k, frames):
@@ -125,6 +126,22 @@ class SessionBatch(object):
         frames = np.ascontiguousarray(frames, np.uint8)
         assert frames.shape == (self.S, self.kb.rows, self.kb.cols)
         self.d_frames.upload(frames, offset=k * self.S * self.frame_bytes)
+
+    def fit_capacity(self):
+        """After a first (untimed) run: size the per-ping point capacity by what the pings really hold.  The resident
+        downsample's LDS is sized by the capacity -- 128 KB (one frame per CU) at 16 384 points, 64 KB (two per CU) at
+        8 192 -- so sessions whose pings stay below 8 192 raw detections run their filters twice as dense."""
+        from .pipeline import KeyframeBatch
+        if self.max_raw <= 0 or self.max_raw > 7800 or self.kb.cap <= 8192:
+            return self.kb.cap
+        old = self.kb
+        old.d_img = self._kb_img
+        self.kb = KeyframeBatch(self.ctx, old.geom, (old.train_hs, old.guard_hs, old.tau), "SOCA", 0, self.icp_params, self.S,
+                                max_points=8192)
+        self.kb.alg, self.kb.k, self.kb.intensity_thr = old.alg, old.k, old.intensity_thr
+        self._kb_img = self.kb.d_img
+        old.free()
+        return self.kb.cap
 
     def reset(self):
         self.store.truncate(0)
@@ -213,6 +230,7 @@ class SessionBatch(object):
     def _check_raw(self, k):
         """a ping with more detections than the batch's point capacity would be truncated silently"""
         raw = self.kb.d_cnt.download(np.int32, self.S)
+        self.max_raw = max(self.max_raw, int(raw.max()))
         if int(raw.max()) > self.kb.cap:
             f = int(raw.argmax())
             raise _L.SonarFEError("step %d, session %d: %d points extracted, more than the batch capacity %d "

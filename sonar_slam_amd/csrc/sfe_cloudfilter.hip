@@ -661,7 +661,12 @@ int sfe_cf_run_staged(sfe_ctx *ctx, int n_frames, int64_t cap, float resolution,
                 hipLaunchKernelGGL((cf_downsample_kernel<true, unsigned>), dim3(n_frames), dim3(1024), 4 * n2, ctx->stream,
                                    d_p32, (long long)cap, d_hdr, d_ds, d_seg, (unsigned *)nullptr, 0LL, 0, d_lkeys);
             } else {
-                // indices + keys + counters for the sort, then (same bytes) every point of the frame in sorted order
+                // indices + keys + counters for the sort, then (same bytes) every point of the frame in sorted order.
+                // (The LDS is sized by the CAPACITY: 128 KB = one frame per CU at 16 384 points, 64 KB = two per CU at 8 192.
+                // Round 4 tried a launch per size class -- frames of <= 8 192 points in a 64 KB launch of their own, the
+                // others behind it, a workgroup of the other class returning at once: 0.29 -> 0.42 ms per 512 frames,
+                // because dispatching 512 workgroups of 1024 threads costs ~0.12 ms even when they do nothing.  A caller
+                // whose pings are small passes a smaller capacity instead: chained.SessionBatch sizes it from its warm-up.)
                 const size_t rdx_smem = std::max<size_t>(3 * 2 * n2 + 2 * 16 * CF_RDX_DIGITS, sizeof(float2) * n2);
                 SFE_HIP(ctx, hipFuncSetAttribute((const void *)cf_downsample_radix_kernel,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)rdx_smem));

@@ -425,6 +425,9 @@ def chained(ctx, det, threads, n_sessions=4096, n_steps=8, n_distinct=64, parity
                          ("p2plane30", icp_config.shipped_params(minimizer=1, use_diff_checker=0, max_iter=30))):
         sb.icp_params = params
         sb.run()                                # untimed: scratch and store allocations
+        out["points_capacity"] = sb.fit_capacity()      # (sized by the largest ping of the warm-up run)
+        out["max_raw_points_per_ping"] = sb.max_raw
+        sb.run()
         ctx.sync()
         best = None
         for _ in range(reps):
