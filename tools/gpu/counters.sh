@@ -37,6 +37,6 @@ run extract_fetch FETCH_SIZE -- python $R/tools/extract_times.py 256
 run extract_write WRITE_SIZE -- python $R/tools/extract_times.py 256
 run icp_sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY -- python $R/tools/stage_times.py --batch 4096 --icp-variants 0 --p2plane-only
 cd $R
-python tools/make_counter_json.py $tag
-rm -f gpurun_out/${tag}_*.db
+python tools/make_counter_json.py $tag || true
+ls -la gpurun_out/${tag}_*.db | head
 head -6 gpurun_out/${tag}_cfar_bits_kernels.txt

@@ -14,15 +14,19 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 G = os.path.join(ROOT, "gpurun_out")
 
 
+ROWS = {}     # kernel -> counter rows of the last database read (dispatches x shader engines)
+
+
 def counters(name):
     """-> {kernel: {counter: avg}}, {kernel: avg duration us} of gpurun_out/<tag>_<name>.db"""
     db = sqlite3.connect(os.path.join(G, "%s_%s.db" % (tag, name)))
     c, d = {}, {}
-    for kname, cn, avg, dur in db.execute("select name, counter_name, avg(counter_value), avg(duration) from pmc_events "
-                                          "group by name, counter_name"):
+    for kname, cn, avg, dur, rows in db.execute("select name, counter_name, avg(counter_value), avg(duration), count(*) from "
+                                                "pmc_events group by name, counter_name"):
         k = kname.split("(")[0].replace("void ", "")
         c.setdefault(k, {})[cn] = avg
         d[k] = dur / 1e3
+        ROWS[k] = rows
     return c, d
 
 
@@ -78,7 +82,9 @@ def main():
         return {"kernel": k, "avg_us_per_launch": du[k], "per_shader_engine": v,
                 "valu_active_frac": v["SQ_ACTIVE_INST_VALU"] * 4.0 / (32.0 * v["SQ_BUSY_CYCLES"]),
                 "wave_wait_frac": v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"]}
-    loops = sorted((x for x in c if x.startswith("icp_sweep_kernel")), key=lambda x: -du[x])
+    # (the launch set holds one profiled launch of the PROF build next to the plain launches: the kernel with the most
+    # dispatches is the one the step runs)
+    loops = sorted((x for x in c if x.startswith("icp_sweep_kernel")), key=lambda x: -ROWS[x])
     preps = sorted((x for x in c if x.startswith("icp_sweep_prep_kernel")), key=lambda x: -du[x])
     loop = sq(loops[0])
     out = {"source": files % "icp_sq" + " (tools/gpu/counters.sh %s: rocprofv3 --kernel-trace --pmc SQ_* -- python "
