@@ -509,7 +509,8 @@ def main():
             # (what cfar.soca() of the drop-in returns).  All flat, so that they survive into the driver's record.
             "roofline": {"kernel": "cfar_u8_ring<20,5,SOCA,%s>" % ("BITS" if bits else "bytes"), "bound": "hbm",
                          "limiter": "valu" if bits else "hbm",
-                         "limiter_note": "~29 VALU instructions per 256-pixel row and wave at 5 waves per SIMD" if bits else "",
+                         "limiter_note": ("27 VALU instructions per 256-pixel row and wave, 3 waves per SIMD (168 VGPRs: the ring): ~370 cycles per "
+                                          "row against 324 of VALU issue; LDS table latency and the 4-deep load FIFO within 15 % (DESIGN 5.1)") if bits else "",
                          "achieved": cfar_moved / (ms_cfar * 1e-3) / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cfar_moved / (ms_cfar * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "traffic": traffic,
