@@ -77,6 +77,11 @@ struct sfe_geom {
     uint2 *d_inv_lut = nullptr;     // {canvas index, decision table of the entry} (extract_gather_kernel)
     uint2 *d_inv_ob = nullptr;      // compact form (round 4): per polar pixel {offset into d_inv_c4, base bit index}
     uint32_t *d_inv_c4 = nullptr;   //   4-byte entries {table, tap place, dx, dy}, dead entries dropped
+    // fused extraction (round 4, extract_fused_kernel): per polar pixel {offset | max dy << 25, base row << 16 | base col},
+    // the canvas cut into parts of fused_pr rows, per part the polar rows whose pixels reach it
+    uint2 *d_inv_ob2 = nullptr;
+    int32_t *d_part_rows = nullptr; // [n_parts][2]: first, last polar row (first > last: nothing reaches the part)
+    int fused_pr = 0, fused_parts = 0;
     // px -> m of feature_extraction.py:236-237 per canvas row / column (fp64, the reference's operation order,
     // evaluated once on the host: extract_expand_words_kernel looks the metres up instead of dividing per point)
     double *d_ytab = nullptr, *d_xtab = nullptr;

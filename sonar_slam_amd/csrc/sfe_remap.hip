@@ -1182,6 +1182,304 @@ __global__ __launch_bounds__(256, 8) void extract_gather_kernel(const uint32_t *
 }
 
 // ---------------------------------------------------------------------------------------------
+// Round 4: the extraction without a canvas bitmap in HBM.
+// The three-kernel path above keeps a frame's detection bitmap (0.25 MB, one bit per canvas pixel) in HBM: the gather kernel
+// ORs ~2 300 of its 30 720 words with global atomics, the scan kernel streams all of it to find them, the expansion reads them
+// again and zeroes them -- 0.84 MB of traffic per frame for 0.25 MB of mask bits in and points out, and three launches.
+// Here the canvas is cut into parts of PR rows (PR x words_per_row x 8 B of LDS: 30 KB for config A at PR = 128) and a
+// workgroup takes ONE part of ONE frame (blockIdx.x = part, blockIdx.y = frame):
+//   1. the polar rows whose pixels can reach the part (a range per part, from the geometry) are scanned in the frame's bit
+//      stream, set pixels collected in an LDS list and expanded one lane per set pixel exactly like
+//      extract_gather_kernel<true> (same 4-byte entries, same decision tables, same first-tap rule) -- but the bits go into
+//      the LDS bitmap with ds atomics, and a pixel whose candidates lie outside the part's rows is dropped after one read;
+//   2. popcounts of the part's words -> exclusive prefix (a thread owns consecutive words, one block scan); the part's
+//      total is PUBLISHED (release store) and the totals of the parts above are awaited (acquire loads): the parts of a
+//      frame are consecutive workgroups of the launch, dispatched in order, so whoever is waited for is resident or done
+//      (the decoupled look-back of a device-wide scan; a bounded wait guards against the impossible);
+//   3. a lane per POINT of the part: binary search for its word in the prefix array, rank-select of its bit, the metres
+//      from the px->m tables (x staged in LDS), one 16-byte store at (points of the parts above) + its rank: contiguous,
+//      in np.nonzero order.
+// A polar pixel is looked at by every part whose polar range holds it (3.3 parts on average for a 130 degree fan): the
+// price of a canvas that never leaves the CU.  (First form of this kernel: one workgroup per FRAME going through the parts
+// one after the other -- no hand-over at all, and 0.69 ms per 512 frames against 0.19: eight parts x ~10 dependent memory
+// round trips each are a chain of ~0.3 ms per frame whatever the occupancy.)  No global bitmap, no global atomics, no word
+// lists, nothing to clean.  Same points in the same order (tests/test_gpu_extract.py runs every path).
+// ---------------------------------------------------------------------------------------------
+#define FX_NT 512
+#define FX_LIST 1536
+__device__ __forceinline__ int fx_block_excl_scan(int v, int *s_w, int *total) // FX_NT threads; s_w: >= FX_NT / 64 ints
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int incl = scan_wave_incl(v);
+    __syncthreads();
+    if (lane == 63)
+        s_w[wave] = incl;
+    __syncthreads();
+    int pre = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < FX_NT / 64; ++w) {
+        const int x = s_w[w];
+        pre += w < wave ? x : 0;
+        tot += x;
+    }
+    *total = tot;
+    return pre + incl - v;
+}
+
+__global__ __launch_bounds__(FX_NT, 2) void extract_fused_kernel(const uint32_t *__restrict__ bits,
+                                                                  const uint2 *__restrict__ ob2,
+                                                                  const uint32_t *__restrict__ ent4,
+                                                                  const int32_t *__restrict__ part_rows, int n_parts, int PR,
+                                                                  int prows, int pcols, int crows, int ccols, int wpr,
+                                                                  long long words_per_frame,
+                                                                  const double *__restrict__ ytab,
+                                                                  const double *__restrict__ xtab,
+                                                                  long long *__restrict__ rc_out,
+                                                                  double *__restrict__ pts_out, long long cap,
+                                                                  int32_t *__restrict__ counts,
+                                                                  int32_t *__restrict__ part_cnt)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char fx_raw[]; // bitmap PR*wpr u64 | prefix PR*wpr+1 int | x table
+    __shared__ uint32_t s_list[FX_LIST];
+    __shared__ int s_n, s_want[2], s_w[FX_NT / 64], s_base;
+    const int nwp = PR * wpr; // words of a part
+    unsigned long long *s_bm = reinterpret_cast<unsigned long long *>(fx_raw);
+    int *s_pre = reinterpret_cast<int *>(s_bm + nwp);
+    double *s_x = reinterpret_cast<double *>(s_pre + ((nwp + 2) & ~1));
+    // (workgroup b runs on XCD b % 8: with 8 parts every XCD would get ONE part of every frame, and the parts differ in
+    // work -- the middle of the canvas is reached from 64 % of the polar rows, the far edge from 12 %; rotating the parts
+    // from frame to frame gives every XCD every part.  The hand-over only needs that a frame's workgroups are dispatched
+    // once the frames before it are: every XCD goes through its workgroups in launch order.)
+    const int f = blockIdx.y, part = (int)((blockIdx.x + blockIdx.y) % (unsigned)n_parts), tid = threadIdx.x, lane = tid & 63;
+    const uint32_t *__restrict__ src = bits + (long long)f * words_per_frame;
+    const int pw = pcols >> 5;
+    if (tid == 0) {
+        s_n = 0;
+        s_want[0] = s_want[1] = 0;
+        s_base = 0;
+    }
+    int base_pts = 0; // points of the parts above (the same in every thread)
+    int par = 0;      // which of the two s_want counters the next collection step uses (the other one is zero)
+    {
+        const int R0 = part * PR, R1 = min(R0 + PR, crows);
+        const int pr_lo = part_rows[2 * part], pr_hi = part_rows[2 * part + 1];
+        for (int i = tid; i < nwp; i += FX_NT)
+            s_bm[i] = 0ull;
+        __syncthreads();
+        // ---- 1. set pixels of the part's polar rows -> LDS list -> one lane per set pixel (cf. extract_gather_kernel)
+        const int w_lo = pr_lo * pw, my_words = pr_lo <= pr_hi ? (pr_hi - pr_lo + 1) * pw : 0;
+        int v0 = 0, blk = 4 * FX_NT;
+        while (my_words > 0) {
+            while (v0 < my_words) {
+                uint32_t w[4];
+                int gw[4], pc = 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int v = v0 + u * FX_NT + tid;
+                    gw[u] = w_lo + v;
+                    w[u] = (u * FX_NT + tid < blk && v < my_words) ? src[gw[u]] : 0u;
+                    pc += __popc(w[u]);
+                }
+                const int incl = scan_wave_incl(pc);
+                const int wtotal = __builtin_amdgcn_readlane(incl, 63);
+                int base = 0;
+                if (wtotal != 0 && lane == 63)
+                    base = atomicAdd(&s_want[par], wtotal);
+                base = __builtin_amdgcn_readlane(base, 63);
+                __syncthreads();
+                const int want = s_want[par], at = s_n;
+                if (tid == 0)
+                    s_want[par ^ 1] = 0;
+                __syncthreads();
+                par ^= 1;
+                if (at + want > FX_LIST) {
+                    if (at == 0)
+                        blk = 32; // (more than FX_LIST set pixels in one step: 32 words = 1024 pixels always fit)
+                    break;
+                }
+                if (want != 0) {
+                    int pos = at + base + incl - pc;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        uint32_t word = w[u];
+                        if (word) {
+                            const int row = gw[u] / pw, c0 = (gw[u] - row * pw) * 32;
+                            do {
+                                const int bb = __ffs((int)word) - 1;
+                                s_list[pos++] = ((uint32_t)row << 16) | (uint32_t)(c0 + bb);
+                                word &= word - 1u;
+                            } while (word);
+                        }
+                    }
+                    __syncthreads();
+                    if (tid == 0)
+                        s_n = at + want;
+                }
+                v0 += blk;
+            }
+            __syncthreads();
+            const int n = s_n;
+            for (int j = tid; j < n; j += FX_NT) {
+                const uint32_t ent = s_list[j];
+                const int py = (int)(ent >> 16), px = (int)(ent & 0xFFFFu);
+                const int pi = py * pcols + px;
+                uint4 ob; // {offset | max dy << 25, base row << 16 | base col} of this pixel, offset of the next one
+                __builtin_memcpy(&ob, ob2 + pi, 16);
+                const int off0 = (int)(ob.x & 0x1FFFFFFu), cnt = (int)(ob.z & 0x1FFFFFFu) - off0;
+                const int brow = (int)(ob.y >> 16), bcol = (int)(ob.y & 0xFFFFu), maxdy = (int)(ob.x >> 25);
+                if (cnt == 0 || brow >= R1 || brow + maxdy < R0)
+                    continue; // none of this pixel's candidates lies in the part
+                unsigned nb; // the 3 x 3 mask bits around the pixel (as in extract_gather_kernel)
+                if (pw >= 2) {
+                    const int wb = min(max((px >> 5) - ((px & 31) < 16 ? 1 : 0), 0), pw - 2);
+                    const int rel = px - 1 - 32 * wb;
+                    auto bits3 = [&](int yy) -> unsigned {
+                        const bool in = yy >= 0 && yy < prows;
+                        unsigned long long ww;
+                        __builtin_memcpy(&ww, src + (long long)(in ? yy : py) * pw + wb, 8);
+                        ww = rel >= 0 ? ww >> rel : ww << 1;
+                        return in ? (unsigned)ww & 7u : 0u;
+                    };
+                    nb = bits3(py - 1) | (bits3(py) << 3) | (bits3(py + 1) << 6);
+                } else {
+                    auto bits3 = [&](int yy) -> unsigned {
+                        if (yy < 0 || yy >= prows)
+                            return 0u;
+                        return (unsigned)(((unsigned long long)src[yy] << 1) >> px) & 7u;
+                    };
+                    nb = bits3(py - 1) | (bits3(py) << 3) | (bits3(py + 1) << 6);
+                }
+                int run_w = -1;
+                unsigned long long run_m = 0ull;
+                auto cand4 = [&](uint32_t e, bool live) {
+                    const unsigned sc = (e >> 16) & 3u;
+                    const unsigned sh = nb >> (sc + (sc >> 1)); // tap place ry * 2 + rx -> shift ry * 3 + rx
+                    const unsigned pat = (sh & 3u) | ((sh >> 1) & 12u);
+                    const int row = brow + (int)(e >> 25);
+                    if (live && ((e >> pat) & 1u) && row >= R0 && row < R1) {
+                        const int col = bcol + (int)((e >> 18) & 127u);
+                        const int wd = (row - R0) * wpr + (col >> 6);
+                        if (wd != run_w) {
+                            if (run_m)
+                                atomicOr(&s_bm[run_w], run_m);
+                            run_w = wd;
+                            run_m = 0ull;
+                        }
+                        run_m |= 1ull << (col & 63);
+                    }
+                };
+                for (int k = 0; k < cnt; k += 8) {
+                    uint4 a, b2;
+                    __builtin_memcpy(&a, ent4 + off0 + k, 16);
+                    __builtin_memcpy(&b2, ent4 + off0 + min(k + 4, cnt - 1), 16);
+                    const bool two = k + 4 < cnt;
+                    cand4(a.x, true);
+                    cand4(a.y, k + 1 < cnt);
+                    cand4(a.z, k + 2 < cnt);
+                    cand4(a.w, k + 3 < cnt);
+                    cand4(b2.x, two);
+                    cand4(b2.y, k + 5 < cnt);
+                    cand4(b2.z, k + 6 < cnt);
+                    cand4(b2.w, k + 7 < cnt);
+                }
+                if (run_m)
+                    atomicOr(&s_bm[run_w], run_m);
+            }
+            __syncthreads();
+            if (tid == 0)
+                s_n = 0;
+            __syncthreads();
+            if (v0 >= my_words)
+                break;
+        }
+        __syncthreads();
+        // ---- 2. points in front of every word of the part (row-major = np.nonzero order)
+        const int wpt = (nwp + FX_NT - 1) / FX_NT; // words per thread, consecutive
+        const int w0 = min(tid * wpt, nwp), w1 = min(w0 + wpt, nwp);
+        int mine = 0;
+        for (int w = w0; w < w1; ++w)
+            mine += __popcll(s_bm[w]);
+        int total;
+        int run = fx_block_excl_scan(mine, s_w, &total);
+        for (int w = w0; w < w1; ++w) {
+            s_pre[w] = run;
+            run += __popcll(s_bm[w]);
+        }
+        if (tid == FX_NT - 1 || w1 == nwp)
+            s_pre[nwp] = total;
+        // hand-over: this part's total goes out, the totals of the parts above come in
+        int32_t *pc = part_cnt + (long long)f * n_parts;
+        if (tid == 0)
+            __hip_atomic_store(pc + part, total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (total > 0 && pts_out)
+            for (int i = tid; i < ccols; i += FX_NT) // (only a part with points needs the table)
+                s_x[i] = xtab[i];
+        for (int q = tid; q < part; q += FX_NT) {
+            int v = __hip_atomic_load(pc + q, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            if (v < 0) {
+                const unsigned long long t0 = wall_clock64(); // 100 MHz
+                while (true) {
+                    __builtin_amdgcn_s_sleep(4);
+                    v = __hip_atomic_load(pc + q, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    if (v >= 0 || wall_clock64() - t0 > 20000000ull) // (0.2 s: never seen; a wrong count beats a hung device)
+                        break;
+                }
+            }
+            atomicAdd(&s_base, max(v, 0));
+        }
+        __syncthreads();
+        base_pts = s_base;
+        // ---- 3. a lane per point
+        for (int j = tid; j < total; j += FX_NT) {
+            const long long t = (long long)base_pts + j;
+            if (t >= cap)
+                break; // (the count goes on; only the first cap points are stored: sonarfe.h)
+            int lo = 0, hi = nwp - 1; // the last word whose prefix is <= j and that holds a point
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (s_pre[mid] <= j)
+                    lo = mid;
+                else
+                    hi = mid - 1;
+            }
+            // (words with equal prefix: the search ends on the last of them, which is the non-empty one or lies behind
+            // it -- step back to the word whose range really holds j)
+            while (s_pre[lo + 1] <= j)
+                ++lo; // never taken: kept for clarity of the invariant s_pre[lo] <= j < s_pre[lo + 1]
+            const unsigned long long wbits = s_bm[lo];
+            int rr = j - s_pre[lo], bit = 0;
+            unsigned w32 = (unsigned)wbits;
+            {
+                const int c = __popc(w32);
+                if (rr >= c) {
+                    rr -= c;
+                    w32 = (unsigned)(wbits >> 32);
+                    bit = 32;
+                }
+            }
+#pragma unroll
+            for (int h = 16; h >= 1; h >>= 1) {
+                const int c = __popc(w32 & ((1u << h) - 1u));
+                if (rr >= c) {
+                    rr -= c;
+                    w32 >>= h;
+                    bit += h;
+                }
+            }
+            const int rrow = lo / wpr;
+            const int row = R0 + rrow, col = (lo - rrow * wpr) * 64 + bit;
+            const long long o = (long long)f * cap + t;
+            if (rc_out)
+                reinterpret_cast<longlong2 *>(rc_out)[o] = make_longlong2(row, col);
+            if (pts_out)
+                reinterpret_cast<double2 *>(pts_out)[o] = make_double2(ytab[row], s_x[col]);
+        }
+        if (tid == 0 && part == n_parts - 1)
+            counts[f] = base_pts + total;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // byte mask -> bit stream (mask_pack_kernel) for n_frames frames of px pixels; d_nonbin (optional, n_frames ints,
 // zeroed by the caller) is set for frames holding a byte > 1
 int sfe_mask_pack(sfe_ctx *ctx, const uint8_t *d_mask, int n_frames, long long px, uint32_t *d_bits, int32_t *d_nonbin)
@@ -1274,6 +1572,36 @@ static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_f
         // with a capacity: extract_expand_words_kernel clears the words it expands, extract_clean_queued_kernel the
         // frames without a list): the memset is only needed when the scratch is new or another path (or a failed
         // call) has left bits behind.
+        // Round 4: the fused kernel (canvas bitmap in LDS, one workgroup per part of a frame) for binary bit streams.
+        // OFF by default (SFE_EXTRACT_FUSED=1 switches it on; read per call so that the tests cover it): measured on
+        // MI355X it moves a third of the bytes and is 4-5 x slower -- 0.98 ms per 512 frames against 0.19 (0.69 ms in its
+        // first form, one workgroup per frame): every part rescans its share of the bit stream and re-reads the offsets of
+        // the set pixels there (3.3 parts see a pixel), and a 512-thread workgroup with 66 KB of LDS hides the dependent
+        // reads of the per-pixel walk far worse than the gather kernel's eight small workgroups per CU.
+        {
+            const char *fe_ = getenv("SFE_EXTRACT_FUSED");
+            const int fused_mode = fe_ ? atoi(fe_) : 0;
+            const bool fused = gather && d_bits_in && cap > 0 && cap < (1ll << 31) && g->d_inv_ob2 && g->d_ytab && g->d_xtab &&
+                               fused_mode == 1;
+            if (fused) {
+                const int PR = g->fused_pr, nwp = PR * wpr;
+                const size_t lds = (size_t)nwp * 8 + (size_t)((nwp + 2) & ~1) * 4 + (size_t)g->cart_cols * 8;
+                SFE_HIP(ctx, hipFuncSetAttribute((const void *)extract_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)lds));
+                int32_t *d_pcnt = (int32_t *)sfe_scratch(ctx, 52, (size_t)chunk * g->fused_parts * 4);
+                if (!d_pcnt)
+                    return SFE_ERR_HIP;
+                SFE_HIP(ctx, hipMemsetAsync(d_pcnt, 0xFF, (size_t)nf * g->fused_parts * 4, ctx->stream)); // -1 = not there yet
+                hipLaunchKernelGGL(extract_fused_kernel, dim3(g->fused_parts, nf), dim3(FX_NT), lds, ctx->stream, d_bits,
+                                   (const uint2 *)g->d_inv_ob2, (const uint32_t *)g->d_inv_c4, (const int32_t *)g->d_part_rows,
+                                   g->fused_parts, PR, g->polar_rows, g->polar_cols, crows, g->cart_cols, wpr, wpf,
+                                   (const double *)g->d_ytab, (const double *)g->d_xtab,
+                                   d_rc ? d_rc + (size_t)f0 * cap * 2 : (long long *)nullptr,
+                                   d_pts ? d_pts + (size_t)f0 * cap * 2 : (double *)nullptr, (long long)cap, d_counts + f0,
+                                   d_pcnt);
+                continue; // (the canvas bitmap in HBM is not touched: what is known about its state stays)
+            }
+        }
         const bool self_clean = gather && d_bits_in && use_words && cap > 0 && !nosc;
         const size_t bm_need = (size_t)nf * crows * wpr * sizeof(unsigned long long);
         if (!self_clean)
@@ -1583,6 +1911,50 @@ int sfe_geom_create(sfe_ctx *ctx, const float *map_x, const float *map_y, int ca
                 ob[npix] = make_uint2((uint32_t)c4.size(), 0u);
                 c4.resize(c4.size() + 8, 0u); // (the kernel reads entries in fours, two reads ahead)
                 ob.resize(ob.size() + 1, make_uint2((uint32_t)c4.size(), 0u)); // (16-byte reads of {offset, base} pairs)
+                // ... and the tables of the fused kernel: {offset | max dy << 25, base row << 16 | base col} per polar pixel,
+                // the canvas in parts of PR rows (bitmap + prefix array + x table of a part within 64 KB of LDS: two
+                // workgroups per CU), per part the polar rows that reach it
+                {
+                    const long long budget = 64 * 1024 - 8 * (long long)cart_cols - 64;
+                    int PR = (int)std::min<long long>(128, budget / (12ll * g->words_per_row));
+                    PR &= ~7;
+                    bool ok2 = PR >= 8 && c4.size() < (1u << 25) && cart_rows < 65536 && (long long)rowbits < 65536;
+                    if (ok2) {
+                        const int n_parts = (cart_rows + PR - 1) / PR;
+                        std::vector<uint2> ob2(npix + 2);
+                        std::vector<int32_t> prange(2 * (size_t)n_parts);
+                        for (int q = 0; q < n_parts; ++q) {
+                            prange[2 * q] = polar_rows;
+                            prange[2 * q + 1] = -1;
+                        }
+                        for (size_t pi = 0; pi < npix; ++pi) {
+                            const uint32_t o0 = ob[pi].x, o1 = ob[pi + 1].x;
+                            unsigned maxdy = 0;
+                            for (uint32_t j = o0; j < o1; ++j)
+                                maxdy = std::max(maxdy, c4[j] >> 25);
+                            const unsigned brow = (unsigned)(ob[pi].y / rowbits), bcol = (unsigned)(ob[pi].y % rowbits);
+                            ob2[pi] = make_uint2(o0 | (maxdy << 25), (brow << 16) | bcol);
+                            if (o1 > o0) {
+                                const int py = (int)(pi / (size_t)polar_cols);
+                                for (unsigned q = brow / PR; q <= std::min<unsigned>((brow + maxdy) / PR, n_parts - 1); ++q) {
+                                    prange[2 * q] = std::min(prange[2 * q], py);
+                                    prange[2 * q + 1] = std::max(prange[2 * q + 1], py);
+                                }
+                            }
+                        }
+                        ob2[npix] = make_uint2(ob[npix].x, 0u);
+                        ob2[npix + 1] = ob2[npix];
+                        if (hipMalloc((void **)&g->d_inv_ob2, ob2.size() * sizeof(uint2)) != hipSuccess ||
+                            hipMalloc((void **)&g->d_part_rows, prange.size() * 4) != hipSuccess ||
+                            hipMemcpy(g->d_inv_ob2, ob2.data(), ob2.size() * sizeof(uint2), hipMemcpyHostToDevice) != hipSuccess ||
+                            hipMemcpy(g->d_part_rows, prange.data(), prange.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+                            sfe_geom_destroy(g);
+                            return sfe_set_err(ctx, SFE_ERR_HIP, "fused extraction table upload failed");
+                        }
+                        g->fused_pr = PR;
+                        g->fused_parts = n_parts;
+                    }
+                }
                 if (hipMalloc((void **)&g->d_inv_ob, ob.size() * sizeof(uint2)) != hipSuccess ||
                     hipMalloc((void **)&g->d_inv_c4, c4.size() * 4) != hipSuccess ||
                     hipMemcpy(g->d_inv_ob, ob.data(), ob.size() * sizeof(uint2), hipMemcpyHostToDevice) != hipSuccess ||
@@ -1663,6 +2035,10 @@ void sfe_geom_destroy(sfe_geom *g)
         (void)hipFree(g->d_inv_lut);
     if (g->d_inv_ob)
         (void)hipFree(g->d_inv_ob);
+    if (g->d_inv_ob2)
+        (void)hipFree(g->d_inv_ob2);
+    if (g->d_part_rows)
+        (void)hipFree(g->d_part_rows);
     if (g->d_inv_c4)
         (void)hipFree(g->d_inv_c4);
     if (g->d_ytab)

@@ -9,14 +9,20 @@ from sonar_slam_amd.feature_extraction import FeatureExtraction, Geometry, Sonar
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["default", "second-level", "entries8"])
+@pytest.fixture(autouse=True, params=["default", "fused", "second-level", "entries8"])
 def extraction_build(request, monkeypatch):
-    """Every test of this module runs three times: the default (4-byte inverse-map entries, streaming scan of the
-    canvas bitmap), with the second-level flags + extract_scan_l2_kernel (round 4, off by default: DESIGN 5.2), and with
-    round 3's 8-byte entries.  The knobs are read per call (extract_dev)."""
-    if request.param == "second-level":
+    """Every test of this module runs four times: the default (three kernels, 4-byte inverse-map entries, streaming scan
+    of the canvas bitmap), the fused kernel (canvas bitmap in LDS, one workgroup per part of a frame, look-back hand-over
+    of the point counts: round 4, off by default), the three kernels with the second-level flags +
+    extract_scan_l2_kernel (round 4, off by default), and with round 3's 8-byte entries.  The knobs are
+    read per call (extract_dev)."""
+    if request.param == "fused":
+        monkeypatch.setenv("SFE_EXTRACT_FUSED", "1")
+    elif request.param == "second-level":
+        monkeypatch.setenv("SFE_EXTRACT_FUSED", "0")
         monkeypatch.setenv("SFE_EXTRACT_L2", "1")
     elif request.param == "entries8":
+        monkeypatch.setenv("SFE_EXTRACT_FUSED", "0")
         monkeypatch.setenv("SFE_EXTRACT_NO_COMPACT", "1")
     return request.param
 
