@@ -369,6 +369,7 @@ def main():
     # candidates are generated and screened on the device, untimed -- a ping whose detections exceed the batch's point
     # capacity would be an error on the resident path -- and the batch's frames are re-tiled over the accepted ones.
     n_distinct = min(args.batch, 32)
+    n_screened = 0      # candidate pings rejected because their detections exceed the batch's point capacity
     if args.distinct_frames > 32 and args.batch > 32:
         from sonar_slam_amd import synth
         want = min(args.distinct_frames, args.batch)
@@ -383,6 +384,7 @@ def main():
             ctx.sync()
             cnt = kb.d_cnt.download(np.int32, len(cand))
             accepted += [cand[j] for j in range(len(cand)) if cnt[j] <= kb.cap]
+            n_screened += int((cnt > kb.cap).sum())
         accepted = accepted[:want]
         n_distinct = len(accepted)
         frames = np.stack([accepted[j % n_distinct] for j in range(args.batch)])
@@ -496,7 +498,7 @@ def main():
                                    " -> remap+nonzero+px2m%s -> 5000x5000-pt ICP (%s)"
                                    % (args.batch, "" if args.no_filters else " -> downsample 0.5 -> remove_outlier 1.0/5",
                                       args.icp_mode),
-                       "batch_per_gpu": args.batch, "distinct_frames": n_distinct, "icp_mode": args.icp_mode, "parallelism": "job farm x%d" % world,
+                       "batch_per_gpu": args.batch, "distinct_frames": n_distinct, "screened_out_pings": n_screened, "icp_mode": args.icp_mode, "parallelism": "job farm x%d" % world,
                        "icp_prep_stream": "main" if args.serial_prep else "side", "batches_in_flight": n_inflight,
                        "icp_converged_jobs": ok, "mean_icp_iters": iters_total / float(args.batch),
                        "mean_points_per_frame": float(res["counts"].mean()),
