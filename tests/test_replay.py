@@ -73,3 +73,71 @@ def test_compute_icp_with_cov_many_guesses_one_launch(ctx):
     # too few successes -> the reference's message
     msg2, *_ = fe.compute_icp_with_cov(src, tgt, guesses[:3])
     assert msg2 == "Too few samples for covariance computation"
+
+
+def test_pose2_batch_equals_the_scalar_class_bit_for_bit():
+    """chained.Pose2Batch (the SLAM node's gtsam.Pose2 algebra for many sessions at once) must give the bits of
+    pose2.Pose2, element by element: the session batch's records are compared with the scalar front end's exactly."""
+    from sonar_slam_amd.chained import Pose2Batch
+    rng = np.random.default_rng(4)
+    n = 257
+    A = rng.normal(0, [20, 20, 2.0], (n, 3))
+    B = rng.normal(0, [3, 3, 0.4], (n, 3))
+    a, b = Pose2Batch(A[:, 0], A[:, 1], A[:, 2]), Pose2Batch(B[:, 0], B[:, 1], B[:, 2])
+    sa, sb = [Pose2(*r) for r in A], [Pose2(*r) for r in B]
+    chain = a.compose(b).between(a).inverse().compose(b.between(a))
+    sc = [x.compose(y).between(x).inverse().compose(y.between(x)) for x, y in zip(sa, sb)]
+    got = chain.xytheta()
+    want = np.array([[p.x(), p.y(), p.theta()] for p in sc])
+    assert np.array_equal(got, want)
+    assert np.array_equal(chain.matrix32(), np.stack([p.matrix() for p in sc]).astype(np.float32))
+    assert np.array_equal(chain.T6(), np.stack([p.matrix()[:2, :3].reshape(6) for p in sc]).astype(np.float32))
+    # the renormalisation branch of Rot2 (|c^2 + s^2 - 1| > 1e-10) on a few elements only
+    c, s = np.cos(A[:, 2]), np.sin(A[:, 2])
+    c[::7] *= 1.0 + 1e-6
+    pb = Pose2Batch(A[:, 0], A[:, 1], cs=(c, s))
+    ps = [Pose2(x, y, _cs=(cc, ss)) for x, y, cc, ss in zip(A[:, 0], A[:, 1], c, s)]
+    assert np.array_equal(pb.theta(), np.array([p.theta() for p in ps]))
+    idx = np.array([3, 50, 200])
+    sub = pb.take(idx)
+    assert np.array_equal(sub.x, pb.x[idx]) and np.array_equal(sub.c, pb.c[idx])
+    pb.put(idx, b.take(idx))
+    assert np.array_equal(pb.x[idx], b.x[idx]) and np.array_equal(pb.s[idx], b.s[idx])
+
+
+def test_oracle_chain_restates_one_session_on_the_cpu():
+    """oracle/chain.py (test infrastructure: the CPU checker of the device-resident chained path) on a small synthetic
+    session: every keyframe scan-matched against its predecessors, the chain closer to ground truth than the odometry it
+    starts from, pose algebra equal to pose2.Pose2 (two independent restatements of gtsam's published Rot2 / Pose2)."""
+    import oracle
+    from types import SimpleNamespace
+    from oracle import chain
+    from sonar_slam_amd.CFAR import CFAR
+    from sonar_slam_amd.feature_extraction import build_maps, oculus_bearings
+    a, b = (1.5, -2.0, 0.7), (0.3, 0.4, -1.2)
+    pa, pb = Pose2(*a), Pose2(*b)
+    for got, want in ((chain.compose(chain.pose(*a), chain.pose(*b)), pa.compose(pb)),
+                      (chain.between(chain.pose(*a), chain.pose(*b)), pa.between(pb)),
+                      (chain.inverse(chain.pose(*a)), pa.inverse())):
+        assert (got[0], got[1], chain.theta(got)) == (want.x(), want.y(), want.theta())
+    rows, beams, K = 256, 128, 5
+    bearings = oculus_bearings(beams)
+    res, height, _, width, cols, mx, my = build_maps(bearings, 30.0 / rows, rows)
+    fe = SimpleNamespace(map_x=mx, map_y=my, rows=rows, cols=cols, width=width, height=height)
+    world = synth.world_structure(seed=2, n=5000)
+    true, dr = synth.trajectory(n=K, step=1.7, turn=0.04, seed=11)
+    det = CFAR(40, 10, 0.1, 10)
+    clouds = []
+    for k in range(K):
+        img = synth.render_ping(world, true[k], bearings, rows=rows, seed=k)
+        m, pts = chain.feature_cloud(img, det.params["SOCA"], "SOCA", 65, fe)
+        assert m.sum() > 50 and pts.dtype == np.float32
+        clouds.append(chain.slam_cloud(pts))
+    recs = chain.run_session(clouds, dr, oracle.shipped_icp_params(precision=1), ssm_min_points=20)
+    assert [r["status"] for r in recs][0] == "PRIOR" and sum(r["status"] == "SUCCESS" for r in recs) >= K - 2
+
+    def end_err(p):
+        want = Pose2(*true[0]).between(Pose2(*true[-1]))
+        got = Pose2(*p[0]).between(Pose2(*p[-1]))
+        return np.hypot(got.x() - want.x(), got.y() - want.y())
+    assert end_err([r["pose"] for r in recs]) < end_err(dr) + 0.05
