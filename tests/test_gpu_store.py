@@ -267,3 +267,30 @@ def test_sessions_in_lock_step_equal_the_front_end_and_the_oracle_chain(ctx, shi
         return float(np.mean(e))
     assert rel_err(est) < rel_err(dr)
     sb.free()
+
+
+def test_large_targets_and_many_guesses_over_handles(ctx):
+    """get_points on more points than the LDS sort of the resident downsample holds (3 keyframes of 9 000 points: the
+    global-memory sort path), and the NSSM shape of slam.py:346-358 over handles: 30 guesses on ONE (source, target) pair
+    (the jobs share the target's preparation) -- equal to ICP.compute_batch on the host clouds."""
+    rng = np.random.default_rng(9)
+    s = st.CloudStore(ctx, capacity_points=1 << 18, max_clouds=64)
+    clouds = _clouds(rng, (9000, 9000, 9000))
+    hs = [s.put(c) for c in clouds]
+    poses = [Pose2(0.0, 0.0, 0.0), Pose2(1.0, -0.5, 0.1), Pose2(2.2, 0.3, -0.07)]
+    T6 = [[st.pose_T6(poses[0].between(p)) for p in poses]]
+    h = s.get_points([hs], T6, 0.5)[0]
+    want = oracle.get_points(clouds, [poses[0].between(p).matrix() for p in poses], 0.5)
+    assert np.array_equal(s.read(h), want) and len(want) > 1000
+    src, tgt, guess, _ = synth.scan_pair(seed=77, n_src=800, n_tgt=800)
+    hsrc, htgt = s.put(src), s.put(tgt)
+    base = synth.pose_of(guess)
+    guesses = [synth.pose_matrix(base[0] + dx, base[1] + dy, base[2] + dt).astype(np.float32)
+               for dx, dy, dt in rng.normal(0, [0.2, 0.2, 0.02], (30, 3))]
+    T, status, iters = s.icp(icp_config.shipped_params(), [(hsrc, htgt)] * 30, guesses)
+    icp = pcl.ICP(ctx)
+    icp.setParams(icp_config.shipped_params())
+    msgs, Tb, itb = icp.compute_batch(src, tgt, guesses)
+    assert np.array_equal(T, Tb) and np.array_equal(iters, itb)
+    assert [_lib.ICP_STATUS_MESSAGES[int(x)] for x in status] == list(msgs)
+    s.close()
