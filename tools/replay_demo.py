@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--pings", type=int, default=40)
     ap.add_argument("--rows", type=int, default=1024)
     ap.add_argument("--beams", type=int, default=512)
+    ap.add_argument("--store", action="store_true", help="keyframe clouds stay on the device (CloudStore): no wire hop")
     ap.add_argument("--save")
     ap.add_argument("--load")
     a = ap.parse_args()
@@ -45,11 +46,16 @@ def main():
     fe.resolution, fe.outlier_filter_radius, fe.outlier_filter_min_points, fe.skip = 0.5, 1.0, 5, 1
     fe.configure()
     fe.callback(pings[0])      # warm-up: maps + device geometry
-    front = FrontEnd(ctx, keyframe_translation=1.5, keyframe_duration=0.5)
+    store = None
+    if a.store:
+        from sonar_slam_amd.store import CloudStore
+        store = CloudStore(ctx, capacity_points=1 << 20, max_clouds=4096)
+    front = FrontEnd(ctx, keyframe_translation=1.5, keyframe_duration=0.5, store=store)
     log, t_fe, t_slam = replay(pings, stamps, dr, fe, front)
     print("%d pings, %d keyframes; feature extraction %.2f ms/ping, SLAM front end %.2f ms/keyframe (host wall, "
-          "single-ping host API incl. PCIe copies)" % (len(pings), len(log), 1e3 * t_fe / len(pings),
-                                                        1e3 * t_slam / max(len(log), 1)))
+          "single-ping host API incl. PCIe copies%s)" % (len(pings), len(log), 1e3 * t_fe / len(pings),
+                                                          1e3 * t_slam / max(len(log), 1),
+                                                          "; keyframe clouds device-resident" if a.store else ""))
     for r in log:
         k = int(r["time"])
         line = "kf %2d ping %3d %-20s src %5d tgt %5d" % (r["source_key"], k, r["status"], r.get("n_source", 0),
