@@ -361,7 +361,10 @@ int sfe_cloud_store_truncate(sfe_ctx *ctx, sfe_cloud_store *s, int32_t n_slots);
 /* SLAM.get_points(frames, ref_frame) for n_jobs target clouds at once (slam.py:229-292): job j takes the clouds
  * handles[j*m .. j*m+m) (-1 = unused), moves cloud k by T6[(j*m+k)*6 ..] = {T00 T01 T02 T10 T11 T12} of
  * ref_pose.between(pose).matrix().astype(float32) like Keyframe.transform_points, concatenates them in that order and
- * runs pcl.downsample(resolution) (resolution <= 0: no downsample); the results become new slots (handles_out, host). */
+ * runs pcl.downsample(resolution) (resolution <= 0: no downsample); the results become new slots (handles_out, host).
+ * Targets of up to 65 536 points run on the resident filters, all jobs of the call in one launch each; a call with a
+ * larger one (the loop-closure target of a long session, slam.py:999) takes its jobs one by one through a path without
+ * a size limit.  A cloud whose count is < 0 is refused (SFE_ERR_ARG). */
 int sfe_cloud_store_get_points(sfe_ctx *ctx, sfe_cloud_store *s, const int32_t *handles, const float *T6, int n_jobs, int m,
                                float resolution, int flags, const int64_t *stamps, int32_t *handles_out);
 /* SLAM.compute_icp over handles (slam.py:294-323): pairs = n_jobs x (source handle, target handle); otherwise like
@@ -376,10 +379,41 @@ int sfe_icp_store_compute(sfe_ctx *ctx, const sfe_icp_params *p, sfe_cloud_store
  * pose's matrix as float32), pcl.match(target, source, 1, max_dist), counts_out[j] = matched points (host) */
 int sfe_cloud_store_overlap(sfe_ctx *ctx, sfe_cloud_store *s, const int32_t *pairs, const float *T6, int n_jobs,
                             float max_dist, int flags, int32_t *counts_out);
+/* ---- loop-closure search over the store: slam.py:839-1001 (initialize_nonsequential_scan_matching) ----
+ * get_points(target_frames, None, return_keys=True) (slam.py:873 -> :229-292): m keyframe clouds, cloud k moved by
+ * T6[k*6 ..] (its own pose's matrix as float32) and tagged with keys[k]; pcl.downsample(points, keys, resolution), the
+ * descriptor overload (pcl.cpp:143-159): a leaf's medoid brings its key along.  No size limit (every keyframe older than
+ * k - min_st_sep goes in).  One new slot; its keys stay on the device next to its points. */
+int sfe_cloud_store_get_points_keys(sfe_ctx *ctx, sfe_cloud_store *s, const int32_t *handles, const float *T6,
+                                    const int32_t *keys, int m, float resolution, int flags, int64_t stamp, int32_t *handle_out);
+int sfe_cloud_store_read_keys(sfe_ctx *ctx, sfe_cloud_store *s, int32_t handle, int32_t *out, int cap, int *n_out);
+/* The field-of-view gate (slam.py:875-899) on a keyed cloud: source frame f sees a point iff, moved by Tinv6[f*6 ..]
+ * (pose.inverse().matrix() as float32, float32 arithmetic like numpy's), its range is < range_bound[f] and |bearing| <
+ * bearing_bound[f]; a point is selected iff some frame sees it.  key_counts_out[k] (host, n_keys entries) = selected
+ * points with key k -- np.unique(keys[sel], return_counts=True), slam.py:902; *n_selected_out their number.  The
+ * selection stays on the device for sfe_cloud_store_compact_selected.  *n_ambiguous_out = points whose bearing lies
+ * within float32 rounding of a bound (numpy's float32 arctan2 is not reproduced bit for bit): if it is not 0 the caller
+ * evaluates the gate with numpy and hands the selection over with sfe_cloud_store_set_selection. */
+int sfe_cloud_store_fov_select(sfe_ctx *ctx, sfe_cloud_store *s, int32_t handle, const float *Tinv6, const double *range_bound,
+                               const double *bearing_bound, int n_frames, int n_keys, int32_t *key_counts_out,
+                               int32_t *n_selected_out, int32_t *n_ambiguous_out);
+int sfe_cloud_store_set_selection(sfe_ctx *ctx, sfe_cloud_store *s, int32_t handle, const uint8_t *sel, int n);
+/* target_points[sel], target_keys[sel] (slam.py:898-899): a new slot, order kept, keys kept */
+int sfe_cloud_store_compact_selected(sfe_ctx *ctx, sfe_cloud_store *s, int32_t handle, int64_t stamp, int32_t *handle_out);
+/* get_overlap(source under T6, target, return_indices=True) + np.unique(target_keys[indices[indices != -1]],
+ * return_counts=True) (slam.py:977-985): pcl.match's neighbour (nearest, lowest index among equals, within max_dist) of
+ * every source point; key_counts_out[k] = matches whose target carries key k, *overlap_out their number */
+int sfe_cloud_store_match_keys(sfe_ctx *ctx, sfe_cloud_store *s, int32_t source, const float *T6, int32_t target, float max_dist,
+                               int flags, int n_keys, int32_t *key_counts_out, int32_t *overlap_out);
+/* bounding boxes of n clouds: bbox_out[i*4 ..] = {min x, min y, max x, max y} (float32 min / max: what np.min / np.max
+ * of the cloud give, slam.py:506-507) */
+int sfe_cloud_store_bbox(sfe_ctx *ctx, sfe_cloud_store *s, const int32_t *handles, int n, float *bbox_out);
+
 /* sfe_feature_extract_ping with the cloud left in the store instead of copied to the host: the
  * filtered cloud becomes a new slot (with SFE_STORE_NEGATE_Y in flags: as the SLAM node holds it), *handle_out its
  * handle, *n_out its size; cloud_out (nullable, host [cap x 2], (forward, lateral) as published) receives the points
- * only when the caller wants to publish them.  On SFE_ERR_CAP / *n_out = -1 no slot is kept (*handle_out = -1).
+ * only when the caller wants to publish them.  On SFE_ERR_CAP / *n_out = -1 no slot is kept (*handle_out = -1); a store
+ * whose pool has no room for the cloud is SFE_ERR_CAP as well (the slot's own count is read back with the two sizes).
  * s may be NULL (then cloud_out is required and handle_out may be NULL): the same call without a store, for the flags
  * sfe_feature_extract_ping has no argument for (SFE_PING_VIS_JET). */
 int sfe_feature_extract_ping_store(sfe_ctx *ctx, sfe_geom *g, sfe_cloud_store *s, int64_t stamp, const uint8_t *img, int alg,
@@ -401,17 +435,34 @@ int sfe_feature_extract_ping_store(sfe_ctx *ctx, sfe_geom *g, sfe_cloud_store *s
 typedef struct sfe_costgrid sfe_costgrid;
 int sfe_costgrid_create(sfe_ctx *ctx, const int32_t *tgt_r, const int32_t *tgt_c, int n_tgt, int rows,
                         int cols, int dilate_hs, sfe_costgrid **out);
+/* The same for n device-resident target clouds at once (one grid each, e.g. one per session): grid i is built from
+ * cloud target_handles[i] of the store with the cells of slam.py:514-517 computed on the device in the cloud's dtype
+ * (float32: (p - min) / float32(resolution), half to even, clipped); xmin / ymin / rows / cols [n] are what the
+ * caller's numpy made of the cloud's bounding box (slam.py:506-511; sfe_cloud_store_bbox brings the box).  Enqueue only. */
+int sfe_costgrid_create_store(sfe_ctx *ctx, sfe_cloud_store *s, const int32_t *target_handles, int n, const float *xmin,
+                              const float *ymin, float resolution, const int32_t *rows, const int32_t *cols, int dilate_hs,
+                              sfe_costgrid **out);
 void sfe_costgrid_destroy(sfe_costgrid *g);
-/* the dilated grid as the reference holds it: rows x cols uint8, 0 / 255 (host buffer) */
-int sfe_costgrid_download(sfe_ctx *ctx, sfe_costgrid *g, uint8_t *grid_out);
+/* dilated grid `index` as the reference holds it: rows x cols uint8, 0 / 255 (host buffer) */
+int sfe_costgrid_download(sfe_ctx *ctx, sfe_costgrid *g, int index, uint8_t *grid_out);
 /*
  * The body of `subroutine` (slam.py:531-564) for n_poses transforms.  src: n_src x 2 float32 source
  * points (host); T6: per pose the float32 entries T00 T01 T02 T10 T11 T12 of
- * sample_transform.matrix(); xmin, ymin, resolution as float32 (slam.py:508-510);
+ * sample_transform.matrix(); xmin, ymin (float32, slam.py:506), resolution (slam.py:508);
  * cost_out[p] = -(number of source points on a set cell).
+ * flags & SFE_COST_F64_POINTS: the source cloud is a float64 numpy array of float32 values (the SLAM node's keyframe
+ * clouds, slam_ros.py:169-170): moved point and cell in double, as numpy promotes them; otherwise a float32 cloud (what
+ * get_points returns: sgemm arithmetic, cell in float32 with float32(resolution)).
  */
+#define SFE_COST_F64_POINTS 1
 int sfe_matching_cost_batch(sfe_ctx *ctx, sfe_costgrid *g, const float *src, int n_src, const float *T6,
-                            int n_poses, float xmin, float ymin, float resolution, int32_t *cost_out);
+                            int n_poses, float xmin, float ymin, double resolution, int flags, int32_t *cost_out);
+/* ... over store handles, n_jobs (source cloud, grid) pairs in one launch: job i scores source cloud source_handles[i]
+ * against grid grid_index[i] of `g` (NULL: grid i, n_jobs = the number of grids) under the transforms
+ * T6[(i * n_poses + p) * 6 ..]; cost_out[i * n_poses + p] (host).  One synchronisation. */
+int sfe_matching_cost_store(sfe_ctx *ctx, sfe_costgrid *g, sfe_cloud_store *s, const int32_t *source_handles,
+                            const int32_t *grid_index, int n_jobs, const float *T6, int n_poses, double resolution, int flags,
+                            int32_t *cost_out);
 
 #ifdef __cplusplus
 }

@@ -341,15 +341,19 @@ def cost_grid(tgt_r, tgt_c, rows, cols, dilate_hs):
     return g
 
 
-def matching_cost(grid, src, T6, xmin, ymin, resolution):
-    """costs (= -hits, slam.py:549-562) of n_poses float32 transforms [n x 6]."""
+def matching_cost(grid, src, T6, xmin, ymin, resolution, f64_points=False):
+    """costs (= -hits, slam.py:549-562) of n_poses float32 transforms [n x 6].  f64_points: the source is a float64
+    array of float32 values (the SLAM node's keyframe clouds): numpy evaluates the body in double, with the Python
+    float resolution; else a float32 cloud (sgemm transform, float32 cell arithmetic with float32(resolution))."""
     grid = np.ascontiguousarray(grid, np.uint8)
     src = np.ascontiguousarray(src, np.float32).reshape(-1, 2)
     T6 = np.ascontiguousarray(T6, np.float32).reshape(-1, 6)
     out = np.zeros(len(T6), np.int32)
-    lib().orc_matching_cost(_p(grid, C.c_uint8), grid.shape[0], grid.shape[1], _p(src, C.c_float), len(src),
-                            _p(T6, C.c_float), len(T6), np.float32(xmin), np.float32(ymin), np.float32(resolution),
-                            _p(out, C.c_int32))
+    fn = lib().orc_matching_cost2
+    fn.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int,
+                   C.c_float, C.c_float, C.c_double, C.c_int, C.POINTER(C.c_int32)]
+    fn(_p(grid, C.c_uint8), grid.shape[0], grid.shape[1], _p(src, C.c_float), len(src), _p(T6, C.c_float), len(T6),
+       np.float32(xmin), np.float32(ymin), float(resolution), 1 if f64_points else 0, _p(out, C.c_int32))
     return out
 
 

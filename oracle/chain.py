@@ -11,6 +11,10 @@ Flow restated (reference file:line):
     get_points / transform_points  slam.py:229-292, slam_objects.py:178-198
     compute_icp                    slam.py:294-323
     get_overlap                    slam.py:389-424
+    global initialisation          slam.py:461-570 (cost function), :665-716 / :922-973 (scipy.optimize.shgo), the reference's
+                                   DEFAULT (slam.py:77,89): ``initialization=True``
+    loop-closure search            slam.py:839-1087 (initialize_nonsequential_scan_matching, compute_icp_with_cov, the gates;
+                                   PCM and the graph update are the back end): ``nssm=dict(...)``
 
 Pose algebra: gtsam.Pose2 / Rot2 from gtsam's published source (rotation kept as (c, s), products renormalised only
 when |c^2 + s^2 - 1| > 1e-10), written here on plain tuples, independently of sonar_slam_amd.pose2.  gtsam itself is
@@ -84,17 +88,219 @@ def slam_cloud(points):
     return np.c_[p[:, 0], -1 * p[:, 1]]
 
 
+# ---- global initialisation (slam.py:461-570) ----
+def grid_geometry(target_points, point_noise):
+    """slam.py:506-511, :521 numpy verbatim (target_points: what pcl.downsample returned, float32)"""
+    xmin, ymin = np.min(target_points, axis=0) - 2 * point_noise
+    xmax, ymax = np.max(target_points, axis=0) + 2 * point_noise
+    resolution = point_noise / 10.0
+    xs = np.arange(xmin, xmax, resolution)
+    ys = np.arange(ymin, ymax, resolution)
+    return xmin, ymin, resolution, len(ys), len(xs), int(np.ceil(point_noise / resolution))
+
+
+def matching_cost_subroutine(source_points, source_pose, target_points, target_pose, point_noise, f64_points):
+    """get_matching_cost_subroutine1 on the CPU -> (subroutine(x) -> cost, pose_samples).  source_points: float32 values;
+    f64_points says whether the reference holds them as a float64 array (keyframe cloud) or a float32 one (get_points)."""
+    target_points = np.asarray(target_points, np.float32)
+    xmin, ymin, resolution, rows, cols, dilate_hs = grid_geometry(target_points, point_noise)
+    r = np.int32(np.round((target_points[:, 1] - ymin) / resolution))
+    c = np.int32(np.round((target_points[:, 0] - xmin) / resolution))
+    r = np.clip(r, 0, rows - 1)
+    c = np.clip(c, 0, cols - 1)
+    grid = oracle.cost_grid(r, c, rows, cols, dilate_hs)
+    src = np.ascontiguousarray(source_points, np.float32)
+    samples = []
+
+    def subroutine(x):
+        sp = compose(source_pose, pose(x[0], x[1], x[2]))
+        T = matrix(between(target_pose, sp)).astype(np.float32)
+        cost = oracle.matching_cost(grid, src, T[:2, :3].reshape(1, 6), xmin, ymin, resolution, f64_points)[0]
+        samples.append(np.r_[[sp[0], sp[1], theta(sp)], cost])
+        return np.int64(cost)
+    return subroutine, samples
+
+
+def run_shgo(subroutine, pose_bounds, params):
+    """slam.py:692-701 / :952-961"""
+    from scipy.optimize import shgo
+    return shgo(func=subroutine, bounds=pose_bounds, n=params[0], iters=params[1], sampling_method="sobol",
+                minimizer_kwargs={"options": {"ftol": params[2]}})
+
+
+def initial_transforms(pose_samples, target_pose, sample_eps=0.01):
+    """ICPResult.__init__ (slam_objects.py:287-300) with the canonical tie order of replay.FrontEnd.initial_transforms"""
+    ps = np.asarray(pose_samples, np.float64)
+    idx = np.lexsort((ps[:, 2], ps[:, 1], ps[:, 0], ps[:, 3]))
+    transforms = [between(target_pose, pose(*g)) for g in ps[idx, :3]]
+    filtered = [transforms[0]]
+    for b in transforms[1:]:
+        d = between(filtered[-1], b)
+        if np.linalg.norm([d[0], d[1], theta(d)]) < sample_eps:
+            continue
+        filtered.append(b)
+    return filtered
+
+
+# ---- loop-closure search (slam.py:839-1087) ----
+NSSM_DEFAULTS = dict(initialization=True, initialization_params=(100, 5, 0.01), min_st_sep=8, min_points=50, max_translation=10.0,
+                     max_rotation=np.deg2rad(60), source_frames=5, cov_samples=30, oculus_max_range=30.0,
+                     oculus_horizontal_aperture=np.radians(130.0), icp_odom_sigmas=(0.1, 0.1, 0.01), mcd_random_state=None)
+
+
+def _tp32(points32, T):
+    """Keyframe.transform_points on a float32 cloud (sgemm) -> float32"""
+    return oracle.transform_points(points32, T, f64_points=False)
+
+
+def nssm_search(clouds, poses, covs, current_frame_pose, icp_params, point_resolution=0.5, point_noise=0.5, **kw):
+    """One call of add_nonsequential_scan_matching (slam.py:1003-1087) right after keyframe K-1 = len(clouds)-1 was
+    appended.  clouds: SLAM-node clouds (float32 values of float64 arrays); poses: tuples; covs: 3x3 per keyframe.
+    -> record or None"""
+    from sklearn.covariance import MinCovDet
+    P = dict(NSSM_DEFAULTS)
+    P.update(kw)
+    K = len(clouds)
+    if K < P["min_st_sep"]:
+        return None
+    rec = {"source_key": K - 1}
+    source_key = K - 1
+    source_pose = current_frame_pose
+    source_frames = list(range(source_key, source_key - P["source_frames"], -1))
+    source_points = oracle.get_points([clouds[f] for f in source_frames],
+                                      [matrix(between(poses[source_key], poses[f])) for f in source_frames], point_resolution, f64_points=True)
+    rec["n_source"] = len(source_points)
+    if len(source_points) < P["min_points"]:
+        rec["status"] = "NOT_ENOUGH_POINTS"
+        return rec
+    target_frames = list(range(K - P["min_st_sep"]))
+    parts = [oracle.transform_points(clouds[f], matrix(poses[f]), f64_points=True) for f in target_frames]
+    allp = np.concatenate(parts) if parts else np.zeros((0, 2), np.float32)
+    allk = np.concatenate([np.full(len(p), f, np.float32) for p, f in zip(parts, target_frames)]) if parts else np.zeros(0, np.float32)
+    if len(allp):
+        target_points, idx = oracle.downsample(allp, point_resolution, return_index=True)
+        target_keys = allk[idx]
+    else:
+        target_points, target_keys = allp, allk
+    sel = np.zeros(len(target_points), bool)
+    for f in source_frames:                                                     # slam.py:878-895
+        cov = covs[f]
+        translation_std = np.sqrt(np.max(np.linalg.eigvals(cov[:2, :2])))
+        rotation_std = np.sqrt(cov[2, 2])
+        range_bound = translation_std * 5.0 + P["oculus_max_range"]
+        bearing_bound = rotation_std * 5.0 + P["oculus_horizontal_aperture"] * 0.5
+        local_points = _tp32(target_points, matrix(inverse(poses[f])))
+        ranges = np.linalg.norm(local_points, axis=1)
+        bearings = np.arctan2(local_points[:, 1], local_points[:, 0])
+        sel |= (ranges < range_bound) & (abs(bearings) < bearing_bound)
+    target_points, target_keys = target_points[sel], target_keys[sel]
+    rec["n_target_global"] = len(target_points)
+    frames1, counts = np.unique(np.int32(target_keys), return_counts=True)
+    frames1, counts = frames1[counts > 10], counts[counts > 10]
+    if len(frames1) == 0 or len(target_points) < P["min_points"]:
+        rec["status"] = "NOT_ENOUGH_POINTS"
+        return rec
+    target_key = int(frames1[np.argmax(counts)])
+    rec["target_key_fov"] = target_key
+    target_pose = poses[target_key]
+    target_local = _tp32(target_points, matrix(inverse(target_pose)))
+    estimated_source_pose, pose_samples = source_pose, None
+    if P["initialization"]:
+        c = covs[source_frames[-1]]
+        translation_std = np.sqrt(np.max(np.linalg.eigvals(c[:2, :2])))
+        rotation_std = np.sqrt(c[2, 2])
+        pose_stds = np.array([[translation_std, translation_std, rotation_std]]).T
+        pose_bounds = 5.0 * np.c_[-pose_stds, pose_stds]
+        np.linalg.inv(covs[source_key])
+        sub, pose_samples = matching_cost_subroutine(source_points, source_pose, target_local, target_pose, point_noise, f64_points=False)
+        result = run_shgo(sub, pose_bounds, P["initialization_params"])
+        if not result.success:
+            rec["status"] = "INITIALIZATION_FAILURE"
+            return rec
+        rec["init_x"], rec["init_cost"] = tuple(float(v) for v in result.x), float(result.fun)
+        estimated_source_pose = compose(source_pose, pose(*result.x))
+        moved = _tp32(source_points, matrix(estimated_source_pose))
+        ids, _ = oracle.match(target_points, moved, point_noise)
+        ids = ids.reshape(-1)
+        rec["overlap_global"] = int(np.sum(ids != -1))
+        t1, c1 = np.unique(np.int32(target_keys[ids[ids != -1]]), return_counts=True)
+        if len(c1) == 0:
+            rec["status"] = "NOT_ENOUGH_OVERLAP"
+            return rec
+        target_key = int(t1[np.argmax(c1)])
+        target_pose = poses[target_key]
+        target_local = oracle.get_points([clouds[f] for f in target_frames],
+                                         [matrix(between(target_pose, poses[f])) for f in target_frames], point_resolution, f64_points=True)
+    rec["target_key"], rec["n_target"] = target_key, len(target_local)
+    initial = between(target_pose, estimated_source_pose)
+    if P["initialization"] and P["cov_samples"] > 0:
+        guesses = initial_transforms(pose_samples, target_pose)[:P["cov_samples"]]
+        rec["n_guesses"] = len(guesses)
+        xyt, icp_recs = [], []
+        for g in guesses:
+            st, T, it = oracle.icp(source_points, target_local, matrix(g).astype(np.float32), icp_params)
+            icp_recs.append((st, it))
+            if st == 0:
+                xyt.append((T[0, 2], T[1, 2], np.arctan2(T[1, 0], T[0, 0])))
+        rec["icp_runs"] = icp_recs
+        xyt = np.array(xyt, np.float64).reshape(-1, 3)
+        if len(xyt) < 5:
+            rec["icp"], rec["status"] = "Too few samples for covariance computation", "NOT_CONVERGED"
+            return rec
+        try:
+            est = MinCovDet(store_precision=False, support_fraction=0.8, random_state=P["mcd_random_state"]).fit(xyt)
+        except ValueError:
+            rec["icp"], rec["status"] = "Failed to calculate covariance", "NOT_CONVERGED"
+            return rec
+        odom = pose(*est.location_)
+        cov = est.covariance_
+        R = matrix(odom)[:2, :2]
+        cov[:2, :] = R.T.dot(cov[:2, :])
+        cov[:, :2] = cov[:, :2].dot(R)
+        floor = np.diag(P["icp_odom_sigmas"]) ** 2
+        if np.linalg.det(cov) < np.linalg.det(floor):
+            cov = floor
+        rec["icp"], rec["n_converged"], rec["sample_transforms"], rec["cov"] = "success", len(xyt), xyt, cov
+    else:
+        st, T, it = oracle.icp(source_points, target_local, matrix(initial).astype(np.float32), icp_params)
+        rec["icp_runs"] = [(st, it)]
+        if st != 0:
+            rec["icp"], rec["status"] = "failure", "NOT_CONVERGED"
+            return rec
+        odom = pose(T[0, 2], T[1, 2], np.arctan2(T[1, 0], T[0, 0]))
+        rec["icp"], rec["cov"] = "success", None
+    rec["transform"] = (odom[0], odom[1], theta(odom))
+    d = between(initial, odom)
+    if float(np.hypot(d[0], d[1])) > P["max_translation"] or abs(theta(d)) > P["max_rotation"]:
+        rec["status"] = "LARGE_TRANSFORMATION"
+        return rec
+    rec["overlap"] = oracle.overlap(source_points, target_local, matrix(odom), point_noise, f64_points=False)
+    rec["status"] = "SUCCESS" if rec["overlap"] >= P["min_points"] else "NOT_ENOUGH_OVERLAP"
+    return rec
+
+
+def chain_covariance(prev_cov, kind):
+    """the stand-in of replay.ChainBackend.marginal_covariance (an INPUT of the loop-closure search)"""
+    sig = {"prior": (0.1, 0.1, 0.01), "icp": (0.1, 0.1, 0.01), "odometry": (0.2, 0.2, 0.02)}[kind]
+    add = np.diag(np.square(sig))
+    return add if prev_cov is None else prev_cov + add
+
+
 # ---- the SLAM node ----
 def run_session(clouds, dr, icp_params, point_resolution=0.5, point_noise=0.5, ssm_min_points=50,
-                ssm_max_translation=3.0, ssm_max_rotation=np.deg2rad(30), ssm_target_frames=3):
+                ssm_max_translation=3.0, ssm_max_rotation=np.deg2rad(30), ssm_target_frames=3, initialization=False,
+                initialization_params=(50, 1, 0.01), odom_sigmas=(0.2, 0.2, 0.02), nssm=None):
     """clouds: per keyframe the SLAM node's cloud (``slam_cloud``); dr: [K x 3] dead-reckoned poses; icp_params:
-    oracle.IcpParams.  -> list of records (status, sizes, ICP status / iterations / T, overlap, transform, pose)."""
+    oracle.IcpParams.  -> list of records (status, sizes, ICP status / iterations / T, overlap, transform, pose).
+    initialization: the shgo global initialisation in front of every scan match (the reference's default, slam.py:77);
+    nssm: dict of loop-closure parameters (NSSM_DEFAULTS) -> every record carries the search's record under "nssm"."""
     K = len(clouds)
     drp = [pose(*d) for d in dr]
-    poses, recs = [], []
+    poses, recs, covs = [], [], []
     for k in range(K):
         if k == 0:
             poses.append(drp[0])
+            covs.append(chain_covariance(None, "prior"))
             recs.append({"k": 0, "status": "PRIOR", "n_source": len(clouds[0]), "pose": (drp[0][0], drp[0][1], theta(drp[0]))})
             continue
         prev = poses[k - 1]
@@ -109,6 +315,18 @@ def run_session(clouds, dr, icp_params, point_resolution=0.5, point_noise=0.5, s
             rec["status"] = "NOT_ENOUGH_POINTS"
         else:
             initial = between(prev, cur)
+            if initialization:                                                  # slam.py:665-716
+                pose_stds = np.array([odom_sigmas]).T
+                pose_bounds = 5.0 * np.c_[-pose_stds, pose_stds]
+                sub, _ = matching_cost_subroutine(source, cur, target, prev, point_noise, f64_points=True)
+                result = run_shgo(sub, pose_bounds, initialization_params)
+                rec["init_success"] = bool(result.success)
+                if result.success:
+                    rec["init_x"], rec["init_cost"] = tuple(float(v) for v in result.x), float(result.fun)
+                    initial = between(prev, compose(cur, pose(*result.x)))
+        if "status" not in rec and initialization and not rec["init_success"]:
+            rec["status"] = "INITIALIZATION_FAILURE"
+        elif "status" not in rec:
             st, T, it = oracle.icp(source, target, matrix(initial).astype(np.float32), icp_params)
             rec.update(icp_status=st, iters=it, T=T)
             th32 = np.arctan2(T[1, 0], T[0, 0])
@@ -127,6 +345,10 @@ def run_session(clouds, dr, icp_params, point_resolution=0.5, point_noise=0.5, s
             if status == "SUCCESS":
                 new_pose = compose(prev, est)
         poses.append(new_pose)
+        covs.append(chain_covariance(covs[-1], "icp" if rec["status"] == "SUCCESS" else "odometry"))
         rec["pose"] = (new_pose[0], new_pose[1], theta(new_pose))
+        if nssm is not None:
+            # slam_ros.py:207 with self.current_frame still the frame of the previous callback (:211), i.e. keyframe k - 1
+            rec["nssm"] = nssm_search(clouds[:k + 1], poses, covs, poses[k - 1], icp_params, point_resolution, point_noise, **nssm)
         recs.append(rec)
     return recs

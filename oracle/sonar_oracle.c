@@ -1123,31 +1123,51 @@ void orc_cost_grid(const int32_t *tr, const int32_t *tc, int n_tgt, int rows, in
     free(j2);
 }
 
-/* T6 per pose: T00 T01 T02 T10 T11 T12 (float32 of pose.matrix()); cost_out[p] = -hits */
-void orc_matching_cost(const uint8_t *grid, int rows, int cols, const float *src, int n_src, const float *T6,
-                       int n_poses, float xmin, float ymin, float res, int32_t *cost_out)
+/* T6 per pose: T00 T01 T02 T10 T11 T12 (float32 of pose.matrix()); cost_out[p] = -hits.
+ * slam.py:549-562 in the dtype numpy evaluates it in:
+ *   f64_points == 0: `source_points` is a float32 array (what get_points returns): transform_points through sgemm
+ *     (fma over k, see orc_transform_points), (p - min) / resolution in float32 with float32(resolution);
+ *   f64_points != 0: a float64 array of float32 values (the SLAM node's keyframe clouds, slam_ros.py:169-170): products
+ *     exact in double, one rounding of their sum, translation added in double, (p - float32 min) / resolution in double
+ *     with the Python float resolution. */
+void orc_matching_cost2(const uint8_t *grid, int rows, int cols, const float *src, int n_src, const float *T6,
+                        int n_poses, float xmin, float ymin, double res, int f64_points, int32_t *cost_out)
 {
+    const float res32 = (float)res;
     for (int p = 0; p < n_poses; ++p) {
         const float *T = T6 + 6 * (size_t)p;
         int hits = 0;
         for (int i = 0; i < n_src; ++i) {
             const float px = src[2 * i], py = src[2 * i + 1];
-            volatile float a = px * T[0], b = py * T[1];
-            volatile float s = a + b;
-            const float x = s + T[2];
-            a = px * T[3];
-            b = py * T[4];
-            s = a + b;
-            const float y = s + T[5];
-            volatile float ux = x - xmin, uy = y - ymin;
-            const float qx = ux / res, qy = uy / res;
-            const double rc = rint((double)qx), rr = rint((double)qy);
+            double rc, rr;
+            if (f64_points) {
+                volatile double x = ((double)px * (double)T[0] + (double)py * (double)T[1]) + (double)T[2];
+                volatile double y = ((double)px * (double)T[3] + (double)py * (double)T[4]) + (double)T[5];
+                volatile double ux = x - (double)xmin, uy = y - (double)ymin;
+                rc = rint(ux / res);
+                rr = rint(uy / res);
+            } else {
+                volatile float a = px * T[0];
+                const float x = fmaf(py, T[1], a) + T[2];
+                a = px * T[3];
+                const float y = fmaf(py, T[4], a) + T[5];
+                volatile float ux = x - xmin, uy = y - ymin;
+                const float qx = ux / res32, qy = uy / res32;
+                rc = rint((double)qx);
+                rr = rint((double)qy);
+            }
             if (!(rr >= 0 && rr < rows && rc >= 0 && rc < cols))
                 continue; /* also NaN */
             hits += grid[(size_t)(int)rr * cols + (int)rc] > 0;
         }
         cost_out[p] = -hits;
     }
+}
+
+void orc_matching_cost(const uint8_t *grid, int rows, int cols, const float *src, int n_src, const float *T6,
+                       int n_poses, float xmin, float ymin, float res, int32_t *cost_out)
+{
+    orc_matching_cost2(grid, rows, cols, src, n_src, T6, n_poses, xmin, ymin, (double)res, 0, cost_out);
 }
 
 /* ------------------------------------------------------------------------- */

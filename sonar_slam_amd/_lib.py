@@ -144,9 +144,19 @@ SIGNATURES = {
                                                  _i32p, _i32p, _i32p, _f32p, _u8p]),
     "sfe_costgrid_create": (C.c_int, [_vp, _i32p, _i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     "sfe_costgrid_destroy": (None, [_vp]),
-    "sfe_costgrid_download": (C.c_int, [_vp, _vp, _u8p]),
+    "sfe_costgrid_download": (C.c_int, [_vp, _vp, C.c_int, _u8p]),
     "sfe_matching_cost_batch": (C.c_int, [_vp, _vp, _f32p, C.c_int, _f32p, C.c_int, C.c_float, C.c_float,
-                                          C.c_float, _i32p]),
+                                          C.c_double, C.c_int, _i32p]),
+    "sfe_costgrid_create_store": (C.c_int, [_vp, _vp, _i32p, C.c_int, _f32p, _f32p, C.c_float, _i32p, _i32p, C.c_int,
+                                            C.POINTER(_vp)]),
+    "sfe_matching_cost_store": (C.c_int, [_vp, _vp, _vp, _i32p, _i32p, C.c_int, _f32p, C.c_int, C.c_double, C.c_int, _i32p]),
+    "sfe_cloud_store_bbox": (C.c_int, [_vp, _vp, _i32p, C.c_int, _f32p]),
+    "sfe_cloud_store_get_points_keys": (C.c_int, [_vp, _vp, _i32p, _f32p, _i32p, C.c_int, C.c_float, C.c_int, C.c_int64, _i32p]),
+    "sfe_cloud_store_read_keys": (C.c_int, [_vp, _vp, C.c_int32, _i32p, C.c_int, C.POINTER(C.c_int)]),
+    "sfe_cloud_store_fov_select": (C.c_int, [_vp, _vp, C.c_int32, _f32p, _f64p, _f64p, C.c_int, C.c_int, _i32p, _i32p, _i32p]),
+    "sfe_cloud_store_set_selection": (C.c_int, [_vp, _vp, C.c_int32, _u8p, C.c_int]),
+    "sfe_cloud_store_compact_selected": (C.c_int, [_vp, _vp, C.c_int32, C.c_int64, _i32p]),
+    "sfe_cloud_store_match_keys": (C.c_int, [_vp, _vp, C.c_int32, _f32p, C.c_int32, C.c_float, C.c_int, C.c_int, _i32p, _i32p]),
 }
 
 _lib = None

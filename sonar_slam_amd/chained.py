@@ -17,6 +17,14 @@ ssm_min_points / max translation / max rotation / overlap tests, the factor list
 exactly the arithmetic of ``pose2.Pose2`` (so a session's records equal those of ``replay.FrontEnd`` on the same
 pings bit for bit: tests/test_gpu_store.py).  Per step three small synchronisations (cloud sizes; scan-match
 results; overlap counts); no cloud crosses PCIe.
+
+``initialization=True`` adds the reference's default step in front of every scan match (slam.py:77, :665-716): the
+global initialisation by ``scipy.optimize.shgo`` over the matching cost.  shgo itself is host Python per session (its
+Delaunay / minimiser-pool bookkeeping: tens of milliseconds per call, far more than the scoring); what the device
+takes is the cost function: the target grids of all S sessions are built in one launch, shgo's sampling points -- the
+same Sobol set for every session, since the bounds are the odometry sigmas -- are scored for all sessions in one more
+(``matching_cost.batch_store``), and each session's shgo then runs on that table; the handful of further points its
+local minimiser asks for (finite-difference neighbours) are scored one call each.
 """
 import math
 
@@ -101,7 +109,8 @@ class SessionBatch(object):
     def __init__(self, ctx, geometry, cfar_params, alg, intensity_thr, icp_params, n_sessions, n_steps, dr_poses,
                  max_points=16384, resolution=0.5, outlier_radius=1.0, outlier_min_points=5, point_resolution=0.5,
                  point_noise=0.5, ssm_min_points=50, ssm_max_translation=3.0, ssm_max_rotation=np.deg2rad(30),
-                 ssm_target_frames=3, store_points=None):
+                 ssm_target_frames=3, store_points=None, initialization=False, initialization_params=(50, 1, 0.01),
+                 odom_sigmas=(0.2, 0.2, 0.02)):
         from .pipeline import KeyframeBatch
         self.ctx, self.S, self.K = ctx, int(n_sessions), int(n_steps)
         self.icp_params = icp_params
@@ -119,6 +128,10 @@ class SessionBatch(object):
         dr = np.asarray(dr_poses, np.float64).reshape(self.S, self.K, 3)
         self.dr = [Pose2Batch(dr[:, k, 0], dr[:, k, 1], dr[:, k, 2]) for k in range(self.K)]
         self.max_raw = 0
+        self.initialization, self.initialization_params = initialization, tuple(initialization_params)
+        self.odom_sigmas = np.array(odom_sigmas, np.float64)
+        self._sobol = None
+        self.init_stats = {"shgo_s": 0.0, "cost_calls": 0, "table_hits": 0}
         self.reset()
 
     def upload_frames(self, k, frames):
@@ -180,6 +193,13 @@ class SessionBatch(object):
             th[:, j] = self.handles[:, key]
             T6[:, j] = prev.between(self.poses[key]).T6()
         n_keep = len(store)
+        try:
+            return self._scan_match_step(k, rec, src_h, th, T6, prev, pose)
+        finally:
+            store.truncate(n_keep)                                          # the targets are dropped, the keyframes stay
+
+    def _scan_match_step(self, k, rec, src_h, th, T6, prev, pose):
+        S, store = self.S, self.store
         tgt_h = store.get_points(th, T6, self.point_resolution)
         counts = store.counts(np.concatenate([src_h, tgt_h]))
         n_src, n_tgt = counts[:S], counts[S:]
@@ -197,6 +217,16 @@ class SessionBatch(object):
         iters = np.zeros(S, np.int32)
         overlap = np.full(S, -1, np.int32)
         est = Pose2Batch(dr_between.x.copy(), dr_between.y.copy(), cs=(dr_between.c.copy(), dr_between.s.copy()))
+        if self.initialization and len(idx):
+            # slam.py:665-716: ICP starts from the pose shgo found; a failed initialisation leaves the odometry factor
+            ok_init, est_src, xs, fs = self._global_init(idx, src_h, tgt_h, pose, prev)
+            rec["init_success"] = np.zeros(S, bool)
+            rec["init_success"][idx] = ok_init
+            rec["init_x"], rec["init_cost"] = np.zeros((S, 3)), np.zeros(S)
+            rec["init_x"][idx], rec["init_cost"][idx] = xs, fs
+            rec["status"][idx[~ok_init]] = INITIALIZATION_FAILURE
+            initial.put(idx[ok_init], prev.take(idx[ok_init]).between(est_src.take(np.nonzero(ok_init)[0])))
+            idx = idx[ok_init]
         if len(idx):
             pairs = np.stack([src_h[idx], tgt_h[idx]], axis=1)
             Ti, sti, iti = store.icp(self.icp_params, pairs, initial.take(idx).matrix32())
@@ -221,11 +251,82 @@ class SessionBatch(object):
         if len(gi):
             new_pose.put(gi, prev.take(gi).compose(est.take(gi)))
         self.poses[k] = new_pose
-        store.truncate(n_keep)                                              # the targets are dropped, the keyframes stay
         rec.update(T=T, icp_status=icp_status, iters=iters, overlap=overlap, transform=est.xytheta(),
                    pose=new_pose.xytheta())
         self.records.append(rec)
         return rec
+
+    # -- global initialisation (slam.py:665-716) for the sessions `idx` --
+    def _sobol_points(self, pose_bounds):
+        """the points shgo's first sampling stage evaluates for these bounds and parameters: the same for every session
+        and every step, so they are asked for once (a dry run of shgo whose `workers` hook stops at the first pool)"""
+        from scipy.optimize import shgo
+        if self._sobol is None:
+            class _Stop(Exception):
+                pass
+            got = []
+
+            def pool(_fn, xs):
+                got.extend(np.asarray(x, np.float64).copy() for x in xs)
+                raise _Stop()
+            try:
+                shgo(func=lambda x: 0.0, bounds=pose_bounds, n=self.initialization_params[0], iters=self.initialization_params[1],
+                     sampling_method="sobol", minimizer_kwargs={"options": {"ftol": self.initialization_params[2]}}, workers=pool)
+            except _Stop:
+                pass
+            self._sobol = np.array(got, np.float64).reshape(-1, 3)
+        return self._sobol
+
+    def _global_init(self, idx, src_h, tgt_h, pose, prev):
+        """-> (success [n], estimated source poses Pose2Batch [n], result.x [n x 3], result.fun [n]) for sessions idx"""
+        import time
+        from scipy.optimize import shgo
+        from . import matching_cost as mc
+        n = len(idx)
+        pose_stds = np.array([self.odom_sigmas]).T
+        pose_bounds = 5.0 * np.c_[-pose_stds, pose_stds]
+        X0 = self._sobol_points(pose_bounds)
+        src_pose, tgt_pose = pose.take(idx), prev.take(idx)
+
+        def transforms(sel, X):
+            """T6 [len(sel) x len(X) x 6] of target_pose.between(source_pose.compose(n2g(x))) (slam.py:548-550)"""
+            m = len(sel)
+            out = np.zeros((m, len(X), 6), np.float32)
+            sp, tp = src_pose.take(sel), tgt_pose.take(sel)
+            for j, x in enumerate(X):
+                d = Pose2Batch(np.full(m, x[0]), np.full(m, x[1]), np.full(m, x[2]))
+                out[:, j] = tp.between(sp.compose(d)).T6()
+            return out
+        grids = mc._StoreGrids(self.store, tgt_h[idx], self.point_noise)
+        try:
+            table = grids.cost(src_h[idx], transforms(np.arange(n), X0), f64_points=True)      # [n x len(X0)]: one launch
+            keys = [x.tobytes() for x in X0]
+            ok, xs, fs = np.zeros(n, bool), np.zeros((n, 3)), np.zeros(n)
+            t0 = time.perf_counter()
+            for i in range(n):
+                cache = dict(zip(keys, table[i]))
+
+                def f(x, i=i, cache=cache):
+                    x = np.asarray(x, np.float64)
+                    v = cache.get(x.tobytes())
+                    if v is None:
+                        v = grids.cost(src_h[idx[i:i + 1]], transforms(np.array([i]), [x]), True, grid_index=[i])[0, 0]
+                        cache[x.tobytes()] = v
+                        self.init_stats["cost_calls"] += 1
+                    else:
+                        self.init_stats["table_hits"] += 1
+                    return np.int64(v)
+                res = shgo(func=f, bounds=pose_bounds, n=self.initialization_params[0], iters=self.initialization_params[1],
+                           sampling_method="sobol", minimizer_kwargs={"options": {"ftol": self.initialization_params[2]}},
+                           workers=lambda _fn, pts: [f(p) for p in pts])
+                ok[i] = bool(res.success)
+                if res.success:
+                    xs[i], fs[i] = res.x, res.fun
+            self.init_stats["shgo_s"] += time.perf_counter() - t0
+        finally:
+            grids.close()
+        est = src_pose.compose(Pose2Batch(xs[:, 0], xs[:, 1], xs[:, 2]))
+        return ok, est, xs, fs
 
     def _check_raw(self, k):
         """a ping with more detections than the batch's point capacity would be truncated silently"""
@@ -255,5 +356,6 @@ class SessionBatch(object):
         self.store.close()
 
 
-PRIOR, SUCCESS, NOT_ENOUGH_POINTS, NOT_CONVERGED, LARGE_TRANSFORMATION, NOT_ENOUGH_OVERLAP = range(6)
-STATUS_NAMES = ("PRIOR", "SUCCESS", "NOT_ENOUGH_POINTS", "NOT_CONVERGED", "LARGE_TRANSFORMATION", "NOT_ENOUGH_OVERLAP")
+PRIOR, SUCCESS, NOT_ENOUGH_POINTS, NOT_CONVERGED, LARGE_TRANSFORMATION, NOT_ENOUGH_OVERLAP, INITIALIZATION_FAILURE = range(7)
+STATUS_NAMES = ("PRIOR", "SUCCESS", "NOT_ENOUGH_POINTS", "NOT_CONVERGED", "LARGE_TRANSFORMATION", "NOT_ENOUGH_OVERLAP",
+                "INITIALIZATION_FAILURE")

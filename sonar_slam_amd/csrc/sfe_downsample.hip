@@ -19,11 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 
-struct DsHeader {
-    float cx, cy, radius;
-    int levels;
-    int n_seg;
-};
+typedef SfeDsHeader DsHeader; // {cx, cy, radius, levels, n_seg}: sfe_internal.h
 
 #define DS_MAX_LEVELS 31
 
@@ -194,6 +190,35 @@ __global__ __launch_bounds__(256) void ds_medoid_kernel(const float2 *__restrict
     out_idx[s] = bi;
 }
 
+// The chain above on a cloud that is already on the device (sfe_store.hip: targets beyond the resident filter's capacity,
+// and the descriptor overload of pcl.downsample, which needs the indices).  Enqueue only: d_out / d_out_idx hold the
+// medoids and their indices into d_pts, d_hdr->n_seg their number.  Scratch slots 1-4.
+int sfe_ds_run_dev(sfe_ctx *ctx, const float *d_pts_, int n, float resolution, float *d_out_, int32_t *d_out_idx,
+                   SfeDsHeader *d_hdr_)
+{
+    const float2 *d_pts = (const float2 *)d_pts_;
+    float2 *d_out = (float2 *)d_out_;
+    DsHeader *d_hdr = (DsHeader *)d_hdr_;
+    char buf[64];
+    snprintf(buf, sizeof buf, "%f", (double)resolution); // pcl.cpp:134: std::to_string(float)
+    const float max_size = strtof(buf, nullptr);
+    unsigned long long *d_keys = (unsigned long long *)sfe_scratch(ctx, 1, 8 * (size_t)n);
+    unsigned long long *d_skeys = (unsigned long long *)sfe_scratch(ctx, 2, 8 * (size_t)n);
+    int *d_sidx = (int *)sfe_scratch(ctx, 3, 4 * (size_t)n);
+    int *d_seg = (int *)sfe_scratch(ctx, 4, 4 * ((size_t)n + 1));
+    if (!d_keys || !d_skeys || !d_sidx || !d_seg)
+        return SFE_ERR_HIP;
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(ds_bbox_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_pts, n, max_size, d_hdr);
+    hipLaunchKernelGGL(ds_key_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_pts, n, d_hdr, d_keys);
+    hipLaunchKernelGGL(ds_rank_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_keys, n, d_sidx, d_skeys);
+    hipLaunchKernelGGL(ds_segment_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_skeys, n, d_seg, d_hdr);
+    hipLaunchKernelGGL(ds_medoid_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_pts, d_sidx, d_seg, d_hdr, d_out,
+                       d_out_idx);
+    SFE_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
 extern "C" {
 
 int sfe_downsample(sfe_ctx *ctx, const float *pts, int n, float resolution, float *out, int32_t *out_idx,
@@ -205,11 +230,6 @@ int sfe_downsample(sfe_ctx *ctx, const float *pts, int n, float resolution, floa
     *n_out = 0;
     if (n == 0)
         return 0; // pcl.cpp:130-131
-    // pcl.cpp:134 hands the resolution over as std::to_string(float): six decimals survive
-    char buf[64];
-    snprintf(buf, sizeof buf, "%f", (double)resolution);
-    const float max_size = strtof(buf, nullptr);
-
     // Without the indices (pcl.downsample(points, resolution), the call of every ping and every get_points; only the
     // descriptor overload needs them) the cloud goes through the resident batch path as a batch of one: radix / bitonic
     // sort in LDS instead of the rank counting below (every point against every point: 0.65 ms for an 11 000-point
@@ -246,24 +266,14 @@ int sfe_downsample(sfe_ctx *ctx, const float *pts, int n, float resolution, floa
         // (-1: an octree deeper than 24 levels -- the rank counting below handles any depth)
     }
     float2 *d_pts = (float2 *)sfe_scratch(ctx, 0, sizeof(float2) * (size_t)n);
-    unsigned long long *d_keys = (unsigned long long *)sfe_scratch(ctx, 1, 8 * (size_t)n);
-    unsigned long long *d_skeys = (unsigned long long *)sfe_scratch(ctx, 2, 8 * (size_t)n);
-    int *d_sidx = (int *)sfe_scratch(ctx, 3, 4 * (size_t)n);
-    int *d_seg = (int *)sfe_scratch(ctx, 4, 4 * ((size_t)n + 1));
     float2 *d_out = (float2 *)sfe_scratch(ctx, 5, sizeof(float2) * (size_t)n);
     int *d_oidx = (int *)sfe_scratch(ctx, 6, 4 * (size_t)n);
     DsHeader *d_hdr = (DsHeader *)sfe_scratch(ctx, 7, sizeof(DsHeader));
-    if (!d_pts || !d_keys || !d_skeys || !d_sidx || !d_seg || !d_out || !d_oidx || !d_hdr)
+    if (!d_pts || !d_out || !d_oidx || !d_hdr)
         return SFE_ERR_HIP;
     SFE_HIP(ctx, hipMemcpyAsync(d_pts, pts, sizeof(float2) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-    const unsigned nb = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(ds_bbox_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_pts, n, max_size, d_hdr);
-    hipLaunchKernelGGL(ds_key_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_pts, n, d_hdr, d_keys);
-    hipLaunchKernelGGL(ds_rank_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_keys, n, d_sidx, d_skeys);
-    hipLaunchKernelGGL(ds_segment_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_skeys, n, d_seg, d_hdr);
-    hipLaunchKernelGGL(ds_medoid_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_pts, d_sidx, d_seg, d_hdr, d_out,
-                       d_oidx);
-    SFE_LAUNCH_CHECK(ctx);
+    if (int rc = sfe_ds_run_dev(ctx, (const float *)d_pts, n, resolution, (float *)d_out, d_oidx, (SfeDsHeader *)d_hdr))
+        return rc;
     DsHeader h;
     SFE_HIP(ctx, hipMemcpyAsync(&h, d_hdr, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     SFE_HIP(ctx, hipStreamSynchronize(ctx->stream));

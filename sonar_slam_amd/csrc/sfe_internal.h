@@ -125,6 +125,30 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
 struct sfe_cloud_store;
 int sfe_store_append_dev(sfe_cloud_store *s, const int64_t *stamps, const float *d_clouds, const int32_t *d_counts,
                          int n_frames, int64_t cap, int flags, int32_t *handles_out);
+// ... the count its commit wrote for a slot (< 0: SFE_STORE_*), copied in stream order to pinned memory; the store's context
+int sfe_store_slot_count_async(sfe_cloud_store *s, int32_t handle, int32_t *h_pinned);
+sfe_ctx *sfe_store_ctx(sfe_cloud_store *s);
+
+// what a store is made of, for the other translation units that read clouds by handle (sfe_cost.hip); syncs the host
+// mirror of the slot table first
+struct SfeStoreView {
+    const void *d_pool;     // float2 points
+    const int64_t *d_off;   // device slot table
+    const int32_t *d_cnt;
+    const int64_t *off;     // host mirror (valid for slots < n_slots)
+    const int32_t *cnt;
+    int n_slots;
+};
+int sfe_store_view(sfe_cloud_store *s, SfeStoreView *v);
+
+// sfe_downsample.hip: pcl.downsample with indices on a device-resident cloud of any size (rank sort in global memory)
+struct SfeDsHeader {
+    float cx, cy, radius;
+    int levels;
+    int n_seg;
+};
+int sfe_ds_run_dev(sfe_ctx *ctx, const float *d_pts, int n, float resolution, float *d_out, int32_t *d_out_idx,
+                   SfeDsHeader *d_hdr);
 
 static inline int sfe_use(sfe_ctx *ctx)
 {

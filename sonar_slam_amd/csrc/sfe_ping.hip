@@ -83,18 +83,24 @@ static int ping_impl(sfe_ctx *ctx, sfe_geom *g, sfe_cloud_store *store, int64_t 
     // the points come down only when somebody wants them on the host
     const size_t b_down = 16 + ((!store || cloud_out) ? (size_t)cap * 8 : 0);
     SFE_HIP(ctx, hipMemcpyAsync(h_res, d_res, b_down, hipMemcpyDeviceToHost, ctx->stream));
+    // ... and what the store made of the cloud: the slot's own count (-3: the pool is full), behind the block above in
+    // stream order, into the unused third word of its header
+    if (store)
+        if (int rc = sfe_store_slot_count_async(store, handle, reinterpret_cast<int32_t *>(h_res) + 2))
+            return rc;
     if (vis_out)
         SFE_HIP(ctx, hipMemcpyAsync(h_res + 16 + (size_t)cap * 8, d_vis, nvis, hipMemcpyDeviceToHost, ctx->stream));
     SFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const int32_t n_raw = reinterpret_cast<int32_t *>(h_res)[0], n = reinterpret_cast<int32_t *>(h_res)[1];
+    const int32_t n_slot = store ? reinterpret_cast<int32_t *>(h_res)[2] : n;
     if (n_raw_out)
         *n_raw_out = n_raw;
     if (vis_out)
         memcpy(vis_out, h_res + 16 + (size_t)cap * 8, nvis);
     if (handle_out)
         *handle_out = handle;
-    if (n_raw > cap || n < 0) {
-        if (store) { // no slot for a cloud that is truncated or was refused
+    if (n_raw > cap || n < 0 || n_slot < 0) {
+        if (store) { // no slot for a cloud that is truncated, was refused or did not fit the pool
             if (int rc = sfe_cloud_store_truncate(ctx, store, handle))
                 return rc;
             if (handle_out)
@@ -103,6 +109,10 @@ static int ping_impl(sfe_ctx *ctx, sfe_geom *g, sfe_cloud_store *store, int64_t 
         if (n_raw > cap) {
             *n_out = 0;
             return sfe_set_err(ctx, SFE_ERR_CAP, "feature_extract_ping: %d points exceed capacity %lld", n_raw, (long long)cap);
+        }
+        if (n >= 0) { // the filters delivered, the store had no room: a full pool is an error, not an empty cloud
+            *n_out = 0;
+            return sfe_set_err(ctx, SFE_ERR_CAP, "feature_extract_ping: the cloud store is full (%d points did not fit its pool)", n);
         }
         *n_out = -1; // octree deeper than 24 levels (sfe_cloud_filter_batch_dev): the caller takes the per-cloud path
         return 0;
@@ -134,6 +144,7 @@ extern "C" int sfe_feature_extract_ping_store(sfe_ctx *ctx, sfe_geom *g, sfe_clo
     if (int rc = sfe_use(ctx))
         return rc;
     SFE_ARG(ctx, g && img && n_out && g->ctx == ctx && cap > 0 && cap <= 65536 && (s ? handle_out != nullptr : cloud_out != nullptr));
+    SFE_ARG(ctx, !s || sfe_store_ctx(s) == ctx); // the append runs on the store's stream: it must be the filters' stream
     return ping_impl(ctx, g, s, stamp, flags, img, alg, train_hs, guard_hs, k, tau, intensity_thr, resolution, radius,
                      min_points, cap, cloud_out, n_out, n_raw_out, vis_out, handle_out);
 }

@@ -13,6 +13,16 @@ run on the GPU:
 evaluates ``n`` points before any local minimisation: slam.py:692-701 passes n =
 initialization_params[0]); ``subroutine(x)`` is ``batch([x])[0]``.
 
+``get_matching_cost_subroutine1_store`` is the same over handles of a ``store.CloudStore``: the target
+grid is built on the device from the target handle (only the cloud's bounding box comes down, for the numpy
+bookkeeping of slam.py:506-511), the source cloud is read where it lies.  ``batch_store`` builds the grids of MANY
+(source, target) pairs at once and scores all their candidate poses in one launch (chained.SessionBatch).
+
+dtypes.  numpy evaluates slam.py:549-562 in the dtype of ``source_points``: float32 clouds (what get_points returns: the
+NSSM source) in float32 -- the transform through sgemm -- and the SLAM node's keyframe clouds (float64 arrays of float32
+values, slam_ros.py:169-170: the SSM source) in double.  Both are implemented (``SFE_COST_F64_POINTS``) and chosen from
+the array's dtype; over handles the caller says which one the cloud stands for (``f64_points``).
+
 Poses: any object with gtsam.Pose2's ``compose / between / matrix / x / y / theta`` is used through
 those methods (so with the real gtsam installed the host-side pose algebra IS gtsam's); plain
 ``(x, y, theta)`` triples go through ``pose2.Pose2``, a restatement of gtsam's Pose2/Rot2 algebra
@@ -70,9 +80,13 @@ def get_matching_cost_subroutine1(source_points, source_pose, target_points, tar
         ctx._check(ctx.lib.sfe_costgrid_create(ctx.handle, _L.ptr(r, _C.c_int32), _L.ptr(c, _C.c_int32), len(r),
                                                rows, cols, dilate_hs, _C.byref(handle)))
     grid = _Grid(ctx, handle, rows, cols)
-    # the division / subtraction happen in the points' dtype in the reference (float32 clouds)
+    # the division / subtraction happen in the points' dtype in the reference: float32 for float32 clouds, double for
+    # the SLAM node's float64 keyframe clouds (whose values are float32 numbers: slam_ros.py:169-170)
     f32 = np.float32
+    flags = F64_POINTS if source_points.dtype == np.float64 else 0
     src32 = np.ascontiguousarray(source_points, f32).reshape(-1, 2)
+    if flags and not np.array_equal(src32.astype(np.float64).reshape(-1), np.asarray(source_points, np.float64).reshape(-1)):
+        raise ValueError("float64 source clouds must hold float32 values (slam_ros.py:169-170); cast the cloud to float32 first")
     x0, y0, res32 = f32(xmin), f32(ymin), f32(resolution)
 
     def batch(X):
@@ -89,7 +103,7 @@ def get_matching_cost_subroutine1(source_points, source_pose, target_points, tar
         cost = np.zeros(len(X), np.int32)
         with ctx.lock:
             ctx._check(ctx.lib.sfe_matching_cost_batch(ctx.handle, grid.handle, _L.ptr(src32, _C.c_float), len(src32),
-                                                       _L.ptr(T6, _C.c_float), len(T6), x0, y0, res32,
+                                                       _L.ptr(T6, _C.c_float), len(T6), x0, y0, float(resolution), flags,
                                                        _L.ptr(cost, _C.c_int32)))
         for sp, cst in zip(sample_poses, cost):
             pose_samples.append(np.r_[[sp.x(), sp.y(), sp.theta()], cst])   # np.r_[g2n(pose), cost]
@@ -105,6 +119,122 @@ def get_matching_cost_subroutine1(source_points, source_pose, target_points, tar
     return subroutine, pose_samples
 
 
+F64_POINTS = 1      # SFE_COST_F64_POINTS
+
+
+def grid_geometry(bbox, point_noise):
+    """slam.py:506-511 + :521 from a cloud's bounding box (min x, min y, max x, max y as the float32 numbers np.min /
+    np.max of the float32 cloud give): numpy verbatim -> (xmin, ymin, resolution, rows, cols, dilate_hs)"""
+    mn = np.array([bbox[0], bbox[1]], np.float32)
+    mx = np.array([bbox[2], bbox[3]], np.float32)
+    xmin, ymin = mn - 2 * point_noise
+    xmax, ymax = mx + 2 * point_noise
+    resolution = point_noise / 10.0
+    xs = np.arange(xmin, xmax, resolution)
+    ys = np.arange(ymin, ymax, resolution)
+    return xmin, ymin, resolution, len(ys), len(xs), int(np.ceil(point_noise / resolution))
+
+
+def batch_store(store, source_handles, target_handles, T6, point_noise=0.5, f64_points=True):
+    """Costs of n_poses candidate transforms for each of n (source, target) pairs of ``store`` in ONE launch: T6
+    [n x n_poses x 6] float32 (``store.pose_T6`` of sample_transform).  -> (costs [n x n_poses] int32, grids): ``grids``
+    can score further poses of the same pairs (``grids.cost``) and must be closed."""
+    grids = _StoreGrids(store, target_handles, point_noise)
+    return grids.cost(source_handles, T6, f64_points), grids
+
+
+class _StoreGrids(object):
+    """the dilated target grids of n store clouds (slam.py:505-527), device-resident"""
+
+    def __init__(self, store, target_handles, point_noise):
+        self.store, self.ctx = store, store.ctx
+        th = np.ascontiguousarray(target_handles, np.int32).reshape(-1)
+        self.n = len(th)
+        bbox = store.bbox(th)
+        geo = [grid_geometry(b, point_noise) for b in bbox]
+        self.xmin = np.array([g[0] for g in geo], np.float32)
+        self.ymin = np.array([g[1] for g in geo], np.float32)
+        self.resolution = float(geo[0][2])
+        self.rows = np.array([g[3] for g in geo], np.int32)
+        self.cols = np.array([g[4] for g in geo], np.int32)
+        self.dilate_hs = int(geo[0][5])
+        h = _C.c_void_p()
+        with self.ctx.lock:
+            self.ctx._check(self.ctx.lib.sfe_costgrid_create_store(
+                self.ctx.handle, store.handle, _L.ptr(th, _C.c_int32), self.n, _L.ptr(self.xmin, _C.c_float),
+                _L.ptr(self.ymin, _C.c_float), np.float32(self.resolution), _L.ptr(self.rows, _C.c_int32),
+                _L.ptr(self.cols, _C.c_int32), self.dilate_hs, _C.byref(h)))
+        self.handle = h
+
+    def cost(self, source_handles, T6, f64_points=True, grid_index=None):
+        """costs [n_jobs x n_poses]: job i = source cloud source_handles[i] against grid grid_index[i] (default: grid i)"""
+        sh = np.ascontiguousarray(source_handles, np.int32).reshape(-1)
+        gi = None if grid_index is None else np.ascontiguousarray(grid_index, np.int32).reshape(-1)
+        assert len(sh) == (self.n if gi is None else len(gi))
+        T6 = np.ascontiguousarray(T6, np.float32).reshape(len(sh), -1, 6)
+        out = np.zeros((len(sh), T6.shape[1]), np.int32)
+        with self.ctx.lock:
+            self.ctx._check(self.ctx.lib.sfe_matching_cost_store(
+                self.ctx.handle, self.handle, self.store.handle, _L.ptr(sh, _C.c_int32),
+                None if gi is None else _L.ptr(gi, _C.c_int32), len(sh), _L.ptr(T6, _C.c_float), T6.shape[1],
+                self.resolution, F64_POINTS if f64_points else 0, _L.ptr(out, _C.c_int32)))
+        return out
+
+    def download(self, index=0):
+        out = np.zeros((int(self.rows[index]), int(self.cols[index])), np.uint8)
+        with self.ctx.lock:
+            self.ctx._check(self.ctx.lib.sfe_costgrid_download(self.ctx.handle, self.handle, int(index), _L.ptr(out, _C.c_uint8)))
+        return out
+
+    def close(self):
+        if self.handle is not None and self.ctx.handle is not None:
+            self.ctx.lib.sfe_costgrid_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def get_matching_cost_subroutine1_store(store, source_handle, source_pose, target_handle, target_pose, source_pose_cov=None,
+                                        point_noise=0.5, f64_points=True):
+    """``get_matching_cost_subroutine1`` (slam.py:461-570) for two clouds of a ``store.CloudStore``: -> (subroutine,
+    pose_samples) with ``subroutine.batch``.  ``f64_points``: the SOURCE handle stands for a keyframe cloud of the SLAM node
+    (float64 array of float32 values: the sequential scan match, slam.py:683-689); False for a cloud get_points returned
+    (float32: the loop-closure search, slam.py:943-949)."""
+    source_pose, target_pose = _as_pose(source_pose), _as_pose(target_pose)
+    if source_pose_cov is not None:
+        np.linalg.inv(source_pose_cov)                          # slam.py:529 (raises like the reference)
+    grids = _StoreGrids(store, [target_handle], point_noise)
+    pose_samples = []
+    f32 = np.float32
+
+    def batch(X):
+        X = np.asarray(X, np.float64).reshape(-1, 3)
+        T6 = np.zeros((len(X), 6), f32)
+        sample_poses = []
+        for i, x in enumerate(X):
+            sample_source_pose = source_pose.compose(_like(source_pose, x))
+            T = np.asarray(target_pose.between(sample_source_pose).matrix()).astype(f32)
+            T6[i] = (T[0, 0], T[0, 1], T[0, 2], T[1, 0], T[1, 1], T[1, 2])
+            sample_poses.append(sample_source_pose)
+        cost = grids.cost([source_handle], T6[None], f64_points)[0] if len(X) else np.zeros(0, np.int32)
+        for sp, cst in zip(sample_poses, cost):
+            pose_samples.append(np.r_[[sp.x(), sp.y(), sp.theta()], cst])
+        return cost
+
+    def subroutine(x):
+        return batch([x])[0]
+
+    subroutine.batch = batch
+    subroutine.grid = grids
+    subroutine.geometry = dict(xmin=grids.xmin[0], ymin=grids.ymin[0], resolution=f32(grids.resolution), rows=int(grids.rows[0]),
+                               cols=int(grids.cols[0]), dilate_hs=grids.dilate_hs)
+    return subroutine, pose_samples
+
+
 class _Grid(object):
     def __init__(self, ctx, handle, rows, cols):
         self.ctx, self.handle, self.rows, self.cols = ctx, handle, rows, cols
@@ -113,7 +243,7 @@ class _Grid(object):
         """target_grids after the dilation (rows x cols uint8, 0 / 255)."""
         out = np.zeros((self.rows, self.cols), np.uint8)
         with self.ctx.lock:
-            self.ctx._check(self.ctx.lib.sfe_costgrid_download(self.ctx.handle, self.handle, _L.ptr(out, _C.c_uint8)))
+            self.ctx._check(self.ctx.lib.sfe_costgrid_download(self.ctx.handle, self.handle, 0, _L.ptr(out, _C.c_uint8)))
         return out
 
     def close(self):

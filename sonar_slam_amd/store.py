@@ -133,6 +133,79 @@ class CloudStore(object):
                 int(flags), _L.ptr(out, _C.c_int32)))
         return out
 
+    # -- the loop-closure search (slam.py:839-1001) --
+    def bbox(self, handles):
+        """-> [n x 4] float32 (min x, min y, max x, max y) of the named clouds"""
+        h = np.ascontiguousarray(handles, np.int32).reshape(-1)
+        out = np.zeros((len(h), 4), np.float32)
+        with self.ctx.lock:
+            self.ctx._check(self.ctx.lib.sfe_cloud_store_bbox(self.ctx.handle, self.handle, _L.ptr(h, _C.c_int32), len(h),
+                                                              _L.ptr(out, _C.c_float)))
+        return out
+
+    def get_points_keys(self, handles, T6, keys, resolution, flags=0, stamp=0):
+        """SLAM.get_points(frames, None, return_keys=True) (slam.py:873): cloud k under T6[k] (its pose's matrix) tagged
+        keys[k]; the descriptor overload of pcl.downsample.  Any size.  -> the new handle (its keys: ``read_keys``)"""
+        handles = np.ascontiguousarray(handles, np.int32).reshape(-1)
+        m = len(handles)
+        T6 = np.ascontiguousarray(T6, np.float32).reshape(m, 6)
+        keys = np.ascontiguousarray(keys, np.int32).reshape(m)
+        out = _C.c_int32(-1)
+        with self.ctx.lock:
+            self.ctx._check(self.ctx.lib.sfe_cloud_store_get_points_keys(
+                self.ctx.handle, self.handle, _L.ptr(handles, _C.c_int32), _L.ptr(T6, _C.c_float), _L.ptr(keys, _C.c_int32), m,
+                float(resolution), int(flags), int(stamp), _C.byref(out)))
+        return out.value
+
+    def read_keys(self, handle):
+        n = int(self.counts([handle])[0])
+        out = np.zeros(max(n, 0), np.int32)
+        m = _C.c_int(0)
+        with self.ctx.lock:
+            self.ctx._check(self.ctx.lib.sfe_cloud_store_read_keys(self.ctx.handle, self.handle, int(handle),
+                                                                   _L.ptr(out, _C.c_int32), len(out), _C.byref(m)))
+        return out
+
+    def fov_select(self, handle, Tinv6, range_bounds, bearing_bounds, n_keys):
+        """the field-of-view gate of slam.py:875-899 on a keyed cloud -> (per-key counts of the selected points [n_keys],
+        number selected, number the device could not decide: then ``set_selection``)"""
+        Tinv6 = np.ascontiguousarray(Tinv6, np.float32).reshape(-1, 6)
+        rb = np.ascontiguousarray(range_bounds, np.float64).reshape(-1)
+        bb = np.ascontiguousarray(bearing_bounds, np.float64).reshape(-1)
+        assert len(rb) == len(bb) == len(Tinv6)
+        hist = np.zeros(int(n_keys), np.int32)
+        n_sel, n_amb = _C.c_int32(0), _C.c_int32(0)
+        with self.ctx.lock:
+            self.ctx._check(self.ctx.lib.sfe_cloud_store_fov_select(
+                self.ctx.handle, self.handle, int(handle), _L.ptr(Tinv6, _C.c_float), _L.ptr(rb, _C.c_double),
+                _L.ptr(bb, _C.c_double), len(Tinv6), int(n_keys), _L.ptr(hist, _C.c_int32), _C.byref(n_sel), _C.byref(n_amb)))
+        return hist, n_sel.value, n_amb.value
+
+    def set_selection(self, handle, sel):
+        sel = np.ascontiguousarray(sel, np.uint8).reshape(-1)
+        with self.ctx.lock:
+            self.ctx._check(self.ctx.lib.sfe_cloud_store_set_selection(self.ctx.handle, self.handle, int(handle),
+                                                                       _L.ptr(sel, _C.c_uint8), len(sel)))
+
+    def compact_selected(self, handle, stamp=0):
+        """target_points[sel], target_keys[sel] (slam.py:898-899) -> new keyed handle"""
+        out = _C.c_int32(-1)
+        with self.ctx.lock:
+            self.ctx._check(self.ctx.lib.sfe_cloud_store_compact_selected(self.ctx.handle, self.handle, int(handle), int(stamp),
+                                                                          _C.byref(out)))
+        return out.value
+
+    def match_keys(self, source, T6, target, max_dist, n_keys, flags=0):
+        """slam.py:977-985 -> (per-key counts of the matched targets [n_keys], overlap)"""
+        T6 = np.ascontiguousarray(T6, np.float32).reshape(6)
+        hist = np.zeros(int(n_keys), np.int32)
+        ov = _C.c_int32(0)
+        with self.ctx.lock:
+            self.ctx._check(self.ctx.lib.sfe_cloud_store_match_keys(
+                self.ctx.handle, self.handle, int(source), _L.ptr(T6, _C.c_float), int(target), float(max_dist), int(flags),
+                int(n_keys), _L.ptr(hist, _C.c_int32), _C.byref(ov)))
+        return hist, ov.value
+
     def close(self):
         if self.handle is not None and self.ctx.handle is not None:
             self.ctx.lib.sfe_cloud_store_destroy(self.handle)

@@ -39,6 +39,18 @@ def test_put_read_meta_truncate(ctx):
         s.icp(icp_config.shipped_params(), [(0, hb)], [np.eye(3)])
     with pytest.raises(_lib.SonarFEError):
         s.read(hb)
+    # ... get_points and the overlap count refuse it as well instead of reading it as an empty cloud
+    with pytest.raises(_lib.SonarFEError, match="not stored"):
+        s.get_points([[0, hb]], [[st.pose_T6(np.eye(3))] * 2], 0.5)
+    with pytest.raises(_lib.SonarFEError, match="not stored"):
+        s.overlap([(0, hb)], [st.pose_T6(np.eye(3))], 0.5)
+    # a cloud that did not fit owns no pool space: the fill level stayed behind the last cloud that did, so a smaller
+    # one still goes in behind it, and dropping the failed slot leaves everything else where it was
+    hc = s.put(clouds[2])
+    assert hc == hb + 1 and s.counts([hc])[0] == 1 and s.meta(hc, 1)[1].tolist() == [2000]
+    assert np.array_equal(s.read(hc), clouds[2])
+    s.truncate(hb)
+    assert s.put(clouds[0]) == hb and s.meta(hb, 1)[1].tolist() == [2000] and np.array_equal(s.read(hb), clouds[0])
     s.truncate(0)
     assert len(s) == 0 and s.put(clouds[0]) == 0 and s.meta()[1].tolist() == [0]
     for _ in range(15):
@@ -132,6 +144,39 @@ def test_ping_into_the_store_equals_the_ping_to_the_host(ctx):
         h2, n2, none = fe.callback_store(ping, s, stamp=i)                           # nothing published: no copy
         assert none is None and n2 == n and np.array_equal(s.read(h2), s.read(h))
     assert s.meta()[0].tolist() == [0, 0, 1, 1, 2, 2]
+    s.close()
+
+
+def test_ping_into_a_full_store_is_an_error_and_leaves_the_store_usable(ctx):
+    """sfe_feature_extract_ping_store reads the slot's own count; a pool that has no room returns
+    SFE_ERR_CAP (no handle, no slot), later pings are not poisoned, and a store of another context is refused"""
+    from sonar_slam_amd.feature_extraction import SonarPing, oculus_bearings
+    fe = _fe(ctx)
+    ping = SonarPing(synth.sonar_frame(seed=3, rows=512, cols=256, n_blobs=25), oculus_bearings(256), 30.0 / 512, ping_id=0)
+    n = len(fe.callback(ping))
+    assert n > 50
+    s = st.CloudStore(ctx, capacity_points=2 * n + n // 2, max_clouds=8)
+    h0, n0, _ = fe.callback_store(ping, s, stamp=0)
+    h1, n1, _ = fe.callback_store(ping, s, stamp=1)
+    assert (h0, h1) == (0, 1) and n0 == n1 == n
+    with pytest.raises(_lib.SonarFEError, match="full"):
+        fe.callback_store(ping, s, stamp=2)
+    assert len(s) == 2 and s.meta()[2].tolist() == [n, n]
+    with pytest.raises(_lib.SonarFEError, match="full"):          # and again: the first failure did not pin the fill level
+        fe.callback_store(ping, s, stamp=3)
+    small = _clouds(np.random.default_rng(0), (n // 4,))[0]
+    assert s.put(small) == 2 and np.array_equal(s.read(2), small)
+    s.truncate(1)
+    h, m, _ = fe.callback_store(ping, s, stamp=4)                  # room again after a release
+    assert h == 1 and m == n and np.array_equal(s.read(1), s.read(0))
+    other = _lib.Context(0)
+    try:
+        s2 = st.CloudStore(other, capacity_points=1 << 14, max_clouds=4)
+        with pytest.raises(_lib.SonarFEError):
+            fe.callback_store(ping, s2, stamp=5)
+        s2.close()
+    finally:
+        other.close()
     s.close()
 
 
