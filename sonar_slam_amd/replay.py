@@ -500,6 +500,7 @@ class FrontEnd(object):
                 return
             rec["n_converged"] = len(samples)
             rec["sample_transforms"] = samples
+            rec["cov"] = cov_icp
         else:
             message, odom = self.compute_icp(source_points, target_local, initial_transform)
             cov_icp = None
@@ -518,7 +519,6 @@ class FrontEnd(object):
             rec["status"] = "NOT_ENOUGH_OVERLAP"
             return
         rec["status"] = "SUCCESS"
-        rec["cov"] = cov_icp
         self.backend.add_loop(target_key, source_key, odom, cov_icp)           # -> PCM + ISAM2 (slam.py:1089-1130): back end
 
     @staticmethod

@@ -271,7 +271,7 @@ def test_sessions_in_lock_step_equal_the_front_end_and_the_oracle_chain(ctx, shi
     for s in range(S):
         # (a) the scalar front end on its own store
         store = st.CloudStore(ctx, capacity_points=1 << 18, max_clouds=64)
-        front = FrontEnd(ctx, keyframe_translation=1.5, keyframe_duration=0.5, store=store)
+        front = FrontEnd(ctx, keyframe_translation=1.5, keyframe_duration=0.5, store=store, ssm_initialization=False)
         pings = [SonarPing(frames[k, s], bearings, 30.0 / rows, ping_id=k) for k in range(K)]
         log, _, _ = replay(pings, np.arange(K, dtype=float), dr[s], fe, front)
         assert len(log) == K, "every ping is meant to be a keyframe"
