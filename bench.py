@@ -300,7 +300,14 @@ def parity_check(kb, res, frames, srcs, tgts, guesses, det, fe, icp_mode, filter
         raise AssertionError("parity: ICP pose differs from the oracle in float by %.3e" % worst)
     return {"jobs": len(picks), "frames_bit_exact": bit_exact, "icp_max_pose_diff": worst,
             "icp_float_oracle_beyond_1e-4": "%d / %d" % (beyond, len(picks)),
-            "icp_max_pose_diff_vs_f64_sums": worst64, "icp_tolerance": 1e-4, "icp_tolerance_f64_sums": 1e-6,
+            "icp_max_pose_diff_vs_f64_sums": worst64,
+            # what this function ENFORCES (it raises beyond them) and what north_star asks for, kept apart:
+            "icp_tolerance_enforced_f64_sums": 1e-6, "icp_tolerance_enforced_float_oracle": 1e-3,
+            "icp_tolerance_north_star": 1e-4, "north_star_1e-4_met_vs_float_oracle": beyond == 0,
+            "north_star_1e-4_met_vs_f64_sum_oracle": worst64 <= 1e-4,
+            "icp_tolerance_note": "the float (PointMatcher<float>-style, sequential float sums) oracle leaves its OWN fp64-sum "
+                                  "version by up to ~1e-3 on 5000-point pairs; the HIP path equals the fp64-sum version, so "
+                                  "jobs beyond 1e-4 of the float oracle are reported, not hidden (DESIGN 3, `float_oracle` leg)",
             "checked": "CFAR mask, extracted points (np.nonzero order), %sICP pose/status/iterations of keyframes %s of "
                        "the last timed step vs the CPU oracle (exact kd-tree)"
                        % ("downsample+remove_outlier cloud, " if filters else "", picks)}

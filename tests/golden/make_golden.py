@@ -20,7 +20,8 @@ are executed straight from the reference sources:
     (slam_objects.py:178-198) are cut out by AST and run on a synthetic scan pair and candidate
     poses, with stand-ins for the two things they call that are not in this image: ``cv2``
     (getStructuringElement / dilate from the oracle's restatement: those two stay unpinned) and
-    ``gtsam.Pose2`` (sonar_slam_amd.pose2.Pose2) -> ``matching_cost.npz`` (target cells, grid shape,
+    ``gtsam.Pose2`` (the 20-line ``Pose2`` below: gtsam's published Rot2 / Pose2 algebra, independent of the
+    product's pose2.py; only its matrix reaches the reference functions) -> ``matching_cost.npz`` (target cells, grid shape,
     costs per pose, float32 transformed points of one pose).  Everything numpy does in there
     (bounds, np.arange lengths, rounding, clipping, BLAS dot of transform_points, inside test, sum)
     is the reference's own code on this image's numpy.
@@ -38,6 +39,41 @@ import numpy as np
 
 REF = "/root/reference/bruce_slam/src/bruce_slam"
 HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class Pose2(object):
+    """gtsam.Pose2 stand-in for the reference functions cut out below (gtsam is absent from this image).  Written here,
+    not imported from the product: a fixture "from the reference" must not depend on the code it pins.  gtsam keeps the
+    rotation as (c, s), renormalises a product only when |c^2 + s^2 - 1| > 1e-10 (Rot2::normalize), theta = atan2(s, c)."""
+
+    def __init__(self, x=0.0, y=0.0, theta=0.0, cs=None):
+        import math
+        self._x, self._y = float(x), float(y)
+        c, s = (math.cos(theta), math.sin(theta)) if cs is None else cs
+        n = c * c + s * s
+        if cs is not None and abs(n - 1.0) > 1e-10:
+            c, s = c / math.sqrt(n), s / math.sqrt(n)
+        self._c, self._s = c, s
+
+    x = lambda self: self._x
+    y = lambda self: self._y
+
+    def theta(self):
+        import math
+        return math.atan2(self._s, self._c)
+
+    def compose(self, o):
+        return Pose2(self._x + self._c * o._x - self._s * o._y, self._y + self._s * o._x + self._c * o._y,
+                     cs=(self._c * o._c - self._s * o._s, self._s * o._c + self._c * o._s))
+
+    def inverse(self):
+        return Pose2(-(self._c * self._x + self._s * self._y), -(-self._s * self._x + self._c * self._y), cs=(self._c, -self._s))
+
+    def between(self, o):
+        return self.inverse().compose(o)
+
+    def matrix(self):
+        return np.array([[self._c, -self._s, self._x], [self._s, self._c, self._y], [0.0, 0.0, 1.0]])
 
 
 def reference_cfar_class():
@@ -81,7 +117,6 @@ def reference_matching_cost():
     """-> (get_matching_cost_subroutine1 as a plain function of a stub `self`, Keyframe stub)"""
     sys.path.insert(0, os.path.join(HERE, "..", ".."))
     import oracle
-    from sonar_slam_amd.pose2 import Pose2
 
     tp_src = _cut("slam_objects.py", "transform_points").replace("@staticmethod", "")
     ns_k = {"np": np, "gtsam": types.SimpleNamespace(Pose2=Pose2)}
