@@ -495,6 +495,16 @@ def main():
         except (OSError, KeyError, ValueError):
             pass
 
+        # the cloud filters: 16 B in (the float64 point of the extraction) + 8 B out (the float32 point that survives)
+        filters_bytes = filters_traffic = None
+        if not args.no_filters:
+            filters_bytes = 16.0 * float(res["counts"].sum()) + 8.0 * float(res["cloud_counts"].sum())
+            try:
+                with open(os.path.join(ROOT, "profiles", "filters_pmc.json")) as f:
+                    filters_traffic = json.load(f)["traffic_bytes_per_frame"] * args.batch
+            except (OSError, KeyError, ValueError):
+                pass
+
         value = args.batch * args.steps * world / dt
         out = {
             "metric": "keyframes/sec (CFAR+ICP) on 512x1024 sonar, 5k-pt pairs",
@@ -552,6 +562,16 @@ def main():
                                          "bound by gathers into the inverse remap table (19 MB, one 16-byte read per two candidates of a set pixel), not "
                                          "by streaming"},
         }
+        if filters_bytes is not None:
+            out["roofline_filters"] = {
+                "kernel": "cf_cast_bbox + cf_downsample_radix + cf_radius_filter", "bound": "hbm",
+                "limiter": "LDS radix sort and per-leaf medoid loops of the octree downsample: one 1024-thread workgroup and 132 KB of "
+                           "LDS per frame (instruction issue at ~55 % VALU-active; profiles/filters_pmc.json)",
+                "achieved": filters_bytes / (ms_filter_b * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": filters_bytes / (ms_filter_b * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": filters_bytes,
+                "ms_per_launch": ms_filter_b, "traffic": filters_traffic,
+                "bytes_note": "16 B per extracted point in + 8 B per filtered point out (SURVEY 8 f1 / pcl.cpp:128-141,54-74)",
+                "traffic_note": "bytes/launch from the committed PMC passes (profiles/filters_pmc.json), scaled to this launch's frames"}
         try:  # committed SQ counter pass of the ICP loop kernel (rocprofv3 cannot run inside the timed process)
             with open(os.path.join(ROOT, "profiles", "icp_sq.json")) as f:
                 sq = json.load(f)

@@ -242,17 +242,26 @@ __device__ __forceinline__ int cf_block_excl_scan(int v, int *s_tmp, int *total)
 // computed once and kept in LDS next to the two uint16 index buffers; afterwards the same LDS (128 KiB for 16384
 // points: one frame per CU) holds the frame's points in sorted order for the per-leaf loops.  Leaves, medoids and outputs are exactly those of
 // cf_downsample_kernel.
-#define CF_RDX_BITS 8
+// Round 5: the sort's ranking no longer goes through wave ballots.  Rounds 2-4 ranked 64 indices at a time with a match mask
+// from 8 ballots per group (stable by construction, no atomics) -- ~200 wave instructions per 64 elements and sweep, 139 k
+// VALU wave-instructions per 11 000-point frame at 69 % VALU-active (profiles/filters_pmc.json): the kernel was bound by
+// exactly those instructions.  Now every thread owns a CONTIGUOUS chunk of the current order (m <= 17 elements) and a
+// private column of 16 digit counters in LDS; it counts its chunk, the counters are scanned digit-major / thread-minor
+// (so equal digits keep the order of their positions: stable), and the thread scatters its chunk in order from its own
+// running offsets.  A wave instruction now serves 64 elements instead of one group interaction: ~25 per element and
+// pass, four passes of 4 bits for the 14 key bits of a sonar fan at 0.5 m.
+#define CF_RDX_BITS 4
 #define CF_RDX_DIGITS (1 << CF_RDX_BITS)
+#define CF_RDX_CHUNK 17 // elements per thread: (16384 / 1024) | 1
 __global__ __launch_bounds__(1024) void cf_downsample_radix_kernel(const float2 *__restrict__ p32, long long cap,
                                                                    CfHeader *__restrict__ hdrs, float2 *__restrict__ ds_out,
                                                                    int *__restrict__ seg_all, int n2cap,
                                                                    unsigned *__restrict__ leaf_keys_all,
-                                                                   float2 *__restrict__ spts_all, int lds_bytes)
+                                                                   float2 *__restrict__ spts_all, int lds_bytes, int sort_cols)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[]; // ids[2][n2cap], key[n2cap], cnt[16][256]: u16
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[]; // ids[2][n2cap], key[n2cap], cnt[16][sort_cols]: u16
     __shared__ int s_scan[1024];
-    const int f = blockIdx.x, tid = threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int f = blockIdx.x, tid = threadIdx.x;
     const CfHeader h = hdrs[f];
     const int n = h.n;
     const float2 *pts = p32 + (size_t)f * cap;
@@ -267,73 +276,63 @@ __global__ __launch_bounds__(1024) void cf_downsample_radix_kernel(const float2 
     unsigned short *idA = reinterpret_cast<unsigned short *>(lds_raw);
     unsigned short *idB = idA + n2cap;
     unsigned short *skey = idB + n2cap; // path key of point i (<= 16 bits), computed once: the sort only moves indices
-    unsigned short *cnt = skey + n2cap; // [wave][digit]
+    unsigned short *cnt = skey + n2cap; // [digit][column]
     for (int i = tid; i < n; i += 1024) {
         idA[i] = (unsigned short)i;
         skey[i] = (unsigned short)cf_path_key(pts[i], h);
     }
-    // a wave's range of the current order: whole groups of 64
-    const int groups = (n + 63) >> 6, gpw = (groups + 15) >> 4;
-    const int g0 = min(wave * gpw, groups), g1 = min(g0 + gpw, groups);
+    // a column's chunk of the current order: m consecutive positions, m odd so that the columns' 16-bit reads spread
+    // over the LDS banks (sort_cols = 1024, or 512 for capacities of <= 8192 points, whose LDS share is 64 KB)
+    const int m = ((n + sort_cols - 1) / sort_cols) | 1;
+    const bool col = tid < sort_cols;
+    const int p0 = col ? min(tid * m, n) : n, p1 = min(p0 + m, n);
     const int passes = (2 * h.levels + CF_RDX_BITS - 1) / CF_RDX_BITS;
     for (int pass = 0; pass < passes; ++pass) {
         const int shift = CF_RDX_BITS * pass;
-        volatile unsigned short *wc = cnt + wave * CF_RDX_DIGITS; // (lanes read what another lane of the wave wrote)
-        for (int d = lane; d < CF_RDX_DIGITS; d += 64)
-            wc[d] = 0;
+        if (col)
+#pragma unroll
+            for (int d = 0; d < CF_RDX_DIGITS; ++d)
+                cnt[d * sort_cols + tid] = 0;
         __syncthreads(); // idA complete (first pass: the identity; later: the previous scatter)
-        // lanes of the same digit: `same`; `valid` lanes only
-        auto match = [&](bool valid, unsigned d) {
-            unsigned long long same = __ballot(valid);
+        // the chunk's indices and digits: independent LDS reads, in flight together
+        unsigned id[CF_RDX_CHUNK], dg[CF_RDX_CHUNK];
 #pragma unroll
-            for (int b = 0; b < CF_RDX_BITS; ++b) {
-                const bool bit = (d >> b) & 1u;
-                const unsigned long long bb = __ballot(bit);
-                same &= bit ? bb : ~bb;
-            }
-            return same;
-        };
-        for (int g = g0; g < g1; ++g) { // sweep 1: digit counts of this wave's range
-            const int pos = g * 64 + lane;
-            const bool valid = pos < n;
-            const unsigned d = valid ? ((unsigned)skey[idA[pos]] >> shift) & (CF_RDX_DIGITS - 1) : 0u;
-            const unsigned long long same = match(valid, d);
-            if (valid && lane == __ffsll((long long)same) - 1)
-                wc[d] += (unsigned short)__popcll(same); // one lane per digit, this wave's own row: no atomic
-        }
+        for (int k = 0; k < CF_RDX_CHUNK; ++k)
+            id[k] = p0 + k < p1 ? idA[p0 + k] : 0u;
+#pragma unroll
+        for (int k = 0; k < CF_RDX_CHUNK; ++k)
+            dg[k] = p0 + k < p1 ? ((unsigned)skey[id[k]] >> shift) & (CF_RDX_DIGITS - 1) : 0u;
+#pragma unroll
+        for (int k = 0; k < CF_RDX_CHUNK; ++k) // count: the column is this thread's own, plain read-modify-write
+            if (p0 + k < p1)
+                cnt[dg[k] * sort_cols + tid] += 1;
         __syncthreads();
-        { // exclusive scan over (digit major, wave minor): thread t owns digits/waves L = 4t .. 4t+3
-            int v[4], s = 0;
+        { // exclusive scan over (digit major, column minor): 16 * sort_cols counters, 16 (or 8) consecutive ones per thread
+            const int per_t = CF_RDX_DIGITS * sort_cols / 1024;
+            int v[16], s = 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int L = 4 * tid + k, d = L >> 4, w = L & 15;
-                v[k] = cnt[w * CF_RDX_DIGITS + d];
+            for (int k = 0; k < 16; ++k) {
+                v[k] = k < per_t ? cnt[per_t * tid + k] : 0;
                 s += v[k];
             }
             int tot_;
             int run = cf_block_excl_scan(s, s_scan, &tot_);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int L = 4 * tid + k, d = L >> 4, w = L & 15;
-                cnt[w * CF_RDX_DIGITS + d] = (unsigned short)run;
-                run += v[k];
-            }
+            for (int k = 0; k < 16; ++k)
+                if (k < per_t) {
+                    cnt[per_t * tid + k] = (unsigned short)run;
+                    run += v[k];
+                }
         }
         __syncthreads();
-        for (int g = g0; g < g1; ++g) { // sweep 2: scatter in lane order
-            const int pos = g * 64 + lane;
-            const bool valid = pos < n;
-            const unsigned id = valid ? idA[pos] : 0u;
-            const unsigned d = valid ? ((unsigned)skey[id] >> shift) & (CF_RDX_DIGITS - 1) : 0u;
-            const unsigned long long same = match(valid, d);
-            if (valid) {
-                const unsigned base = wc[d];
-                idB[base + (unsigned)__popcll(same & ((1ull << lane) - 1ull))] = (unsigned short)id;
+#pragma unroll
+        for (int k = 0; k < CF_RDX_CHUNK; ++k) // scatter in position order from the column's running offsets
+            if (p0 + k < p1) {
+                const unsigned a = dg[k] * sort_cols + tid;
+                const unsigned off = cnt[a];
+                idB[off] = (unsigned short)id[k];
+                cnt[a] = (unsigned short)(off + 1);
             }
-            // (the reads of wc[d] above and the update below are LDS operations of one wave: executed in order)
-            if (valid && lane == __ffsll((long long)same) - 1)
-                wc[d] += (unsigned short)__popcll(same);
-        }
         __syncthreads();
         unsigned short *t_ = idA;
         idA = idB;
@@ -667,11 +666,14 @@ int sfe_cf_run_staged(sfe_ctx *ctx, int n_frames, int64_t cap, float resolution,
                 // others behind it, a workgroup of the other class returning at once: 0.29 -> 0.42 ms per 512 frames,
                 // because dispatching 512 workgroups of 1024 threads costs ~0.12 ms even when they do nothing.  A caller
                 // whose pings are small passes a smaller capacity instead: chained.SessionBatch sizes it from its warm-up.)
-                const size_t rdx_smem = std::max<size_t>(3 * 2 * n2 + 2 * 16 * CF_RDX_DIGITS, sizeof(float2) * n2);
+                // (digit counters: one column of 16 per sorting thread -- 1024 of them, 512 at capacities of <= 8192 points so
+                // that indices + keys + counters stay inside the 64 KB that let two frames share a CU)
+                const int sort_cols = n2 <= 8192 ? 512 : 1024;
+                const size_t rdx_smem = std::max<size_t>(3 * 2 * n2 + 2 * CF_RDX_DIGITS * (size_t)sort_cols, sizeof(float2) * n2);
                 SFE_HIP(ctx, hipFuncSetAttribute((const void *)cf_downsample_radix_kernel,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)rdx_smem));
                 hipLaunchKernelGGL(cf_downsample_radix_kernel, dim3(n_frames), dim3(1024), rdx_smem, ctx->stream, d_p32,
-                                   (long long)cap, d_hdr, d_ds, d_seg, (int)n2, d_lkeys, d_spts, (int)rdx_smem);
+                                   (long long)cap, d_hdr, d_ds, d_seg, (int)n2, d_lkeys, d_spts, (int)rdx_smem, sort_cols);
             }
             SFE_HIP(ctx, hipFuncSetAttribute((const void *)cf_downsample_kernel<true, unsigned long long>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(8 * n2)));

@@ -194,9 +194,9 @@ class Geometry(object):
             if ret == _L.SFE_ERR_CAP and n_raw.value > cap and n_raw.value <= 65536:
                 cap = int(n_raw.value)
                 continue
-            if ret == _L.SFE_ERR_CAP:
-                return None
-            self.ctx._check(ret)
+            if ret == _L.SFE_ERR_CAP and n_raw.value > cap:
+                return None         # more than 65 536 raw detections: the caller takes the per-stage path
+            self.ctx._check(ret)    # (SFE_ERR_CAP with the points inside the capacity: the STORE is full -> raises)
             if n.value < 0:
                 return None
             return h.value, n.value, (cloud[:n.value].copy() if want_cloud else None), vis
@@ -359,6 +359,10 @@ class FeatureExtraction(object):
         points = self._callback_stages(img)
         pts32 = np.ascontiguousarray(points, np.float32).reshape(-1, 2)
         h = store.put(np.c_[pts32[:, 0], -1 * pts32[:, 1]], stamp)
+        if store.counts([h])[0] < 0:        # the pool had no room: no slot is kept, and the caller hears about it
+            store.truncate(h)
+            raise _L.SonarFEError("libsonarfe error %d: the cloud store is full (%d points did not fit its pool)"
+                                  % (_L.SFE_ERR_CAP, len(pts32)))
         return h, len(pts32), (points if publish else None)
 
     def _callback_stages(self, img):

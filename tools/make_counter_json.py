@@ -36,7 +36,46 @@ def kernel_us(name):
             db.execute("select name, count(*), avg(duration), min(duration), max(duration) from kernels group by name")}
 
 
+def have(name):
+    return os.path.exists(os.path.join(G, "%s_%s.db" % (tag, name)))
+
+
+def filters():
+    """the resident cloud filters (cf_cast_bbox / cf_downsample_radix / cf_radius_filter): traffic and SQ counters of
+    `python tools/extract_times.py 512` -> profiles/filters_pmc.json"""
+    files = "profiles/%s_%%s.txt" % tag
+    f, du = counters("filters_fetch")
+    w, _ = counters("filters_write")
+    c, _ = counters("filters_sq")
+    ks = sorted(x for x in f if x.startswith("cf_") and du[x] > 10.0)    # (the 64-bit fallback kernel returns at once)
+    nf = 512
+    per = {}
+    for k in ks:
+        v = c.get(k, {})
+        per[k] = {"avg_us_per_launch": du[k], "fetch_bytes": 2 * 1024 * f[k]["FETCH_SIZE"],
+                  "write_bytes": 1024 * w.get(k, {}).get("WRITE_SIZE", 0.0)}
+        if v:
+            per[k].update({"valu_active_frac": v["SQ_ACTIVE_INST_VALU"] * 4.0 / (32.0 * v["SQ_BUSY_CYCLES"]),
+                           "wave_wait_frac": v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"],
+                           "valu_insts_per_frame": v["SQ_INSTS_VALU"] * 32.0 / nf, "salu_insts_per_frame": v["SQ_INSTS_SALU"] * 32.0 / nf,
+                           "lds_insts_per_frame": v["SQ_INSTS_LDS"] * 32.0 / nf})
+    fb, wb = sum(p["fetch_bytes"] for p in per.values()), sum(p["write_bytes"] for p in per.values())
+    out = {"kernels": " + ".join(ks),
+           "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE / SQ_* (one pass each) on `python tools/extract_times.py 512` "
+                     "(512 bench frames 1024 x 512 per launch, ~11 400 raw points per frame)",
+           "source_files": [files % "filters_kernels", files % "filters_fetch", files % "filters_write", files % "filters_sq"],
+           "frames_per_launch": nf, "correction": "fetch bytes = 2 * FETCH_SIZE, write bytes = WRITE_SIZE",
+           "per_kernel": per, "traffic_bytes_per_launch": fb + wb, "traffic_bytes_per_frame": (fb + wb) / nf,
+           "us_per_launch": sum(p["avg_us_per_launch"] for p in per.values())}
+    json.dump(out, open(os.path.join(ROOT, "profiles", "filters_pmc.json"), "w"), indent=1)
+    print("wrote profiles/filters_pmc.json from the %s passes" % tag)
+
+
 def main():
+    if have("filters_fetch"):
+        filters()
+    if not have("cfar_bits_fetch"):
+        return
     files = "profiles/%s_%%s.txt" % tag
     # ---- CFAR bit-stream kernel ----
     f, _ = counters("cfar_bits_fetch")
