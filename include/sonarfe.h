@@ -27,24 +27,9 @@
  *     SFE_ICP_*; the reference turns these into (what(), guess)); < 0 = hard error
  *     (bad argument, HIP failure) with text in sfe_last_error().  There is no CPU
  *     fallback anywhere: without a gfx950 device every compute entry point fails.
- *   - A/B knobs read from the environment (measurement only: every setting returns identical results):
- *     SFE_SW_STRIP_PTS, SFE_SW_BUDGET, SFE_SW_BUDGET_A, SFE_SW_RTRIPS, SFE_SW_MARGIN, SFE_SW_JUMP, SFE_SW_CACHE,
- *     SFE_SW_GRID, SFE_SW_GRID_SKIP, SFE_SW_NO_LDSQ, SFE_SW_WIDE, SFE_SW_MINW, SFE_SW_SHARE_KB (strip-sweep ICP:
- *     strip population, search budgets, cap margin, cap jump, iteration cache, first-iteration grid witnesses, results
- *     in LDS, one workgroup per CU, VGPR budget, LDS share), SFE_SW_REC, SFE_SW_TRIAGE, SFE_SW_RECM, SFE_SW_RECK
- *     (clearance records of long chains: on / off, triage pass, relative margin in percent, multiple of the last step),
- *     SFE_SC_ROWS, SFE_SC_XCD, SFE_EXTRACT_CHUNK, SFE_EXPAND_POINTS, SFE_EXPAND_WG (extraction: polar rows per scatter
- *     workgroup, row-block -> XCD map, frames per pass, per-point instead of word-list expansion, its workgroups per
- *     frame), SFE_CFAR_NO_BITS, SFE_CFAR_NO_LDS_RING (CFAR: byte kernel + pack instead of the bit-stream kernel, sliding
- *     sums without the LDS ring), SFE_CF_BITONIC (resident downsample by bitonic sort), SFE_ICP_DEBUG (watchdog report).
- *     Round 3: SFE_SW_TIERS, SFE_SW_TINY, SFE_SW_TINY_PAIRS, SFE_SW_MULTI, SFE_SW_MULTI_G, SFE_SW_T0_SRC, SFE_SW_T1_SRC,
- *     SFE_SW_T0_MIN_JOBS, SFE_SW_T1_MIN_JOBS, SFE_SW_WIN, SFE_SW_UNION_ITERS, SFE_SW_UNION_MAX, SFE_SW_LEAN_TRIAGE,
- *     SFE_SW_GRID_DEFER, SFE_SW_UNBOUNDED_COOP, SFE_SW_NORMALS_SPLIT, SFE_SW_PREP_GTAIL (ICP job classes and their
- *     limits, jobs shared by several workgroups, search variants, the prep kernel's two-workgroups-per-CU build),
- *     SFE_SG_SLICES, SFE_SG_PIECE, SFE_NO_SELF_CLEAN (list-driven extraction: workgroups per frame, rows per piece,
- *     a memset of the canvas bitmap per batch), SFE_DS_RANK (per-cloud downsample by rank counting), SFE_CFAR_NO_OS_GATED,
- *     SFE_CFAR_OS_GATED_MIN, SFE_CFAR_OSG_V4, SFE_CFAR_THR_TABLE, SFE_CFAR_NO_RING_THR (CFAR: OS behind the gate,
- *     threshold maps from a table / from the sliding-sum kernel).
+ *   - the library reads a number of SFE_* environment variables that switch between measured alternatives of the same
+ *     computation (every setting returns identical results).  They are measurement tools, not part of this interface:
+ *     DESIGN.md, appendix A lists them.
  *   - one sfe_ctx = one device + one HIP stream + its scratch; a ctx is not
  *     re-entrant (the reference's pybind calls hold the GIL and its ICP object is
  *     stateful, SURVEY 8b "Threading"); use one ctx per worker thread/process.
@@ -181,9 +166,8 @@ int sfe_remap_u8_colormap_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_src, i
 int sfe_extract_points(sfe_ctx *ctx, sfe_geom *g, const uint8_t *mask, int64_t cap,
                        int64_t *rc_out, double *pts_out, int64_t *n_out);
 /* A-B knob of the extraction: 0 = binary masks go through the inverse map (walk the set polar pixels,
- * evaluate only the canvas pixels that tap them; default: the list-driven kernel of round 3), 1 = dense pass
- * over the whole canvas for every frame, 2 = the inverse map through the row-block kernel of round 2.
- * Identical results. */
+ * evaluate only the canvas pixels that tap them; default), 1 = dense pass over the whole canvas for every frame
+ * (what non-binary masks take anyway).  Identical results. */
 int sfe_extract_set_tuning(sfe_ctx *ctx, int variant);
 /* device-resident batch: per frame f, points go to d_pts + f*cap*2 (float64), count to d_counts[f]
  * (count is the true number even if it exceeds cap; only the first cap points are stored) */

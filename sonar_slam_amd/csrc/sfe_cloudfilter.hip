@@ -653,13 +653,7 @@ int sfe_cf_run_staged(sfe_ctx *ctx, int n_frames, int64_t cap, float resolution,
         if (cap <= CF_SORT_CAP) {
             // trees of <= 8 levels (every frame of a sonar fan at 0.5 m): radix sort of the indices; then the bitonic
             // sort with 64-bit keys for the frames that marked themselves
-            static const bool bitonic32 = getenv("SFE_CF_BITONIC") != nullptr; // A/B: the round-1 narrow-key bitonic sort
-            if (bitonic32) {
-                SFE_HIP(ctx, hipFuncSetAttribute((const void *)cf_downsample_kernel<true, unsigned>,
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * n2)));
-                hipLaunchKernelGGL((cf_downsample_kernel<true, unsigned>), dim3(n_frames), dim3(1024), 4 * n2, ctx->stream,
-                                   d_p32, (long long)cap, d_hdr, d_ds, d_seg, (unsigned *)nullptr, 0LL, 0, d_lkeys);
-            } else {
+            {
                 // indices + keys + counters for the sort, then (same bytes) every point of the frame in sorted order.
                 // (The LDS is sized by the CAPACITY: 128 KB = one frame per CU at 16 384 points, 64 KB = two per CU at 8 192.
                 // Round 4 tried a launch per size class -- frames of <= 8 192 points in a 64 KB launch of their own, the

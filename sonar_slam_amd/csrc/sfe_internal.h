@@ -54,7 +54,7 @@ struct sfe_ctx {
     int cfar_tile_rows = 0;
     int cfar_variant = 0;
     int icp_variant = 0;
-    int extract_variant = 0;     // 0 = inverse-map scatter for binary masks (default), 1 = dense pass only (A/B)
+    int extract_variant = 0;     // 0 = inverse map for binary masks (default), 1 = dense pass only (A/B)
     int icp_prof = 0;            // debug: per-phase cycle counts of workgroup 0 of the sweep kernel
     long long icp_prof_host[SFE_ICP_PROF_N] = {0};
     int n_cu = 256;
@@ -73,15 +73,9 @@ struct sfe_geom {
     // inverse map for sparse binary masks: for every polar pixel the canvas pixels that tap it with a
     // non-zero weight (CSR: offsets [polar_rows * polar_cols + 1], entries = linear canvas indices)
     int32_t *d_inv_off = nullptr;
-    uint2 *d_inv_ent = nullptr;     // {canvas index, its remap code}
     uint2 *d_inv_lut = nullptr;     // {canvas index, decision table of the entry} (extract_gather_kernel)
     uint2 *d_inv_ob = nullptr;      // compact form (round 4): per polar pixel {offset into d_inv_c4, base bit index}
     uint32_t *d_inv_c4 = nullptr;   //   4-byte entries {table, tap place, dx, dy}, dead entries dropped
-    // fused extraction (round 4, extract_fused_kernel): per polar pixel {offset | max dy << 25, base row << 16 | base col},
-    // the canvas cut into parts of fused_pr rows, per part the polar rows whose pixels reach it
-    uint2 *d_inv_ob2 = nullptr;
-    int32_t *d_part_rows = nullptr; // [n_parts][2]: first, last polar row (first > last: nothing reaches the part)
-    int fused_pr = 0, fused_parts = 0;
     // px -> m of feature_extraction.py:236-237 per canvas row / column (fp64, the reference's operation order,
     // evaluated once on the host: extract_expand_words_kernel looks the metres up instead of dividing per point)
     double *d_ytab = nullptr, *d_xtab = nullptr;

@@ -166,11 +166,11 @@ __global__ __launch_bounds__(256) void extract_bits_kernel(const uint8_t *__rest
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_bits[];
     // grid = tiles x (frames or fewer): a workgroup takes its tile of frames f0, f0 + stride, ...  When the binary
-    // frames were done by extract_scatter_kernel (only_general) the launcher keeps the grid small -- a sonar batch
+    // frames were done by extract_gather_kernel (only_general) the launcher keeps the grid small -- a sonar batch
     // normally has no other frame, and 100 000 workgroups that only find that out cost 30 us per launch.
     const int tile = blockIdx.x % tiles_per_frame;
     for (int f = blockIdx.x / tiles_per_frame; f < n_frames; f += gridDim.x / tiles_per_frame) {
-    if (only_general && nonbinary[f] == 0) // binary frames were done by extract_scatter_kernel (block-uniform)
+    if (only_general && nonbinary[f] == 0) // binary frames were done by extract_gather_kernel (block-uniform)
         continue;
     const int w = (tile % word_groups) * 4 + (threadIdx.x >> 6); // wave-uniform
     const int r0 = (tile / word_groups) * EXTRACT_RG, r1 = min(r0 + EXTRACT_RG, crows);
@@ -408,174 +408,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void extract_scan_kernel(const unsign
 }
 
 
-// pass 2 from the second level (round 4): the frame's non-empty canvas words are enumerated from the flag bytes
-// extract_gather_kernel sets (one per canvas word; 64 of them make an l2 word: bit w = word w is not empty) instead of
-// found by streaming the whole canvas bitmap.  One workgroup
-// per frame: the l2 words (480 for config A) are read and cleared; a thread's l2 word gives up to 64 word indices in
-// ascending order = row-major order = np.nonzero order, so the exclusive prefix of the popcounts in LIST order is the
-// number of the frame's points in front of a word: no row bookkeeping for the list at all.  Rounds of L2_ROUND entries:
-// indices -> LDS, then every thread gathers its words' 64 bits (8-byte reads of lines the gather kernel has just
-// written: L2 hits), block scan of the popcounts, entries {row << 16 | word of the row, points in front, 64 bits}
-// straight to the list.  Row counts / offsets (needed by the per-point fallback of frames above the capacity) from LDS
-// counters as in extract_scan_kernel.  Same outputs as extract_scan_kernel.
-#define L2_THREADS 256
-#define L2_ROUND 2048
-__device__ __forceinline__ int l2_block_excl_scan(int v, int *s_w, int *total) // 256 threads; s_w: >= 5 ints
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int incl = scan_wave_incl(v);
-    __syncthreads(); // (s_w may still be read from a previous call)
-    if (lane == 63)
-        s_w[wave] = incl;
-    __syncthreads();
-    int pre = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < L2_THREADS / 64; ++w) {
-        const int x = s_w[w];
-        pre += w < wave ? x : 0;
-        tot += x;
-    }
-    *total = tot;
-    return pre + incl - v;
-}
-
-__global__ __launch_bounds__(L2_THREADS) void extract_scan_l2_kernel(unsigned long long *__restrict__ l2_all, int l2_words,
-                                                                     const unsigned long long *__restrict__ bitmap,
-                                                                     int32_t *__restrict__ row_count,
-                                                                     int32_t *__restrict__ row_off,
-                                                                     int32_t *__restrict__ frame_count, int crows, int wpr,
-                                                                     int4 *__restrict__ wlist, int32_t *__restrict__ wlist_n,
-                                                                     int list_cap, long long cap, int32_t *__restrict__ ovf_n,
-                                                                     int32_t *__restrict__ ovf_list)
-{
-    extern __shared__ __attribute__((aligned(16))) int s_dyn[]; // crows row counts | l2 bases | l2 words (8 B each)
-    __shared__ int s_idx[L2_ROUND];
-    __shared__ int s_w[8];
-    int *s_cntp = s_dyn, *s_base = s_dyn + crows;
-    unsigned long long *s_l2 = reinterpret_cast<unsigned long long *>(s_dyn + crows + ((l2_words + 1) & ~1));
-    const int f = blockIdx.x, tid = threadIdx.x;
-    // flag bytes of the frame's canvas words (extract_gather_kernel), 64 per l2 word
-    uint4 *__restrict__ flags = reinterpret_cast<uint4 *>(reinterpret_cast<uint8_t *>(l2_all) + (long long)f * l2_words * 64);
-    const unsigned long long *__restrict__ bm = bitmap + (long long)f * crows * wpr;
-    int4 *__restrict__ wl = wlist + (long long)f * list_cap;
-    for (int i = tid; i < crows; i += L2_THREADS)
-        s_cntp[i] = 0;
-    // ---- 64 flag bytes -> one l2 word (bit b = canvas word 64 i + b is not empty); the flags that were set are cleared
-    //      (the next batch finds them zero, like the canvas words the expansion clears); exclusive prefix of the
-    //      popcounts = list position of a word's first entry
-    int n_ent = 0;
-    {
-        int carry = 0;
-        for (int b = 0; b < l2_words; b += L2_THREADS) {
-            const int i = b + tid;
-            unsigned long long w = 0ull;
-            if (i < l2_words) {
-                uint4 q[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    q[k] = flags[4 * i + k];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const unsigned n16 = __builtin_amdgcn_udot4(q[k].x, 0x08040201u, 0u, false) |
-                                         (__builtin_amdgcn_udot4(q[k].y, 0x08040201u, 0u, false) << 4) |
-                                         (__builtin_amdgcn_udot4(q[k].z, 0x08040201u, 0u, false) << 8) |
-                                         (__builtin_amdgcn_udot4(q[k].w, 0x08040201u, 0u, false) << 12);
-                    w |= (unsigned long long)n16 << (16 * k);
-                    if (n16)
-                        flags[4 * i + k] = make_uint4(0u, 0u, 0u, 0u);
-                }
-                s_l2[i] = w;
-            }
-            int tot;
-            const int ex = l2_block_excl_scan(__popcll(w), s_w, &tot);
-            if (i < l2_words)
-                s_base[i] = carry + ex;
-            carry += tot;
-        }
-        n_ent = carry;
-    }
-    __syncthreads();
-    // ---- rounds of L2_ROUND list entries
-    int pts_before = 0; // points of the frame in front of this round's first entry (the same in every thread)
-    for (int r0 = 0; r0 < n_ent; r0 += L2_ROUND) {
-        const int r1 = min(r0 + L2_ROUND, n_ent);
-        for (int i = tid; i < l2_words; i += L2_THREADS) { // (few l2 words intersect a round: the loop is short)
-            const int b = s_base[i];
-            unsigned long long w = s_l2[i];
-            const int pc = __popcll(w);
-            if (pc == 0 || b >= r1 || b + pc <= r0)
-                continue;
-            int e = b;
-            while (w) {
-                const int bit = __ffsll((long long)w) - 1;
-                w &= w - 1ull;
-                if (e >= r0 && e < r1)
-                    s_idx[e - r0] = i * 64 + bit;
-                ++e;
-            }
-        }
-        __syncthreads();
-        // a thread owns L2_ROUND / L2_THREADS consecutive entries of the round: their words are requested together (one
-        // exposed round trip per round; one entry per thread and scan step waited for eight of them, one after the other)
-        constexpr int EPT = L2_ROUND / L2_THREADS;
-        int wi[EPT], pc[EPT], sum = 0;
-        unsigned long long wv[EPT];
-#pragma unroll
-        for (int u = 0; u < EPT; ++u) {
-            const int e = r0 + tid * EPT + u;
-            wi[u] = e < r1 ? s_idx[e - r0] : 0;
-            wv[u] = e < r1 ? bm[wi[u]] : 0ull;
-        }
-#pragma unroll
-        for (int u = 0; u < EPT; ++u) {
-            pc[u] = __popcll(wv[u]);
-            sum += pc[u];
-        }
-        int tot;
-        int run = pts_before + l2_block_excl_scan(sum, s_w, &tot);
-#pragma unroll
-        for (int u = 0; u < EPT; ++u) {
-            const int e = r0 + tid * EPT + u;
-            if (e < r1) {
-                const int row = wi[u] / wpr;
-                if (pc[u])
-                    atomicAdd(&s_cntp[row], pc[u]);
-                if (e < list_cap)
-                    wl[e] = make_int4((row << 16) | (wi[u] - row * wpr), run, (int)(unsigned)(wv[u] & 0xFFFFFFFFull),
-                                      (int)(unsigned)(wv[u] >> 32));
-                run += pc[u];
-            }
-        }
-        const int carry = pts_before + tot;
-        pts_before = carry;
-        __syncthreads(); // s_idx is rewritten by the next round
-    }
-    __syncthreads();
-    // ---- row counts -> offsets
-    int32_t *__restrict__ cnt = row_count + (long long)f * crows;
-    int32_t *__restrict__ off = row_off + (long long)f * crows;
-    int carry = 0;
-    for (int b = 0; b < crows; b += L2_THREADS) {
-        const int i = b + tid;
-        const int c = i < crows ? s_cntp[i] : 0;
-        int tot;
-        const int ex = l2_block_excl_scan(c, s_w, &tot);
-        if (i < crows) {
-            cnt[i] = c;
-            off[i] = carry + ex;
-        }
-        carry += tot;
-    }
-    const int total = carry;
-    const bool listed = total <= cap && n_ent <= list_cap; // (total <= cap implies the second: a word holds a point)
-    if (tid == 0) {
-        frame_count[f] = total;
-        wlist_n[f] = listed ? n_ent : 0;
-        if (!listed)
-            ovf_list[atomicAdd(ovf_n, 1)] = f;
-    }
-}
-
 // pass 3, word form: one lane per BYTE of a non-empty bitmap word (extract_scan_kernel's list; 8 lanes share a word):
 // the set bits of a word are consecutive points of the frame (np.nonzero order: row-major), the byte's first one
 // comes after the word's offset + the set bits of the lower bytes.  A lane walks its <= 8 bits -- next set bit,
@@ -778,168 +610,12 @@ __global__ __launch_bounds__(256) void extract_expand_kernel(const unsigned long
     }
 }
 
-// pass 1 for BINARY masks, inverted: CFAR detections are sparse (~1 % of the polar pixels), so instead
-// of evaluating all ~2 M canvas pixels of a frame, walk the set polar pixels and evaluate only the
-// canvas pixels that tap them (precomputed inverse map, sfe_geom_create): ~9 candidates per set
-// pixel, each with exactly the blend of the dense pass; a detection sets its bit with atomicOr
-// (a canvas pixel reached through two of its taps is evaluated twice, idempotent).  40x less work
-// than the dense pass on sonar frames; the bitmap must be zero beforehand.  One workgroup = one frame
-// x SC_ROWS polar rows, which it stages (+1 halo row each side) as bits in LDS.
-#define SC_ROWS 64 // (16 measured 2 % slower: four times the workgroups, each with a handful of set pixels)
-#define SC_LIST 256 // set pixels a wave collects before it expands them
-#define SC_U 4      // candidates per lane whose dependent loads (inverse map entry, taps) overlap; 8 measured 3 % slower
-__global__ __launch_bounds__(256) void extract_scatter_kernel(const uint32_t *__restrict__ bits,
-                                                              const int32_t *__restrict__ nonbinary,
-                                                              const uint32_t *__restrict__ code,
-                                                              const int32_t *__restrict__ inv_off,
-                                                              const uint2 *__restrict__ inv_ent,
-                                                              unsigned long long *__restrict__ bitmap, int prows,
-                                                              int pcols, unsigned rcp, int crows, int ccols, int wpr,
-                                                              long long words_per_frame, int sc_rows, int xcd_contig)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_rows[]; // (sc_rows + 2) x pw words, then per-wave lists
-    // Workgroups are dealt to the 8 XCDs round robin in launch order (x fastest).  Mode 1 arranges row block -> XCD so
-    // that XCD k works on ONE contiguous eighth of the polar rows of every frame (its slice of the inverse map stays
-    // in that XCD's 4 MB L2: -4 % in round 1) -- but sonar detections sit in a few range bands, and the SQ counters of
-    // round 2 showed the XCDs 3x apart in work (VALU instructions per instance 1.08 M .. 4.65 M).  Mode 2 (default) rotates
-    // the row blocks from frame to frame instead, so that every XCD sees every band: -2.5 % against mode 1.
-    int rb = blockIdx.x;
-    if ((gridDim.x & 7) == 0 && xcd_contig == 1)
-        rb = (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
-    else if (xcd_contig == 2) // rotate the row blocks from frame to frame: every XCD sees every range band
-        rb = (int)((blockIdx.x + 5u * blockIdx.y) % gridDim.x);
-    const int f = blockIdx.y, y0 = rb * sc_rows;
-    if (nonbinary[f] != 0)
-        return;
-    const int pw = pcols >> 5;
-    const uint32_t *__restrict__ src = bits + (long long)f * words_per_frame;
-    // the staged rows are one contiguous run of the frame's words: [(y0 - 1) * pw, (y0 + sc_rows + 1) * pw)
-    for (int i = threadIdx.x; i < (sc_rows + 2) * pw; i += 256) {
-        const long long gi = (long long)(y0 - 1) * pw + i;
-        s_rows[i] = (gi >= 0 && gi < (long long)prows * pw) ? src[gi] : 0u; // rows outside the image: no taps
-    }
-    __syncthreads();
-    auto tap = [&](int y, int x) -> int { // bit (y, x) of the mask, 0 outside the image
-        if (x < 0 || x >= pcols)
-            return 0;
-        return (s_rows[(y - (y0 - 1)) * pw + (x >> 5)] >> (x & 31)) & 1;
-    };
-    // Per wave, 64 mask words (2048 polar pixels) at a time:
-    //   1. compact the set pixels into an LDS list (ballot per bit position, no memory traffic);
-    //   2. 64 set pixels per pass: their inverse-map ranges in one batch of loads, wave prefix sum;
-    //   3. load-balanced expansion: lane k takes candidate k of the concatenated ranges (binary search in
-    //      the prefix), so the dependent loads inv_ent -> code run 64 wide instead of as a per-lane chain.
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t *s_list = s_rows + (sc_rows + 2) * pw + wave * (SC_LIST + 128); // set pixels collected by this wave
-    uint32_t *s_off = s_list + SC_LIST, *s_excl = s_off + 64;                // per pass: range start, exclusive prefix
-    int nset = 0;
-    auto flush = [&]() { // expand the collected set pixels (wave-uniform)
-        for (int j0 = 0; j0 < nset; j0 += 64) {
-            const int j = j0 + lane;
-            int off0 = 0, cnt = 0;
-            if (j < nset) {
-                const int pi = (int)s_list[j];
-                off0 = inv_off[pi];
-                cnt = inv_off[pi + 1] - off0;
-            }
-            const int incl = scan_wave_incl(cnt);
-            const int total = __builtin_amdgcn_readlane(incl, 63);
-            s_off[lane] = (uint32_t)off0;
-            s_excl[lane] = (uint32_t)(incl - cnt);
-            for (int k0 = lane; k0 < total; k0 += 64 * SC_U) { // SC_U independent candidates per lane in flight
-                uint32_t o[SC_U], cd[SC_U];
-                int src_pi[SC_U];
-#pragma unroll
-                for (int u = 0; u < SC_U; ++u) {
-                    const int k = k0 + 64 * u;
-                    int lo = 0, hi = 63; // largest source lane whose exclusive prefix is <= k
-                    while (lo < hi) {
-                        const int mid = (lo + hi + 1) >> 1;
-                        if ((int)s_excl[mid] <= k)
-                            lo = mid;
-                        else
-                            hi = mid - 1;
-                    }
-                    // one 8-byte entry = {canvas pixel, its remap code}: the code table itself (another scattered
-                    // 4-byte read per candidate, three cache lines per set pixel) is not touched here
-                    const uint2 e = k < total ? inv_ent[s_off[lo] + (uint32_t)(k - (int)s_excl[lo])]
-                                              : make_uint2(0xFFFFFFFFu, SFE_CODE_NONE);
-                    o[u] = e.x;
-                    cd[u] = e.y;
-                    src_pi[u] = (int)s_list[j0 + lo]; // the set pixel this candidate was reached from
-                }
-#pragma unroll
-                for (int u = 0; u < SC_U; ++u) {
-                    if (o[u] == 0xFFFFFFFFu)
-                        continue;
-                    const unsigned lin = cd[u] >> 10;
-                    const int fy = (int)((cd[u] >> 5) & 31u), fx = (int)(cd[u] & 31u);
-                    const unsigned q = __umulhi(lin, rcp);
-                    const int iy = (int)q - 1, ix = (int)(lin - q * (unsigned)(pcols + 1)) - 1;
-                    // iy, iy + 1 lie within one row of the set pixel: inside the staged rows
-                    const int v00 = tap(iy, ix), v01 = tap(iy, ix + 1), v10 = tap(iy + 1, ix), v11 = tap(iy + 1, ix + 1);
-                    int w00 = (32 - fy) * (32 - fx) * 32, w01 = (32 - fy) * fx * 32;
-                    int w10 = fy * (32 - fx) * 32, w11 = fy * fx * 32;
-                    if ((fx | fy) == 0) {
-                        w00 = 32767;
-                        w11 = 1;
-                    }
-                    const int acc = w00 * v00 + w01 * v01 + w10 * v10 + w11 * v11;
-                    // a canvas pixel is reached once per set tap: only the visit through its FIRST set tap
-                    // with a non-zero weight (the taps the inverse map lists) writes, which removes the
-                    // duplicate atomics on clustered detections
-                    // which tap of this canvas pixel the set pixel is: pi - (iy * pcols + ix) = dy * pcols + dx, dy, dx in {0, 1}
-                    const int dlt = src_pi[u] - (iy * pcols + ix);
-                    const int t_src = dlt >= pcols ? 2 + (dlt - pcols) : dlt;
-                    const int first = (v00 && w00) ? 0 : (v01 && w01) ? 1 : (v10 && w10) ? 2 : 3;
-                    if (((acc + 16384) >> 15) != 0 && t_src == first) // o = bit index inside the frame's bitmap
-                        atomicOr(&bitmap[(long long)f * crows * wpr + (o[u] >> 6)], 1ull << (o[u] & 63u));
-                }
-            }
-        }
-        nset = 0;
-    };
-    for (int c0 = wave * 64; c0 < sc_rows * pw; c0 += 4 * 64) {
-        const int wi = c0 + lane;
-        const int gw = y0 * pw + wi; // word index inside the frame: its pixels are gw * 32 .. gw * 32 + 31
-        uint32_t word = (wi < sc_rows * pw && gw < prows * pw) ? s_rows[pw + wi] : 0u;
-        const int pc = __popc(word);
-        if (!__ballot(pc != 0))
-            continue;
-        // every lane appends the set bits of its own word behind those of the lanes before it (wave prefix sum of
-        // the popcounts): a handful of steps for a sparse mask, where one ballot per bit position costs 32
-        const int incl = scan_wave_incl(pc);
-        const int total = __builtin_amdgcn_readlane(incl, 63);
-        if (total <= SC_LIST) {
-            if (nset + total > SC_LIST)
-                flush();
-            int pos = nset + incl - pc;
-            while (word) {
-                const int bb = __ffs((int)word) - 1;
-                s_list[pos++] = (uint32_t)(gw * 32 + bb);
-                word &= word - 1u;
-            }
-            nset += total;
-            continue;
-        }
-        for (int bb = 0; bb < 32; ++bb) { // a dense stretch of the mask: bit position by bit position, <= 64 at a time
-            const bool set = (word >> bb) & 1u;
-            const unsigned long long m = __ballot(set);
-            if (!m)
-                continue;
-            if (nset + 64 > SC_LIST)
-                flush();
-            if (set)
-                s_list[nset + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)(gw * 32 + bb);
-            nset += __popcll(m);
-        }
-    }
-    flush();
-}
-
-// The same pass, round 3: list first, then one lane per set pixel.  The kernel above gives a workgroup a block of polar
-// rows; a sonar frame's ~5 000 detections sit in a few range bands, so most waves find a handful of set pixels and pay
-// ~900 instructions of staging, scanning and prefix searches around them.  Here a workgroup takes every
+// pass 1 for BINARY masks, inverted: CFAR detections are sparse (~1 % of the polar pixels), so instead of evaluating all
+// ~2 M canvas pixels of a frame, walk the set polar pixels and evaluate only the canvas pixels that tap them (precomputed
+// inverse map, sfe_geom_create): a few candidates per set pixel, each with exactly the blend of the dense pass.  (Round 2's
+// form gave a workgroup a block of polar rows: a sonar frame's ~5 000 detections sit in a few range bands, so most waves
+// found a handful of set pixels and paid ~900 instructions of staging, scanning and prefix searches around them;
+// profiles/r05_pruned_variants.txt)  List first, then one lane per set pixel: a workgroup takes every
 // `slices`-th 64-word piece of the frame's bit stream (interleaved: every workgroup sees every band), collects the
 // set pixels of its pieces in ONE LDS list (unordered: the canvas bits are OR-ed), and then all 256 threads draw from
 // that list: a lane owns one set pixel, reads the 3 x 3 mask bits around it once from the frame's bit stream (rows
@@ -970,8 +646,7 @@ __global__ __launch_bounds__(256, 8) void extract_gather_kernel(const uint32_t *
                                                                 const uint2 *__restrict__ inv_ent,
                                                                 unsigned long long *__restrict__ bitmap, int prows,
                                                                 int pcols, int crows, int wpr, long long words_per_frame,
-                                                                int piece_shift, unsigned long long *__restrict__ l2_all,
-                                                                int l2_words)
+                                                                int piece_shift)
 {
     __shared__ uint32_t s_list[SG_LIST]; // (row << 16 | column) of a set pixel
     __shared__ int s_n, s_want[2]; // (s_want: by step parity -- the other one is cleared while this one is read)
@@ -996,17 +671,7 @@ __global__ __launch_bounds__(256, 8) void extract_gather_kernel(const uint32_t *
     const int sl = (int)((blockIdx.x + 5u * blockIdx.y) % (unsigned)slices);
     const uint32_t *__restrict__ src = bits + (long long)f * words_per_frame;
     unsigned long long *__restrict__ bm = bitmap + (long long)f * crows * wpr;
-    // second level (round 4): one FLAG BYTE per canvas word of the frame, set by a plain store next to the OR into the
-    // word, so the scan kernel visits the ~2 300 non-empty words of a frame instead of streaming all 30 720 (0.24 MB per
-    // frame: the largest single stream the stage had).  Measured on the way: a second-level BIT map needs an atomic per
-    // flushed word -- returning ("was the word empty?") or not, the gather kernel went from 113 to 140 us per 512 frames:
-    // it is bound by its ~1.3 M global atomics per launch.  A byte store is idempotent and needs no atomic.
-    uint8_t *__restrict__ l2 = l2_all ? reinterpret_cast<uint8_t *>(l2_all) + (long long)f * l2_words * 64 : nullptr;
-    auto or_word = [&](unsigned wd, unsigned long long m) {
-        atomicOr(&bm[wd], m);
-        if (l2)
-            l2[wd] = 1;
-    };
+    auto or_word = [&](unsigned wd, unsigned long long m) { atomicOr(&bm[wd], m); };
     // pieces of 64 << piece_shift words (64 words = 4 polar rows of 512 beams); piece p belongs to slice p % slices.  The
     // workgroup's words, piece after piece, are looked at `blk` at a time: thread t takes words t, t + 256, ...
     const int pwords = 64 << piece_shift;
@@ -1182,304 +847,6 @@ __global__ __launch_bounds__(256, 8) void extract_gather_kernel(const uint32_t *
 }
 
 // ---------------------------------------------------------------------------------------------
-// Round 4: the extraction without a canvas bitmap in HBM.
-// The three-kernel path above keeps a frame's detection bitmap (0.25 MB, one bit per canvas pixel) in HBM: the gather kernel
-// ORs ~2 300 of its 30 720 words with global atomics, the scan kernel streams all of it to find them, the expansion reads them
-// again and zeroes them -- 0.84 MB of traffic per frame for 0.25 MB of mask bits in and points out, and three launches.
-// Here the canvas is cut into parts of PR rows (PR x words_per_row x 8 B of LDS: 30 KB for config A at PR = 128) and a
-// workgroup takes ONE part of ONE frame (blockIdx.x = part, blockIdx.y = frame):
-//   1. the polar rows whose pixels can reach the part (a range per part, from the geometry) are scanned in the frame's bit
-//      stream, set pixels collected in an LDS list and expanded one lane per set pixel exactly like
-//      extract_gather_kernel<true> (same 4-byte entries, same decision tables, same first-tap rule) -- but the bits go into
-//      the LDS bitmap with ds atomics, and a pixel whose candidates lie outside the part's rows is dropped after one read;
-//   2. popcounts of the part's words -> exclusive prefix (a thread owns consecutive words, one block scan); the part's
-//      total is PUBLISHED (release store) and the totals of the parts above are awaited (acquire loads): the parts of a
-//      frame are consecutive workgroups of the launch, dispatched in order, so whoever is waited for is resident or done
-//      (the decoupled look-back of a device-wide scan; a bounded wait guards against the impossible);
-//   3. a lane per POINT of the part: binary search for its word in the prefix array, rank-select of its bit, the metres
-//      from the px->m tables (x staged in LDS), one 16-byte store at (points of the parts above) + its rank: contiguous,
-//      in np.nonzero order.
-// A polar pixel is looked at by every part whose polar range holds it (3.3 parts on average for a 130 degree fan): the
-// price of a canvas that never leaves the CU.  (First form of this kernel: one workgroup per FRAME going through the parts
-// one after the other -- no hand-over at all, and 0.69 ms per 512 frames against 0.19: eight parts x ~10 dependent memory
-// round trips each are a chain of ~0.3 ms per frame whatever the occupancy.)  No global bitmap, no global atomics, no word
-// lists, nothing to clean.  Same points in the same order (tests/test_gpu_extract.py runs every path).
-// ---------------------------------------------------------------------------------------------
-#define FX_NT 512
-#define FX_LIST 1536
-__device__ __forceinline__ int fx_block_excl_scan(int v, int *s_w, int *total) // FX_NT threads; s_w: >= FX_NT / 64 ints
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int incl = scan_wave_incl(v);
-    __syncthreads();
-    if (lane == 63)
-        s_w[wave] = incl;
-    __syncthreads();
-    int pre = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < FX_NT / 64; ++w) {
-        const int x = s_w[w];
-        pre += w < wave ? x : 0;
-        tot += x;
-    }
-    *total = tot;
-    return pre + incl - v;
-}
-
-__global__ __launch_bounds__(FX_NT, 2) void extract_fused_kernel(const uint32_t *__restrict__ bits,
-                                                                  const uint2 *__restrict__ ob2,
-                                                                  const uint32_t *__restrict__ ent4,
-                                                                  const int32_t *__restrict__ part_rows, int n_parts, int PR,
-                                                                  int prows, int pcols, int crows, int ccols, int wpr,
-                                                                  long long words_per_frame,
-                                                                  const double *__restrict__ ytab,
-                                                                  const double *__restrict__ xtab,
-                                                                  long long *__restrict__ rc_out,
-                                                                  double *__restrict__ pts_out, long long cap,
-                                                                  int32_t *__restrict__ counts,
-                                                                  int32_t *__restrict__ part_cnt)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char fx_raw[]; // bitmap PR*wpr u64 | prefix PR*wpr+1 int | x table
-    __shared__ uint32_t s_list[FX_LIST];
-    __shared__ int s_n, s_want[2], s_w[FX_NT / 64], s_base;
-    const int nwp = PR * wpr; // words of a part
-    unsigned long long *s_bm = reinterpret_cast<unsigned long long *>(fx_raw);
-    int *s_pre = reinterpret_cast<int *>(s_bm + nwp);
-    double *s_x = reinterpret_cast<double *>(s_pre + ((nwp + 2) & ~1));
-    // (workgroup b runs on XCD b % 8: with 8 parts every XCD would get ONE part of every frame, and the parts differ in
-    // work -- the middle of the canvas is reached from 64 % of the polar rows, the far edge from 12 %; rotating the parts
-    // from frame to frame gives every XCD every part.  The hand-over only needs that a frame's workgroups are dispatched
-    // once the frames before it are: every XCD goes through its workgroups in launch order.)
-    const int f = blockIdx.y, part = (int)((blockIdx.x + blockIdx.y) % (unsigned)n_parts), tid = threadIdx.x, lane = tid & 63;
-    const uint32_t *__restrict__ src = bits + (long long)f * words_per_frame;
-    const int pw = pcols >> 5;
-    if (tid == 0) {
-        s_n = 0;
-        s_want[0] = s_want[1] = 0;
-        s_base = 0;
-    }
-    int base_pts = 0; // points of the parts above (the same in every thread)
-    int par = 0;      // which of the two s_want counters the next collection step uses (the other one is zero)
-    {
-        const int R0 = part * PR, R1 = min(R0 + PR, crows);
-        const int pr_lo = part_rows[2 * part], pr_hi = part_rows[2 * part + 1];
-        for (int i = tid; i < nwp; i += FX_NT)
-            s_bm[i] = 0ull;
-        __syncthreads();
-        // ---- 1. set pixels of the part's polar rows -> LDS list -> one lane per set pixel (cf. extract_gather_kernel)
-        const int w_lo = pr_lo * pw, my_words = pr_lo <= pr_hi ? (pr_hi - pr_lo + 1) * pw : 0;
-        int v0 = 0, blk = 4 * FX_NT;
-        while (my_words > 0) {
-            while (v0 < my_words) {
-                uint32_t w[4];
-                int gw[4], pc = 0;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int v = v0 + u * FX_NT + tid;
-                    gw[u] = w_lo + v;
-                    w[u] = (u * FX_NT + tid < blk && v < my_words) ? src[gw[u]] : 0u;
-                    pc += __popc(w[u]);
-                }
-                const int incl = scan_wave_incl(pc);
-                const int wtotal = __builtin_amdgcn_readlane(incl, 63);
-                int base = 0;
-                if (wtotal != 0 && lane == 63)
-                    base = atomicAdd(&s_want[par], wtotal);
-                base = __builtin_amdgcn_readlane(base, 63);
-                __syncthreads();
-                const int want = s_want[par], at = s_n;
-                if (tid == 0)
-                    s_want[par ^ 1] = 0;
-                __syncthreads();
-                par ^= 1;
-                if (at + want > FX_LIST) {
-                    if (at == 0)
-                        blk = 32; // (more than FX_LIST set pixels in one step: 32 words = 1024 pixels always fit)
-                    break;
-                }
-                if (want != 0) {
-                    int pos = at + base + incl - pc;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        uint32_t word = w[u];
-                        if (word) {
-                            const int row = gw[u] / pw, c0 = (gw[u] - row * pw) * 32;
-                            do {
-                                const int bb = __ffs((int)word) - 1;
-                                s_list[pos++] = ((uint32_t)row << 16) | (uint32_t)(c0 + bb);
-                                word &= word - 1u;
-                            } while (word);
-                        }
-                    }
-                    __syncthreads();
-                    if (tid == 0)
-                        s_n = at + want;
-                }
-                v0 += blk;
-            }
-            __syncthreads();
-            const int n = s_n;
-            for (int j = tid; j < n; j += FX_NT) {
-                const uint32_t ent = s_list[j];
-                const int py = (int)(ent >> 16), px = (int)(ent & 0xFFFFu);
-                const int pi = py * pcols + px;
-                uint4 ob; // {offset | max dy << 25, base row << 16 | base col} of this pixel, offset of the next one
-                __builtin_memcpy(&ob, ob2 + pi, 16);
-                const int off0 = (int)(ob.x & 0x1FFFFFFu), cnt = (int)(ob.z & 0x1FFFFFFu) - off0;
-                const int brow = (int)(ob.y >> 16), bcol = (int)(ob.y & 0xFFFFu), maxdy = (int)(ob.x >> 25);
-                if (cnt == 0 || brow >= R1 || brow + maxdy < R0)
-                    continue; // none of this pixel's candidates lies in the part
-                unsigned nb; // the 3 x 3 mask bits around the pixel (as in extract_gather_kernel)
-                if (pw >= 2) {
-                    const int wb = min(max((px >> 5) - ((px & 31) < 16 ? 1 : 0), 0), pw - 2);
-                    const int rel = px - 1 - 32 * wb;
-                    auto bits3 = [&](int yy) -> unsigned {
-                        const bool in = yy >= 0 && yy < prows;
-                        unsigned long long ww;
-                        __builtin_memcpy(&ww, src + (long long)(in ? yy : py) * pw + wb, 8);
-                        ww = rel >= 0 ? ww >> rel : ww << 1;
-                        return in ? (unsigned)ww & 7u : 0u;
-                    };
-                    nb = bits3(py - 1) | (bits3(py) << 3) | (bits3(py + 1) << 6);
-                } else {
-                    auto bits3 = [&](int yy) -> unsigned {
-                        if (yy < 0 || yy >= prows)
-                            return 0u;
-                        return (unsigned)(((unsigned long long)src[yy] << 1) >> px) & 7u;
-                    };
-                    nb = bits3(py - 1) | (bits3(py) << 3) | (bits3(py + 1) << 6);
-                }
-                int run_w = -1;
-                unsigned long long run_m = 0ull;
-                auto cand4 = [&](uint32_t e, bool live) {
-                    const unsigned sc = (e >> 16) & 3u;
-                    const unsigned sh = nb >> (sc + (sc >> 1)); // tap place ry * 2 + rx -> shift ry * 3 + rx
-                    const unsigned pat = (sh & 3u) | ((sh >> 1) & 12u);
-                    const int row = brow + (int)(e >> 25);
-                    if (live && ((e >> pat) & 1u) && row >= R0 && row < R1) {
-                        const int col = bcol + (int)((e >> 18) & 127u);
-                        const int wd = (row - R0) * wpr + (col >> 6);
-                        if (wd != run_w) {
-                            if (run_m)
-                                atomicOr(&s_bm[run_w], run_m);
-                            run_w = wd;
-                            run_m = 0ull;
-                        }
-                        run_m |= 1ull << (col & 63);
-                    }
-                };
-                for (int k = 0; k < cnt; k += 8) {
-                    uint4 a, b2;
-                    __builtin_memcpy(&a, ent4 + off0 + k, 16);
-                    __builtin_memcpy(&b2, ent4 + off0 + min(k + 4, cnt - 1), 16);
-                    const bool two = k + 4 < cnt;
-                    cand4(a.x, true);
-                    cand4(a.y, k + 1 < cnt);
-                    cand4(a.z, k + 2 < cnt);
-                    cand4(a.w, k + 3 < cnt);
-                    cand4(b2.x, two);
-                    cand4(b2.y, k + 5 < cnt);
-                    cand4(b2.z, k + 6 < cnt);
-                    cand4(b2.w, k + 7 < cnt);
-                }
-                if (run_m)
-                    atomicOr(&s_bm[run_w], run_m);
-            }
-            __syncthreads();
-            if (tid == 0)
-                s_n = 0;
-            __syncthreads();
-            if (v0 >= my_words)
-                break;
-        }
-        __syncthreads();
-        // ---- 2. points in front of every word of the part (row-major = np.nonzero order)
-        const int wpt = (nwp + FX_NT - 1) / FX_NT; // words per thread, consecutive
-        const int w0 = min(tid * wpt, nwp), w1 = min(w0 + wpt, nwp);
-        int mine = 0;
-        for (int w = w0; w < w1; ++w)
-            mine += __popcll(s_bm[w]);
-        int total;
-        int run = fx_block_excl_scan(mine, s_w, &total);
-        for (int w = w0; w < w1; ++w) {
-            s_pre[w] = run;
-            run += __popcll(s_bm[w]);
-        }
-        if (tid == FX_NT - 1 || w1 == nwp)
-            s_pre[nwp] = total;
-        // hand-over: this part's total goes out, the totals of the parts above come in
-        int32_t *pc = part_cnt + (long long)f * n_parts;
-        if (tid == 0)
-            __hip_atomic_store(pc + part, total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        if (total > 0 && pts_out)
-            for (int i = tid; i < ccols; i += FX_NT) // (only a part with points needs the table)
-                s_x[i] = xtab[i];
-        for (int q = tid; q < part; q += FX_NT) {
-            int v = __hip_atomic_load(pc + q, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-            if (v < 0) {
-                const unsigned long long t0 = wall_clock64(); // 100 MHz
-                while (true) {
-                    __builtin_amdgcn_s_sleep(4);
-                    v = __hip_atomic_load(pc + q, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                    if (v >= 0 || wall_clock64() - t0 > 20000000ull) // (0.2 s: never seen; a wrong count beats a hung device)
-                        break;
-                }
-            }
-            atomicAdd(&s_base, max(v, 0));
-        }
-        __syncthreads();
-        base_pts = s_base;
-        // ---- 3. a lane per point
-        for (int j = tid; j < total; j += FX_NT) {
-            const long long t = (long long)base_pts + j;
-            if (t >= cap)
-                break; // (the count goes on; only the first cap points are stored: sonarfe.h)
-            int lo = 0, hi = nwp - 1; // the last word whose prefix is <= j and that holds a point
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                if (s_pre[mid] <= j)
-                    lo = mid;
-                else
-                    hi = mid - 1;
-            }
-            // (words with equal prefix: the search ends on the last of them, which is the non-empty one or lies behind
-            // it -- step back to the word whose range really holds j)
-            while (s_pre[lo + 1] <= j)
-                ++lo; // never taken: kept for clarity of the invariant s_pre[lo] <= j < s_pre[lo + 1]
-            const unsigned long long wbits = s_bm[lo];
-            int rr = j - s_pre[lo], bit = 0;
-            unsigned w32 = (unsigned)wbits;
-            {
-                const int c = __popc(w32);
-                if (rr >= c) {
-                    rr -= c;
-                    w32 = (unsigned)(wbits >> 32);
-                    bit = 32;
-                }
-            }
-#pragma unroll
-            for (int h = 16; h >= 1; h >>= 1) {
-                const int c = __popc(w32 & ((1u << h) - 1u));
-                if (rr >= c) {
-                    rr -= c;
-                    w32 >>= h;
-                    bit += h;
-                }
-            }
-            const int rrow = lo / wpr;
-            const int row = R0 + rrow, col = (lo - rrow * wpr) * 64 + bit;
-            const long long o = (long long)f * cap + t;
-            if (rc_out)
-                reinterpret_cast<longlong2 *>(rc_out)[o] = make_longlong2(row, col);
-            if (pts_out)
-                reinterpret_cast<double2 *>(pts_out)[o] = make_double2(ytab[row], s_x[col]);
-        }
-        if (tid == 0 && part == n_parts - 1)
-            counts[f] = base_pts + total;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // byte mask -> bit stream (mask_pack_kernel) for n_frames frames of px pixels; d_nonbin (optional, n_frames ints,
 // zeroed by the caller) is set for frames holding a byte > 1
 int sfe_mask_pack(sfe_ctx *ctx, const uint8_t *d_mask, int n_frames, long long px, uint32_t *d_bits, int32_t *d_nonbin)
@@ -1507,17 +874,7 @@ static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_f
     const int crows = g->cart_rows, wpr = g->words_per_row;
     static const int chunk = getenv("SFE_EXTRACT_CHUNK") ? std::max(1, atoi(getenv("SFE_EXTRACT_CHUNK"))) : 1024; // frames per pass: bounds the bitmap scratch (0.25 MB per frame), fewer passes = fewer launches
     const size_t bm_bytes = (size_t)chunk * crows * wpr * sizeof(unsigned long long);
-    // second-level bitmap: one bit per canvas word, behind the canvas bitmaps in the same slot (they are clean together)
-    const int l2_words = (int)(((long long)crows * wpr + 63) / 64);
-    const size_t l2_bytes = (size_t)chunk * l2_words * 64; // one flag byte per canvas word, 64 per l2 word
-    unsigned long long *d_bm = (unsigned long long *)sfe_scratch(ctx, 39, bm_bytes + l2_bytes); // (a slot of its own: its contents outlive the call, see self_clean)
-    unsigned long long *d_l2 = d_bm ? d_bm + (size_t)chunk * crows * wpr : nullptr;
-    // The second level is OFF by default (SFE_EXTRACT_L2=1 switches it on; read per call so that the tests cover both):
-    // measured on MI355X it saves the scan kernel's stream over the canvas bitmap (0.24 MB per frame) but its own kernel
-    // gathers the ~2 300 non-empty words of a frame one 64-byte line each -- 150 MB per 1024 frames against a 256 MB
-    // sequential stream at 6 TB/s -- and came out level at 512 frames per launch (0.182 vs 0.184 ms) and 9 % slower at
-    // the bench's 4096 (1.62 vs 1.48 ms): DESIGN 5.2.
-    const bool no_l2 = !(getenv("SFE_EXTRACT_L2") && atoi(getenv("SFE_EXTRACT_L2")) != 0);
+    unsigned long long *d_bm = (unsigned long long *)sfe_scratch(ctx, 39, bm_bytes); // (a slot of its own: its contents outlive the call, see self_clean)
     int32_t *d_rcnt = (int32_t *)sfe_scratch(ctx, 5, (size_t)chunk * crows * 4);
     int32_t *d_roff = (int32_t *)sfe_scratch(ctx, 6, (size_t)chunk * crows * 4);
     if (!d_bm || !d_rcnt || !d_roff)
@@ -1565,52 +922,20 @@ static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_f
         if (!d_bits_in)
             hipLaunchKernelGGL(mask_pack_kernel, dim3((unsigned)((wpf + 255) / 256), nf), dim3(256), 0, ctx->stream, m,
                                d_bits_own, d_nonbin, px, wpf);
-        const bool scatter = g->d_inv_off != nullptr && (g->polar_cols & 31) == 0 && ctx->extract_variant != 1;
-        // (row << 16 | column) list entries: images up to 65 535 x 65 535; variant 2 = the row-block kernel of round 2
-        const bool gather = scatter && ctx->extract_variant == 0 && g->polar_rows < 65536 && g->polar_cols < 65536;
+        // binary frames through the inverse map ((row << 16 | column) list entries: images up to 65 535 x 65 535)
+        const bool gather = g->d_inv_off != nullptr && (g->polar_cols & 31) == 0 && ctx->extract_variant != 1 &&
+                            g->polar_rows < 65536 && g->polar_cols < 65536;
         // The bitmap cleans up after itself on this path (binary frames through the list kernel, word-list expansion
         // with a capacity: extract_expand_words_kernel clears the words it expands, extract_clean_queued_kernel the
         // frames without a list): the memset is only needed when the scratch is new or another path (or a failed
         // call) has left bits behind.
-        // Round 4: the fused kernel (canvas bitmap in LDS, one workgroup per part of a frame) for binary bit streams.
-        // OFF by default (SFE_EXTRACT_FUSED=1 switches it on; read per call so that the tests cover it): measured on
-        // MI355X it moves a third of the bytes and is 4-5 x slower -- 0.98 ms per 512 frames against 0.19 (0.69 ms in its
-        // first form, one workgroup per frame): every part rescans its share of the bit stream and re-reads the offsets of
-        // the set pixels there (3.3 parts see a pixel), and a 512-thread workgroup with 66 KB of LDS hides the dependent
-        // reads of the per-pixel walk far worse than the gather kernel's eight small workgroups per CU.
-        {
-            const char *fe_ = getenv("SFE_EXTRACT_FUSED");
-            const int fused_mode = fe_ ? atoi(fe_) : 0;
-            const bool fused = gather && d_bits_in && cap > 0 && cap < (1ll << 31) && g->d_inv_ob2 && g->d_ytab && g->d_xtab &&
-                               fused_mode == 1;
-            if (fused) {
-                const int PR = g->fused_pr, nwp = PR * wpr;
-                const size_t lds = (size_t)nwp * 8 + (size_t)((nwp + 2) & ~1) * 4 + (size_t)g->cart_cols * 8;
-                SFE_HIP(ctx, hipFuncSetAttribute((const void *)extract_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                 (int)lds));
-                int32_t *d_pcnt = (int32_t *)sfe_scratch(ctx, 52, (size_t)chunk * g->fused_parts * 4);
-                if (!d_pcnt)
-                    return SFE_ERR_HIP;
-                SFE_HIP(ctx, hipMemsetAsync(d_pcnt, 0xFF, (size_t)nf * g->fused_parts * 4, ctx->stream)); // -1 = not there yet
-                hipLaunchKernelGGL(extract_fused_kernel, dim3(g->fused_parts, nf), dim3(FX_NT), lds, ctx->stream, d_bits,
-                                   (const uint2 *)g->d_inv_ob2, (const uint32_t *)g->d_inv_c4, (const int32_t *)g->d_part_rows,
-                                   g->fused_parts, PR, g->polar_rows, g->polar_cols, crows, g->cart_cols, wpr, wpf,
-                                   (const double *)g->d_ytab, (const double *)g->d_xtab,
-                                   d_rc ? d_rc + (size_t)f0 * cap * 2 : (long long *)nullptr,
-                                   d_pts ? d_pts + (size_t)f0 * cap * 2 : (double *)nullptr, (long long)cap, d_counts + f0,
-                                   d_pcnt);
-                continue; // (the canvas bitmap in HBM is not touched: what is known about its state stays)
-            }
-        }
         const bool self_clean = gather && d_bits_in && use_words && cap > 0 && !nosc;
         const size_t bm_need = (size_t)nf * crows * wpr * sizeof(unsigned long long);
         if (!self_clean)
             clean_bytes = 0; // (this pass leaves its bits in the bitmap)
         if (gather) {
-            if (!(self_clean && clean_bytes >= bm_need)) {
+            if (!(self_clean && clean_bytes >= bm_need))
                 SFE_HIP(ctx, hipMemsetAsync(d_bm, 0, bm_need, ctx->stream));
-                SFE_HIP(ctx, hipMemsetAsync(d_l2, 0, (size_t)nf * l2_words * 64, ctx->stream));
-            }
             if (self_clean)
                 clean_bytes = std::max(clean_bytes, bm_need);
             // workgroups per frame: enough of them to fill the device with a few frames, few enough that a
@@ -1632,43 +957,23 @@ static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_f
                 hipLaunchKernelGGL(extract_gather_kernel<true>, dim3((unsigned)slices, nf), dim3(256), 0, ctx->stream, d_bits,
                                    d_nonbin, reinterpret_cast<const int32_t *>(g->d_inv_ob),
                                    reinterpret_cast<const uint2 *>(g->d_inv_c4), d_bm, g->polar_rows, g->polar_cols, crows, wpr,
-                                   wpf, sg_piece, (self_clean && !no_l2) ? d_l2 : (unsigned long long *)nullptr, l2_words);
+                                   wpf, sg_piece);
             else
-            hipLaunchKernelGGL(extract_gather_kernel<false>, dim3((unsigned)slices, nf), dim3(256), 0, ctx->stream, d_bits, d_nonbin,
-                               g->d_inv_off, g->d_inv_lut, d_bm, g->polar_rows, g->polar_cols, crows, wpr, wpf, sg_piece,
-                               (self_clean && !no_l2) ? d_l2 : (unsigned long long *)nullptr, l2_words);
-        } else if (scatter) {
-            // sparse binary masks: inverse map (binary frames), dense pass only for frames with other values
-            SFE_HIP(ctx, hipMemsetAsync(d_bm, 0, (size_t)nf * crows * wpr * sizeof(unsigned long long), ctx->stream));
-            const int pw = g->polar_cols >> 5;
-            static const int sc_xcd = getenv("SFE_SC_XCD") ? atoi(getenv("SFE_SC_XCD")) : 2; // 2: rotate (measured -2.5 % against 1: contiguous eighths)
-            static const int sc_rows = getenv("SFE_SC_ROWS") ? std::max(1, atoi(getenv("SFE_SC_ROWS"))) : SC_ROWS;
-            hipLaunchKernelGGL(extract_scatter_kernel, dim3((unsigned)((g->polar_rows + sc_rows - 1) / sc_rows), nf),
-                               dim3(256), ((size_t)(sc_rows + 2) * pw + 4 * (SC_LIST + 128)) * 4, ctx->stream, d_bits, d_nonbin,
-                               (const uint32_t *)g->d_code, g->d_inv_off, g->d_inv_ent, d_bm, g->polar_rows,
-                               g->polar_cols, g->rcp, crows, g->cart_cols, wpr, wpf, sc_rows, sc_xcd);
+                hipLaunchKernelGGL(extract_gather_kernel<false>, dim3((unsigned)slices, nf), dim3(256), 0, ctx->stream, d_bits,
+                                   d_nonbin, g->d_inv_off, g->d_inv_lut, d_bm, g->polar_rows, g->polar_cols, crows, wpr, wpf,
+                                   sg_piece);
         }
-        if (!(scatter && d_bits_in)) // bit streams are binary: nothing is left for the general pass
-        hipLaunchKernelGGL(extract_bits_kernel, dim3((unsigned)((scatter ? std::min(nf, 8) : nf) * tiles)), dim3(256),
+        if (!(gather && d_bits_in)) // bit streams are binary: nothing is left for the general pass
+        hipLaunchKernelGGL(extract_bits_kernel, dim3((unsigned)((gather ? std::min(nf, 8) : nf) * tiles)), dim3(256),
                            g->lds_bytes, ctx->stream, m, d_bits, d_nonbin, (const uint32_t *)g->d_code, g->d_span,
                            g->d_tile_rows, d_bm, g->polar_rows, g->polar_cols, g->rcp, crows, g->cart_cols, wpr, word_groups,
-                           tiles, wpf, scatter ? 1 : 0, nf);
+                           tiles, wpf, gather ? 1 : 0, nf);
         if (use_words)
             SFE_HIP(ctx, hipMemsetAsync(d_ovf, 0, 4, ctx->stream));
         const size_t scan_lds = sizeof(int) * ((size_t)crows + SCAN_THREADS + (use_words ? (words_pf + 63) / 64 + 4 * SCAN_LDS_LIST : 0));
         if (scan_lds > 48 * 1024)
             SFE_HIP(ctx, hipFuncSetAttribute((const void *)extract_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)scan_lds));
-        if (gather && self_clean && !no_l2) {
-            // (self_clean: binary frames only, every bit of the canvas bitmap came through the gather kernel's or_word)
-            const size_t l2_lds = sizeof(int) * ((size_t)crows + ((l2_words + 1) & ~1) + 2 * (size_t)l2_words);
-            if (l2_lds > 32 * 1024)
-                SFE_HIP(ctx, hipFuncSetAttribute((const void *)extract_scan_l2_kernel,
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2_lds));
-            hipLaunchKernelGGL(extract_scan_l2_kernel, dim3(nf), dim3(L2_THREADS), l2_lds, ctx->stream, d_l2, l2_words,
-                               (const unsigned long long *)d_bm, d_rcnt, d_roff, d_counts + f0, crows, wpr, d_wlist, d_wlist_n,
-                               list_cap, cap, d_ovf, d_ovf + 1);
-        } else
         hipLaunchKernelGGL(extract_scan_kernel, dim3(nf), dim3(SCAN_THREADS), scan_lds,
                            ctx->stream, d_bm, d_rcnt, d_roff, d_counts + f0, crows, wpr, d_wlist, d_wlist_n,
                            use_words ? list_cap : 0, cap, d_ovf, d_ovf ? d_ovf + 1 : nullptr);
@@ -1715,7 +1020,7 @@ int sfe_extract_set_tuning(sfe_ctx *ctx, int variant)
 {
     if (!ctx)
         return SFE_ERR_ARG;
-    SFE_ARG(ctx, variant >= 0 && variant <= 2);
+    SFE_ARG(ctx, variant >= 0 && variant <= 1);
     ctx->extract_variant = variant;
     return 0;
 }
@@ -1833,7 +1138,7 @@ int sfe_geom_create(sfe_ctx *ctx, const float *map_x, const float *map_y, int ca
         inv_ent.resize((size_t)inv_off.back());
         std::vector<int32_t> cur(inv_off.begin(), inv_off.end() - 1);
         // entry = {bit index of the canvas pixel inside a frame's bitmap (row * words_per_row * 64 + col), its remap code}:
-        // the scatter kernel sets that bit without dividing by the canvas width
+        // the gather kernel sets that bit without dividing by the canvas width
         const bool bit_index_fits = (unsigned long long)cart_rows * g->words_per_row * 64ull < (1ull << 32) - 1;
         if (!bit_index_fits) {
             sfe_geom_destroy(g);
@@ -1911,50 +1216,6 @@ int sfe_geom_create(sfe_ctx *ctx, const float *map_x, const float *map_y, int ca
                 ob[npix] = make_uint2((uint32_t)c4.size(), 0u);
                 c4.resize(c4.size() + 8, 0u); // (the kernel reads entries in fours, two reads ahead)
                 ob.resize(ob.size() + 1, make_uint2((uint32_t)c4.size(), 0u)); // (16-byte reads of {offset, base} pairs)
-                // ... and the tables of the fused kernel: {offset | max dy << 25, base row << 16 | base col} per polar pixel,
-                // the canvas in parts of PR rows (bitmap + prefix array + x table of a part within 64 KB of LDS: two
-                // workgroups per CU), per part the polar rows that reach it
-                {
-                    const long long budget = 64 * 1024 - 8 * (long long)cart_cols - 64;
-                    int PR = (int)std::min<long long>(128, budget / (12ll * g->words_per_row));
-                    PR &= ~7;
-                    bool ok2 = PR >= 8 && c4.size() < (1u << 25) && cart_rows < 65536 && (long long)rowbits < 65536;
-                    if (ok2) {
-                        const int n_parts = (cart_rows + PR - 1) / PR;
-                        std::vector<uint2> ob2(npix + 2);
-                        std::vector<int32_t> prange(2 * (size_t)n_parts);
-                        for (int q = 0; q < n_parts; ++q) {
-                            prange[2 * q] = polar_rows;
-                            prange[2 * q + 1] = -1;
-                        }
-                        for (size_t pi = 0; pi < npix; ++pi) {
-                            const uint32_t o0 = ob[pi].x, o1 = ob[pi + 1].x;
-                            unsigned maxdy = 0;
-                            for (uint32_t j = o0; j < o1; ++j)
-                                maxdy = std::max(maxdy, c4[j] >> 25);
-                            const unsigned brow = (unsigned)(ob[pi].y / rowbits), bcol = (unsigned)(ob[pi].y % rowbits);
-                            ob2[pi] = make_uint2(o0 | (maxdy << 25), (brow << 16) | bcol);
-                            if (o1 > o0) {
-                                const int py = (int)(pi / (size_t)polar_cols);
-                                for (unsigned q = brow / PR; q <= std::min<unsigned>((brow + maxdy) / PR, n_parts - 1); ++q) {
-                                    prange[2 * q] = std::min(prange[2 * q], py);
-                                    prange[2 * q + 1] = std::max(prange[2 * q + 1], py);
-                                }
-                            }
-                        }
-                        ob2[npix] = make_uint2(ob[npix].x, 0u);
-                        ob2[npix + 1] = ob2[npix];
-                        if (hipMalloc((void **)&g->d_inv_ob2, ob2.size() * sizeof(uint2)) != hipSuccess ||
-                            hipMalloc((void **)&g->d_part_rows, prange.size() * 4) != hipSuccess ||
-                            hipMemcpy(g->d_inv_ob2, ob2.data(), ob2.size() * sizeof(uint2), hipMemcpyHostToDevice) != hipSuccess ||
-                            hipMemcpy(g->d_part_rows, prange.data(), prange.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
-                            sfe_geom_destroy(g);
-                            return sfe_set_err(ctx, SFE_ERR_HIP, "fused extraction table upload failed");
-                        }
-                        g->fused_pr = PR;
-                        g->fused_parts = n_parts;
-                    }
-                }
                 if (hipMalloc((void **)&g->d_inv_ob, ob.size() * sizeof(uint2)) != hipSuccess ||
                     hipMalloc((void **)&g->d_inv_c4, c4.size() * 4) != hipSuccess ||
                     hipMemcpy(g->d_inv_ob, ob.data(), ob.size() * sizeof(uint2), hipMemcpyHostToDevice) != hipSuccess ||
@@ -1971,11 +1232,9 @@ int sfe_geom_create(sfe_ctx *ctx, const float *map_x, const float *map_y, int ca
             sfe_geom_destroy(g);
             return sfe_set_err(ctx, SFE_ERR_HIP, "inverse remap table upload failed");
         }
+        // (the {canvas pixel, remap code} entries themselves stay on the host: only round 2's row-block kernel read them)
         if (hipMalloc((void **)&g->d_inv_off, inv_off.size() * 4) != hipSuccess ||
-            hipMalloc((void **)&g->d_inv_ent, std::max<size_t>(inv_ent.size(), 1) * sizeof(uint2)) != hipSuccess ||
-            hipMemcpy(g->d_inv_off, inv_off.data(), inv_off.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
-            (!inv_ent.empty() &&
-             hipMemcpy(g->d_inv_ent, inv_ent.data(), inv_ent.size() * sizeof(uint2), hipMemcpyHostToDevice) != hipSuccess)) {
+            hipMemcpy(g->d_inv_off, inv_off.data(), inv_off.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
             sfe_geom_destroy(g);
             return sfe_set_err(ctx, SFE_ERR_HIP, "inverse remap table upload failed");
         }
@@ -2029,16 +1288,10 @@ void sfe_geom_destroy(sfe_geom *g)
         (void)hipFree(g->d_tile_rows);
     if (g->d_inv_off)
         (void)hipFree(g->d_inv_off);
-    if (g->d_inv_ent)
-        (void)hipFree(g->d_inv_ent);
     if (g->d_inv_lut)
         (void)hipFree(g->d_inv_lut);
     if (g->d_inv_ob)
         (void)hipFree(g->d_inv_ob);
-    if (g->d_inv_ob2)
-        (void)hipFree(g->d_inv_ob2);
-    if (g->d_part_rows)
-        (void)hipFree(g->d_part_rows);
     if (g->d_inv_c4)
         (void)hipFree(g->d_inv_c4);
     if (g->d_ytab)

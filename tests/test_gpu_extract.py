@@ -9,20 +9,13 @@ from sonar_slam_amd.feature_extraction import FeatureExtraction, Geometry, Sonar
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["default", "fused", "second-level", "entries8"])
+@pytest.fixture(autouse=True, params=["default", "entries8"])
 def extraction_build(request, monkeypatch):
-    """Every test of this module runs four times: the default (three kernels, 4-byte inverse-map entries, streaming scan
-    of the canvas bitmap), the fused kernel (canvas bitmap in LDS, one workgroup per part of a frame, look-back hand-over
-    of the point counts: round 4, off by default), the three kernels with the second-level flags +
-    extract_scan_l2_kernel (round 4, off by default), and with round 3's 8-byte entries.  The knobs are
-    read per call (extract_dev)."""
-    if request.param == "fused":
-        monkeypatch.setenv("SFE_EXTRACT_FUSED", "1")
-    elif request.param == "second-level":
-        monkeypatch.setenv("SFE_EXTRACT_FUSED", "0")
-        monkeypatch.setenv("SFE_EXTRACT_L2", "1")
-    elif request.param == "entries8":
-        monkeypatch.setenv("SFE_EXTRACT_FUSED", "0")
+    """Every test of this module runs twice: with the 4-byte inverse-map entries of round 4 (default) and with round 3's
+    8-byte entries, which stay as the fallback for geometries whose candidates span more than 127 canvas rows or columns
+    (DESIGN 5.2).  The knob is read per call (extract_dev).  (The fused kernel, the second-level flags and round 2's
+    row-block kernel ran here until round 5: measured slower, removed, profiles/r05_pruned_variants.txt.)"""
+    if request.param == "entries8":
         monkeypatch.setenv("SFE_EXTRACT_NO_COMPACT", "1")
     return request.param
 
@@ -190,14 +183,13 @@ def test_inverse_map_extraction_equals_dense_pass_and_oracle(ctx, density):
             mask[:, 0] = 1
             mask[:, -1] = 1                                # image borders: out-of-image taps
         out = {}
-        for variant in (0, 1, 2):   # list + lane per set pixel (default), dense pass, row-block scatter of round 2
+        for variant in (0, 1):   # list + lane per set pixel (default), dense pass
             ctx._check(ctx.lib.sfe_extract_set_tuning(ctx.handle, variant))
             try:
                 out[variant] = fe.geometry.extract(mask)
             finally:
                 ctx._check(ctx.lib.sfe_extract_set_tuning(ctx.handle, 0))
-        for v in (1, 2):
-            assert np.array_equal(out[0][0], out[v][0]) and np.array_equal(out[0][1], out[v][1]), v
+        assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
         rc = oracle.nonzero(oracle.remap_u8(mask, fe.map_x, fe.map_y))
         assert np.array_equal(out[0][0], rc)
 
@@ -293,7 +285,7 @@ def test_bit_stream_batches_leave_the_canvas_bitmap_clean(ctx, shipped_cfar):
     batch([4, 1], big)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1])
 def test_bit_stream_extraction_equals_the_byte_mask_path(ctx, shipped_cfar, variant):
     """KeyframeBatch hands the detections to the extraction as bit streams (sfe_cfar_u8_bits_batch_dev ->
     sfe_extract_points_bits_batch_dev): same masks and the same points as the 0/1 byte path and the oracle,

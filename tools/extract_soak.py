@@ -33,12 +33,12 @@ def main():
             if rng.random() < 0.2:
                 mask *= rng.integers(1, 255, mask.shape, dtype=np.uint8)   # non-binary values
             out = {}
-            for v in (0, 1, 2):
+            for v in (0, 1):
                 ctx._check(ctx.lib.sfe_extract_set_tuning(ctx.handle, v))
                 out[v] = fe.geometry.extract(mask)
             ctx._check(ctx.lib.sfe_extract_set_tuning(ctx.handle, 0))
             rc = oracle.nonzero(oracle.remap_u8(mask, fe.map_x, fe.map_y))
-            ok = (all(np.array_equal(out[0][0], out[v][0]) and np.array_equal(out[0][1], out[v][1]) for v in (1, 2)) and
+            ok = (all(np.array_equal(out[0][0], out[v][0]) and np.array_equal(out[0][1], out[v][1]) for v in (1,)) and
                   np.array_equal(out[0][0], rc))
             n += 1
             if not ok:

@@ -9,6 +9,5 @@ for seed in 1717 2828; do
 done
 { timeout 300 python tools/pipeline_soak.py --seconds 90 2>&1 | tail -2
   timeout 200 python tools/extract_soak.py --seconds 60 2>&1 | tail -2
-  SFE_EXTRACT_L2=1 timeout 200 python tools/extract_soak.py --seconds 30 2>&1 | tail -2
   timeout 300 python tools/icp_soak.py --seconds 90 2>&1 | tail -2; } > gpurun_out/${tag}_soaks.txt 2>&1
 cat gpurun_out/${tag}_soaks.txt
