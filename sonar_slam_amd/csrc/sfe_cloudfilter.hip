@@ -287,13 +287,20 @@ __global__ __launch_bounds__(1024) void cf_downsample_radix_kernel(const float2 
     const bool col = tid < sort_cols;
     const int p0 = col ? min(tid * m, n) : n, p1 = min(p0 + m, n);
     const int passes = (2 * h.levels + CF_RDX_BITS - 1) / CF_RDX_BITS;
+    if (col)
+#pragma unroll
+        for (int d = 0; d < CF_RDX_DIGITS; ++d) {
+            const int f0 = d * sort_cols + tid;
+            cnt[f0 + (f0 >> 4)] = 0;
+        }
+    // counter (digit d, column t) lives at flat index f = d * sort_cols + t, padded by one slot per 16 so that both access
+    // patterns spread over the LDS banks: a column's own counters (consecutive lanes, consecutive slots) and the scan's
+    // 16 consecutive counters per thread (stride 17 slots instead of 16: round 5 counters showed 37 % of the LDS cycles
+    // lost to bank conflicts with the unpadded layout)
+    auto slot = [&](int f) { return f + (f >> 4); };
     for (int pass = 0; pass < passes; ++pass) {
         const int shift = CF_RDX_BITS * pass;
-        if (col)
-#pragma unroll
-            for (int d = 0; d < CF_RDX_DIGITS; ++d)
-                cnt[d * sort_cols + tid] = 0;
-        __syncthreads(); // idA complete (first pass: the identity; later: the previous scatter)
+        __syncthreads(); // idA complete (first pass: the identity and the keys; later: the previous scatter)
         // the chunk's indices and digits: independent LDS reads, in flight together
         unsigned id[CF_RDX_CHUNK], dg[CF_RDX_CHUNK];
 #pragma unroll
@@ -302,25 +309,30 @@ __global__ __launch_bounds__(1024) void cf_downsample_radix_kernel(const float2 
 #pragma unroll
         for (int k = 0; k < CF_RDX_CHUNK; ++k)
             dg[k] = p0 + k < p1 ? ((unsigned)skey[id[k]] >> shift) & (CF_RDX_DIGITS - 1) : 0u;
+        // (the column's counters were zeroed behind the previous pass's scatter / before the first pass)
 #pragma unroll
         for (int k = 0; k < CF_RDX_CHUNK; ++k) // count: the column is this thread's own, plain read-modify-write
             if (p0 + k < p1)
-                cnt[dg[k] * sort_cols + tid] += 1;
+                cnt[slot(dg[k] * sort_cols + tid)] += 1;
+        // (measured and dropped: the counts in registers -- two 64-bit words of eight 8-bit counters, the value before an
+        // increment being the element's rank in the chunk, so that neither sweep reads or writes a counter: 39 % fewer
+        // LDS operations, but 128 VGPRs and ~15 64-bit VALU operations per element: 0.262 -> 0.328 ms per 512 frames)
         __syncthreads();
         { // exclusive scan over (digit major, column minor): 16 * sort_cols counters, 16 (or 8) consecutive ones per thread
             const int per_t = CF_RDX_DIGITS * sort_cols / 1024;
-            int v[16], s = 0;
+            const int base = slot(per_t * tid); // (per_t consecutive flat indices share their padding: per_t divides 16)
+            int v[16], sum = 0;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                v[k] = k < per_t ? cnt[per_t * tid + k] : 0;
-                s += v[k];
+                v[k] = k < per_t ? cnt[base + k] : 0;
+                sum += v[k];
             }
             int tot_;
-            int run = cf_block_excl_scan(s, s_scan, &tot_);
+            int run = cf_block_excl_scan(sum, s_scan, &tot_);
 #pragma unroll
             for (int k = 0; k < 16; ++k)
                 if (k < per_t) {
-                    cnt[per_t * tid + k] = (unsigned short)run;
+                    cnt[base + k] = (unsigned short)run;
                     run += v[k];
                 }
         }
@@ -328,12 +340,15 @@ __global__ __launch_bounds__(1024) void cf_downsample_radix_kernel(const float2 
 #pragma unroll
         for (int k = 0; k < CF_RDX_CHUNK; ++k) // scatter in position order from the column's running offsets
             if (p0 + k < p1) {
-                const unsigned a = dg[k] * sort_cols + tid;
+                const unsigned a = slot(dg[k] * sort_cols + tid);
                 const unsigned off = cnt[a];
                 idB[off] = (unsigned short)id[k];
                 cnt[a] = (unsigned short)(off + 1);
             }
-        __syncthreads();
+        if (col && pass + 1 < passes) // the column's own counters again: no barrier needed before the next pass's counts
+#pragma unroll
+            for (int d = 0; d < CF_RDX_DIGITS; ++d)
+                cnt[slot(d * sort_cols + tid)] = 0;
         unsigned short *t_ = idA;
         idA = idB;
         idB = t_;
@@ -663,7 +678,8 @@ int sfe_cf_run_staged(sfe_ctx *ctx, int n_frames, int64_t cap, float resolution,
                 // (digit counters: one column of 16 per sorting thread -- 1024 of them, 512 at capacities of <= 8192 points so
                 // that indices + keys + counters stay inside the 64 KB that let two frames share a CU)
                 const int sort_cols = n2 <= 8192 ? 512 : 1024;
-                const size_t rdx_smem = std::max<size_t>(3 * 2 * n2 + 2 * CF_RDX_DIGITS * (size_t)sort_cols, sizeof(float2) * n2);
+                const size_t n_cnt = CF_RDX_DIGITS * (size_t)sort_cols;
+                const size_t rdx_smem = std::max<size_t>(3 * 2 * n2 + 2 * (n_cnt + n_cnt / 16), sizeof(float2) * n2);
                 SFE_HIP(ctx, hipFuncSetAttribute((const void *)cf_downsample_radix_kernel,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)rdx_smem));
                 hipLaunchKernelGGL(cf_downsample_radix_kernel, dim3(n_frames), dim3(1024), rdx_smem, ctx->stream, d_p32,

@@ -389,14 +389,20 @@ def chained_inputs(n_distinct, n_steps, rows=1024, beams=512, world_seed=2, scat
     return frames, dr, true, bearings
 
 
-def chained(ctx, det, threads, n_sessions=4096, n_steps=8, n_distinct=64, parity_sessions=4, reps=3):
+def chained(ctx, det, threads, n_sessions=4096, n_steps=8, n_distinct=64, parity_sessions=None, reps=3, init_sessions=64,
+            init_parity_sessions=4):
     """the path end to end on the device, every scan match consuming the cloud its own CFAR produced.
     `n_sessions` independent SLAM sessions advance in lock-step (chained.SessionBatch): step k = ping k of every session
     through CFAR + gate -> remap + nonzero + px->m -> downsample -> outlier filter -> keyframe store -> target cloud =
     get_points(previous <= 3 keyframes under the poses their own scan matches gave them, slam.py:740-741) -> ICP(source,
     target, odometry guess) -> overlap; pings resident in HBM, no cloud crosses PCIe, the host does the SLAM node's
     pose bookkeeping between the calls.  Timed with the host clock around whole runs (the loop has host work in it).
-    Parity: `parity_sessions` sessions through the oracle's chain (oracle/chain.py) on the same pings."""
+    Parity: `parity_sessions` sessions (default: every distinct one) through the oracle's chain (oracle/chain.py) on the
+    same pings.  `with_initialization`: the same path as the reference runs it by DEFAULT (slam.py:77): scipy's shgo global
+    initialisation in front of every scan match, its cost function on the device (chained.SessionBatch(initialization=True)),
+    on `init_sessions` sessions (shgo itself is tens of milliseconds of host Python per scan match)."""
+    if parity_sessions is None:
+        parity_sessions = n_distinct
     import oracle
     from oracle import chain
     from sonar_slam_amd import chained as ch
@@ -415,6 +421,9 @@ def chained(ctx, det, threads, n_sessions=4096, n_steps=8, n_distinct=64, parity
                        "1.7 m apart, drifting odometry): CFAR -> cloud -> store -> get_points(last 3) -> ICP -> overlap, "
                        "device-resident" % (n_sessions, n_steps, n_distinct),
            "sessions": n_sessions, "keyframes_per_session": n_steps, "distinct_sessions": n_distinct,
+           "replication": "%d distinct trajectories x %d copies: the copies do identical work on identical pings (they share "
+                          "nothing on the device, but their inverse-map / table reads hit the same cache lines)"
+                          % (n_distinct, n_sessions // max(1, n_distinct)),
            "render_s": t_render}
     # the pings go up once (n_sessions x n_steps x 512 KB resident: 16 GB at the default size) and serve both chains
     sb = ch.SessionBatch(ctx, fe.geometry, det.params["SOCA"], "SOCA", 65, icp_config.shipped_params(), n_sessions, n_steps,
@@ -494,4 +503,137 @@ def chained(ctx, det, threads, n_sessions=4096, n_steps=8, n_distinct=64, parity
         out[name] = leg
     sb.free()
     out["keyframes_per_s"] = out["shipped_chain"]["keyframes_per_s"]
+    # ---- the reference's default flow: shgo global initialisation in front of every scan match ----
+    if init_sessions:
+        S = int(init_sessions)
+        sel_i = np.arange(S) % n_distinct
+        sbi = ch.SessionBatch(ctx, fe.geometry, det.params["SOCA"], "SOCA", 65, icp_config.shipped_params(), S, n_steps, dr[sel_i],
+                              initialization=True)
+        for k in range(n_steps):
+            sbi.upload_frames(k, frames[k][sel_i])
+        sbi.run()                               # untimed: scratch, store, the Sobol set
+        sbi.fit_capacity()
+        sbi.init_stats = {"shgo_s": 0.0, "cost_calls": 0, "table_hits": 0}
+        ctx.sync()
+        t0 = time.perf_counter()
+        recs = sbi.run()
+        ctx.sync()
+        dt = time.perf_counter() - t0
+        status = np.stack([r["status"] for r in recs[1:]], axis=1)
+        moved = np.stack([np.any(r["init_x"] != 0, axis=1) for r in recs[1:] if "init_x" in r], axis=1)
+        leg = {"sessions": S, "seconds_per_run": dt, "keyframes_per_s": S * n_steps / dt, "ms_per_scan_match": 1e3 * dt / (S * (n_steps - 1)),
+               "host_shgo_seconds": sbi.init_stats["shgo_s"], "host_shgo_share": sbi.init_stats["shgo_s"] / dt,
+               "cost_evaluations_from_the_batched_table": sbi.init_stats["table_hits"],
+               "cost_evaluations_single_calls": sbi.init_stats["cost_calls"],
+               "scan_matches_whose_start_shgo_moved": int(moved.sum()),
+               "status_counts": {ch.STATUS_NAMES[c]: int((status == c).sum()) for c in range(1, 7) if (status == c).any()},
+               "note": "slam.py:665-716 per scan match: 61 Sobol / corner poses scored for ALL sessions in one launch "
+                       "(sfe_matching_cost_store), then scipy.optimize.shgo per session on that table; the throughput is scipy's "
+                       "host-side bookkeeping (triangulation, minimiser pool), not the device"}
+        picks = sorted(set(int(round(i * (min(S, n_distinct) - 1) / max(1, init_parity_sessions - 1))) for i in range(init_parity_sessions)))
+        oprm = oracle.IcpParams(precision=1, **icp_config.shipped_params().as_dict())
+        oracle.set_kdtree(1)
+        try:
+            def one_i(s):
+                clouds = [chain.slam_cloud(chain.feature_cloud(frames[k, s], det.params["SOCA"], "SOCA", 65, fe)[1]) for k in range(n_steps)]
+                return chain.run_session(clouds, dr[s], oprm, initialization=True)
+            with ThreadPool(max(1, threads)) as tp:
+                ref = tp.map(one_i, picks, chunksize=1)
+        finally:
+            oracle.set_kdtree(0)
+        worst = 0.0
+        for s, orc in zip(picks, ref):
+            for k, o in enumerate(orc):
+                r = recs[k]
+                if ch.STATUS_NAMES[r["status"][s]] != o["status"]:
+                    raise AssertionError("chained/with_initialization: session %d keyframe %d: %s vs the oracle's %s"
+                                         % (s, k, ch.STATUS_NAMES[r["status"][s]], o["status"]))
+                if "init_x" in o and (tuple(r["init_x"][s]) != o["init_x"] or r["init_cost"][s] != o["init_cost"]):
+                    raise AssertionError("chained/with_initialization: session %d keyframe %d: shgo found %r (%g), the oracle chain %r (%g)"
+                                         % (s, k, tuple(r["init_x"][s]), r["init_cost"][s], o["init_x"], o["init_cost"]))
+                d = max(abs(a - b) for a, b in zip(r["pose"][s], o["pose"]))
+                if not d <= 1e-6:
+                    raise AssertionError("chained/with_initialization: session %d keyframe %d pose is %.3e from the oracle chain" % (s, k, d))
+                worst = max(worst, d)
+        leg["parity"] = {"sessions": picks, "max_pose_diff_vs_oracle_chain": worst,
+                         "checked": "per keyframe: status, shgo's result x and value (equal), pose <= 1e-6 vs oracle/chain.py with "
+                                    "initialization=True (CPU cost function + the same scipy shgo)"}
+        out["with_initialization"] = leg
+        sbi.free()
     return out
+
+
+def loop_closure(ctx, det, threads, n_keyframes=24, rows=1024, beams=512, world_seed=2, scatterers=9000):
+    """The loop-closure search of slam.py:839-1087 over the device-resident keyframe store (VERDICT r4 missing 3): one
+    session on a closed trajectory (13 keyframes per lap), replay.FrontEnd(store, nssm_enable=True): after every keyframe the
+    aggregated source cloud, the keyed global target cloud of every keyframe older than k - 8 (descriptor overload of
+    pcl.downsample), the field-of-view gate, shgo (100 x 5) on the device cost function, the target-key refinement, <= 30 ICPs on
+    one pair in one launch, MinCovDet, the gates.  Parity: the whole session through oracle/chain.py (initialization + nssm)."""
+    import oracle
+    from oracle import chain
+    from sonar_slam_amd import icp_config, synth
+    from sonar_slam_amd import store as st
+    from sonar_slam_amd.feature_extraction import FeatureExtraction, SonarPing, oculus_bearings
+    from sonar_slam_amd.replay import FrontEnd, replay
+    bearings = oculus_bearings(beams)
+    world = synth.world_structure(seed=world_seed, n=scatterers)
+    true, dr = synth.trajectory(n=n_keyframes, step=1.7, turn=2 * np.pi / 13, seed=21, start=(20.0, 0.0, 0.0))
+    frames = [synth.render_ping(world, true[k], bearings, rows=rows, seed=7000 + k) for k in range(n_keyframes)]
+    fe = FeatureExtraction(ctx)
+    fe.Ntc, fe.Ngc, fe.Pfa, fe.rank, fe.alg, fe.threshold = 40, 10, 0.1, 10, "SOCA", 65
+    fe.resolution, fe.outlier_filter_radius, fe.outlier_filter_min_points, fe.skip = 0.5, 1.0, 5, 1
+    fe.configure()
+    pings = [SonarPing(f, bearings, 30.0 / rows, ping_id=k) for k, f in enumerate(frames)]
+    fe.generate_map_xy(pings[0])
+
+    def run():
+        s = st.CloudStore(ctx, capacity_points=1 << 20, max_clouds=1024)
+        front = FrontEnd(ctx, keyframe_translation=1.5, keyframe_duration=0.5, store=s, nssm_enable=True, mcd_random_state=0)
+        t0 = time.perf_counter()
+        log, t_fe, t_slam = replay(pings, np.arange(n_keyframes, dtype=float), dr, fe, front)
+        dt = time.perf_counter() - t0
+        s.close()
+        return front, log, dt, t_fe, t_slam
+    run()
+    front, log, dt, t_fe, t_slam = run()
+    searches = [r["nssm"] for r in log if r.get("nssm") is not None]
+    clouds = [chain.slam_cloud(chain.feature_cloud(f, det.params["SOCA"], "SOCA", 65, fe)[1]) for f in frames]
+    oracle.set_kdtree(1)
+    try:
+        t0 = time.perf_counter()
+        orc = chain.run_session(clouds, dr, oracle.IcpParams(precision=1, **icp_config.shipped_params().as_dict()), initialization=True,
+                                nssm=dict(mcd_random_state=0))
+        t_oracle = time.perf_counter() - t0
+    finally:
+        oracle.set_kdtree(0)
+    n_checked = 0
+    for a, o in zip(log, orc):
+        na, no = a.get("nssm"), o.get("nssm")
+        if (na is None) != (no is None):
+            raise AssertionError("loop_closure: keyframe %d: a search on one side only" % a["source_key"])
+        if a["status"] != o["status"] or max(abs(x - y) for x, y in zip(a["pose"], o["pose"])) > 1e-6:
+            raise AssertionError("loop_closure: keyframe %d: sequential scan match differs from the oracle chain" % a["source_key"])
+        if na is None:
+            continue
+        for key in ("status", "n_source", "n_target_global", "target_key_fov", "init_x", "init_cost", "overlap_global", "target_key",
+                    "n_target", "n_guesses", "n_converged", "overlap"):
+            if (key in na) != (key in no) or (key in na and na[key] != no[key]):
+                raise AssertionError("loop_closure: keyframe %d: %s = %r, the oracle chain has %r" % (a["source_key"], key, na.get(key), no.get(key)))
+        if "transform" in no and max(abs(x - y) for x, y in zip(na["transform"], no["transform"])) > 1e-6:
+            raise AssertionError("loop_closure: keyframe %d: loop transform differs from the oracle chain" % a["source_key"])
+        n_checked += 1
+    status = {}
+    for n in searches:
+        status[n["status"]] = status.get(n["status"], 0) + 1
+    return {"workload": "1 session, %d keyframes %dx%d on a closed trajectory (13 per lap): SSM with global initialisation + the "
+                        "loop-closure search after every keyframe >= 8, all clouds device-resident" % (n_keyframes, rows, beams),
+            "searches": len(searches), "status_counts": status, "accepted_loops": status.get("SUCCESS", 0),
+            "seconds_per_session": dt, "ms_per_keyframe_front_end": 1e3 * t_fe / n_keyframes,
+            "ms_per_keyframe_slam_side": 1e3 * t_slam / n_keyframes, "ms_per_search_incl_ssm": 1e3 * t_slam / max(1, len(searches)),
+            "largest_global_target_points": max([n.get("n_target_global", 0) for n in searches] + [0]),
+            "largest_icp_target_points": max([n.get("n_target", 0) for n in searches] + [0]),
+            "oracle_chain_seconds": t_oracle,
+            "parity": {"searches": n_checked, "checked": "per search: status, cloud sizes, field-of-view target key, shgo's x and value, "
+                                                         "refined target key, number of guesses / converged ICPs, overlap (equal); loop "
+                                                         "transform <= 1e-6 vs oracle/chain.py"},
+            "note": "PCM (slam.py:1089-1130) and the ISAM2 update are the back end: an accepted loop goes to backend.add_loop"}
