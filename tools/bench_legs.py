@@ -271,11 +271,18 @@ def float_oracle(kb, res, srcs, tgts, guesses, params_kw, threads, sample=256):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-def stream_frames(ctx, kb, filters, steps=4, distinct=512, seed0=20000):
+def stream_frames(ctx, kb, filters, steps=4, distinct=512, seed0=20000, n_buffers=3, chunk=512):
     """The step with its frames arriving from the host (feature_extraction.py:196-217: every ping does): `distinct`
-    frames in pinned memory, uploaded on the context's copy stream into the batch that is NOT being computed on (two
-    frame buffers), against the step's kernels on the main stream.  Reports the streamed rate next to the resident one
-    of the same loop, the PCIe rate the uploads achieve alone, and how much of the shorter of the two is hidden."""
+    frames in pinned memory, uploaded on the context's copy stream in pieces of `chunk` frames into a frame buffer that is
+    NOT being computed on (`n_buffers` of them), against the step's kernels on the main stream.  Reports the streamed rate
+    next to the resident one of the same loop, the PCIe rate the uploads achieve alone, and how much of the shorter of the
+    two is hidden.  Round 5: with THREE buffers the upload of step k + 2 is enqueued behind the CFAR of
+    step k -- the only kernel that reads frames, and the last reader of that buffer was the CFAR of step k - 1 -- so the copy
+    stream runs without gaps; with two, the upload of step k + 1 had to wait for CFAR(k), which itself queues behind the
+    scan matches of step k - 1.  The piece size matters more than the buffers (profiles/r05_stream_probe.txt): copies of 256 MB
+    (512 frames) go at 55 GB/s next to the kernels, pieces of 128 MB or less at 40 GB/s -- the runtime moves small copies with a
+    copy kernel, which queues behind the scan matcher's full occupancy (HSA_ENABLE_SDMA=0 forces that for every size: 32 GB/s,
+    nothing hidden)."""
     from sonar_slam_amd import synth
     n, rows, cols = kb.n, kb.rows, kb.cols
     distinct = min(distinct, n)
@@ -297,13 +304,17 @@ def stream_frames(ctx, kb, filters, steps=4, distinct=512, seed0=20000):
         for i in np.flatnonzero(cnt > kb.cap):
             pool[f0 + i] = pool[f0 + good[i % len(good)]]
             replaced += 1
-    other = ctx.alloc(n * frame_b)           # the second frame buffer
-    bufs = [kb.d_img, other]
+    others = [ctx.alloc(n * frame_b) for _ in range(n_buffers - 1)]       # the other frame buffers
+    bufs = [kb.d_img] + others
+    chunk = max(1, min(int(chunk), distinct))
 
     def upload(buf):
-        for f0 in range(0, n, distinct):
-            m = min(distinct, n - f0)
-            buf.upload_async(pool[:m], offset=f0 * frame_b)
+        for f0 in range(0, n, chunk):
+            m = min(chunk, n - f0)
+            p0 = f0 % distinct
+            if p0 + m > distinct:
+                p0 = 0
+            buf.upload_async(pool[p0:p0 + m], offset=f0 * frame_b)
 
     def step(buf):
         keep = kb.d_img
@@ -318,7 +329,7 @@ def stream_frames(ctx, kb, filters, steps=4, distinct=512, seed0=20000):
     ctx.fence(2)
     t0 = time.perf_counter()
     for k in range(steps):
-        upload(bufs[k % 2])
+        upload(bufs[k % n_buffers])
     ctx.fence(2)
     t_copy = (time.perf_counter() - t0) / steps
     # the kernels alone (frames resident: what the headline times)
@@ -326,23 +337,27 @@ def stream_frames(ctx, kb, filters, steps=4, distinct=512, seed0=20000):
     ctx.sync()
     t0 = time.perf_counter()
     for k in range(steps):
-        step(bufs[k % 2])
+        step(bufs[k % n_buffers])
     ctx.sync()
     t_comp = (time.perf_counter() - t0) / steps
-    # streamed: upload of step k+1 next to the kernels of step k
-    upload(bufs[0])
+    # streamed: the uploads of the next n_buffers - 1 steps are in flight next to the kernels of step k
+    ahead = n_buffers - 1
+    for a in range(ahead):
+        upload(bufs[a % n_buffers])
     ctx.fence(2)
     ctx.sync()
     t0 = time.perf_counter()
     for k in range(steps):
-        ctx.fence(0)                 # this step's kernels behind this step's upload
-        kb_buf = bufs[k % 2]
+        # this step's kernels behind this step's upload.  (sfe_stream_fence(0) waits for every upload enqueued SO FAR: with
+        # three buffers that includes the one for step k + 1, enqueued a step ago and normally done by now)
+        ctx.fence(0)
+        kb_buf = bufs[k % n_buffers]
         keep = kb.d_img
         kb.d_img = kb_buf
         try:
             kb.run_cfar()            # the only kernel that reads the frames
-            ctx.fence(1)             # the next upload overwrites the OTHER buffer, read by the previous step's CFAR: behind it
-            upload(bufs[(k + 1) % 2])   # (also behind the last step: `steps` uploads inside the timed region)
+            ctx.fence(1)             # the next upload overwrites the buffer CFAR(k + ahead - n_buffers) read: behind CFAR(k)
+            upload(bufs[(k + ahead) % n_buffers])   # (also behind the last steps: `steps` uploads inside the timed region)
             kb.run_extract()
             if filters:
                 kb.run_filter()
@@ -353,12 +368,15 @@ def stream_frames(ctx, kb, filters, steps=4, distinct=512, seed0=20000):
     ctx.fence(2)
     t_stream = (time.perf_counter() - t0) / steps
     res = kb.results()
-    other.free()
+    for o in others:
+        o.free()
     ctx.host_free(pool)
     hidden = (t_copy + t_comp - t_stream) / max(1e-12, min(t_copy, t_comp))
     return {"workload": "%d keyframes per step, frames uploaded from pinned host memory (%d distinct frames, %d of them "
-                        "replaced by another because they exceed the batch's point capacity; %d MiB per step)"
-                        % (n, distinct, replaced, n * frame_b // (1 << 20)),
+                        "replaced by another because they exceed the batch's point capacity; %d MiB per step) in pieces of %d "
+                        "frames into %d frame buffers"
+                        % (n, distinct, replaced, n * frame_b // (1 << 20), chunk, n_buffers),
+            "frame_buffers": n_buffers, "upload_chunk_frames": chunk,
             "keyframes_per_s_streamed": n / t_stream, "keyframes_per_s_resident_same_loop": n / t_comp,
             "ms_per_step_streamed": 1e3 * t_stream, "ms_per_step_resident": 1e3 * t_comp, "ms_upload_alone": 1e3 * t_copy,
             "pcie_gb_per_s_upload_alone": n * frame_b / t_copy / 1e9, "pcie_gb_per_s_while_streaming": n * frame_b / t_stream / 1e9,
