@@ -110,7 +110,7 @@ class SessionBatch(object):
                  max_points=16384, resolution=0.5, outlier_radius=1.0, outlier_min_points=5, point_resolution=0.5,
                  point_noise=0.5, ssm_min_points=50, ssm_max_translation=3.0, ssm_max_rotation=np.deg2rad(30),
                  ssm_target_frames=3, store_points=None, initialization=False, initialization_params=(50, 1, 0.01),
-                 odom_sigmas=(0.2, 0.2, 0.02)):
+                 odom_sigmas=(0.2, 0.2, 0.02), shgo_workers=1):
         from .pipeline import KeyframeBatch
         self.ctx, self.S, self.K = ctx, int(n_sessions), int(n_steps)
         self.icp_params = icp_params
@@ -131,7 +131,8 @@ class SessionBatch(object):
         self.initialization, self.initialization_params = initialization, tuple(initialization_params)
         self.odom_sigmas = np.array(odom_sigmas, np.float64)
         self._sobol = None
-        self.init_stats = {"shgo_s": 0.0, "cost_calls": 0, "table_hits": 0}
+        self.shgo_workers, self._shgo_pool = int(shgo_workers), None    # > 1: shgo_pool.ShgoPool (host processes)
+        self.init_stats = {"shgo_s": 0.0, "cost_calls": 0, "table_hits": 0, "speculated": 0, "speculation_failed": 0}
         self.reset()
 
     def upload_frames(self, k, frames):
@@ -303,7 +304,35 @@ class SessionBatch(object):
             keys = [x.tobytes() for x in X0]
             ok, xs, fs = np.zeros(n, bool), np.zeros((n, 3)), np.zeros(n)
             t0 = time.perf_counter()
-            for i in range(n):
+            todo = range(n)
+            if self.shgo_workers > 1 and n > 1:
+                # speculative runs on the host cores (shgo_pool.py), every assumed cost verified in one launch
+                from . import shgo_pool
+                if self._shgo_pool is None:
+                    self._shgo_pool = shgo_pool.ShgoPool(self.shgo_workers)
+                    t0 = time.perf_counter()
+                out = self._shgo_pool.map([(pose_bounds, self.initialization_params, X0, table[i].astype(np.int64)) for i in range(n)])
+                who = np.concatenate([np.full(len(o[4]), i, np.int64) for i, o in enumerate(out)]) if n else np.zeros(0, np.int64)
+                bad = np.zeros(n, bool)
+                if len(who):
+                    asked = np.concatenate([o[4] for o in out])
+                    assumed = np.concatenate([o[5] for o in out])
+                    T6 = np.zeros((len(who), 1, 6), np.float32)
+                    d = Pose2Batch(asked[:, 0], asked[:, 1], asked[:, 2])
+                    T6[:, 0] = tgt_pose.take(who).between(src_pose.take(who).compose(d)).T6()
+                    true = grids.cost(src_h[idx[who]], T6, True, grid_index=who)[:, 0]
+                    np.logical_or.at(bad, who, true != assumed)
+                    self.init_stats["cost_calls"] += len(who)
+                self.init_stats["speculated"] += n
+                self.init_stats["speculation_failed"] += int(bad.sum())
+                self.init_stats["table_hits"] += n * len(X0)
+                for i, o in enumerate(out):
+                    if not bad[i]:
+                        ok[i] = o[0]
+                        if o[0]:
+                            xs[i], fs[i] = o[1], o[2]
+                todo = np.nonzero(bad)[0]
+            for i in todo:
                 cache = dict(zip(keys, table[i]))
 
                 def f(x, i=i, cache=cache):
@@ -350,6 +379,9 @@ class SessionBatch(object):
         return self.records
 
     def free(self):
+        if self._shgo_pool is not None:
+            self._shgo_pool.close()
+            self._shgo_pool = None
         self.kb.d_img = self._kb_img
         self.kb.free()
         self.d_frames.free()

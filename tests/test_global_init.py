@@ -282,6 +282,18 @@ def test_sessions_in_lock_step_with_the_global_initialisation(ctx, shipped_cfar)
         sb.upload_frames(k, np.stack([x[0][k] for x in sess]))
     recs = sb.run()
     assert sb.init_stats["table_hits"] >= S * (K - 1) * 50
+    # ... and with shgo on worker processes (speculative on the table, assumptions verified in one launch): the same records
+    sbp = chained.SessionBatch(ctx, fe.geometry, shipped_cfar.params["SOCA"], "SOCA", 65, icp_config.shipped_params(), S, K, dr,
+                               ssm_min_points=20, initialization=True, shgo_workers=2)
+    for k in range(K):
+        sbp.upload_frames(k, np.stack([x[0][k] for x in sess]))
+    recs_p = sbp.run()
+    assert sbp.init_stats["speculated"] >= S * (K - 1) - 2 and sbp.init_stats["speculation_failed"] == 0
+    for a, b in zip(recs, recs_p):
+        assert set(a) == set(b)
+        for key in a:
+            assert np.array_equal(np.asarray(a[key]), np.asarray(b[key])), key
+    sbp.free()
     for s in range(S):
         store = st.CloudStore(ctx, capacity_points=1 << 17, max_clouds=64)
         front, log = _replay_session(ctx, sess[s][0], bearings, dr[s], rows, store, ssm_min_points=20)

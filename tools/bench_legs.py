@@ -407,8 +407,8 @@ def chained_inputs(n_distinct, n_steps, rows=1024, beams=512, world_seed=2, scat
     return frames, dr, true, bearings
 
 
-def chained(ctx, det, threads, n_sessions=4096, n_steps=8, n_distinct=64, parity_sessions=None, reps=3, init_sessions=64,
-            init_parity_sessions=4):
+def chained(ctx, det, threads, n_sessions=4096, n_steps=8, n_distinct=64, parity_sessions=None, reps=3, init_sessions=256,
+            init_parity_sessions=4, init_sessions_one_process=32):
     """the path end to end on the device, every scan match consuming the cloud its own CFAR produced.
     `n_sessions` independent SLAM sessions advance in lock-step (chained.SessionBatch): step k = ping k of every session
     through CFAR + gate -> remap + nonzero + px->m -> downsample -> outlier filter -> keyframe store -> target cloud =
@@ -523,31 +523,44 @@ def chained(ctx, det, threads, n_sessions=4096, n_steps=8, n_distinct=64, parity
     out["keyframes_per_s"] = out["shipped_chain"]["keyframes_per_s"]
     # ---- the reference's default flow: shgo global initialisation in front of every scan match ----
     if init_sessions:
+        def timed_init(S, workers):
+            sel_i = np.arange(S) % n_distinct
+            sbi = ch.SessionBatch(ctx, fe.geometry, det.params["SOCA"], "SOCA", 65, icp_config.shipped_params(), S, n_steps, dr[sel_i],
+                                  initialization=True, shgo_workers=workers)
+            for k in range(n_steps):
+                sbi.upload_frames(k, frames[k][sel_i])
+            sbi.run()                           # untimed: scratch, store, the Sobol set, the worker processes
+            sbi.fit_capacity()
+            for key in sbi.init_stats:
+                sbi.init_stats[key] = 0
+            ctx.sync()
+            t0 = time.perf_counter()
+            recs = sbi.run()
+            ctx.sync()
+            return sbi, recs, time.perf_counter() - t0
+        one = None
+        if init_sessions_one_process and threads > 1:
+            sb1, _, dt1 = timed_init(int(init_sessions_one_process), 1)
+            one = {"sessions": int(init_sessions_one_process), "keyframes_per_s": init_sessions_one_process * n_steps / dt1,
+                   "host_shgo_share": sb1.init_stats["shgo_s"] / dt1}
+            sb1.free()
         S = int(init_sessions)
-        sel_i = np.arange(S) % n_distinct
-        sbi = ch.SessionBatch(ctx, fe.geometry, det.params["SOCA"], "SOCA", 65, icp_config.shipped_params(), S, n_steps, dr[sel_i],
-                              initialization=True)
-        for k in range(n_steps):
-            sbi.upload_frames(k, frames[k][sel_i])
-        sbi.run()                               # untimed: scratch, store, the Sobol set
-        sbi.fit_capacity()
-        sbi.init_stats = {"shgo_s": 0.0, "cost_calls": 0, "table_hits": 0}
-        ctx.sync()
-        t0 = time.perf_counter()
-        recs = sbi.run()
-        ctx.sync()
-        dt = time.perf_counter() - t0
+        sbi, recs, dt = timed_init(S, max(1, threads))
         status = np.stack([r["status"] for r in recs[1:]], axis=1)
         moved = np.stack([np.any(r["init_x"] != 0, axis=1) for r in recs[1:] if "init_x" in r], axis=1)
-        leg = {"sessions": S, "seconds_per_run": dt, "keyframes_per_s": S * n_steps / dt, "ms_per_scan_match": 1e3 * dt / (S * (n_steps - 1)),
+        leg = {"sessions": S, "shgo_worker_processes": max(1, threads), "seconds_per_run": dt, "keyframes_per_s": S * n_steps / dt,
+               "ms_per_scan_match": 1e3 * dt / (S * (n_steps - 1)),
                "host_shgo_seconds": sbi.init_stats["shgo_s"], "host_shgo_share": sbi.init_stats["shgo_s"] / dt,
+               "one_process": one,
                "cost_evaluations_from_the_batched_table": sbi.init_stats["table_hits"],
-               "cost_evaluations_single_calls": sbi.init_stats["cost_calls"],
+               "cost_evaluations_verified_afterwards": sbi.init_stats["cost_calls"],
+               "speculative_runs": sbi.init_stats["speculated"], "speculative_runs_redone": sbi.init_stats["speculation_failed"],
                "scan_matches_whose_start_shgo_moved": int(moved.sum()),
                "status_counts": {ch.STATUS_NAMES[c]: int((status == c).sum()) for c in range(1, 7) if (status == c).any()},
                "note": "slam.py:665-716 per scan match: 61 Sobol / corner poses scored for ALL sessions in one launch "
-                       "(sfe_matching_cost_store), then scipy.optimize.shgo per session on that table; the throughput is scipy's "
-                       "host-side bookkeeping (triangulation, minimiser pool), not the device"}
+                       "(sfe_matching_cost_store), then scipy.optimize.shgo per session on that table, the sessions dealt to worker "
+                       "processes on the host cores (shgo_pool.py: speculative on the table, every assumed cost verified in one more "
+                       "launch); the throughput is scipy's host-side bookkeeping (triangulation, minimiser pool), not the device"}
         picks = sorted(set(int(round(i * (min(S, n_distinct) - 1) / max(1, init_parity_sessions - 1))) for i in range(init_parity_sessions)))
         oprm = oracle.IcpParams(precision=1, **icp_config.shipped_params().as_dict())
         oracle.set_kdtree(1)
