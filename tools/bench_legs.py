@@ -594,7 +594,7 @@ def chained(ctx, det, threads, n_sessions=4096, n_steps=8, n_distinct=64, parity
     return out
 
 
-def loop_closure(ctx, det, threads, n_keyframes=24, rows=1024, beams=512, world_seed=2, scatterers=9000):
+def loop_closure(ctx, det, threads, n_keyframes=14, rows=1024, beams=512, world_seed=2, scatterers=9000):
     """The loop-closure search of slam.py:839-1087 over the device-resident keyframe store (VERDICT r4 missing 3): one
     session on a closed trajectory (13 keyframes per lap), replay.FrontEnd(store, nssm_enable=True): after every keyframe the
     aggregated source cloud, the keyed global target cloud of every keyframe older than k - 8 (descriptor overload of
@@ -625,8 +625,7 @@ def loop_closure(ctx, det, threads, n_keyframes=24, rows=1024, beams=512, world_
         dt = time.perf_counter() - t0
         s.close()
         return front, log, dt, t_fe, t_slam
-    run()
-    front, log, dt, t_fe, t_slam = run()
+    front, log, dt, t_fe, t_slam = run()    # (one run: a search is seconds of scipy's shgo (100 x 5) on the host)
     searches = [r["nssm"] for r in log if r.get("nssm") is not None]
     clouds = [chain.slam_cloud(chain.feature_cloud(f, det.params["SOCA"], "SOCA", 65, fe)[1]) for f in frames]
     oracle.set_kdtree(1)
