@@ -151,6 +151,10 @@ class _StoreGrids(object):
         th = np.ascontiguousarray(target_handles, np.int32).reshape(-1)
         self.n = len(th)
         bbox = store.bbox(th)
+        if not np.all(np.isfinite(bbox)):
+            raise ValueError("matching cost: target cloud %d is empty or holds non-finite points (np.min of an empty cloud raises "
+                             "in the reference too: slam.py:506); the caller tests min_points first (slam.py:659)"
+                             % int(th[int(np.argmax(~np.isfinite(bbox).all(axis=1)))]))
         geo = [grid_geometry(b, point_noise) for b in bbox]
         self.xmin = np.array([g[0] for g in geo], np.float32)
         self.ymin = np.array([g[1] for g in geo], np.float32)

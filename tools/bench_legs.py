@@ -407,7 +407,7 @@ def chained_inputs(n_distinct, n_steps, rows=1024, beams=512, world_seed=2, scat
     return frames, dr, true, bearings
 
 
-def chained(ctx, det, threads, n_sessions=4096, n_steps=8, n_distinct=64, parity_sessions=None, reps=3, init_sessions=256,
+def chained(ctx, det, threads, n_sessions=4096, n_steps=8, n_distinct=64, parity_sessions=None, reps=3, init_sessions=1024,
             init_parity_sessions=4, init_sessions_one_process=32):
     """the path end to end on the device, every scan match consuming the cloud its own CFAR produced.
     `n_sessions` independent SLAM sessions advance in lock-step (chained.SessionBatch): step k = ping k of every session

@@ -1,6 +1,6 @@
 #!/bin/bash
 # end-of-round soaks on the final kernels: oracle (2 seeds), pipeline, extraction (both scan paths), sweep-vs-brute-force
-tag=${1:-r04}
+tag=${1:-r05}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 for seed in 1717 2828; do
