@@ -35,6 +35,10 @@ ctx.sync()
 ctx._check(ctx.lib.sfe_icp_set_tuning(ctx.handle, 8))
 kb.run()
 ctx.sync()
-for nb, ch in ((2, 512), (3, 512), (3, 256), (3, 64), (4, 256)):
-    r = bench_legs.stream_frames(ctx, kb, True, steps=4, distinct=512, n_buffers=nb, chunk=ch)
+combos = ((2, 512), (3, 512), (3, 256), (3, 64), (4, 256))
+if len(sys.argv) > 2:       # e.g. "3x64,3x256,3x512,2x512,3x512": the order matters for what is being asked (does a setting or the process's age decide?)
+    combos = tuple(tuple(int(v) for v in c.split("x")) for c in sys.argv[2].split(","))
+keep = {} if os.environ.get("STREAM_PROBE_KEEP") else None     # one pinned pool and one set of frame buffers for every call
+for nb, ch in combos:
+    r = bench_legs.stream_frames(ctx, kb, True, steps=4, distinct=512, n_buffers=nb, chunk=ch, reuse=keep)
     print(json.dumps({k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items() if k not in ("workload", "note")}))
