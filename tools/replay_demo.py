@@ -23,6 +23,11 @@ def main():
     ap.add_argument("--rows", type=int, default=1024)
     ap.add_argument("--beams", type=int, default=512)
     ap.add_argument("--store", action="store_true", help="keyframe clouds stay on the device (CloudStore): no wire hop")
+    ap.add_argument("--no-initialization", action="store_true",
+                    help="scan matches start from the odometry (slam.py:665-666 with the flag off) instead of the shgo global "
+                         "initialisation the reference runs by default (slam.py:77)")
+    ap.add_argument("--loop-closures", action="store_true", help="the loop-closure search of slam.py:839-1087 after every keyframe")
+    ap.add_argument("--turn", type=float, default=0.03, help="heading change per ping of the synthetic trajectory (2 pi / N closes a loop)")
     ap.add_argument("--save")
     ap.add_argument("--load")
     a = ap.parse_args()
@@ -32,7 +37,7 @@ def main():
                                                    z["stamps"], z["odom"], z["truth"] if "truth" in z else None)
     else:
         world = synth.world_structure(seed=2, n=12000)
-        true, dr = synth.trajectory(n=a.pings, step=0.9, turn=0.03, seed=3)
+        true, dr = synth.trajectory(n=a.pings, step=0.9, turn=a.turn, seed=3, start=(20.0, 0.0, 0.0) if a.turn > 0.1 else (2.0, 0.0, 0.0))
         bearings = oculus_bearings(a.beams)
         images = np.stack([synth.render_ping(world, p, bearings, rows=a.rows, seed=i) for i, p in enumerate(true)])
         res, stamps = 30.0 / a.rows, np.arange(a.pings, dtype=float)
@@ -50,7 +55,8 @@ def main():
     if a.store:
         from sonar_slam_amd.store import CloudStore
         store = CloudStore(ctx, capacity_points=1 << 20, max_clouds=4096)
-    front = FrontEnd(ctx, keyframe_translation=1.5, keyframe_duration=0.5, store=store)
+    front = FrontEnd(ctx, keyframe_translation=1.5, keyframe_duration=0.5, store=store, ssm_initialization=not a.no_initialization,
+                     nssm_enable=a.loop_closures)
     log, t_fe, t_slam = replay(pings, stamps, dr, fe, front)
     print("%d pings, %d keyframes; feature extraction %.2f ms/ping, SLAM front end %.2f ms/keyframe (host wall, "
           "single-ping host API incl. PCIe copies%s)" % (len(pings), len(log), 1e3 * t_fe / len(pings),
@@ -66,6 +72,13 @@ def main():
             odo = Pose2(*dr[0]).between(Pose2(*dr[k]))
             line += "  |err| icp-chain %.3f m  odometry %.3f m" % (np.hypot(got.x() - want.x(), got.y() - want.y()),
                                                                    np.hypot(odo.x() - want.x(), odo.y() - want.y()))
+        if "init_x" in r:
+            line += "  shgo x (%+.3f %+.3f %+.4f) cost %d" % (r["init_x"] + (int(r["init_cost"]),))
+        n = r.get("nssm")
+        if n is not None:
+            line += "  | loop search: %s" % n["status"]
+            if "target_key" in n:
+                line += " -> kf %d, %d/%d ICPs converged" % (n["target_key"], n.get("n_converged", 0), n.get("n_guesses", 0))
         print(line)
 
 
