@@ -120,21 +120,6 @@ __device__ __forceinline__ int strip_of(float y, float ylo, float inv_g, int ns)
     return (int)v;
 }
 
-// Sorted target of a job whose cloud does not fit LDS (beyond SW_TCAP points): positions [lo, lo + n) -- the strips its
-// queries live in and as many around them as the LDS holds -- are read from LDS, everything else from the HBM scratch
-// copy (through L2).  A walk is a chain of dependent reads: one LDS latency per step instead of one L2 round trip.
-struct TgtWin {
-    const float2 *g; // the whole sorted cloud (HBM scratch)
-    const float2 *l; // LDS copy of positions [lo, lo + n)
-    int lo;
-    unsigned n;
-    __device__ __forceinline__ float2 operator[](int j) const
-    {
-        const unsigned o = (unsigned)(j - lo);
-        return o < n ? l[o] : g[j];
-    }
-};
-
 // first position in [lo, hi) whose x is not < px (hi if there is none; NaN x counts as "not <").
 // Convergent form: every lane of the wave must call it, lanes without work pass lo == hi.
 template <class TV>
@@ -270,7 +255,6 @@ struct SweepShared {
     long long prof_t, prof[PROF ? 16 : 1], prof_it[PROF ? 64 : 1], prof_b0;
     unsigned xr[16]; // split jobs: the scalars of an exchange between the workgroups of a job
     int xabort;      // ... and its time-out flag
-    int win_smin, win_smax, win_lo, win_n; // WIN: strips of this workgroup's queries; the target positions held in LDS
     StripTab tab;
 };
 
@@ -383,7 +367,7 @@ constexpr size_t sweep_ctl_bytes()
 }
 
 // one launch of the loop kernel: n workgroups, job ids d_ids[0..n), `body` bytes of LDS behind the control block
-template <int NT, int MINW, bool LDS_TGT, bool LDS_Q, bool PROF, bool REC, bool MULTI, bool WIN = false>
+template <int NT, int MINW, bool LDS_TGT, bool LDS_Q, bool PROF, bool REC, bool MULTI>
 int sweep_launch_loop(const SweepLaunchArgs &a, int n, const int *d_ids, size_t body, int t_cap, int q_cap);
 
 // one launch of the prep kernel: n targets, ids d_pids[0..n) into d_preps, on stream ps

@@ -459,25 +459,13 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
             return rc;
         ids += n_lds;
     }
-    // Targets beyond SW_TCAP points stay in HBM scratch and are read through L2.  SFE_SW_WIN=1 (A/B) holds as much of the
-    // sorted target as fits next to the control block in LDS instead (TgtWin: the strips around the workgroup's queries;
-    // 19 700 of a 20 000-point cloud's 20 068 positions), one workgroup per CU.  Measured, 30 guesses x one 20 000 x
-    // 20 000 pair over 8 shares: 7.97 ms with the window, 7.82 without; 16 batches unsplit: 62.4 / 60.1 ms -- the target
-    // is L2-resident and sixteen waves per workgroup hide its latency; every read pays the window test.  Off by default.
-    const int win_on = env_int("SFE_SW_WIN", 0);
-    constexpr size_t ctl_g = sweep_ctl_bytes<ICP_THREADS, false, false>();
-    int glb_tmax = 0;
-    for (int j = 0; j < n_jobs; ++j)
-        if (jobs4[4 * (size_t)j + 3] > SW_TCAP)
-            glb_tmax = std::max(glb_tmax, (int)jobs4[4 * (size_t)j + 3]);
-    const int win_cap = std::min(glb_tmax + SW_PAD, (int)((160 * 1024 - ctl_g - 64) / 8));
-    const size_t body_win = 8 * (size_t)std::max(win_cap, SW_TCAP); // (the query sort uses the same bytes first)
+    // Targets beyond SW_TCAP points stay in HBM scratch and are read through L2.  (Rounds 3-4 carried a build that held the
+    // strips around a workgroup's queries in LDS instead -- 7.97 ms with it, 7.82 without on 30 guesses x one 20 000 x 20 000
+    // pair: the target is L2-resident and sixteen waves hide its latency, while every read paid the window test; removed in
+    // round 5, profiles/r05_pruned_variants.txt.)
     if (n_glb) {
         const size_t body = sizeof(unsigned long long) * SW_TCAP; // without a window the LDS behind the control block only serves the query sort
-        if (win_on)
-            rc = sweep_launch_loop<ICP_THREADS, 4, false, false, false, false, false, true>(a, n_glb, ids, body_win, win_cap, 0);
-        else
-            rc = wide ? sweep_launch_loop<ICP_THREADS, 4, false, false, false, false, false>(a, n_glb, ids, body, SW_TCAP, 0)
+        rc = wide ? sweep_launch_loop<ICP_THREADS, 4, false, false, false, false, false>(a, n_glb, ids, body, SW_TCAP, 0)
                       : sweep_launch_loop<ICP_THREADS, 8, false, false, false, false, false>(a, n_glb, ids, body, SW_TCAP, 0);
         if (rc)
             return rc;
@@ -487,8 +475,7 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
         const size_t body = sizeof(unsigned long long) * SW_TCAP;
         SweepLaunchArgs am = a;
         am.d_src = d_gsrc;
-        rc = win_on ? sweep_launch_loop<ICP_THREADS, 4, false, false, false, false, true, true>(am, n_multi, ids, body_win, win_cap, 0)
-                    : sweep_launch_loop<ICP_THREADS, 4, false, false, false, false, true>(am, n_multi, ids, body, SW_TCAP, 0);
+        rc = sweep_launch_loop<ICP_THREADS, 4, false, false, false, false, true>(am, n_multi, ids, body, SW_TCAP, 0);
         if (rc)
             return rc;
         ids += n_multi;

@@ -51,9 +51,7 @@ __device__ __forceinline__ int sweep_resolve_tie(const TV &T, const StripTab &ta
 // icp_split_kernel).  Every share runs the whole loop on its own queries; what an iteration decides from ALL queries --
 // the census of a search round, the histograms of the radix select, the sums of the error minimiser -- is exchanged
 // through the job's sync area (xreduce below) and every share takes the same decisions and solves the same system.
-// WIN (targets beyond SW_TCAP points): the part of the sorted target around this workgroup's queries is held in LDS
-// (TgtWin), t_cap = its capacity in points.
-template <int NT, int MINW, bool LDS_TGT, bool LDS_Q, bool PROF, bool REC, bool MULTI, bool WIN = false>
+template <int NT, int MINW, bool LDS_TGT, bool LDS_Q, bool PROF, bool REC, bool MULTI>
 __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
     sfe_icp_params P, const SweepJob *__restrict__ jobs, const int *__restrict__ job_ids, const float2 *__restrict__ src_all,
     const float *__restrict__ guess_all, const float2 *__restrict__ stgt_all, const int *__restrict__ perm_all,
@@ -66,7 +64,6 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
 {
     static_assert(LDS_TGT || !LDS_Q, "LDS_Q needs the LDS-resident target layout");
     static_assert(!MULTI || !PROF, "the profile build runs whole jobs");
-    static_assert(!WIN || !LDS_TGT, "a window is for targets that do not fit LDS");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     using Shared = SweepShared<NT, PROF, REC>;
     Shared &S = *reinterpret_cast<Shared *>(smem_raw);
@@ -88,12 +85,8 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
     const float2 *__restrict__ src = src_all + J.src_start;
     const float2 *__restrict__ stgt = stgt_all + J.tgt_off;
     float2 *lds_tgt = reinterpret_cast<float2 *>(smem_raw + ((sizeof(Shared) + 15) & ~(size_t)15));
-    using TV = std::conditional_t<WIN, TgtWin, const float2 *>;
-    TV T; // sorted target incl. sentinels
-    if constexpr (WIN)
-        T = TgtWin{stgt, lds_tgt, 0, 0u}; // (the window is chosen and filled behind the query sort)
-    else
-        T = LDS_TGT ? (const float2 *)lds_tgt : stgt;
+    using TV = const float2 *;
+    const TV T = LDS_TGT ? (const float2 *)lds_tgt : stgt; // sorted target incl. sentinels (LDS, or HBM scratch through L2)
     const float2 *__restrict__ snrm = snrm_all ? snrm_all + J.tgt_off : nullptr;
     SweepQ Q;
     Q.st = q_st_all + J.q_off;
@@ -149,8 +142,6 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
     if (tid == 0) {
         S.rmax_bits = 0u;
         S.xabort = 0;
-        S.win_smin = 0x7FFFFFFF;
-        S.win_smax = -1;
     }
     { // strip table -> LDS
         const int *tsrc = reinterpret_cast<const int *>(tab_all + J.prep);
@@ -266,7 +257,6 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
     {
         unsigned long long *skeys = reinterpret_cast<unsigned long long *>(lds_tgt);
         float rloc = 0.0f; // largest |T0 * src| among this thread's queries (for the movement bounds of the clearance records)
-        int smin_l = 0x7FFFFFFF, smax_l = -1; // WIN: the strips this thread's queries start in
         for (int c0 = 0; c0 < ns; c0 += sort_chunk) { // sort_chunk = the power of two of keys this LDS region holds
             const int n = min(sort_chunk, ns - c0);
             unsigned n2 = 2;
@@ -280,10 +270,6 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
                     const float ry = affine1(T0[3], T0[4], T0[5], sp.x, sp.y);
                     const int st_ = strip_of(ry, S.tab.ylo, S.tab.inv_g, S.tab.ns);
                     k = SW_KEY(st_, mono_key(rx), c0 + i);
-                    if (WIN) {
-                        smin_l = min(smin_l, st_);
-                        smax_l = max(smax_l, st_);
-                    }
                     const float rr = sqrtf(f_add(f_mul(rx, rx), f_mul(ry, ry)));
                     rloc = (rr > rloc || rr != rr) ? rr : rloc; // (a NaN sticks: no bound, no record is ever used)
                 }
@@ -301,58 +287,11 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
             __syncthreads();
         }
         atomicMax(&S.rmax_bits, __float_as_uint(rloc)); // rloc >= 0 or NaN (whose pattern is above every finite one)
-        if (WIN && smax_l >= 0) {
-            atomicMin(&S.win_smin, smin_l);
-            atomicMax(&S.win_smax, smax_l);
-        }
     }
     // sorted centred target (with its NaN sentinels: a NaN stops a walk direction) -> LDS
     if (LDS_TGT) {
         for (int i = tid; i < nt + SW_PAD; i += NT)
             lds_tgt[i] = stgt[i];
-    }
-    if constexpr (WIN) {
-        // The window: whole strips, in the sorted cloud's own layout (the sentinel in front of the first strip and the one
-        // behind the last included).  From the band of strips the queries start in -- shrunk from both ends if the
-        // band alone exceeds the capacity (an unsplit job: its queries are everywhere), else grown by whole strips on both
-        // sides while they fit.  Reads outside fall back to HBM, so any window is correct; a good one is fast.
-        __syncthreads();
-        if (tid == 0) {
-            const int nst_ = S.tab.ns;
-            int a = S.win_smin, b = S.win_smax + 1, lo = 0, n = 0;
-            if (S.win_smax >= 0 && t_cap > 0) {
-                auto len = [&](int a_, int b_) { return S.tab.sbeg[b_] - S.tab.sbeg[a_] + 1; };
-                while (b - a > 1 && len(a, b) > t_cap) {
-                    if ((b - a) & 1)
-                        --b;
-                    else
-                        ++a;
-                }
-                if (len(a, b) <= t_cap) {
-                    for (bool grow = true; grow;) {
-                        grow = false;
-                        if (a > 0 && len(a - 1, b) <= t_cap) {
-                            --a;
-                            grow = true;
-                        }
-                        if (b < nst_ && len(a, b + 1) <= t_cap) {
-                            ++b;
-                            grow = true;
-                        }
-                    }
-                    lo = S.tab.sbeg[a] - 1;
-                    n = len(a, b);
-                }
-            }
-            S.win_lo = lo;
-            S.win_n = n;
-        }
-        __syncthreads();
-        const int wlo = __builtin_amdgcn_readfirstlane(S.win_lo), wn = __builtin_amdgcn_readfirstlane(S.win_n);
-        for (int i = tid; i < wn; i += NT)
-            lds_tgt[i] = stgt[wlo + i];
-        T.lo = wlo;
-        T.n = (unsigned)wn;
     }
     IcpCheck chk = {S.hist_c, S.hist_s, S.hist_x, S.hist_y, 1, 0, 0};
     if (tid == 0) {
@@ -1662,11 +1601,11 @@ static int pow2_floor(size_t v)
     return (int)p;
 }
 
-template <int NT, int MINW, bool LDS_TGT, bool LDS_Q, bool PROF, bool REC, bool MULTI, bool WIN>
+template <int NT, int MINW, bool LDS_TGT, bool LDS_Q, bool PROF, bool REC, bool MULTI>
 int sweep_launch_loop(const SweepLaunchArgs &a, int n, const int *d_ids, size_t body, int t_cap, int q_cap)
 {
     sfe_ctx *ctx = a.ctx;
-    auto kernel = icp_sweep_kernel<NT, MINW, LDS_TGT, LDS_Q, PROF, REC, MULTI, WIN>;
+    auto kernel = icp_sweep_kernel<NT, MINW, LDS_TGT, LDS_Q, PROF, REC, MULTI>;
     const size_t smem = sweep_ctl_bytes<NT, PROF, REC>() + body;
     SFE_HIP(ctx, hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(kernel, dim3(n), dim3(NT), smem, ctx->stream, *a.p, a.d_jobs, d_ids, a.d_src, a.d_guess9, a.d_stgt,
@@ -1678,7 +1617,7 @@ int sweep_launch_loop(const SweepLaunchArgs &a, int n, const int *d_ids, size_t 
 }
 
 // the builds the host side asks for: {threads, min waves per EU (the VGPR budget), target in LDS, results in LDS, counted
-// profile, clearance records, job shared by several workgroups, target window in LDS}
+// profile, clearance records, job shared by several workgroups}
 #define SW_LOOP_INST(...) template int sweep_launch_loop<__VA_ARGS__>(const SweepLaunchArgs &, int, const int *, size_t, int, int);
 SW_LOOP_INST(SW_T0_NT, 4, true, true, false, true, false)
 SW_LOOP_INST(SW_T0_NT, 4, true, true, false, false, false)
@@ -1695,10 +1634,8 @@ SW_LOOP_INST(ICP_THREADS, 4, true, false, false, false, false)
 SW_LOOP_INST(ICP_THREADS, 8, true, false, true, false, false)
 SW_LOOP_INST(ICP_THREADS, 8, true, false, false, true, false)
 SW_LOOP_INST(ICP_THREADS, 8, true, false, false, false, false)
-SW_LOOP_INST(ICP_THREADS, 4, false, false, false, false, false, true)
 SW_LOOP_INST(ICP_THREADS, 4, false, false, false, false, false)
 SW_LOOP_INST(ICP_THREADS, 8, false, false, false, false, false)
-SW_LOOP_INST(ICP_THREADS, 4, false, false, false, false, true, true)
 SW_LOOP_INST(ICP_THREADS, 4, false, false, false, false, true)
 
 int sweep_launch_split(sfe_ctx *ctx, hipStream_t ps, int n_split, SweepJob *d_jobs, const int *d_split, const float2 *d_src,

@@ -25,7 +25,7 @@ for name, kw in (("p2plane30", dict(minimizer=1, use_diff_checker=0, max_iter=30
     for ng in (30,):
         one = ScanMatchBatch(ctx, p, [s], [t], [(0, 0)] * ng, gs[:ng])
         for label, env in (("G=1", {"SFE_SW_MULTI": "0"}), ("G=8 one-WG normals", {"SFE_SW_MULTI_G": "8", "SFE_SW_NORMALS_SPLIT": "0"}),
-                           ("G=8", {"SFE_SW_MULTI_G": "8"}), ("G=16", {"SFE_SW_MULTI_G": "16"}), ("G=8 no window", {"SFE_SW_MULTI_G": "8", "SFE_SW_WIN": "0"})):
+                           ("G=8", {"SFE_SW_MULTI_G": "8"}), ("G=16", {"SFE_SW_MULTI_G": "16"})):
             os.environ.update(env)
             try:
                 ms = timed(ctx, one.run, 3)
