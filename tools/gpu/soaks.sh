@@ -9,5 +9,6 @@ for seed in 1717 2828; do
 done
 { timeout 300 python tools/pipeline_soak.py --seconds 90 2>&1 | tail -2
   timeout 200 python tools/extract_soak.py --seconds 60 2>&1 | tail -2
-  timeout 300 python tools/icp_soak.py --seconds 90 2>&1 | tail -2; } > gpurun_out/${tag}_soaks.txt 2>&1
+  timeout 300 python tools/icp_soak.py --seconds 90 2>&1 | tail -2
+  timeout 200 python tools/default_flow_soak.py --seconds 60 2>&1 | tail -2; } > gpurun_out/${tag}_soaks.txt 2>&1
 cat gpurun_out/${tag}_soaks.txt
