@@ -318,6 +318,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        # the legs beyond the timed step, the live-latency leg and the farm leg measure ONE device; in a multi-rank launch
+        # they would only keep rank 0's GPU busy for a minute after the line's figure is known (the driver's scaling runs)
+        args.no_legs = args.no_latency = args.no_farm = True
     dist = None
     if world > 1:
         import torch.distributed as dist
