@@ -362,7 +362,9 @@ __global__ __launch_bounds__(256) void store_fov_kernel(const float2 *__restrict
         for (int f = 0; f < n_frames; ++f) {
             const FovFrame fr = frames[f];
             const float2 q = store_transform<false>(p, fr.T[0], fr.T[1], fr.T[2], fr.T[3], fr.T[4], fr.T[5]);
-            const float range = __fsqrt_rn(__fadd_rn(__fmul_rn(q.x, q.x), __fmul_rn(q.y, q.y)));
+            // sqrtf, not __fsqrt_rn: the intrinsic lowers to a bare v_sqrt_f32 (1 ulp), sqrtf to the correctly rounded
+            // sequence numpy's float32 sqrt gives (a point 0.95 ulp outside its range bound showed the difference)
+            const float range = sqrtf(__fadd_rn(__fmul_rn(q.x, q.x), __fmul_rn(q.y, q.y)));
             if (!((double)range < fr.range_bound))
                 continue;
             const double a = fabs(atan2((double)q.y, (double)q.x));

@@ -373,6 +373,45 @@ def test_loop_closure_primitives_over_the_store(ctx):
 
 
 @pytest.mark.gpu
+def test_fov_gate_ranges_on_their_bound(ctx):
+    """points on circles around the frames, each range bound placed ON a float32 value those ranges take: a point whose range
+    is that value is outside (slam.py:892 `ranges < range_bound`), one ulp less is inside -- so a device range that is not the
+    correctly rounded float32 of numpy's norm (slam.py:880) changes the selection.  (default_flow_soak, seed 1 round 4458: one
+    point 0.95 ulp outside its bound was taken by a 1-ulp square root.)"""
+    from sonar_slam_amd import store as st
+    from sonar_slam_amd.replay import FrontEnd, Keyframe
+    rng = np.random.default_rng(4458)
+    s = st.CloudStore(ctx, capacity_points=1 << 16, max_clouds=1024)
+    n_on_bound = 0
+    for trial in range(150):
+        s.truncate(0)
+        frames = [Pose2(*q) for q in np.c_[rng.normal(0, 6, 3), rng.normal(0, 6, 3), rng.normal(0, 1.5, 3)]]
+        Tinv = [f.inverse() for f in frames]
+        pts, radii = [], []
+        for f, t in zip(frames, Tinv):
+            r = rng.uniform(4, 40)
+            a = rng.uniform(-np.pi, np.pi, 400)
+            p = Keyframe.transform_points(np.c_[r * np.cos(a), r * np.sin(a)], f).astype(np.float32)
+            rr = np.linalg.norm(Keyframe.transform_points(p, t), axis=1)
+            v = np.unique(rr)
+            assert 2 <= len(v) <= 12
+            radii.append(float(v[len(v) // 2]))         # a float32 value, held exactly by the float64 bound
+            n_on_bound += int(np.sum(rr == v[len(v) // 2]))
+            pts.append(p)
+        gp = np.concatenate(pts)
+        bb = [3.3, 3.3, 3.3]
+        sel = FrontEnd._fov_numpy(gp, Tinv, radii, bb)
+        assert 0 < sel.sum() < len(gp)
+        gk = s.get_points_keys([s.put(gp)], [st.pose_T6(Pose2(0, 0, 0))], [5], 0.0)
+        assert np.array_equal(s.read(gk), gp)
+        hist, n_sel, n_amb = s.fov_select(gk, [st.pose_T6(t) for t in Tinv], radii, bb, 8)
+        assert n_amb == 0 and n_sel == int(sel.sum()) and hist[5] == n_sel, trial
+        assert np.array_equal(s.read(s.compact_selected(gk)), gp[sel]), trial
+    assert n_on_bound > 10000
+    s.close()
+
+
+@pytest.mark.gpu
 def test_front_end_loop_closure_search_equals_the_oracle_chain(ctx):
     """replay.FrontEnd(nssm_enable=True) on host arrays == on store handles == oracle/chain.py on a trajectory that
     comes back to its start: every search record (sizes, field-of-view target key, shgo result, refined target key, number of

@@ -38,6 +38,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--dump", help="npz to write the first mismatching round's inputs to")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     ctx = _lib.default_context()
@@ -66,11 +67,19 @@ def main():
         else:
             want, wk = allp, allk
         gp, gk = s.read(g), s.read_keys(g)
+        why = []
         ok = np.array_equal(gp, want) and np.array_equal(gk, wk)
+        if not ok:
+            why.append("keyed get_points: %d vs %d points, first difference at %s" % (len(gp), len(want), (np.nonzero((gp != want).any(axis=1))[0][:3] if gp.shape == want.shape else "-")))
         # ---- get_points without keys through the batched entry point (big path when > 65 536) ----
         ref = poses[int(rng.integers(m))]
         h2 = s.get_points([hs], [[st.pose_T6(ref.between(p)) for p in poses]], res)[0]
-        ok &= np.array_equal(s.read(h2), oracle.get_points(clouds, [ref.between(p).matrix() for p in poses], res))
+        w2 = oracle.get_points(clouds, [ref.between(p).matrix() for p in poses], res)
+        g2 = s.read(h2)
+        if not np.array_equal(g2, w2):
+            ok = False
+            why.append("get_points (batched entry): %d vs %d points, first difference at %s"
+                       % (len(g2), len(w2), (np.nonzero((g2 != w2).any(axis=1))[0][:3] if g2.shape == w2.shape else "-")))
         # ---- field-of-view gate + per-key counts + compaction ----
         nf = int(rng.integers(1, 6))
         frames = [Pose2(*q) for q in np.c_[rng.normal(0, 10, nf), rng.normal(0, 10, nf), rng.normal(0, 1.5, nf)]]
@@ -84,9 +93,13 @@ def main():
             n_amb += 1
             s.set_selection(g, sel)
         else:
-            ok &= n_sel == int(sel.sum()) and np.array_equal(hist, np.bincount(gk[sel], minlength=nk))
+            if not (n_sel == int(sel.sum()) and np.array_equal(hist, np.bincount(gk[sel], minlength=nk))):
+                ok = False
+                why.append("fov_select: %d selected vs %d" % (n_sel, int(sel.sum())))
         c = s.compact_selected(g)
-        ok &= np.array_equal(s.read(c), gp[sel]) and np.array_equal(s.read_keys(c), gk[sel])
+        if not (np.array_equal(s.read(c), gp[sel]) and np.array_equal(s.read_keys(c), gk[sel])):
+            ok = False
+            why.append("compact_selected")
         # ---- keyed matching of a moved float32 source ----
         src = cloud(rng, int(rng.choice([0, 1, 50, 700])))
         hsrc = s.put(src)
@@ -95,9 +108,12 @@ def main():
         tsel, ksel = gp[sel], gk[sel]
         if len(src) and len(tsel):
             ids = oracle.match(tsel, oracle.transform_points(src, est.matrix(), f64_points=False), 0.5)[0].reshape(-1)
-            ok &= ov == int(np.sum(ids != -1)) and np.array_equal(h1, np.bincount(ksel[ids[ids != -1]], minlength=nk))
-        else:
-            ok &= ov == 0 and not h1.any()
+            if not (ov == int(np.sum(ids != -1)) and np.array_equal(h1, np.bincount(ksel[ids[ids != -1]], minlength=nk))):
+                ok = False
+                why.append("match_keys: overlap %d vs %d" % (ov, int(np.sum(ids != -1))))
+        elif not (ov == 0 and not h1.any()):
+            ok = False
+            why.append("match_keys on an empty cloud")
         # ---- cost grids over handles: several (source, target) pairs in one launch, both dtypes ----
         pairs = [(i, j) for i in range(m) for j in range(m) if sizes[i] >= 1 and sizes[j] >= 2 and sizes[j] <= 3000][:6]
         if pairs:
@@ -112,14 +128,21 @@ def main():
                     rr = np.clip(np.int32(np.round((tgt[:, 1] - ymin) / r_)), 0, rows - 1)
                     cc = np.clip(np.int32(np.round((tgt[:, 0] - xmin) / r_)), 0, cols - 1)
                     grid = oracle.cost_grid(rr, cc, rows, cols, hsz)
-                    ok &= np.array_equal(costs[q], oracle.matching_cost(grid, clouds[i], T6[q], xmin, ymin, r_, f64_points=f64))
-                    if q == 0:
-                        ok &= np.array_equal(grids.download(0), grid)
+                    if not np.array_equal(costs[q], oracle.matching_cost(grid, clouds[i], T6[q], xmin, ymin, r_, f64_points=f64)):
+                        ok = False
+                        why.append("matching cost, pair %d (f64 %s)" % (q, f64))
+                    if q == 0 and not np.array_equal(grids.download(0), grid):
+                        ok = False
+                        why.append("cost grid")
                 grids.close()
         rounds += 1
         if not ok:
             bad += 1
-            print("MISMATCH in round %d (seed %d): sizes %r res %g" % (rounds, a.seed, sizes, res))
+            print("MISMATCH in round %d (seed %d): sizes %r res %g: %s" % (rounds, a.seed, sizes, res, "; ".join(why)))
+            if a.dump:
+                np.savez(a.dump, poses=np.array([[p.x(), p.y(), p.theta()] for p in poses]), ref=np.array([ref.x(), ref.y(), ref.theta()]),
+                         res=res, fov_frames=np.array([[f.x(), f.y(), f.theta()] for f in frames]), range_bounds=np.array(rb),
+                         bearing_bounds=np.array(bb), keys=np.array(keys), **{"cloud%d" % i: c for i, c in enumerate(clouds)})
     print("default-flow soak: %d rounds in %.0f s (%d with a target beyond 65 536 points, %d undecidable gates handed to numpy), %d mismatches"
           % (rounds, a.seconds, n_big, n_amb, bad))
     s.close()
