@@ -448,6 +448,31 @@ int sfe_matching_cost_store(sfe_ctx *ctx, sfe_costgrid *g, sfe_cloud_store *s, c
                             const int32_t *grid_index, int n_jobs, const float *T6, int n_poses, double resolution, int flags,
                             int32_t *cost_out);
 
+/* ---- replaces: everything scipy.optimize.shgo(func, bounds, n, iters=1, sampling_method="sobol", minimizer_kwargs=
+ * {"options": {"ftol": ...}}) of slam.py:692-701 does AFTER its sampling stage, for n_problems cost tables at once (host only,
+ * no device work).  Holds for the piecewise-constant cost of slam.py:529-567 only.  The vertex graph (CSR nn_off / nn_idx over
+ * n_vertices vertices in shgo's vertex-cache order), the vertices x [n_vertices x 3] and the three forward-difference points of
+ * SLSQP per vertex come from one run of the installed scipy (sonar_slam_amd/shgo_fast.py, SobolPlan);
+ * tables [n_problems x n_vertices x 4]: the cost at each vertex and at its three finite-difference points.
+ * status_out: SFE_SHGO_OK (result = vertex_out), SFE_SHGO_OK_TIED (several local results share the lowest cost: the caller asks
+ * np.argsort over the costs of order_out[.. n_order_out], as shgo does -- its sort kernel is not stable), SFE_SHGO_FAILED (no
+ * vertex strictly below all its neighbours: shgo's success = False, vertex_out = the lowest vertex), SFE_SHGO_FALLBACK (a
+ * finite-difference point costs something else than its vertex, two pool members equally far from the last result, or more
+ * than SFE_SHGO_MAX_POOL minimisers: run scipy.optimize.shgo itself).  order_out [n_problems x SFE_SHGO_MAX_POOL]: the
+ * vertices in the order shgo minimises them. */
+#define SFE_SHGO_OK 0
+#define SFE_SHGO_FAILED 1
+#define SFE_SHGO_FALLBACK 2
+#define SFE_SHGO_OK_TIED 3
+#define SFE_SHGO_MAX_POOL 32
+int sfe_shgo_sobol_replay(int n_vertices, const int32_t *nn_off, const int32_t *nn_idx, const double *x, const int32_t *tables,
+                          int n_problems, uint8_t *status_out, int32_t *vertex_out, int32_t *n_order_out, int32_t *order_out);
+/* T6_out[(i * n_deltas + j) * 6 ..] = float32 rows of target_i.between(source_i.compose(delta_j)).matrix() (slam.py:548-550:
+ * the sample transform of the matching cost) for n_sessions pose pairs x n_deltas deltas; every pose as {x, y, cos(theta),
+ * sin(theta)} doubles.  gtsam.Pose2's expressions as sonar_slam_amd/pose2.py states them, in double, in the same order.  Host only. */
+int sfe_pose2_sample_transforms(const double *target_xycs, const double *source_xycs, int n_sessions, const double *delta_xycs,
+                                int n_deltas, float *T6_out);
+
 #ifdef __cplusplus
 }
 #endif

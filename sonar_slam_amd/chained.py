@@ -95,6 +95,26 @@ class Pose2Batch(object):
         return np.stack([self.x, self.y, self.theta()], axis=1)
 
 
+def sample_transforms(lib, target, source, X):
+    """T6 [n x len(X) x 6] float32 of target_i.between(source_i.compose(Pose2(*x))) for Pose2Batch target / source (n poses each)
+    and deltas X [P x 3]: the cost function's sample transforms (slam.py:548-550) of n sessions at once.  The arithmetic is
+    Pose2's, done by the library's host routine (sfe_pose2_sample_transforms); cos / sin of the deltas through ``math`` like Pose2."""
+    import ctypes as _C
+    X = np.asarray(X, np.float64).reshape(-1, 3)
+    n, P = len(target), len(X)
+    d4 = np.ascontiguousarray(np.stack([X[:, 0], X[:, 1], [math.cos(t) for t in X[:, 2]], [math.sin(t) for t in X[:, 2]]], axis=1)) \
+        if P else np.zeros((0, 4))
+    t4 = np.ascontiguousarray(np.stack([target.x, target.y, target.c, target.s], axis=1), np.float64)
+    s4 = np.ascontiguousarray(np.stack([source.x, source.y, source.c, source.s], axis=1), np.float64)
+    out = np.zeros((n, P, 6), np.float32)
+    f64 = _C.POINTER(_C.c_double)
+    rc = lib.sfe_pose2_sample_transforms(t4.ctypes.data_as(f64), s4.ctypes.data_as(f64), n, d4.ctypes.data_as(f64), P,
+                                         out.ctypes.data_as(_C.POINTER(_C.c_float)))
+    if rc != 0:
+        raise _L.SonarFEError("sfe_pose2_sample_transforms: %d" % rc)
+    return out
+
+
 class _View(object):
     """a window into a DeviceBuffer (what KeyframeBatch reads as .ptr)"""
 
@@ -110,7 +130,7 @@ class SessionBatch(object):
                  max_points=16384, resolution=0.5, outlier_radius=1.0, outlier_min_points=5, point_resolution=0.5,
                  point_noise=0.5, ssm_min_points=50, ssm_max_translation=3.0, ssm_max_rotation=np.deg2rad(30),
                  ssm_target_frames=3, store_points=None, initialization=False, initialization_params=(50, 1, 0.01),
-                 odom_sigmas=(0.2, 0.2, 0.02), shgo_workers=1):
+                 odom_sigmas=(0.2, 0.2, 0.02), shgo_workers=1, shgo_replay=True):
         from .pipeline import KeyframeBatch
         self.ctx, self.S, self.K = ctx, int(n_sessions), int(n_steps)
         self.icp_params = icp_params
@@ -132,7 +152,11 @@ class SessionBatch(object):
         self.odom_sigmas = np.array(odom_sigmas, np.float64)
         self._sobol = None
         self.shgo_workers, self._shgo_pool = int(shgo_workers), None    # > 1: shgo_pool.ShgoPool (host processes)
-        self.init_stats = {"shgo_s": 0.0, "cost_calls": 0, "table_hits": 0, "speculated": 0, "speculation_failed": 0}
+        # shgo_replay: sonar_slam_amd/shgo_fast.py -- what shgo decides after its sampling stage, replayed for all sessions from
+        # one table of costs; scipy.optimize.shgo itself only for the sessions the replay reports as undecidable
+        self.shgo_replay, self._plan = bool(shgo_replay), None
+        self.init_stats = {"shgo_s": 0.0, "cost_calls": 0, "table_hits": 0, "speculated": 0, "speculation_failed": 0,
+                           "replayed": 0, "replay_fallbacks": 0, "transforms_s": 0.0, "table_s": 0.0, "grids_s": 0.0}
         self.reset()
 
     def upload_frames(self, k, frames):
@@ -278,41 +302,70 @@ class SessionBatch(object):
             self._sobol = np.array(got, np.float64).reshape(-1, 3)
         return self._sobol
 
+    def _replay_plan(self, pose_bounds):
+        """shgo_fast.SobolPlan for these bounds, or None (replay switched off, more than one shgo iteration, or the replay does
+        not reproduce the installed scipy: then every problem goes through scipy.optimize.shgo)"""
+        from . import shgo_fast
+        if not self.shgo_replay or self.initialization_params[1] != 1:
+            return None
+        if self._plan is None:
+            self._plan = shgo_fast.plan_for(pose_bounds, self.initialization_params[0], self.initialization_params[2])
+            if self._plan.checked is None:
+                self._plan.self_check()
+        return self._plan if self._plan.checked else None
+
     def _global_init(self, idx, src_h, tgt_h, pose, prev):
         """-> (success [n], estimated source poses Pose2Batch [n], result.x [n x 3], result.fun [n]) for sessions idx"""
         import time
         from scipy.optimize import shgo
         from . import matching_cost as mc
+        from . import shgo_fast
         n = len(idx)
         pose_stds = np.array([self.odom_sigmas]).T
         pose_bounds = 5.0 * np.c_[-pose_stds, pose_stds]
-        X0 = self._sobol_points(pose_bounds)
+        plan = self._replay_plan(pose_bounds)
+        # the poses every session's shgo asks for first: the vertices of its sampling stage (+ with the replay the three
+        # forward-difference points SLSQP adds per vertex)
+        X0 = plan.points.reshape(-1, 3) if plan is not None else self._sobol_points(pose_bounds)
         src_pose, tgt_pose = pose.take(idx), prev.take(idx)
 
         def transforms(sel, X):
             """T6 [len(sel) x len(X) x 6] of target_pose.between(source_pose.compose(n2g(x))) (slam.py:548-550)"""
-            m = len(sel)
-            out = np.zeros((m, len(X), 6), np.float32)
-            sp, tp = src_pose.take(sel), tgt_pose.take(sel)
-            for j, x in enumerate(X):
-                d = Pose2Batch(np.full(m, x[0]), np.full(m, x[1]), np.full(m, x[2]))
-                out[:, j] = tp.between(sp.compose(d)).T6()
-            return out
+            return sample_transforms(self.ctx.lib, tgt_pose.take(sel), src_pose.take(sel), X)
+        t_g = time.perf_counter()
         grids = mc._StoreGrids(self.store, tgt_h[idx], self.point_noise)
+        self.init_stats["grids_s"] += time.perf_counter() - t_g
         try:
-            table = grids.cost(src_h[idx], transforms(np.arange(n), X0), f64_points=True)      # [n x len(X0)]: one launch
+            t_a = time.perf_counter()
+            T6_all = transforms(np.arange(n), X0)
+            t_b = time.perf_counter()
+            table = grids.cost(src_h[idx], T6_all, f64_points=True)                            # [n x len(X0)]: one launch
+            self.init_stats["transforms_s"] += t_b - t_a
+            self.init_stats["table_s"] += time.perf_counter() - t_b
+            self.init_stats["table_hits"] += n * len(X0)
             keys = [x.tobytes() for x in X0]
             ok, xs, fs = np.zeros(n, bool), np.zeros((n, 3)), np.zeros(n)
             t0 = time.perf_counter()
-            todo = range(n)
-            if self.shgo_workers > 1 and n > 1:
+            todo = np.arange(n)
+            if plan is not None:
+                st, vx = plan.solve_many(self.ctx.lib, table.reshape(n, plan.V, 4))
+                done = st != shgo_fast.FALLBACK
+                good = st == shgo_fast.OK
+                ok[good] = True
+                xs[good] = plan.X[vx[good]]
+                fs[good] = table.reshape(n, plan.V, 4)[np.nonzero(good)[0], vx[good], 0]
+                todo = np.nonzero(~done)[0]
+                self.init_stats["replayed"] += int(done.sum())
+                self.init_stats["replay_fallbacks"] += len(todo)
+            if self.shgo_workers > 1 and len(todo) > 1:
                 # speculative runs on the host cores (shgo_pool.py), every assumed cost verified in one launch
                 from . import shgo_pool
                 if self._shgo_pool is None:
+                    t_pool = time.perf_counter()
                     self._shgo_pool = shgo_pool.ShgoPool(self.shgo_workers)
-                    t0 = time.perf_counter()
-                out = self._shgo_pool.map([(pose_bounds, self.initialization_params, X0, table[i].astype(np.int64)) for i in range(n)])
-                who = np.concatenate([np.full(len(o[4]), i, np.int64) for i, o in enumerate(out)]) if n else np.zeros(0, np.int64)
+                    t0 += time.perf_counter() - t_pool
+                out = self._shgo_pool.map([(pose_bounds, self.initialization_params, X0, table[i].astype(np.int64)) for i in todo])
+                who = np.concatenate([np.full(len(o[4]), i, np.int64) for i, o in zip(todo, out)])
                 bad = np.zeros(n, bool)
                 if len(who):
                     asked = np.concatenate([o[4] for o in out])
@@ -323,10 +376,9 @@ class SessionBatch(object):
                     true = grids.cost(src_h[idx[who]], T6, True, grid_index=who)[:, 0]
                     np.logical_or.at(bad, who, true != assumed)
                     self.init_stats["cost_calls"] += len(who)
-                self.init_stats["speculated"] += n
+                self.init_stats["speculated"] += len(todo)
                 self.init_stats["speculation_failed"] += int(bad.sum())
-                self.init_stats["table_hits"] += n * len(X0)
-                for i, o in enumerate(out):
+                for i, o in zip(todo, out):
                     if not bad[i]:
                         ok[i] = o[0]
                         if o[0]:

@@ -135,6 +135,43 @@ def grid_geometry(bbox, point_noise):
     return xmin, ymin, resolution, len(ys), len(xs), int(np.ceil(point_noise / resolution))
 
 
+_MANY_OK = None       # grid_geometry_many agrees with grid_geometry under the installed numpy (checked on first use)
+
+
+def grid_geometry_many(bbox, point_noise):
+    """grid_geometry for n bounding boxes [n x 4] at once -> (xmin [n], ymin [n], resolution, rows [n], cols [n], dilate_hs).
+    np.arange's length is ceil((stop - start) / step) evaluated on the scalars' own types (float32 - float32, divided by the
+    Python float): under NEP 50 (numpy >= 2) that is the float32 array arithmetic below; older numpys promote the scalar
+    division to double.  So the array form is CHECKED against the scalar function -- every box of the first call, eight boxes of
+    every later one -- and the scalar loop takes over for good if they ever differ."""
+    global _MANY_OK
+    bbox = np.asarray(bbox, np.float32).reshape(-1, 4)
+    n = len(bbox)
+
+    def loop():
+        geo = [grid_geometry(b, point_noise) for b in bbox]
+        return (np.array([g[0] for g in geo], np.float32), np.array([g[1] for g in geo], np.float32), float(geo[0][2]),
+                np.array([g[3] for g in geo], np.int32), np.array([g[4] for g in geo], np.int32), int(geo[0][5]))
+    if _MANY_OK is False or n == 0:
+        return loop() if n else (np.zeros(0, np.float32), np.zeros(0, np.float32), point_noise / 10.0, np.zeros(0, np.int32),
+                                 np.zeros(0, np.int32), int(np.ceil(point_noise / (point_noise / 10.0))))
+    lo = bbox[:, :2] - 2 * point_noise
+    hi = bbox[:, 2:] + 2 * point_noise
+    resolution = point_noise / 10.0
+    length = np.maximum(np.ceil(((hi - lo) / resolution).astype(np.float64)), 0).astype(np.int32)
+    out = (np.ascontiguousarray(lo[:, 0]), np.ascontiguousarray(lo[:, 1]), resolution, np.ascontiguousarray(length[:, 1]),
+           np.ascontiguousarray(length[:, 0]), int(np.ceil(point_noise / resolution)))
+    probe = np.arange(n) if _MANY_OK is None else np.unique(np.linspace(0, n - 1, 8).astype(int))
+    for i in probe:
+        g = grid_geometry(bbox[i], point_noise)
+        if not (g[0] == out[0][i] and g[1] == out[1][i] and g[2] == out[2] and g[3] == out[3][i] and g[4] == out[4][i]
+                and g[5] == out[5] and np.asarray(g[0]).dtype == np.float32):
+            _MANY_OK = False
+            return loop()
+    _MANY_OK = True
+    return out
+
+
 def batch_store(store, source_handles, target_handles, T6, point_noise=0.5, f64_points=True):
     """Costs of n_poses candidate transforms for each of n (source, target) pairs of ``store`` in ONE launch: T6
     [n x n_poses x 6] float32 (``store.pose_T6`` of sample_transform).  -> (costs [n x n_poses] int32, grids): ``grids``
@@ -155,13 +192,8 @@ class _StoreGrids(object):
             raise ValueError("matching cost: target cloud %d is empty or holds non-finite points (np.min of an empty cloud raises "
                              "in the reference too: slam.py:506); the caller tests min_points first (slam.py:659)"
                              % int(th[int(np.argmax(~np.isfinite(bbox).all(axis=1)))]))
-        geo = [grid_geometry(b, point_noise) for b in bbox]
-        self.xmin = np.array([g[0] for g in geo], np.float32)
-        self.ymin = np.array([g[1] for g in geo], np.float32)
-        self.resolution = float(geo[0][2])
-        self.rows = np.array([g[3] for g in geo], np.int32)
-        self.cols = np.array([g[4] for g in geo], np.int32)
-        self.dilate_hs = int(geo[0][5])
+        self.xmin, self.ymin, self.resolution, self.rows, self.cols, self.dilate_hs = grid_geometry_many(bbox, point_noise)
+        self.resolution = float(self.resolution)
         h = _C.c_void_p()
         with self.ctx.lock:
             self.ctx._check(self.ctx.lib.sfe_costgrid_create_store(

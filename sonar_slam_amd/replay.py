@@ -125,8 +125,9 @@ class FrontEnd(object):
                  nssm_enable=False, nssm_initialization=True, nssm_initialization_params=(100, 5, 0.01), nssm_min_st_sep=8,
                  nssm_min_points=50, nssm_max_translation=10.0, nssm_max_rotation=np.deg2rad(60), nssm_source_frames=5,
                  nssm_cov_samples=30, oculus_max_range=30.0, oculus_horizontal_aperture=np.radians(130.0),
-                 mcd_random_state=None):
+                 mcd_random_state=None, shgo_replay=True):
         self.ctx = ctx
+        self.shgo_replay = shgo_replay      # FrontEnd.shgo: replay of shgo's decisions from one table of costs (shgo_fast.py)
         self.store = store          # CloudStore: keyframe clouds stay on the device (feed_handle)
         self.icp = pcl.ICP(ctx)
         self.icp.setParams(icp_params if icp_params is not None else icp_config.shipped_params())
@@ -273,11 +274,28 @@ class FrontEnd(object):
                                                 point_noise=self.point_noise, ctx=self.ctx)
 
     @staticmethod
-    def shgo(subroutine, pose_bounds, params):
-        """slam.py:692-701 / :952-961 verbatim; the points of a sampling stage are scored in one launch (``workers`` is
-        shgo's own hook for evaluating the pool of new vertices: the results and their order are those of the
-        one-by-one loop, tests/test_global_init.py)"""
-        from scipy.optimize import shgo
+    def shgo(subroutine, pose_bounds, params, replay=True):
+        """slam.py:692-701 / :952-961.  ``replay`` (one-iteration calls only, i.e. the sequential scan match's): the cost at shgo's
+        sampling points and at the finite-difference points of its local minimiser is taken in ONE launch and what shgo decides
+        from there is replayed (shgo_fast.py; checked against the installed scipy once per process).  Otherwise, and whenever the
+        replay reports a problem as undecidable, scipy.optimize.shgo itself: the reference's call verbatim, the points of a
+        sampling stage scored in one launch (``workers`` is shgo's own hook for evaluating the pool of new vertices: the
+        results and their order are those of the one-by-one loop, tests/test_global_init.py)"""
+        from scipy.optimize import OptimizeResult, shgo
+        from . import shgo_fast
+        if replay and params[1] == 1:
+            plan = shgo_fast.plan_for(pose_bounds, params[0], params[2])
+            if plan.checked is None:
+                plan.self_check()
+            if plan.checked:
+                table = np.array(subroutine.batch(list(plan.points.reshape(-1, 3))), np.int64).reshape(plan.V, 4)
+                st, x, fun, n_local = plan.solve(table, return_pool=True)
+                if st == shgo_fast.OK:
+                    return OptimizeResult(x=x, fun=np.int64(fun), success=True, message="Optimization terminated successfully.",
+                                          nfev=plan.V + 4 * n_local, nlfev=4 * n_local, replayed=True)
+                if st == shgo_fast.FAILED:
+                    return OptimizeResult(x=x, fun=np.int64(fun), success=False, nfev=plan.V, replayed=True,
+                                          message="Failed to find a feasible minimizer point. Lowest sampling point = %s" % fun)
 
         def pool(_fn, xs):
             xs = [np.asarray(x, np.float64) for x in xs]
@@ -309,7 +327,7 @@ class FrontEnd(object):
                 subroutine, _ = self.matching_cost_subroutine(source_points, keyframe.pose, target_points, target_pose,
                                                               np.diag(self.odom_sigmas), f64_source=True)
                 try:
-                    result = self.shgo(subroutine, pose_bounds, self.ssm_initialization_params)
+                    result = self.shgo(subroutine, pose_bounds, self.ssm_initialization_params, replay=self.shgo_replay)
                 finally:
                     subroutine.grid.close()
                 rec["init_success"] = bool(result.success)

@@ -55,7 +55,7 @@ def test_pool_hook_of_shgo_gives_the_results_of_the_one_by_one_loop():
         pose_stds = np.array([[0.2, 0.2, 0.02]]).T
         bounds = 5.0 * np.c_[-pose_stds, pose_stds]
         ra = chain.run_shgo(sub_a, bounds, params)
-        rb = FrontEnd.shgo(sub_b, bounds, params)
+        rb = FrontEnd.shgo(sub_b, bounds, params, replay=False)
         assert ra.success and rb.success and np.array_equal(ra.x, rb.x) and ra.fun == rb.fun and ra.nfev == rb.nfev
         key = lambda s: tuple(map(tuple, np.array(sorted(map(tuple, s)))))
         assert key(samples_a) == key(samples_b) and len(samples_a) >= params[0]
@@ -65,6 +65,104 @@ def test_pool_hook_of_shgo_gives_the_results_of_the_one_by_one_loop():
         assert [tuple(g) for g in ga] == [tuple(g) for g in gb] and len(ga) >= 10
         # ... and the initialisation does its job: the pose it finds overlaps the target better than the guess it started from
         assert ra.fun <= sub_a(np.zeros(3)) and ra.fun < -100
+
+
+def test_shgo_replay_equals_scipy_on_piecewise_constant_costs():
+    """sonar_slam_amd/shgo_fast.py: what shgo (sobol, one iteration) decides after its sampling stage, replayed from a table of
+    costs, against scipy.optimize.shgo itself -- ordinary step functions, plateaus (no strict minimiser: shgo fails), steps finer
+    than SLSQP's finite-difference step (the replay must say FALLBACK, not guess); and the C routine against the Python
+    definition on many tables"""
+    from scipy.optimize import shgo
+    from sonar_slam_amd import _lib, shgo_fast as sf
+    pose_stds = np.array([[0.2, 0.2, 0.02]]).T
+    bounds = 5.0 * np.c_[-pose_stds, pose_stds]
+    plan = sf.plan_for(bounds, 50, 0.01)
+    assert plan.V >= 50 and plan.points.shape == (plan.V, 4, 3) and plan.self_check(rounds=8, seed=3)
+    assert np.array_equal(plan.points[:, 0], plan.X) and np.all(np.abs(plan.points[:, 1:] - plan.X[:, None]).max(axis=2) < 1e-7)
+    rng = np.random.default_rng(12)
+    span = bounds[:, 1] - bounds[:, 0]
+    seen = {sf.OK: 0, sf.FAILED: 0, sf.FALLBACK: 0}
+    tables = []
+    for r in range(40):
+        kind = r % 5
+        if kind == 4:
+            f = sf.piecewise_constant(rng, span * (1e-7 if r % 2 else 1e-5))
+        elif kind == 3:
+            f = sf.piecewise_constant(rng, span, coarse=True, n_planes=int(rng.integers(1, 4)))
+        else:
+            f = sf.piecewise_constant(rng, span, coarse=(kind == 0), n_planes=int(rng.integers(4, 40)))
+        table = np.array([[f(p) for p in row] for row in plan.points])
+        tables.append(table)
+        st, x, fun, n_local = plan.solve(table, return_pool=True)
+        seen[st] += 1
+        if st == sf.FALLBACK:
+            continue
+        res = shgo(func=f, bounds=bounds, n=50, iters=1, sampling_method="sobol", minimizer_kwargs={"options": {"ftol": 0.01}})
+        assert bool(res.success) == (st == sf.OK) and np.array_equal(res.x, x) and res.fun == fun, r
+        if st == sf.OK:
+            assert res.nfev == plan.V + 4 * n_local and res.nlfev == 4 * n_local
+    assert seen[sf.OK] >= 15 and seen[sf.FAILED] >= 1 and seen[sf.FALLBACK] >= 3, seen
+    # many tables through the C routine == the Python definition (random integer tables: ties of every kind)
+    for _ in range(400):
+        t = rng.integers(-6, 0, (plan.V, 1)) * np.ones((1, 4), np.int64) if rng.random() < 0.5 else \
+            np.repeat(rng.integers(-400, 0, (plan.V, 1)), 4, axis=1)
+        if rng.random() < 0.1:
+            t[rng.integers(plan.V), 1 + rng.integers(3)] += 1       # a finite-difference point in another cell
+        tables.append(t)
+    tables = np.array(tables)
+    status, vertex = plan.solve_many(_lib.load_library(), tables)
+    kinds = np.bincount(status, minlength=3)
+    assert kinds[sf.OK] > 100 and kinds[sf.FALLBACK] > 10
+    for t, st, v in zip(tables, status, vertex):
+        want = plan.solve(t)
+        assert want[0] == st
+        if st != sf.FALLBACK:
+            assert np.array_equal(want[1], plan.X[v]) and want[2] == t[v, 0]
+
+
+def test_front_end_shgo_replay_on_the_matching_cost():
+    """FrontEnd.shgo(replay=True) on the oracle's matching-cost subroutine == the reference's shgo call (chain.run_shgo): result,
+    value, success and number of evaluations, for several scan pairs"""
+    from sonar_slam_amd.replay import FrontEnd
+    pose_stds = np.array([[0.2, 0.2, 0.02]]).T
+    bounds = 5.0 * np.c_[-pose_stds, pose_stds]
+    n_replayed = 0
+    for seed in range(6):
+        src, tgt, guess, _ = synth.scan_pair(seed=20 + seed, n_src=300 + 40 * seed, n_tgt=350)
+        sp, tp = chain.pose(*synth.pose_of(guess)), chain.pose(0.0, 0.0, 0.0)
+        sub_a, _ = chain.matching_cost_subroutine(src, sp, tgt, tp, 0.5, f64_points=True)
+        sub_b, _ = chain.matching_cost_subroutine(src, sp, tgt, tp, 0.5, f64_points=True)
+        sub_b.batch = lambda X, sub_b=sub_b: [sub_b(x) for x in X]
+        ra = chain.run_shgo(sub_a, bounds, (50, 1, 0.01))
+        rb = FrontEnd.shgo(sub_b, bounds, (50, 1, 0.01))
+        n_replayed += bool(rb.get("replayed"))
+        assert bool(ra.success) == bool(rb.success) and np.array_equal(ra.x, rb.x) and ra.fun == rb.fun
+        if rb.get("replayed"):
+            assert ra.nfev == rb.nfev
+    assert n_replayed >= 4
+
+
+def test_sample_transforms_of_many_sessions_equal_pose2():
+    """chained.sample_transforms (the library's host routine sfe_pose2_sample_transforms) == the float32 matrix rows of
+    target.between(source.compose(Pose2(*x))) computed with the scalar Pose2, bit for bit -- rotations that need the
+    renormalisation of Rot2 included"""
+    from sonar_slam_amd import _lib
+    from sonar_slam_amd.chained import Pose2Batch, sample_transforms
+    rng = np.random.default_rng(9)
+    n = 40
+    tgt = Pose2Batch(rng.normal(0, 30, n), rng.normal(0, 30, n), rng.uniform(-4, 4, n))
+    src = Pose2Batch(rng.normal(0, 30, n), rng.normal(0, 30, n), rng.uniform(-4, 4, n))
+    src.c[:5] *= 1.0 + 3e-10        # off the unit circle by more than Rot2's tolerance after one product
+    X = np.r_[rng.normal(0, [1.0, 1.0, 0.1], (30, 3)), np.zeros((1, 3)), [[1.0, 1.0, 0.1 + 1.4901161193847656e-08]]]
+    got = sample_transforms(_lib.load_library(), tgt, src, X)
+    assert got.shape == (n, len(X), 6) and got.dtype == np.float32
+    for i in range(n):
+        tp = Pose2(tgt.x[i], tgt.y[i], _cs=(tgt.c[i], tgt.s[i]))
+        sp = Pose2(src.x[i], src.y[i], _cs=(src.c[i], src.s[i]))
+        for j, x in enumerate(X):
+            M = tp.between(sp.compose(Pose2(*x))).matrix().astype(np.float32)
+            assert np.array_equal(M[:2].reshape(-1), got[i, j]), (i, j)
+    assert sample_transforms(_lib.load_library(), tgt, src, np.zeros((0, 3))).shape == (n, 0, 6)
 
 
 def test_f64_and_f32_cost_bodies_follow_numpy():
@@ -257,6 +355,9 @@ def test_front_end_default_flow_equals_the_oracle_chain(ctx):
             assert _same(a["transform"], o["transform"], 1e-6) and a["overlap"] == o["overlap"]
         assert _same(a["pose"], o["pose"], 1e-6)
     assert n_moved >= 1
+    # ... scipy.optimize.shgo itself instead of the replay of its decisions (shgo_fast.py): the same records
+    _, log_scipy = _replay_session(ctx, pings, bearings, dr, rows, None, ssm_min_points=20, shgo_replay=False)
+    assert log_scipy == logs[0]
     # ... and the flag really switches the step off (slam.py:665-666)
     front, log = _replay_session(ctx, pings, bearings, dr, rows, None, ssm_min_points=20, ssm_initialization=False)
     plain = chain.run_session(clouds, dr, oracle.shipped_icp_params(precision=1), ssm_min_points=20)
@@ -282,9 +383,12 @@ def test_sessions_in_lock_step_with_the_global_initialisation(ctx, shipped_cfar)
         sb.upload_frames(k, np.stack([x[0][k] for x in sess]))
     recs = sb.run()
     assert sb.init_stats["table_hits"] >= S * (K - 1) * 50
-    # ... and with shgo on worker processes (speculative on the table, assumptions verified in one launch): the same records
+    # (shgo's decisions replayed from the table: shgo_fast.py; scipy only for what the replay calls undecidable)
+    assert sb.init_stats["replayed"] >= S * (K - 1) - 3 and sb.init_stats["replayed"] + sb.init_stats["replay_fallbacks"] <= S * (K - 1)
+    # ... and with scipy.optimize.shgo itself for every session, on worker processes (speculative on the table, assumptions
+    # verified in one launch): the same records
     sbp = chained.SessionBatch(ctx, fe.geometry, shipped_cfar.params["SOCA"], "SOCA", 65, icp_config.shipped_params(), S, K, dr,
-                               ssm_min_points=20, initialization=True, shgo_workers=2)
+                               ssm_min_points=20, initialization=True, shgo_workers=2, shgo_replay=False)
     for k in range(K):
         sbp.upload_frames(k, np.stack([x[0][k] for x in sess]))
     recs_p = sbp.run()

@@ -181,7 +181,8 @@ def test_bench_legs_carry_their_own_parity_samples():
     assert sf["keyframes_per_s_streamed"] > 0 and 0.0 <= sf["overlap_fraction"] <= 1.0 and sf["frame_buffers"] == 3
     # round 5: the reference's default flow -- shgo in front of every scan match, and the loop-closure search over the store
     wi = out["chained"]["with_initialization"]
-    assert wi["keyframes_per_s"] > 0 and wi["parity"]["max_pose_diff_vs_oracle_chain"] <= 1e-6 and wi["speculative_runs_redone"] == 0
+    assert wi["keyframes_per_s"] > 0 and wi["parity"]["max_pose_diff_vs_oracle_chain"] <= 1e-6 and wi["scipy_only"]["speculative_runs_redone"] == 0
+    assert wi["scan_matches_equal_to_the_scipy_only_run"] > 0 and wi["scan_matches_replayed"] + wi["scan_matches_handed_to_scipy"] > 0
     lc = out["loop_closure"]
     assert lc["searches"] >= 1 and lc["parity"]["searches"] == lc["searches"]
     assert out["config"]["chained_with_initialization_keyframes_per_s"] == wi["keyframes_per_s"]

@@ -422,8 +422,8 @@ def chained_inputs(n_distinct, n_steps, rows=1024, beams=512, world_seed=2, scat
     return frames, dr, true, bearings
 
 
-def chained(ctx, det, threads, n_sessions=4096, n_steps=8, n_distinct=64, parity_sessions=None, reps=3, init_sessions=1024,
-            init_parity_sessions=4, init_sessions_one_process=32):
+def chained(ctx, det, threads, n_sessions=4096, n_steps=8, n_distinct=64, parity_sessions=None, reps=3, init_sessions=512,
+            init_parity_sessions=16, init_sessions_one_process=32):
     """the path end to end on the device, every scan match consuming the cloud its own CFAR produced.
     `n_sessions` independent SLAM sessions advance in lock-step (chained.SessionBatch): step k = ping k of every session
     through CFAR + gate -> remap + nonzero + px->m -> downsample -> outlier filter -> keyframe store -> target cloud =
@@ -431,9 +431,10 @@ def chained(ctx, det, threads, n_sessions=4096, n_steps=8, n_distinct=64, parity
     target, odometry guess) -> overlap; pings resident in HBM, no cloud crosses PCIe, the host does the SLAM node's
     pose bookkeeping between the calls.  Timed with the host clock around whole runs (the loop has host work in it).
     Parity: `parity_sessions` sessions (default: every distinct one) through the oracle's chain (oracle/chain.py) on the
-    same pings.  `with_initialization`: the same path as the reference runs it by DEFAULT (slam.py:77): scipy's shgo global
-    initialisation in front of every scan match, its cost function on the device (chained.SessionBatch(initialization=True)),
-    on `init_sessions` sessions (shgo itself is tens of milliseconds of host Python per scan match)."""
+    same pings.  `with_initialization`: the same path as the reference runs it by DEFAULT (slam.py:77): the shgo global
+    initialisation in front of every scan match, its cost function on the device and shgo's decisions replayed for all sessions
+    (chained.SessionBatch(initialization=True), shgo_fast.py); `init_sessions` of them also through scipy.optimize.shgo itself,
+    record for record the same (shgo is ~8 ms of host Python per scan match)."""
     if parity_sessions is None:
         parity_sessions = n_distinct
     import oracle
@@ -538,13 +539,13 @@ def chained(ctx, det, threads, n_sessions=4096, n_steps=8, n_distinct=64, parity
     out["keyframes_per_s"] = out["shipped_chain"]["keyframes_per_s"]
     # ---- the reference's default flow: shgo global initialisation in front of every scan match ----
     if init_sessions:
-        def timed_init(S, workers):
+        def timed_init(S, workers, replay):
             sel_i = np.arange(S) % n_distinct
             sbi = ch.SessionBatch(ctx, fe.geometry, det.params["SOCA"], "SOCA", 65, icp_config.shipped_params(), S, n_steps, dr[sel_i],
-                                  initialization=True, shgo_workers=workers)
+                                  initialization=True, shgo_workers=workers, shgo_replay=replay)
             for k in range(n_steps):
                 sbi.upload_frames(k, frames[k][sel_i])
-            sbi.run()                           # untimed: scratch, store, the Sobol set, the worker processes
+            sbi.run()                           # untimed: scratch, store, the plan / the Sobol set, the worker processes
             sbi.fit_capacity()
             for key in sbi.init_stats:
                 sbi.init_stats[key] = 0
@@ -553,29 +554,53 @@ def chained(ctx, det, threads, n_sessions=4096, n_steps=8, n_distinct=64, parity
             recs = sbi.run()
             ctx.sync()
             return sbi, recs, time.perf_counter() - t0
-        one = None
+        # scipy.optimize.shgo per session (the way of this round's first half): on the host cores, and on one process
+        S0 = int(init_sessions)
+        sb0, recs0, dt0 = timed_init(S0, max(1, threads), False)
+        scipy_only = {"sessions": S0, "shgo_worker_processes": max(1, threads), "keyframes_per_s": S0 * n_steps / dt0,
+                      "host_shgo_share": sb0.init_stats["shgo_s"] / dt0,
+                      "speculative_runs": sb0.init_stats["speculated"], "speculative_runs_redone": sb0.init_stats["speculation_failed"]}
+        sb0.free()
         if init_sessions_one_process and threads > 1:
-            sb1, _, dt1 = timed_init(int(init_sessions_one_process), 1)
-            one = {"sessions": int(init_sessions_one_process), "keyframes_per_s": init_sessions_one_process * n_steps / dt1,
-                   "host_shgo_share": sb1.init_stats["shgo_s"] / dt1}
+            sb1, _, dt1 = timed_init(int(init_sessions_one_process), 1, False)
+            scipy_only["one_process"] = {"sessions": int(init_sessions_one_process),
+                                         "keyframes_per_s": init_sessions_one_process * n_steps / dt1,
+                                         "host_shgo_share": sb1.init_stats["shgo_s"] / dt1}
             sb1.free()
-        S = int(init_sessions)
-        sbi, recs, dt = timed_init(S, max(1, threads))
+        # ... and with shgo's decisions replayed from one table of costs per step (shgo_fast.py), scipy only where the replay
+        # reports a session as undecidable
+        S = int(n_sessions)
+        sbi, recs, dt = timed_init(S, max(1, threads), True)
         status = np.stack([r["status"] for r in recs[1:]], axis=1)
         moved = np.stack([np.any(r["init_x"] != 0, axis=1) for r in recs[1:] if "init_x" in r], axis=1)
-        leg = {"sessions": S, "shgo_worker_processes": max(1, threads), "seconds_per_run": dt, "keyframes_per_s": S * n_steps / dt,
+        # the replay against scipy inside the product: the first S0 sessions of both runs are the same sessions
+        n_same = 0
+        for r, r0 in zip(recs, recs0):
+            for key in ("status", "init_success", "init_x", "init_cost", "pose", "transform", "overlap"):
+                if key in r0 and not np.array_equal(r[key][:S0], r0[key]):
+                    bad = int(np.nonzero((np.asarray(r[key][:S0]) != np.asarray(r0[key])).reshape(S0, -1).any(axis=1))[0][0])
+                    raise AssertionError("chained/with_initialization: step %d session %d: %s differs between the replayed shgo and "
+                                         "scipy.optimize.shgo: %r vs %r" % (r["k"], bad, key, r[key][bad], r0[key][bad]))
+            n_same += S0 if "init_x" in r0 else 0
+        leg = {"sessions": S, "seconds_per_run": dt, "keyframes_per_s": S * n_steps / dt,
                "ms_per_scan_match": 1e3 * dt / (S * (n_steps - 1)),
-               "host_shgo_seconds": sbi.init_stats["shgo_s"], "host_shgo_share": sbi.init_stats["shgo_s"] / dt,
-               "one_process": one,
+               "host_seconds_after_the_cost_table": sbi.init_stats["shgo_s"], "host_share": sbi.init_stats["shgo_s"] / dt,
+               "seconds_sample_transforms_on_the_host": sbi.init_stats["transforms_s"],
+               "seconds_cost_grids_built": sbi.init_stats["grids_s"], "seconds_cost_table_launches": sbi.init_stats["table_s"],
+               "scan_matches_replayed": sbi.init_stats["replayed"], "scan_matches_handed_to_scipy": sbi.init_stats["replay_fallbacks"],
                "cost_evaluations_from_the_batched_table": sbi.init_stats["table_hits"],
                "cost_evaluations_verified_afterwards": sbi.init_stats["cost_calls"],
-               "speculative_runs": sbi.init_stats["speculated"], "speculative_runs_redone": sbi.init_stats["speculation_failed"],
+               "scan_matches_equal_to_the_scipy_only_run": n_same,
+               "scipy_only": scipy_only,
                "scan_matches_whose_start_shgo_moved": int(moved.sum()),
                "status_counts": {ch.STATUS_NAMES[c]: int((status == c).sum()) for c in range(1, 7) if (status == c).any()},
-               "note": "slam.py:665-716 per scan match: 61 Sobol / corner poses scored for ALL sessions in one launch "
-                       "(sfe_matching_cost_store), then scipy.optimize.shgo per session on that table, the sessions dealt to worker "
-                       "processes on the host cores (shgo_pool.py: speculative on the table, every assumed cost verified in one more "
-                       "launch); the throughput is scipy's host-side bookkeeping (triangulation, minimiser pool), not the device"}
+               "note": "slam.py:665-716 per scan match.  The cost at shgo's 61 sampling vertices and at the 3 finite-difference points "
+                       "SLSQP adds per vertex is taken for ALL sessions in one launch (sfe_matching_cost_store, 244 poses per "
+                       "session); what shgo decides from there (minimiser pool, order of the local minimisations, result) is "
+                       "replayed by sfe_shgo_sobol_replay from the graph of ONE run of the installed scipy (shgo_fast.py); a session "
+                       "whose finite-difference point lands in another cell, or with an exact distance tie, goes through "
+                       "scipy.optimize.shgo itself.  `scipy_only`: every session through scipy.optimize.shgo on the host cores "
+                       "(shgo_pool.py) -- the same records, compared above"}
         picks = sorted(set(int(round(i * (min(S, n_distinct) - 1) / max(1, init_parity_sessions - 1))) for i in range(init_parity_sessions)))
         oprm = oracle.IcpParams(precision=1, **icp_config.shipped_params().as_dict())
         oracle.set_kdtree(1)
