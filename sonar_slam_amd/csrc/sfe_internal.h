@@ -54,7 +54,7 @@ struct sfe_ctx {
     int cfar_tile_rows = 0;
     int cfar_variant = 0;
     int icp_variant = 0;
-    int extract_variant = 0;     // 0 = inverse map for binary masks (default), 1 = dense pass only (A/B)
+    int extract_variant = 0;     // 0 = inverse map for binary masks, records instead of a canvas for bit-stream batches (default); 1 = dense pass only; 2 = inverse map through the canvas bitmap always (A/B)
     int icp_prof = 0;            // debug: per-phase cycle counts of workgroup 0 of the sweep kernel
     long long icp_prof_host[SFE_ICP_PROF_N] = {0};
     int n_cu = 256;

@@ -288,8 +288,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void extract_scan_kernel(const unsign
                                                                     int32_t *__restrict__ frame_count, int crows, int wpr,
                                                                     int4 *__restrict__ wlist, int32_t *__restrict__ wlist_n,
                                                                     int list_cap, long long cap,
-                                                                    int32_t *__restrict__ ovf_n, int32_t *__restrict__ ovf_list)
+                                                                    int32_t *__restrict__ ovf_n, int32_t *__restrict__ ovf_list,
+                                                                    const int32_t *__restrict__ only)
 {
+    if (only && !only[blockIdx.x]) // (the record path has done this frame)
+        return;
     extern __shared__ __attribute__((aligned(16))) int s_cnt[]; // [SCAN_LDS_LIST int4 entries |] crows row counts |
                                                                 // SCAN_THREADS partial sums [| one tail per 64-word chunk]
     __shared__ int s_nlist;
@@ -431,13 +434,16 @@ __global__ __launch_bounds__(256) void extract_expand_words_kernel(const int4 *_
                                                                    double *__restrict__ pts_out, long long cap, int crows,
                                                                    int ccols, const double *__restrict__ ytab,
                                                                    const double *__restrict__ xtab,
-                                                                   unsigned long long *__restrict__ clean_bm, int wpr)
+                                                                   unsigned long long *__restrict__ clean_bm, int wpr,
+                                                                   const int32_t *__restrict__ only)
 {
     extern __shared__ double s_tab[]; // crows y values, ccols x values
     __shared__ int4 s_ent[4][64];
     __shared__ int s_ex[4][64];
     double *s_y = s_tab, *s_x = s_tab + crows;
     const int f = blockIdx.y;
+    if (only && !only[f])
+        return;
     const int n = wlist_n[f];
     const int4 *__restrict__ wl = wlist + (long long)f * list_cap;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -639,21 +645,28 @@ __global__ __launch_bounds__(256) void extract_expand_kernel(const unsigned long
 // pixel's offset, its base and the next offset), four entries per 16-byte read; entries that can never report (their
 // table is 0: a last tap below half weight, ...) are not stored at all.  Half the bytes and fewer reads per set pixel
 // than the 8-byte {bit index, table} entries (inv_off / inv_ent of the other instantiation).
-template <bool COMPACT>
+// RECORDS (round 5): the canvas words a workgroup has combined do not go to the canvas bitmap at all: they are appended to the
+// frame's record list {bitmap word of the frame, 0, its 64 bits} (one allocation per workgroup), and
+// extract_merge_expand_kernel merges the records of a frame in LDS and emits the points -- no canvas in HBM, no stream over it.
+// `only` (canvas form): the frames to work on (the frames the record path handed back: more records / words / points than its
+// capacities); nullptr = all.
+template <bool COMPACT, bool RECORDS>
 __global__ __launch_bounds__(256, 8) void extract_gather_kernel(const uint32_t *__restrict__ bits,
                                                                 const int32_t *__restrict__ nonbinary,
                                                                 const int32_t *__restrict__ inv_off,
                                                                 const uint2 *__restrict__ inv_ent,
                                                                 unsigned long long *__restrict__ bitmap, int prows,
                                                                 int pcols, int crows, int wpr, long long words_per_frame,
-                                                                int piece_shift)
+                                                                int piece_shift, int4 *__restrict__ rec,
+                                                                int32_t *__restrict__ rec_n, int rec_cap,
+                                                                const int32_t *__restrict__ only)
 {
     __shared__ uint32_t s_list[SG_LIST]; // (row << 16 | column) of a set pixel
     __shared__ int s_n, s_want[2]; // (s_want: by step parity -- the other one is cleared while this one is read)
     __shared__ unsigned s_tag[SG_TAB];
     __shared__ unsigned long long s_acc[SG_TAB];
     const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
-    if (nonbinary[f] != 0)
+    if (nonbinary[f] != 0 || (only && !only[f]))
         return;
     for (int i = tid; i < SG_TAB; i += 256) {
         s_tag[i] = 0xFFFFFFFFu;
@@ -671,7 +684,15 @@ __global__ __launch_bounds__(256, 8) void extract_gather_kernel(const uint32_t *
     const int sl = (int)((blockIdx.x + 5u * blockIdx.y) % (unsigned)slices);
     const uint32_t *__restrict__ src = bits + (long long)f * words_per_frame;
     unsigned long long *__restrict__ bm = bitmap + (long long)f * crows * wpr;
-    auto or_word = [&](unsigned wd, unsigned long long m) { atomicOr(&bm[wd], m); };
+    int4 *__restrict__ rl = RECORDS ? rec + (long long)f * rec_cap : nullptr;
+    auto or_word = [&](unsigned wd, unsigned long long m) {
+        if (RECORDS) { // (a word that found no table slot: rare)
+            const int pos = atomicAdd(&rec_n[f], 1);
+            if (pos < rec_cap)
+                rl[pos] = make_int4((int)wd, 0, (int)(unsigned)(m & 0xFFFFFFFFull), (int)(unsigned)(m >> 32));
+        } else
+            atomicOr(&bm[wd], m);
+    };
     // pieces of 64 << piece_shift words (64 words = 4 polar rows of 512 beams); piece p belongs to slice p % slices.  The
     // workgroup's words, piece after piece, are looked at `blk` at a time: thread t takes words t, t + 256, ...
     const int pwords = 64 << piece_shift;
@@ -774,13 +795,18 @@ __global__ __launch_bounds__(256, 8) void extract_gather_kernel(const uint32_t *
             unsigned run_w = 0xFFFFFFFFu;
             unsigned long long run_m = 0ull;
             auto emit = [&](unsigned wd, unsigned long long m) {
-                const unsigned slot = (wd * 0x9E3779B1u) >> (32 - 10);
+                unsigned slot = (wd * 0x9E3779B1u) >> (32 - 10);
                 static_assert(SG_TAB == 1 << 10, "slot bits");
-                const unsigned old = atomicCAS(&s_tag[slot], 0xFFFFFFFFu, wd);
-                if (old == 0xFFFFFFFFu || old == wd)
-                    atomicOr(&s_acc[slot], m);
-                else
-                    or_word(wd, m);
+#pragma unroll 1
+                for (int probe = 0; probe < (RECORDS ? 4 : 1); ++probe) { // (records: a taken slot costs a global allocation)
+                    const unsigned old = atomicCAS(&s_tag[slot], 0xFFFFFFFFu, wd);
+                    if (old == 0xFFFFFFFFu || old == wd) {
+                        atomicOr(&s_acc[slot], m);
+                        return;
+                    }
+                    slot = (slot + 1u) & (SG_TAB - 1u);
+                }
+                or_word(wd, m);
             };
             auto candidate = [&](const uint2 e) { // e.y = 0 (no case reports): the padding of the last round
                 const unsigned sh = nb >> (e.y >> 16);
@@ -841,9 +867,209 @@ __global__ __launch_bounds__(256, 8) void extract_gather_kernel(const uint32_t *
             s_n = 0;
         __syncthreads();
     }
-    for (int i = tid; i < SG_TAB; i += 256)
-        if (s_tag[i] != 0xFFFFFFFFu)
-            or_word(s_tag[i], s_acc[i]);
+    if (!RECORDS) {
+        for (int i = tid; i < SG_TAB; i += 256)
+            if (s_tag[i] != 0xFFFFFFFFu)
+                or_word(s_tag[i], s_acc[i]);
+        return;
+    }
+    // the table as records: thread t holds slots 4 t .. 4 t + 3; one allocation in the frame's list for the workgroup
+    int mine = 0;
+#pragma unroll
+    for (int u = 0; u < SG_TAB / 256; ++u)
+        mine += s_tag[(SG_TAB / 256) * tid + u] != 0xFFFFFFFFu;
+    const int incl = scan_wave_incl(mine);
+    if (tid == 0)
+        s_want[0] = 0;
+    __syncthreads();
+    int wbase = 0;
+    if (lane == 63 && incl)
+        wbase = atomicAdd(&s_want[0], incl);
+    wbase = __builtin_amdgcn_readlane(wbase, 63);
+    __syncthreads();
+    if (tid == 0)
+        s_n = s_want[0] ? atomicAdd(&rec_n[f], s_want[0]) : 0;
+    __syncthreads();
+    int pos = s_n + wbase + incl - mine;
+#pragma unroll
+    for (int u = 0; u < SG_TAB / 256; ++u) {
+        const int i = (SG_TAB / 256) * tid + u;
+        const unsigned wd = s_tag[i];
+        if (wd != 0xFFFFFFFFu) {
+            const unsigned long long m = s_acc[i];
+            if (pos < rec_cap)
+                rl[pos] = make_int4((int)wd, 0, (int)(unsigned)(m & 0xFFFFFFFFull), (int)(unsigned)(m >> 32));
+            ++pos;
+        }
+    }
+}
+
+// The records of a frame -> its points, one workgroup per frame, everything between in LDS (round 5, VERDICT r4 item 5: the canvas
+// bitmap cost 93 KB of atomics + 240 KB of stream + a 50 KB word list per frame to find ~2 300 words).  A presence bit per bitmap
+// word of the frame (3.5 KB for config A) is set by every record; the popcount prefix over the presence bits IS the rank of a
+// word among the frame's non-empty words in np.nonzero order, so the records OR their bits into a compact array at their word's
+// rank -- no sort -- the prefix over the words' popcounts gives the point offsets, and the points are emitted a lane per point like
+// extract_expand_words_kernel (binary search in the 64 offsets of a wave's batch, rank-select by halving, metres from the LDS tables).
+// A frame that does not fit (more records than rec_cap, more non-empty words than capw, more points than cap) is flagged in
+// ovf_flag and left to the canvas kernels, which look at flagged frames only.
+#define ME_THREADS 1024
+#define ME_RPT 8 // records per thread held in registers (rec_cap <= ME_THREADS * ME_RPT)
+__global__ __launch_bounds__(ME_THREADS) void extract_merge_expand_kernel(const int4 *__restrict__ rec, const int32_t *__restrict__ rec_n,
+                                                                          int rec_cap, int32_t *__restrict__ frame_count,
+                                                                          int32_t *__restrict__ ovf_flag, long long *__restrict__ rc_out,
+                                                                          double *__restrict__ pts_out, long long cap, int crows,
+                                                                          int ccols, int wpr, int capw, const double *__restrict__ ytab,
+                                                                          const double *__restrict__ xtab)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char me_raw[];
+    __shared__ int s_wsum[ME_THREADS / 64];
+    __shared__ int s_total;
+    const int nw = crows * wpr, npw = (nw + 31) >> 5;
+    double *s_y = reinterpret_cast<double *>(me_raw), *s_x = s_y + crows;
+    unsigned long long *w_bits = reinterpret_cast<unsigned long long *>(s_x + ccols);
+    unsigned *w_idx = reinterpret_cast<unsigned *>(w_bits + capw);
+    int *w_off = reinterpret_cast<int *>(w_idx + capw); // capw + 1
+    unsigned *pres = reinterpret_cast<unsigned *>(w_off + capw + 1);
+    int *ppre = reinterpret_cast<int *>(pres + npw);
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = rec_n[f];
+    if (n > rec_cap) { // (workgroup-uniform)
+        if (tid == 0)
+            ovf_flag[f] = 1;
+        return;
+    }
+    const int4 *__restrict__ rl = rec + (long long)f * rec_cap;
+    int4 ent[ME_RPT];
+#pragma unroll
+    for (int k = 0; k < ME_RPT; ++k) {
+        const int r = tid + k * ME_THREADS;
+        ent[k] = r < n ? rl[r] : make_int4(-1, 0, 0, 0);
+    }
+    for (int i = tid; i < npw; i += ME_THREADS)
+        pres[i] = 0u;
+    for (int i = tid; i < capw; i += ME_THREADS)
+        w_bits[i] = 0ull;
+    if (pts_out) {
+        for (int i = tid; i < crows; i += ME_THREADS)
+            s_y[i] = ytab[i];
+        for (int i = tid; i < ccols; i += ME_THREADS)
+            s_x[i] = xtab[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ME_RPT; ++k)
+        if (ent[k].x >= 0)
+            atomicOr(&pres[ent[k].x >> 5], 1u << (ent[k].x & 31));
+    __syncthreads();
+    // exclusive prefix of the presence popcounts: thread t owns `per` consecutive presence words
+    auto block_excl = [&](int v) -> int { // -> exclusive prefix of v over the workgroup; s_total = the sum
+        const int incl = scan_wave_incl(v);
+        if (lane == 63)
+            s_wsum[wave] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wave; ++w)
+            base += s_wsum[w];
+        if (tid == ME_THREADS - 1)
+            s_total = base + incl;
+        __syncthreads();
+        return base + incl - v;
+    };
+    {
+        const int per = (npw + ME_THREADS - 1) / ME_THREADS;
+        const int b = tid * per, e = min(b + per, npw);
+        int mine = 0;
+        for (int i = b; i < e; ++i)
+            mine += __popc(pres[i]);
+        int run = block_excl(mine);
+        for (int i = b; i < e; ++i) {
+            ppre[i] = run;
+            run += __popc(pres[i]);
+        }
+    }
+    const int nW = s_total; // non-empty bitmap words of the frame
+    __syncthreads();
+    if (nW > capw) {
+        if (tid == 0)
+            ovf_flag[f] = 1;
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < ME_RPT; ++k)
+        if (ent[k].x >= 0) {
+            const int wd = ent[k].x;
+            const int rank = ppre[wd >> 5] + __popc(pres[wd >> 5] & ((1u << (wd & 31)) - 1u));
+            atomicOr(&w_bits[rank], ((unsigned long long)(unsigned)ent[k].w << 32) | (unsigned long long)(unsigned)ent[k].z);
+            w_idx[rank] = (unsigned)wd;
+        }
+    __syncthreads();
+    {
+        const int per = (nW + ME_THREADS - 1) / ME_THREADS;
+        const int b = min(tid * per, nW), e = min(b + per, nW);
+        int mine = 0;
+        for (int i = b; i < e; ++i)
+            mine += __popcll(w_bits[i]);
+        int run = block_excl(mine);
+        for (int i = b; i < e; ++i) {
+            w_off[i] = run;
+            run += __popcll(w_bits[i]);
+        }
+    }
+    const int total = s_total;
+    if (tid == 0) {
+        w_off[nW] = total;
+        frame_count[f] = total;
+    }
+    if (total > cap) { // the canvas path stores such a frame's first cap points (and reports the same count)
+        if (tid == 0)
+            ovf_flag[f] = 1;
+        return;
+    }
+    __syncthreads();
+    if (cap <= 0)
+        return;
+    for (int b = wave * 64; b < nW; b += (ME_THREADS / 64) * 64) { // a wave takes 64 consecutive words
+        const int hi0 = min(b + 63, nW - 1);
+        const int first = w_off[b], npts = w_off[hi0 + 1] - first;
+        for (int j = lane; j < npts; j += 64) {
+            const int t = first + j;
+            int lo = b, hi = hi0; // the last word whose first point is <= t
+#pragma unroll
+            for (int step = 0; step < 6; ++step) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (w_off[mid] <= t)
+                    lo = mid;
+                else
+                    hi = mid - 1;
+            }
+            const unsigned long long wbits = w_bits[lo];
+            int rr = t - w_off[lo], bit = 0;
+            unsigned w32 = (unsigned)(wbits & 0xFFFFFFFFull);
+            {
+                const int c = __popc(w32);
+                if (rr >= c) {
+                    rr -= c;
+                    w32 = (unsigned)(wbits >> 32);
+                    bit = 32;
+                }
+            }
+#pragma unroll
+            for (int h = 16; h >= 1; h >>= 1) {
+                const int c = __popc(w32 & ((1u << h) - 1u));
+                if (rr >= c) {
+                    rr -= c;
+                    w32 >>= h;
+                    bit += h;
+                }
+            }
+            const int wd = (int)w_idx[lo], row = wd / wpr, col = (wd - row * wpr) * 64 + bit;
+            const long long o = (long long)f * cap + t;
+            if (rc_out)
+                reinterpret_cast<longlong2 *>(rc_out)[o] = make_longlong2(row, col);
+            if (pts_out)
+                reinterpret_cast<double2 *>(pts_out)[o] = make_double2(s_y[row], s_x[col]);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -907,6 +1133,27 @@ static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_f
         SFE_HIP(ctx, hipFuncSetAttribute((const void *)extract_expand_words_kernel,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)tab_bytes));
     }
+    // record path (round 5; default for bit-stream batches): no canvas bitmap for the frames that fit its capacities
+    const int rec_cap_env = getenv("SFE_EXTRACT_REC_CAP") ? atoi(getenv("SFE_EXTRACT_REC_CAP")) : 0; // (read per call: the tests
+    const int capw_env = getenv("SFE_EXTRACT_CAPW") ? atoi(getenv("SFE_EXTRACT_CAPW")) : 0;         //  force the hand-back with them)
+    const int rec_cap = std::max(64, std::min(ME_THREADS * ME_RPT, rec_cap_env > 0 ? rec_cap_env : 6144));
+    const int capw = (int)std::max<long long>(1, std::min<long long>(capw_env > 0 ? capw_env : 4096, std::min(words_pf, std::max<long long>(cap, 1))));
+    const size_t me_lds = tab_bytes + (size_t)capw * 16 + 4 + ((size_t)(words_pf + 31) / 32) * 8 + 16;
+    const bool records = use_words && d_bits_in && ctx->extract_variant == 0 && g->d_inv_off != nullptr &&
+                         (g->polar_cols & 31) == 0 && g->polar_rows < 65536 && g->polar_cols < 65536 && me_lds <= 150 * 1024 &&
+                         words_pf < (1ll << 31);
+    int4 *d_rec = nullptr;
+    int32_t *d_rec_n = nullptr, *d_ovf_flag = nullptr;
+    if (records) {
+        const int nfc = std::min(chunk, n_frames);
+        d_rec = (int4 *)sfe_scratch(ctx, 61, (size_t)nfc * rec_cap * sizeof(int4));
+        d_rec_n = (int32_t *)sfe_scratch(ctx, 62, (size_t)nfc * 2 * 4); // counts | flags
+        if (!d_rec || !d_rec_n)
+            return SFE_ERR_HIP;
+        d_ovf_flag = d_rec_n + nfc;
+        SFE_HIP(ctx, hipFuncSetAttribute((const void *)extract_merge_expand_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)me_lds));
+    }
     // bytes of the bitmap scratch known to be zero (the state is dropped for the duration of the call: an error return
     // leaves it unknown)
     size_t clean_bytes = ctx->bm_clean_ptr == (void *)d_bm ? ctx->bm_clean_bytes : 0;
@@ -953,15 +1200,33 @@ static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_f
             while (sg_piece_env < 0 && sg_piece > 0 && (nwords >> (6 + sg_piece)) < slices)
                 --sg_piece;
             const bool no_compact = getenv("SFE_EXTRACT_NO_COMPACT") != nullptr; // A/B: the 8-byte entries of round 3 (read per call)
-            if (g->d_inv_c4 && !no_compact)
-                hipLaunchKernelGGL(extract_gather_kernel<true>, dim3((unsigned)slices, nf), dim3(256), 0, ctx->stream, d_bits,
-                                   d_nonbin, reinterpret_cast<const int32_t *>(g->d_inv_ob),
-                                   reinterpret_cast<const uint2 *>(g->d_inv_c4), d_bm, g->polar_rows, g->polar_cols, crows, wpr,
-                                   wpf, sg_piece);
+            const bool c4 = g->d_inv_c4 && !no_compact;
+            const int32_t *p_off = c4 ? reinterpret_cast<const int32_t *>(g->d_inv_ob) : g->d_inv_off;
+            const uint2 *p_ent = c4 ? reinterpret_cast<const uint2 *>(g->d_inv_c4) : g->d_inv_lut;
+            if (records) {
+                // records -> points without a canvas; the frames that do not fit are flagged and go through the canvas kernels below
+                SFE_HIP(ctx, hipMemsetAsync(d_rec_n, 0, (size_t)std::min(chunk, n_frames) * 2 * 4, ctx->stream));
+                if (c4)
+                    hipLaunchKernelGGL((extract_gather_kernel<true, true>), dim3((unsigned)slices, nf), dim3(256), 0, ctx->stream,
+                                       d_bits, d_nonbin, p_off, p_ent, d_bm, g->polar_rows, g->polar_cols, crows, wpr, wpf, sg_piece,
+                                       d_rec, d_rec_n, rec_cap, (const int32_t *)nullptr);
+                else
+                    hipLaunchKernelGGL((extract_gather_kernel<false, true>), dim3((unsigned)slices, nf), dim3(256), 0, ctx->stream,
+                                       d_bits, d_nonbin, p_off, p_ent, d_bm, g->polar_rows, g->polar_cols, crows, wpr, wpf, sg_piece,
+                                       d_rec, d_rec_n, rec_cap, (const int32_t *)nullptr);
+                hipLaunchKernelGGL(extract_merge_expand_kernel, dim3(nf), dim3(ME_THREADS), me_lds, ctx->stream, d_rec, d_rec_n,
+                                   rec_cap, d_counts + f0, d_ovf_flag, d_rc ? d_rc + (size_t)f0 * cap * 2 : nullptr,
+                                   d_pts ? d_pts + (size_t)f0 * cap * 2 : nullptr, cap, crows, g->cart_cols, wpr, capw, g->d_ytab,
+                                   g->d_xtab);
+            }
+            if (c4)
+                hipLaunchKernelGGL((extract_gather_kernel<true, false>), dim3((unsigned)slices, nf), dim3(256), 0, ctx->stream, d_bits,
+                                   d_nonbin, p_off, p_ent, d_bm, g->polar_rows, g->polar_cols, crows, wpr, wpf, sg_piece,
+                                   (int4 *)nullptr, (int32_t *)nullptr, 0, (const int32_t *)d_ovf_flag);
             else
-                hipLaunchKernelGGL(extract_gather_kernel<false>, dim3((unsigned)slices, nf), dim3(256), 0, ctx->stream, d_bits,
-                                   d_nonbin, g->d_inv_off, g->d_inv_lut, d_bm, g->polar_rows, g->polar_cols, crows, wpr, wpf,
-                                   sg_piece);
+                hipLaunchKernelGGL((extract_gather_kernel<false, false>), dim3((unsigned)slices, nf), dim3(256), 0, ctx->stream, d_bits,
+                                   d_nonbin, p_off, p_ent, d_bm, g->polar_rows, g->polar_cols, crows, wpr, wpf, sg_piece,
+                                   (int4 *)nullptr, (int32_t *)nullptr, 0, (const int32_t *)d_ovf_flag);
         }
         if (!(gather && d_bits_in)) // bit streams are binary: nothing is left for the general pass
         hipLaunchKernelGGL(extract_bits_kernel, dim3((unsigned)((gather ? std::min(nf, 8) : nf) * tiles)), dim3(256),
@@ -976,7 +1241,7 @@ static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_f
                                              (int)scan_lds));
         hipLaunchKernelGGL(extract_scan_kernel, dim3(nf), dim3(SCAN_THREADS), scan_lds,
                            ctx->stream, d_bm, d_rcnt, d_roff, d_counts + f0, crows, wpr, d_wlist, d_wlist_n,
-                           use_words ? list_cap : 0, cap, d_ovf, d_ovf ? d_ovf + 1 : nullptr);
+                           use_words ? list_cap : 0, cap, d_ovf, d_ovf ? d_ovf + 1 : nullptr, (const int32_t *)d_ovf_flag);
         if (cap > 0) {
             long long *rc_f = d_rc ? d_rc + (size_t)f0 * cap * 2 : nullptr;
             double *pts_f = d_pts ? d_pts + (size_t)f0 * cap * 2 : nullptr;
@@ -987,7 +1252,7 @@ static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_f
                 const int expand_wg = expand_wg_env ? expand_wg_env : std::max(1, std::min(EXPAND_WG, 1024 / std::max(nf, 1)));
                 hipLaunchKernelGGL(extract_expand_words_kernel, dim3(expand_wg, nf), dim3(256), tab_bytes, ctx->stream,
                                    d_wlist, d_wlist_n, list_cap, rc_f, pts_f, cap, crows, g->cart_cols, g->d_ytab, g->d_xtab,
-                                   self_clean ? d_bm : nullptr, wpr);
+                                   self_clean ? d_bm : nullptr, wpr, (const int32_t *)d_ovf_flag);
                 // frames above the capacity (queued by the scan kernel; normally none): their first cap points
                 hipLaunchKernelGGL(extract_expand_kernel, dim3((unsigned)((cap + 255) / 256), 1), dim3(256),
                                    sizeof(int32_t) * (size_t)crows, ctx->stream, d_bm, d_roff, d_counts + f0, rc_f, pts_f, cap,
@@ -1020,7 +1285,7 @@ int sfe_extract_set_tuning(sfe_ctx *ctx, int variant)
 {
     if (!ctx)
         return SFE_ERR_ARG;
-    SFE_ARG(ctx, variant >= 0 && variant <= 1);
+    SFE_ARG(ctx, variant >= 0 && variant <= 2);
     ctx->extract_variant = variant;
     return 0;
 }

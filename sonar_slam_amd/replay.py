@@ -27,8 +27,9 @@ found, not from the odometry.  ``FrontEnd(ssm_initialization=True)`` -- the defa
 the cost function on the GPU (matching_cost.py; over store handles when the clouds are device-resident) and shgo's sampling
 stage scored in one launch.  ``ssm_initialization=False`` is the path slam.py:665-666 takes when the flag is off.
 
-Loop-closure search (NSSM, slam.py:839-1132): ``FrontEnd(nssm_enable=True)`` runs initialize_nonsequential_scan_matching
-and the many-guess ICP of compute_icp_with_cov after every keyframe -- aggregated source cloud, keyed global target cloud
+Loop-closure search (NSSM, slam.py:839-1132): ``FrontEnd(nssm_enable=True)`` -- the default, as config/slam.yaml ships
+``nssm/enable: True`` (slam_ros.py:69); sessions shorter than the exclusion zone of 8 keyframes never search --  runs
+initialize_nonsequential_scan_matching and the many-guess ICP of compute_icp_with_cov after every keyframe -- aggregated source cloud, keyed global target cloud
 (``get_points(..., return_keys=True)``, the descriptor overload of pcl.downsample), field-of-view gate, shgo, target-key
 refinement by overlap, <= 30 ICPs on one pair, MinCovDet, the gates -- on host arrays or, with a store, on handles
 (sfe_cloud_store_get_points_keys / fov_select / compact_selected / match_keys).  What follows it in the reference -- PCM
@@ -122,7 +123,7 @@ class FrontEnd(object):
                  keyframe_rotation=np.deg2rad(30), point_resolution=0.5, point_noise=0.5, ssm_min_points=50,
                  ssm_max_translation=3.0, ssm_max_rotation=np.deg2rad(30), ssm_target_frames=3, store=None,
                  ssm_initialization=True, ssm_initialization_params=(50, 1, 0.01), odom_sigmas=(0.2, 0.2, 0.02),
-                 nssm_enable=False, nssm_initialization=True, nssm_initialization_params=(100, 5, 0.01), nssm_min_st_sep=8,
+                 nssm_enable=True, nssm_initialization=True, nssm_initialization_params=(100, 5, 0.01), nssm_min_st_sep=8,
                  nssm_min_points=50, nssm_max_translation=10.0, nssm_max_rotation=np.deg2rad(60), nssm_source_frames=5,
                  nssm_cov_samples=30, oculus_max_range=30.0, oculus_horizontal_aperture=np.radians(130.0),
                  mcd_random_state=None, shgo_replay=True):

@@ -314,6 +314,7 @@ def test_cost_kernels_in_both_dtypes_on_host_arrays_and_over_handles(ctx):
 def _replay_session(ctx, pings, bearings, dr, rows, store, **kw):
     from sonar_slam_amd.feature_extraction import SonarPing
     from sonar_slam_amd.replay import FrontEnd, replay
+    kw.setdefault("nssm_enable", False)       # (the sessions of these tests are compared record by record: the search is asked for by name)
     front = FrontEnd(ctx, keyframe_translation=1.5, keyframe_duration=0.5, store=store, **kw)
     sp = [SonarPing(p, bearings, 30.0 / rows, ping_id=k) for k, p in enumerate(pings)]
     log, _, _ = replay(sp, np.arange(len(sp), dtype=float), dr, _product_fe(ctx), front)
@@ -398,6 +399,30 @@ def test_sessions_in_lock_step_with_the_global_initialisation(ctx, shipped_cfar)
         for key in a:
             assert np.array_equal(np.asarray(a[key]), np.asarray(b[key])), key
     sbp.free()
+    # ... and when the replay calls sessions undecidable (here: every other one, by force) they go through scipy.optimize.shgo on
+    # the same table: the same records again
+    import copy
+    from sonar_slam_amd import shgo_fast
+    sbf = chained.SessionBatch(ctx, fe.geometry, shipped_cfar.params["SOCA"], "SOCA", 65, icp_config.shipped_params(), S, K, dr,
+                               ssm_min_points=20, initialization=True)
+    pose_stds = np.array([sbf.odom_sigmas]).T
+    plan = copy.copy(sbf._replay_plan(5.0 * np.c_[-pose_stds, pose_stds]))
+    real = plan.solve_many
+
+    def forced(lib, tables):
+        status, vertex = real(lib, tables)
+        status[::2] = shgo_fast.FALLBACK
+        return status, vertex
+    plan.solve_many = forced
+    sbf._plan = plan
+    for k in range(K):
+        sbf.upload_frames(k, np.stack([x[0][k] for x in sess]))
+    recs_f = sbf.run()
+    assert sbf.init_stats["replay_fallbacks"] >= (K - 1) * ((S + 1) // 2) - 2 and sbf.init_stats["replayed"] >= 1
+    for a, b in zip(recs, recs_f):
+        for key in a:
+            assert np.array_equal(np.asarray(a[key]), np.asarray(b[key])), key
+    sbf.free()
     for s in range(S):
         store = st.CloudStore(ctx, capacity_points=1 << 17, max_clouds=64)
         front, log = _replay_session(ctx, sess[s][0], bearings, dr[s], rows, store, ssm_min_points=20)

@@ -1,4 +1,6 @@
 """GPU parity: polar->Cartesian remap, nonzero compaction and px->m vs the oracle, bit-exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -258,9 +260,10 @@ def test_bit_stream_batches_leave_the_canvas_bitmap_clean(ctx, shipped_cfar):
     sizes = sorted(len(w) for w in want)
     small = (sizes[2] + sizes[3]) // 2                    # half of the frames are above it
 
-    def batch(idx, cap, variant=0):
+    def batch(idx, cap, variant=0, env=None):
         kb = KeyframeBatch(ctx, fe.geometry, (th, gh, tau), "SOCA", 65, None, len(idx), max_points=cap, bit_masks=True)
         try:
+            os.environ.update(env or {})
             ctx._check(ctx.lib.sfe_extract_set_tuning(ctx.handle, variant))
             kb.upload_frames(frames[idx])
             kb.run_cfar()
@@ -272,6 +275,8 @@ def test_bit_stream_batches_leave_the_canvas_bitmap_clean(ctx, shipped_cfar):
                 if counts[k] <= cap:
                     assert np.array_equal(kb.points(k), oracle.px_to_m(want[j], fe.rows, fe.cols, fe.width, fe.height)), j
         finally:
+            for key in env or {}:
+                del os.environ[key]
             ctx._check(ctx.lib.sfe_extract_set_tuning(ctx.handle, 0))
             kb.free()
 
@@ -283,13 +288,23 @@ def test_bit_stream_batches_leave_the_canvas_bitmap_clean(ctx, shipped_cfar):
     batch([2, 3, 4], big)
     batch(list(range(6)) * 3, big)      # more frames than before: the scratch grows
     batch([4, 1], big)
+    # round 5: the record path (no canvas for the frames that fit) hands frames back to the canvas kernels when they exceed its
+    # capacities -- the record list, the compact word array -- frame by frame inside one batch; and the canvas path alone
+    words = sorted(len(np.unique(w[:, 0] * 4096 + w[:, 1] // 64)) for w in want)
+    batch(list(range(6)), big, env={"SFE_EXTRACT_CAPW": str((words[2] + words[3]) // 2)})    # half of the frames handed back
+    batch([3, 2, 1], big)
+    batch(list(range(6)), big, env={"SFE_EXTRACT_REC_CAP": "64"})                             # every frame handed back
+    batch(list(range(6)), small, env={"SFE_EXTRACT_CAPW": str(words[4] + 1)})                 # both kinds of overflow
+    batch([0, 5, 2], big, variant=2)    # the canvas path for every frame
+    batch([5, 0], big)
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_bit_stream_extraction_equals_the_byte_mask_path(ctx, shipped_cfar, variant):
     """KeyframeBatch hands the detections to the extraction as bit streams (sfe_cfar_u8_bits_batch_dev ->
     sfe_extract_points_bits_batch_dev): same masks and the same points as the 0/1 byte path and the oracle,
-    through the inverse map (variant 0) and the dense pass (variant 1)."""
+    through the inverse map (variant 0: records merged in LDS for bit streams, the canvas bitmap for byte masks; variant 2: the
+    canvas bitmap for both) and the dense pass (variant 1)."""
     from sonar_slam_amd.pipeline import KeyframeBatch
     th, gh, tau = shipped_cfar.params["SOCA"]
     fe = FeatureExtraction(ctx)

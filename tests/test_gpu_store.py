@@ -217,7 +217,7 @@ def test_front_end_on_the_store_equals_the_host_mediated_front_end(ctx):
     logs = []
     for use_store in (False, True):
         s = st.CloudStore(ctx, capacity_points=1 << 18, max_clouds=256) if use_store else None
-        front = FrontEnd(ctx, keyframe_translation=1.5, keyframe_duration=0.5, store=s)
+        front = FrontEnd(ctx, keyframe_translation=1.5, keyframe_duration=0.5, store=s, nssm_enable=False)
         log, _, _ = replay(pings, stamps, dr, _fe(ctx), front)
         logs.append((log, [f[:3] + ((f[3].x(), f[3].y(), f[3].theta()),) if len(f) > 3 else f[:2] for f in front.backend.factors]))
         if s is not None:
@@ -271,7 +271,7 @@ def test_sessions_in_lock_step_equal_the_front_end_and_the_oracle_chain(ctx, shi
     for s in range(S):
         # (a) the scalar front end on its own store
         store = st.CloudStore(ctx, capacity_points=1 << 18, max_clouds=64)
-        front = FrontEnd(ctx, keyframe_translation=1.5, keyframe_duration=0.5, store=store, ssm_initialization=False)
+        front = FrontEnd(ctx, keyframe_translation=1.5, keyframe_duration=0.5, store=store, ssm_initialization=False, nssm_enable=False)
         pings = [SonarPing(frames[k, s], bearings, 30.0 / rows, ping_id=k) for k in range(K)]
         log, _, _ = replay(pings, np.arange(K, dtype=float), dr[s], fe, front)
         assert len(log) == K, "every ping is meant to be a keyframe"

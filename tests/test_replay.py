@@ -40,7 +40,7 @@ def test_replay_closed_loop_beats_odometry(ctx):
     fe.configure()
     # (odometry-started scan matches: whether the reference's global initialisation helps is its own business --
     # tests/test_global_init.py checks that flow against the oracle chain, not against ground truth)
-    front = FrontEnd(ctx, keyframe_translation=1.5, keyframe_duration=0.5, ssm_initialization=False)
+    front = FrontEnd(ctx, keyframe_translation=1.5, keyframe_duration=0.5, ssm_initialization=False, nssm_enable=False)
     log, _, _ = replay(pings, np.arange(len(pings), dtype=float), dr, fe, front)
     assert len(log) >= 6 and log[0]["status"] == "PRIOR"
     ssm = [r for r in log[1:]]

@@ -36,5 +36,7 @@ def timed(fn, reps):
 
 
 kb.run_cfar()
-print("cfar %.3f  extract %.3f  filter %.3f ms / %d frames; points/frame %.0f"
-      % (timed(kb.run_cfar, 10), timed(kb.run_extract, 10), timed(kb.run_filter, 5), B, kb.results()["counts"].mean()))
+variant = int(os.environ.get("EXTRACT_VARIANT", "0"))      # 0 = records (default), 2 = canvas bitmap
+ctx._check(ctx.lib.sfe_extract_set_tuning(ctx.handle, variant))
+print("variant %d: cfar %.3f  extract %.3f  filter %.3f ms / %d frames; points/frame %.0f"
+      % (variant, timed(kb.run_cfar, 10), timed(kb.run_extract, 10), timed(kb.run_filter, 5), B, kb.results()["counts"].mean()))
