@@ -640,6 +640,7 @@ __global__ __launch_bounds__(256) void extract_expand_kernel(const unsigned long
 #define SG_LIST 1536  // set pixels a workgroup collects before it expands them (list + table: 18 KB, eight workgroups per CU)
 #define SG_BLOCK 1024 // mask words looked at per collection step (4 per thread)
 #define SG_TAB 1024   // slots of the canvas-word table
+#define SG_SPILL 512  // record form: slots per frame for words that found no table slot
 // COMPACT (round 4): 4-byte entries {decision table [15:0], tap place [17:16], dx [24:18], dy [31:25]} relative to a
 // per-pixel base bit index that travels with the pixel's offset ({offset, base} pairs: ONE 16-byte read brings the
 // pixel's offset, its base and the next offset), four entries per 16-byte read; entries that can never report (their
@@ -684,12 +685,16 @@ __global__ __launch_bounds__(256, 8) void extract_gather_kernel(const uint32_t *
     const int sl = (int)((blockIdx.x + 5u * blockIdx.y) % (unsigned)slices);
     const uint32_t *__restrict__ src = bits + (long long)f * words_per_frame;
     unsigned long long *__restrict__ bm = bitmap + (long long)f * crows * wpr;
-    int4 *__restrict__ rl = RECORDS ? rec + (long long)f * rec_cap : nullptr;
+    // records: this workgroup's region of the frame's list (SG_TAB slots: the table holds no more) and, for the few words that
+    // found no table slot, the spill region behind the workgroups' regions (SG_SPILL slots, one returning atomic each)
+    const long long rec_stride = (long long)slices * SG_TAB + SG_SPILL;
+    int4 *__restrict__ rl = RECORDS ? rec + (long long)f * rec_stride : nullptr;
+    int32_t *__restrict__ rcnt = RECORDS ? rec_n + (long long)f * (slices + 1) : nullptr;
     auto or_word = [&](unsigned wd, unsigned long long m) {
-        if (RECORDS) { // (a word that found no table slot: rare)
-            const int pos = atomicAdd(&rec_n[f], 1);
-            if (pos < rec_cap)
-                rl[pos] = make_int4((int)wd, 0, (int)(unsigned)(m & 0xFFFFFFFFull), (int)(unsigned)(m >> 32));
+        if (RECORDS) {
+            const int pos = atomicAdd(&rcnt[slices], 1); // (beyond SG_SPILL: the count says so, the frame is handed back)
+            if (pos < SG_SPILL)
+                rl[(long long)slices * SG_TAB + pos] = make_int4((int)wd, 0, (int)(unsigned)(m & 0xFFFFFFFFull), (int)(unsigned)(m >> 32));
         } else
             atomicOr(&bm[wd], m);
     };
@@ -873,7 +878,7 @@ __global__ __launch_bounds__(256, 8) void extract_gather_kernel(const uint32_t *
                 or_word(s_tag[i], s_acc[i]);
         return;
     }
-    // the table as records: thread t holds slots 4 t .. 4 t + 3; one allocation in the frame's list for the workgroup
+    // the table as records: thread t holds slots 4 t .. 4 t + 3, the workgroup's records go to its own region of the list
     int mine = 0;
 #pragma unroll
     for (int u = 0; u < SG_TAB / 256; ++u)
@@ -888,18 +893,15 @@ __global__ __launch_bounds__(256, 8) void extract_gather_kernel(const uint32_t *
     wbase = __builtin_amdgcn_readlane(wbase, 63);
     __syncthreads();
     if (tid == 0)
-        s_n = s_want[0] ? atomicAdd(&rec_n[f], s_want[0]) : 0;
-    __syncthreads();
-    int pos = s_n + wbase + incl - mine;
+        rcnt[blockIdx.x] = s_want[0];
+    int4 *__restrict__ mine_out = rl + (long long)blockIdx.x * SG_TAB + wbase + incl - mine;
 #pragma unroll
     for (int u = 0; u < SG_TAB / 256; ++u) {
         const int i = (SG_TAB / 256) * tid + u;
         const unsigned wd = s_tag[i];
         if (wd != 0xFFFFFFFFu) {
             const unsigned long long m = s_acc[i];
-            if (pos < rec_cap)
-                rl[pos] = make_int4((int)wd, 0, (int)(unsigned)(m & 0xFFFFFFFFull), (int)(unsigned)(m >> 32));
-            ++pos;
+            *mine_out++ = make_int4((int)wd, 0, (int)(unsigned)(m & 0xFFFFFFFFull), (int)(unsigned)(m >> 32));
         }
     }
 }
@@ -914,8 +916,11 @@ __global__ __launch_bounds__(256, 8) void extract_gather_kernel(const uint32_t *
 // ovf_flag and left to the canvas kernels, which look at flagged frames only.
 #define ME_THREADS 1024
 #define ME_RPT 8 // records per thread held in registers (rec_cap <= ME_THREADS * ME_RPT)
+// IDX: the type of the compact arrays' word indices and point offsets -- uint16_t when the frame has < 65 536 bitmap words and the
+// capacity is < 65 536 points (config A: 78 KB of LDS, two frames per CU), uint32_t otherwise.
+template <typename IDX>
 __global__ __launch_bounds__(ME_THREADS) void extract_merge_expand_kernel(const int4 *__restrict__ rec, const int32_t *__restrict__ rec_n,
-                                                                          int rec_cap, int32_t *__restrict__ frame_count,
+                                                                          int rec_cap, int slices, int32_t *__restrict__ frame_count,
                                                                           int32_t *__restrict__ ovf_flag, long long *__restrict__ rc_out,
                                                                           double *__restrict__ pts_out, long long cap, int crows,
                                                                           int ccols, int wpr, int capw, const double *__restrict__ ytab,
@@ -927,23 +932,51 @@ __global__ __launch_bounds__(ME_THREADS) void extract_merge_expand_kernel(const 
     const int nw = crows * wpr, npw = (nw + 31) >> 5;
     double *s_y = reinterpret_cast<double *>(me_raw), *s_x = s_y + crows;
     unsigned long long *w_bits = reinterpret_cast<unsigned long long *>(s_x + ccols);
-    unsigned *w_idx = reinterpret_cast<unsigned *>(w_bits + capw);
-    int *w_off = reinterpret_cast<int *>(w_idx + capw); // capw + 1
-    unsigned *pres = reinterpret_cast<unsigned *>(w_off + capw + 1);
+    unsigned *pres = reinterpret_cast<unsigned *>(w_bits + capw);
     int *ppre = reinterpret_cast<int *>(pres + npw);
+    IDX *w_idx = reinterpret_cast<IDX *>(ppre + npw);
+    IDX *w_off = w_idx + capw; // capw + 1
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = rec_n[f];
+    // the frame's records: `slices` regions of SG_TAB slots (one per workgroup of the gather kernel) + the spill region
+    __shared__ int s_rp[66]; // s_rp[r] = records in front of region r
+    const int32_t *__restrict__ rcnt = rec_n + (long long)f * (slices + 1);
+    if (tid <= slices)
+        s_rp[tid + 1] = rcnt[tid];
+    if (tid == 0)
+        s_rp[0] = 0;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int r = 0; r <= slices; ++r) {
+            const int c = s_rp[r + 1];
+            s_rp[r] = run;
+            run += c;
+        }
+        s_rp[slices + 1] = run;
+        s_total = s_rp[slices + 1] - s_rp[slices] > SG_SPILL ? 0x7FFFFFFF : run;
+    }
+    __syncthreads();
+    const int n = s_total;
+    __syncthreads();
     if (n > rec_cap) { // (workgroup-uniform)
         if (tid == 0)
             ovf_flag[f] = 1;
         return;
     }
-    const int4 *__restrict__ rl = rec + (long long)f * rec_cap;
+    const int4 *__restrict__ rl = rec + (long long)f * ((long long)slices * SG_TAB + SG_SPILL);
     int4 ent[ME_RPT];
 #pragma unroll
     for (int k = 0; k < ME_RPT; ++k) {
         const int r = tid + k * ME_THREADS;
-        ent[k] = r < n ? rl[r] : make_int4(-1, 0, 0, 0);
+        int lo = 0, hi = slices; // the region record r lies in: the last one that starts at or before r
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (s_rp[mid] <= r)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        ent[k] = r < n ? rl[(long long)lo * SG_TAB + (r - s_rp[lo])] : make_int4(-1, 0, 0, 0);
     }
     for (int i = tid; i < npw; i += ME_THREADS)
         pres[i] = 0u;
@@ -1000,7 +1033,7 @@ __global__ __launch_bounds__(ME_THREADS) void extract_merge_expand_kernel(const 
             const int wd = ent[k].x;
             const int rank = ppre[wd >> 5] + __popc(pres[wd >> 5] & ((1u << (wd & 31)) - 1u));
             atomicOr(&w_bits[rank], ((unsigned long long)(unsigned)ent[k].w << 32) | (unsigned long long)(unsigned)ent[k].z);
-            w_idx[rank] = (unsigned)wd;
+            w_idx[rank] = (IDX)wd;
         }
     __syncthreads();
     {
@@ -1011,39 +1044,39 @@ __global__ __launch_bounds__(ME_THREADS) void extract_merge_expand_kernel(const 
             mine += __popcll(w_bits[i]);
         int run = block_excl(mine);
         for (int i = b; i < e; ++i) {
-            w_off[i] = run;
+            w_off[i] = (IDX)run; // (a run beyond the capacity may wrap: such a frame is handed back below)
             run += __popcll(w_bits[i]);
         }
     }
     const int total = s_total;
-    if (tid == 0) {
-        w_off[nW] = total;
+    if (tid == 0)
         frame_count[f] = total;
-    }
     if (total > cap) { // the canvas path stores such a frame's first cap points (and reports the same count)
         if (tid == 0)
             ovf_flag[f] = 1;
         return;
     }
+    if (tid == 0)
+        w_off[nW] = (IDX)total;
     __syncthreads();
     if (cap <= 0)
         return;
     for (int b = wave * 64; b < nW; b += (ME_THREADS / 64) * 64) { // a wave takes 64 consecutive words
         const int hi0 = min(b + 63, nW - 1);
-        const int first = w_off[b], npts = w_off[hi0 + 1] - first;
+        const int first = (int)w_off[b], npts = (int)w_off[hi0 + 1] - first;
         for (int j = lane; j < npts; j += 64) {
             const int t = first + j;
             int lo = b, hi = hi0; // the last word whose first point is <= t
 #pragma unroll
             for (int step = 0; step < 6; ++step) {
                 const int mid = (lo + hi + 1) >> 1;
-                if (w_off[mid] <= t)
+                if ((int)w_off[mid] <= t)
                     lo = mid;
                 else
                     hi = mid - 1;
             }
             const unsigned long long wbits = w_bits[lo];
-            int rr = t - w_off[lo], bit = 0;
+            int rr = t - (int)w_off[lo], bit = 0;
             unsigned w32 = (unsigned)(wbits & 0xFFFFFFFFull);
             {
                 const int c = __popc(w32);
@@ -1136,24 +1169,19 @@ static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_f
     // record path (round 5; default for bit-stream batches): no canvas bitmap for the frames that fit its capacities
     const int rec_cap_env = getenv("SFE_EXTRACT_REC_CAP") ? atoi(getenv("SFE_EXTRACT_REC_CAP")) : 0; // (read per call: the tests
     const int capw_env = getenv("SFE_EXTRACT_CAPW") ? atoi(getenv("SFE_EXTRACT_CAPW")) : 0;         //  force the hand-back with them)
-    const int rec_cap = std::max(64, std::min(ME_THREADS * ME_RPT, rec_cap_env > 0 ? rec_cap_env : 6144));
+    const int rec_cap = std::max(1, std::min(ME_THREADS * ME_RPT, rec_cap_env > 0 ? rec_cap_env : ME_THREADS * ME_RPT));
     const int capw = (int)std::max<long long>(1, std::min<long long>(capw_env > 0 ? capw_env : 4096, std::min(words_pf, std::max<long long>(cap, 1))));
-    const size_t me_lds = tab_bytes + (size_t)capw * 16 + 4 + ((size_t)(words_pf + 31) / 32) * 8 + 16;
+    const bool me_narrow = words_pf < 65536 && cap < 65536;
+    const size_t me_lds = tab_bytes + (size_t)capw * 8 + ((size_t)(words_pf + 31) / 32) * 8 + ((size_t)capw * 2 + 1) * (me_narrow ? 2 : 4) + 16;
     const bool records = use_words && d_bits_in && ctx->extract_variant == 0 && g->d_inv_off != nullptr &&
                          (g->polar_cols & 31) == 0 && g->polar_rows < 65536 && g->polar_cols < 65536 && me_lds <= 150 * 1024 &&
                          words_pf < (1ll << 31);
     int4 *d_rec = nullptr;
     int32_t *d_rec_n = nullptr, *d_ovf_flag = nullptr;
-    if (records) {
-        const int nfc = std::min(chunk, n_frames);
-        d_rec = (int4 *)sfe_scratch(ctx, 61, (size_t)nfc * rec_cap * sizeof(int4));
-        d_rec_n = (int32_t *)sfe_scratch(ctx, 62, (size_t)nfc * 2 * 4); // counts | flags
-        if (!d_rec || !d_rec_n)
-            return SFE_ERR_HIP;
-        d_ovf_flag = d_rec_n + nfc;
-        SFE_HIP(ctx, hipFuncSetAttribute((const void *)extract_merge_expand_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)me_lds));
-    }
+    if (records)
+        SFE_HIP(ctx, hipFuncSetAttribute(me_narrow ? (const void *)extract_merge_expand_kernel<uint16_t>
+                                                   : (const void *)extract_merge_expand_kernel<uint32_t>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)me_lds));
     // bytes of the bitmap scratch known to be zero (the state is dropped for the duration of the call: an error return
     // leaves it unknown)
     size_t clean_bytes = ctx->bm_clean_ptr == (void *)d_bm ? ctx->bm_clean_bytes : 0;
@@ -1203,9 +1231,16 @@ static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_f
             const bool c4 = g->d_inv_c4 && !no_compact;
             const int32_t *p_off = c4 ? reinterpret_cast<const int32_t *>(g->d_inv_ob) : g->d_inv_off;
             const uint2 *p_ent = c4 ? reinterpret_cast<const uint2 *>(g->d_inv_c4) : g->d_inv_lut;
-            if (records) {
-                // records -> points without a canvas; the frames that do not fit are flagged and go through the canvas kernels below
-                SFE_HIP(ctx, hipMemsetAsync(d_rec_n, 0, (size_t)std::min(chunk, n_frames) * 2 * 4, ctx->stream));
+            d_ovf_flag = nullptr;
+            if (records && slices <= 64) { // (s_rp of the merge kernel holds 64 regions + the spill region)
+                // records -> points without a canvas; the frames that do not fit are flagged and go through the canvas kernels below.
+                // Per frame: `slices` regions of SG_TAB record slots + the spill region; counts per region, then the flags
+                d_rec = (int4 *)sfe_scratch(ctx, 61, (size_t)nf * ((size_t)slices * SG_TAB + SG_SPILL) * sizeof(int4));
+                d_rec_n = (int32_t *)sfe_scratch(ctx, 62, (size_t)nf * ((size_t)slices + 2) * 4);
+                if (!d_rec || !d_rec_n)
+                    return SFE_ERR_HIP;
+                d_ovf_flag = d_rec_n + (size_t)nf * (slices + 1);
+                SFE_HIP(ctx, hipMemsetAsync(d_rec_n, 0, (size_t)nf * ((size_t)slices + 2) * 4, ctx->stream));
                 if (c4)
                     hipLaunchKernelGGL((extract_gather_kernel<true, true>), dim3((unsigned)slices, nf), dim3(256), 0, ctx->stream,
                                        d_bits, d_nonbin, p_off, p_ent, d_bm, g->polar_rows, g->polar_cols, crows, wpr, wpf, sg_piece,
@@ -1214,10 +1249,16 @@ static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_f
                     hipLaunchKernelGGL((extract_gather_kernel<false, true>), dim3((unsigned)slices, nf), dim3(256), 0, ctx->stream,
                                        d_bits, d_nonbin, p_off, p_ent, d_bm, g->polar_rows, g->polar_cols, crows, wpr, wpf, sg_piece,
                                        d_rec, d_rec_n, rec_cap, (const int32_t *)nullptr);
-                hipLaunchKernelGGL(extract_merge_expand_kernel, dim3(nf), dim3(ME_THREADS), me_lds, ctx->stream, d_rec, d_rec_n,
-                                   rec_cap, d_counts + f0, d_ovf_flag, d_rc ? d_rc + (size_t)f0 * cap * 2 : nullptr,
-                                   d_pts ? d_pts + (size_t)f0 * cap * 2 : nullptr, cap, crows, g->cart_cols, wpr, capw, g->d_ytab,
-                                   g->d_xtab);
+                long long *rc_f = d_rc ? d_rc + (size_t)f0 * cap * 2 : nullptr;
+                double *pts_f = d_pts ? d_pts + (size_t)f0 * cap * 2 : nullptr;
+                if (me_narrow)
+                    hipLaunchKernelGGL(extract_merge_expand_kernel<uint16_t>, dim3(nf), dim3(ME_THREADS), me_lds, ctx->stream, d_rec,
+                                       d_rec_n, rec_cap, slices, d_counts + f0, d_ovf_flag, rc_f, pts_f, cap, crows, g->cart_cols, wpr,
+                                       capw, g->d_ytab, g->d_xtab);
+                else
+                    hipLaunchKernelGGL(extract_merge_expand_kernel<uint32_t>, dim3(nf), dim3(ME_THREADS), me_lds, ctx->stream, d_rec,
+                                       d_rec_n, rec_cap, slices, d_counts + f0, d_ovf_flag, rc_f, pts_f, cap, crows, g->cart_cols, wpr,
+                                       capw, g->d_ytab, g->d_xtab);
             }
             if (c4)
                 hipLaunchKernelGGL((extract_gather_kernel<true, false>), dim3((unsigned)slices, nf), dim3(256), 0, ctx->stream, d_bits,
