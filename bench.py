@@ -555,7 +555,8 @@ def main():
                                            (("cfar", ms_cfar_b), ("extract", ms_extract_b), ("filters", ms_filter_b),
                                             ("icp", ms_icp_b))},
             # SURVEY 8d, on-the-fly form: R*B bytes of mask in + 16 B per extracted point out
-            "roofline_extract": {"kernel": ("" if kb.bit_masks else "mask_pack + ") + "extract_gather + extract_scan + extract_expand_words", "bound": "hbm",
+            "roofline_extract": {"kernel": ("extract_gather<records> + extract_merge_expand (no canvas bitmap in HBM; round 5)" if kb.bit_masks
+                                            else "mask_pack + extract_gather + extract_scan + extract_expand_words"), "bound": "hbm",
                                  "limiter": "scattered reads of the inverse-map entries (L1 tag rate: one line per lane and load) and load latency",
                                  "achieved": extract_bytes / (ms_extract_b * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": extract_bytes / (ms_extract_b * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -563,7 +564,7 @@ def main():
                                  "traffic_note": "bytes/launch from the committed PMC passes (profiles/extract_pmc.json: per-frame "
                                                  "FETCH_SIZE x 2 + WRITE_SIZE of the stage's kernels, scaled to this launch's frames)",
                                  "note": "algorithmic bytes = the R*B detections (bits when CFAR hands over bit streams) + 16 B per point per frame; the kernels are "
-                                         "bound by gathers into the inverse remap table (19 MB, one 16-byte read per two candidates of a set pixel), not "
+                                         "bound by gathers into the inverse remap table (10 MB of 4-byte entries, four candidates per 16-byte read), not "
                                          "by streaming"},
         }
         out["roofline"]["extract_frac"] = out["roofline_extract"]["frac"]      # (flat copies: see the note at `chained` below)
