@@ -448,6 +448,14 @@ int sfe_matching_cost_store(sfe_ctx *ctx, sfe_costgrid *g, sfe_cloud_store *s, c
                             const int32_t *grid_index, int n_jobs, const float *T6, int n_poses, double resolution, int flags,
                             int32_t *cost_out);
 
+/* ... the sample transforms computed on the device: job i scores source_handles[i] against its grid under
+ * target_i.between(source_i.compose(delta_j)).matrix() (slam.py:548-550) for n_deltas deltas shared by all jobs; poses as
+ * {x, y, cos(theta), sin(theta)} doubles (host): target_xycs / source_xycs [n_jobs x 4], delta_xycs [n_deltas x 4];
+ * cost_out[i * n_deltas + j].  gtsam.Pose2's double arithmetic as sfe_pose2_sample_transforms below, bit for bit. */
+int sfe_matching_cost_store_samples(sfe_ctx *ctx, sfe_costgrid *g, sfe_cloud_store *s, const int32_t *source_handles,
+                                    const int32_t *grid_index, int n_jobs, const double *target_xycs, const double *source_xycs,
+                                    const double *delta_xycs, int n_deltas, double resolution, int flags, int32_t *cost_out);
+
 /* ---- replaces: everything scipy.optimize.shgo(func, bounds, n, iters=1, sampling_method="sobol", minimizer_kwargs=
  * {"options": {"ftol": ...}}) of slam.py:692-701 does AFTER its sampling stage, for n_problems cost tables at once (host only,
  * no device work).  Holds for the piecewise-constant cost of slam.py:529-567 only.  The vertex graph (CSR nn_off / nn_idx over

@@ -151,6 +151,8 @@ SIGNATURES = {
                                             C.POINTER(_vp)]),
     "sfe_matching_cost_store": (C.c_int, [_vp, _vp, _vp, _i32p, _i32p, C.c_int, _f32p, C.c_int, C.c_double, C.c_int, _i32p]),
     "sfe_shgo_sobol_replay": (C.c_int, [C.c_int, _i32p, _i32p, _f64p, _i32p, C.c_int, _u8p, _i32p, _i32p, _i32p]),
+    "sfe_matching_cost_store_samples": (C.c_int, [_vp, _vp, _vp, _i32p, _i32p, C.c_int, _f64p, _f64p, _f64p, C.c_int, C.c_double, C.c_int,
+                                                  _i32p]),
     "sfe_pose2_sample_transforms": (C.c_int, [_f64p, _f64p, C.c_int, _f64p, C.c_int, _f32p]),
     "sfe_cloud_store_bbox": (C.c_int, [_vp, _vp, _i32p, C.c_int, _f32p]),
     "sfe_cloud_store_get_points_keys": (C.c_int, [_vp, _vp, _i32p, _f32p, _i32p, C.c_int, C.c_float, C.c_int, C.c_int64, _i32p]),

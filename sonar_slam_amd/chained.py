@@ -337,9 +337,12 @@ class SessionBatch(object):
         self.init_stats["grids_s"] += time.perf_counter() - t_g
         try:
             t_a = time.perf_counter()
-            T6_all = transforms(np.arange(n), X0)
+            d4 = np.stack([X0[:, 0], X0[:, 1], [math.cos(t) for t in X0[:, 2]], [math.sin(t) for t in X0[:, 2]]], axis=1)
+            t4 = np.stack([tgt_pose.x, tgt_pose.y, tgt_pose.c, tgt_pose.s], axis=1)
+            s4 = np.stack([src_pose.x, src_pose.y, src_pose.c, src_pose.s], axis=1)
             t_b = time.perf_counter()
-            table = grids.cost(src_h[idx], T6_all, f64_points=True)                            # [n x len(X0)]: one launch
+            # [n x len(X0)]: one launch, the sample transforms target.between(source.compose(x)) computed on the device
+            table = grids.cost_samples(src_h[idx], t4, s4, d4, f64_points=True)
             self.init_stats["transforms_s"] += t_b - t_a
             self.init_stats["table_s"] += time.perf_counter() - t_b
             self.init_stats["table_hits"] += n * len(X0)

@@ -13,6 +13,7 @@
 // Float recipe per point (numpy float32 arithmetic of the reference, no contraction):
 //   x' = fl(fl(fl(px*T00) + fl(py*T01)) + T02);  c = rint(fl(fl(x' - xmin) / res))  (half-even)
 #include "sfe_internal.h"
+#include "sfe_pose2.h"
 
 #include <algorithm>
 #include <cmath>
@@ -342,6 +343,25 @@ static int cost_store_jobs(sfe_ctx *ctx, sfe_cloud_store *s, const int32_t *hand
     return 0;
 }
 
+// T6 [(i * n_deltas + j) * 6 ..] of target_i.between(source_i.compose(delta_j)): sfe_pose2.h
+__global__ __launch_bounds__(256) void cost_sample_transforms_kernel(const double *__restrict__ target, const double *__restrict__ source,
+                                                                     const double *__restrict__ delta, int n_jobs, int n_deltas,
+                                                                     float *__restrict__ T6)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)n_jobs * n_deltas)
+        return;
+    const int i = (int)(t / n_deltas), j = (int)(t - (long long)i * n_deltas);
+    const SfeP2 tgt{target[4 * i], target[4 * i + 1], target[4 * i + 2], target[4 * i + 3]};
+    const SfeP2 src{source[4 * i], source[4 * i + 1], source[4 * i + 2], source[4 * i + 3]};
+    const SfeP2 d{delta[4 * j], delta[4 * j + 1], delta[4 * j + 2], delta[4 * j + 3]};
+    float out[6];
+    sfe_p2_sample_transform(sfe_p2_inverse(tgt), src, d, out);
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+        T6[6 * t + k] = out[k];
+}
+
 extern "C" {
 
 int sfe_costgrid_create(sfe_ctx *ctx, const int32_t *tgt_r, const int32_t *tgt_c, int n_tgt, int rows, int cols,
@@ -537,6 +557,47 @@ int sfe_matching_cost_store(sfe_ctx *ctx, sfe_costgrid *g, sfe_cloud_store *s, c
     if (int rc = sfe_pinned_end(ctx, ctx->stream))
         return rc;
     return cost_launch(ctx, g, d_jobs, n_jobs, d_T, n_poses, resolution, flags, 1, 0.0f, 0.0f, cost_out);
+}
+
+// ... with the sample transforms computed on the device from the poses: job i scores source_handles[i] against its grid under
+// target_i.between(source_i.compose(delta_j)) for the n_deltas deltas shared by all jobs (the 244 poses shgo's replay needs per
+// session, shgo_fast.py) -- 2 x n_jobs + n_deltas poses go up instead of n_jobs x n_deltas transforms
+int sfe_matching_cost_store_samples(sfe_ctx *ctx, sfe_costgrid *g, sfe_cloud_store *s, const int32_t *source_handles,
+                                    const int32_t *grid_index, int n_jobs, const double *target_xycs, const double *source_xycs,
+                                    const double *delta_xycs, int n_deltas, double resolution, int flags, int32_t *cost_out)
+{
+    if (int rc = sfe_use(ctx))
+        return rc;
+    SFE_ARG(ctx, g && g->ctx == ctx && s && sfe_store_ctx(s) == ctx && source_handles && n_deltas >= 0 && n_jobs >= 0 &&
+                     (grid_index || n_jobs == g->n) &&
+                     (n_deltas == 0 || n_jobs == 0 || (target_xycs && source_xycs && delta_xycs && cost_out)));
+    if (n_deltas == 0 || n_jobs == 0)
+        return 0;
+    if (grid_index)
+        for (int i = 0; i < n_jobs; ++i)
+            SFE_ARG(ctx, grid_index[i] >= 0 && grid_index[i] < g->n);
+    CostJob *d_jobs = nullptr;
+    if (int rc = cost_store_jobs(ctx, s, source_handles, n_jobs, 0, "matching cost", &d_jobs, grid_index))
+        return rc;
+    const size_t b_pose = sizeof(double) * 4 * (size_t)n_jobs, b_delta = sizeof(double) * 4 * (size_t)n_deltas;
+    const size_t b_T = sizeof(float) * 6 * (size_t)n_deltas * (size_t)n_jobs;
+    float *d_T = (float *)sfe_scratch(ctx, 1, b_T);
+    double *d_p = (double *)sfe_scratch(ctx, 3, 2 * b_pose + b_delta);
+    double *h_p = (double *)sfe_pinned_begin(ctx, 2 * b_pose + b_delta);
+    if (!d_T || !d_p || !h_p)
+        return SFE_ERR_HIP;
+    memcpy(h_p, target_xycs, b_pose);
+    memcpy(h_p + 4 * (size_t)n_jobs, source_xycs, b_pose);
+    memcpy(h_p + 8 * (size_t)n_jobs, delta_xycs, b_delta);
+    SFE_HIP(ctx, hipMemcpyAsync(d_p, h_p, 2 * b_pose + b_delta, hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = sfe_pinned_end(ctx, ctx->stream))
+        return rc;
+    const long long total = (long long)n_jobs * n_deltas;
+    hipLaunchKernelGGL(cost_sample_transforms_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const double *)d_p, (const double *)(d_p + 4 * (size_t)n_jobs), (const double *)(d_p + 8 * (size_t)n_jobs),
+                       n_jobs, n_deltas, d_T);
+    SFE_LAUNCH_CHECK(ctx);
+    return cost_launch(ctx, g, d_jobs, n_jobs, d_T, n_deltas, resolution, flags, 1, 0.0f, 0.0f, cost_out);
 }
 
 } // extern "C"

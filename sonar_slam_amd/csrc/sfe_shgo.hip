@@ -8,6 +8,7 @@
 // point itself; the result is the lowest local result (`LMapCache.sort_cache_result`).  What cannot be decided the way scipy would
 // is reported, not guessed: see the status values in sonarfe.h.
 #include "../../include/sonarfe.h"
+#include "sfe_pose2.h"
 
 #include <cmath>
 #include <cstdint>
@@ -111,49 +112,19 @@ int sfe_shgo_sobol_replay(int n_vertices, const int32_t *nn_off, const int32_t *
 // for n_sessions (target, source) pairs x n_deltas deltas, every pose as {x, y, cos, sin} in double -- the expressions of
 // sonar_slam_amd/pose2.py (Pose2.compose / inverse / between, rotation renormalised when c^2 + s^2 is off by more than 1e-10), in the
 // same order, so the float32 entries are the ones the one-by-one Python path hands to the cost kernel.  Host only.
-namespace {
-struct P2 {
-    double x, y, c, s;
-};
-inline P2 p2_make(double x, double y, double c, double s)
-{
-    const double scale = c * c + s * s;
-    if (std::fabs(scale - 1.0) > 1e-10) {
-        const double k = 1.0 / std::sqrt(scale);
-        c = c * k;
-        s = s * k;
-    }
-    return P2{x, y, c, s};
-}
-inline P2 p2_compose(const P2 &a, const P2 &o)
-{
-    return p2_make(a.x + a.c * o.x - a.s * o.y, a.y + a.s * o.x + a.c * o.y, a.c * o.c - a.s * o.s, a.s * o.c + a.c * o.s);
-}
-inline P2 p2_inverse(const P2 &a)
-{
-    return p2_make(-(a.c * a.x + a.s * a.y), -(-a.s * a.x + a.c * a.y), a.c, -a.s);
-}
-} // namespace
-
 int sfe_pose2_sample_transforms(const double *target_xycs, const double *source_xycs, int n_sessions, const double *delta_xycs,
                                 int n_deltas, float *T6_out)
 {
     if (n_sessions < 0 || n_deltas < 0 || (n_sessions && n_deltas && (!target_xycs || !source_xycs || !delta_xycs || !T6_out)))
         return SFE_ERR_ARG;
     for (int i = 0; i < n_sessions; ++i) {
-        const P2 tgt{target_xycs[4 * i], target_xycs[4 * i + 1], target_xycs[4 * i + 2], target_xycs[4 * i + 3]};
-        const P2 src{source_xycs[4 * i], source_xycs[4 * i + 1], source_xycs[4 * i + 2], source_xycs[4 * i + 3]};
-        const P2 inv = p2_inverse(tgt);
+        const SfeP2 tgt{target_xycs[4 * i], target_xycs[4 * i + 1], target_xycs[4 * i + 2], target_xycs[4 * i + 3]};
+        const SfeP2 src{source_xycs[4 * i], source_xycs[4 * i + 1], source_xycs[4 * i + 2], source_xycs[4 * i + 3]};
+        const SfeP2 inv = sfe_p2_inverse(tgt);
         float *out = T6_out + (size_t)i * n_deltas * 6;
         for (int j = 0; j < n_deltas; ++j) {
-            const P2 d{delta_xycs[4 * j], delta_xycs[4 * j + 1], delta_xycs[4 * j + 2], delta_xycs[4 * j + 3]};
-            const P2 t = p2_compose(inv, p2_compose(src, d));
-            out[6 * j + 0] = (float)t.c;
-            out[6 * j + 1] = (float)-t.s;
-            out[6 * j + 2] = (float)t.x;
-            out[6 * j + 3] = (float)t.s;
-            out[6 * j + 4] = (float)t.c;
-            out[6 * j + 5] = (float)t.y;
+            const SfeP2 d{delta_xycs[4 * j], delta_xycs[4 * j + 1], delta_xycs[4 * j + 2], delta_xycs[4 * j + 3]};
+            sfe_p2_sample_transform(inv, src, d, out + 6 * j);
         }
     }
     return 0;

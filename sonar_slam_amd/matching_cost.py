@@ -216,6 +216,23 @@ class _StoreGrids(object):
                 self.resolution, F64_POINTS if f64_points else 0, _L.ptr(out, _C.c_int32)))
         return out
 
+    def cost_samples(self, source_handles, target_xycs, source_xycs, delta_xycs, f64_points=True, grid_index=None):
+        """costs [n_jobs x n_deltas] under target_i.between(source_i.compose(delta_j)), the transforms computed on the device from
+        the poses ({x, y, cos, sin} rows, float64): sfe_matching_cost_store_samples"""
+        sh = np.ascontiguousarray(source_handles, np.int32).reshape(-1)
+        gi = None if grid_index is None else np.ascontiguousarray(grid_index, np.int32).reshape(-1)
+        assert len(sh) == (self.n if gi is None else len(gi))
+        t4 = np.ascontiguousarray(target_xycs, np.float64).reshape(len(sh), 4)
+        s4 = np.ascontiguousarray(source_xycs, np.float64).reshape(len(sh), 4)
+        d4 = np.ascontiguousarray(delta_xycs, np.float64).reshape(-1, 4)
+        out = np.zeros((len(sh), len(d4)), np.int32)
+        with self.ctx.lock:
+            self.ctx._check(self.ctx.lib.sfe_matching_cost_store_samples(
+                self.ctx.handle, self.handle, self.store.handle, _L.ptr(sh, _C.c_int32),
+                None if gi is None else _L.ptr(gi, _C.c_int32), len(sh), _L.ptr(t4, _C.c_double), _L.ptr(s4, _C.c_double),
+                _L.ptr(d4, _C.c_double), len(d4), self.resolution, F64_POINTS if f64_points else 0, _L.ptr(out, _C.c_int32)))
+        return out
+
     def download(self, index=0):
         out = np.zeros((int(self.rows[index]), int(self.cols[index])), np.uint8)
         with self.ctx.lock:

@@ -439,6 +439,48 @@ def test_sessions_in_lock_step_with_the_global_initialisation(ctx, shipped_cfar)
 
 
 @pytest.mark.gpu
+def test_sample_transforms_on_the_device_equal_the_host_routine(ctx):
+    """sfe_matching_cost_store_samples (the sample transforms target.between(source.compose(x)) computed by a kernel from the
+    poses) == sfe_matching_cost_store on the transforms of the host routine, for many pose pairs -- a rotation off the unit circle
+    (Rot2's renormalisation: 1 / sqrt in double on the device) among them"""
+    from sonar_slam_amd import matching_cost as mc
+    from sonar_slam_amd import shgo_fast, store as st
+    from sonar_slam_amd.chained import Pose2Batch, sample_transforms
+    rng = np.random.default_rng(31)
+    s = st.CloudStore(ctx, capacity_points=1 << 16, max_clouds=64)
+    n = 12
+    src_h, tgt_h = [], []
+    for i in range(n):
+        a, b, _, _ = synth.scan_pair(seed=40 + i, n_src=200 + 30 * i, n_tgt=260)
+        src_h.append(s.put(a))
+        tgt_h.append(s.put(oracle.downsample(b, 0.5)))
+    tgt = Pose2Batch(rng.normal(0, 20, n), rng.normal(0, 20, n), rng.uniform(-3, 3, n))
+    src = Pose2Batch(tgt.x + rng.normal(0, 0.5, n), tgt.y + rng.normal(0, 0.5, n), tgt.theta() + rng.normal(0, 0.05, n))
+    src.c[:4] *= 1.0 + 5e-10
+    src.s[:4] *= 1.0 + 5e-10
+    pose_stds = np.array([[0.2, 0.2, 0.02]]).T
+    X = shgo_fast.plan_for(5.0 * np.c_[-pose_stds, pose_stds], 50, 0.01).points.reshape(-1, 3)
+    grids = mc._StoreGrids(s, tgt_h, 0.5)
+    try:
+        T6 = sample_transforms(ctx.lib, tgt, src, X)
+        want = grids.cost(src_h, T6, f64_points=True)
+        d4 = np.stack([X[:, 0], X[:, 1], np.cos(X[:, 2]), np.sin(X[:, 2])], axis=1)
+        import math
+        d4[:, 2] = [math.cos(t) for t in X[:, 2]]
+        d4[:, 3] = [math.sin(t) for t in X[:, 2]]
+        got = grids.cost_samples(src_h, np.stack([tgt.x, tgt.y, tgt.c, tgt.s], axis=1), np.stack([src.x, src.y, src.c, src.s], axis=1), d4)
+        assert got.shape == want.shape == (n, len(X)) and np.array_equal(got, want) and (want < -20).any()
+        # a subset of the jobs against named grids
+        sel = [7, 2, 2, 11]
+        got2 = grids.cost_samples([src_h[i] for i in sel], np.stack([tgt.x, tgt.y, tgt.c, tgt.s], axis=1)[sel],
+                                  np.stack([src.x, src.y, src.c, src.s], axis=1)[sel], d4[:9], grid_index=sel)
+        assert np.array_equal(got2, want[sel][:, :9])
+    finally:
+        grids.close()
+        s.close()
+
+
+@pytest.mark.gpu
 def test_loop_closure_primitives_over_the_store(ctx):
     """sfe_cloud_store_get_points_keys (descriptor overload of pcl.downsample, more than 65 536 points in one target),
     get_points beyond the resident filter's capacity, fov_select (+ the undecidable case), compact_selected, match_keys"""

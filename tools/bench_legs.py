@@ -595,7 +595,7 @@ def chained(ctx, det, threads, n_sessions=4096, n_steps=8, n_distinct=64, parity
                "scan_matches_whose_start_shgo_moved": int(moved.sum()),
                "status_counts": {ch.STATUS_NAMES[c]: int((status == c).sum()) for c in range(1, 7) if (status == c).any()},
                "note": "slam.py:665-716 per scan match.  The cost at shgo's 61 sampling vertices and at the 3 finite-difference points "
-                       "SLSQP adds per vertex is taken for ALL sessions in one launch (sfe_matching_cost_store, 244 poses per "
+                       "SLSQP adds per vertex is taken for ALL sessions in one launch (sfe_matching_cost_store_samples: the sample transforms computed on the device, 244 poses per "
                        "session); what shgo decides from there (minimiser pool, order of the local minimisations, result) is "
                        "replayed by sfe_shgo_sobol_replay from the graph of ONE run of the installed scipy (shgo_fast.py); a session "
                        "whose finite-difference point lands in another cell, or with an exact distance tie, goes through "
