@@ -640,7 +640,7 @@ __global__ __launch_bounds__(256) void extract_expand_kernel(const unsigned long
 #define SG_LIST 1536  // set pixels a workgroup collects before it expands them (list + table: 18 KB, eight workgroups per CU)
 #define SG_BLOCK 1024 // mask words looked at per collection step (4 per thread)
 #define SG_TAB 1024   // slots of the canvas-word table
-#define SG_SPILL 512  // record form: slots per frame for words that found no table slot
+#define SG_SPILL 1024 // record form: slots per frame for words that found no table slot
 // COMPACT (round 4): 4-byte entries {decision table [15:0], tap place [17:16], dx [24:18], dy [31:25]} relative to a
 // per-pixel base bit index that travels with the pixel's offset ({offset, base} pairs: ONE 16-byte read brings the
 // pixel's offset, its base and the next offset), four entries per 16-byte read; entries that can never report (their
@@ -803,7 +803,7 @@ __global__ __launch_bounds__(256, 8) void extract_gather_kernel(const uint32_t *
                 unsigned slot = (wd * 0x9E3779B1u) >> (32 - 10);
                 static_assert(SG_TAB == 1 << 10, "slot bits");
 #pragma unroll 1
-                for (int probe = 0; probe < (RECORDS ? 4 : 1); ++probe) { // (records: a taken slot costs a global allocation)
+                for (int probe = 0; probe < (RECORDS ? 8 : 1); ++probe) { // (records: a taken slot costs a global allocation)
                     const unsigned old = atomicCAS(&s_tag[slot], 0xFFFFFFFFu, wd);
                     if (old == 0xFFFFFFFFu || old == wd) {
                         atomicOr(&s_acc[slot], m);
@@ -1222,7 +1222,10 @@ static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_f
             // has that many per workgroup (64 rows of 512 beams: a canvas word collects its bits from neighbouring rows,
             // so whole bands keep the table's words to one workgroup; 0.280 -> 0.259)
             const long long nwords = (long long)g->polar_rows * (g->polar_cols >> 5);
-            int slices = sg_slices > 0 ? sg_slices : std::max(2, std::min(64, 8192 / std::max(nf, 1)));
+            // (record path: twice the workgroups per frame -- a workgroup's table of 1024 canvas words is its record region, and
+            // at 8 workgroups per frame the densest bands of the bench's frames filled it: 77 spilled words per frame, each a
+            // returning atomic, 2 % of the frames handed back; profiles/r05_extract_records_stats.txt)
+            int slices = sg_slices > 0 ? sg_slices : std::max(2, std::min(64, (records ? 16384 : 8192) / std::max(nf, 1)));
             slices = (int)std::max<long long>(1, std::min<long long>(slices, (nwords + 63) / 64));
             int sg_piece = sg_piece_env >= 0 ? sg_piece_env : 4;
             while (sg_piece_env < 0 && sg_piece > 0 && (nwords >> (6 + sg_piece)) < slices)
