@@ -224,6 +224,92 @@ __global__ __launch_bounds__(COST_THREADS) void matching_cost_kernel(const uint3
     }
 }
 
+// Many poses per job (the 244 poses per session of shgo's replay, shgo_fast.py; round 5): the kernel above gives a workgroup of four
+// waves 8 poses and a private copy of the grid in LDS -- at 80 KB per grid that is ONE such workgroup per CU, four waves on a CU that
+// holds 32.  Here a workgroup of 16 waves stages the grid once and every wave scores COST_MANY_PW poses of its own against it
+// (64 poses per workgroup: a quarter of the stagings, four times the waves; no workgroup-wide reduction: a wave owns its poses).
+// F64 only differs from the kernel above in how it finds the cell: rint(fl(d / res)) costs two double divisions per point and
+// pose; q = d * fl(1 / res) is within 4e-16 |q| of the correctly rounded quotient, so rint(q) IS the cell unless q lies within
+// 1e-9 (|q| + 1) of a half-way point -- only then (and for non-finite q) the division is done.  Same integers, always.
+#define COST_MANY_THREADS 1024
+#define COST_MANY_PW 4 // poses per wave
+__device__ __forceinline__ double cost_cell_f64(double d, double res, double rinv)
+{
+    const double q = d * rinv, n = rint(q);
+    if (fabs(fabs(q - n) - 0.5) > 1e-9 * (fabs(q) + 1.0)) // (NaN: false)
+        return n;
+    return rint(__ddiv_rn(d, res));
+}
+
+template <bool F64>
+__global__ __launch_bounds__(COST_MANY_THREADS) void matching_cost_many_kernel(const uint32_t *__restrict__ bits_all,
+                                                                               const CostGridDesc *__restrict__ desc,
+                                                                               const CostJob *__restrict__ jobs,
+                                                                               const float *__restrict__ T6, int n_poses, float res32,
+                                                                               double res64, int use_desc_origin, float xmin_arg,
+                                                                               float ymin_arg, int32_t *__restrict__ cost)
+{
+    extern __shared__ uint32_t s_bits[];
+    const CostJob job = jobs[blockIdx.y];
+    const CostGridDesc d = desc[job.grid];
+    const int rows = d.rows, cols = d.cols, wpr = d.wpr;
+    const float xmin = use_desc_origin ? d.xmin : xmin_arg, ymin = use_desc_origin ? d.ymin : ymin_arg;
+    const uint32_t *__restrict__ bits = bits_all + d.word_off;
+    const int nwords = rows * wpr;
+    for (int i = threadIdx.x; i < nwords; i += COST_MANY_THREADS)
+        s_bits[i] = bits[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p0 = (blockIdx.x * (COST_MANY_THREADS / 64) + wave) * COST_MANY_PW;
+    if (p0 >= n_poses)
+        return;
+    float t[COST_MANY_PW][6];
+#pragma unroll
+    for (int k = 0; k < COST_MANY_PW; ++k) {
+        const float *T = T6 + 6 * ((size_t)blockIdx.y * n_poses + min(p0 + k, n_poses - 1));
+#pragma unroll
+        for (int e = 0; e < 6; ++e)
+            t[k][e] = T[e];
+    }
+    const double rinv = 1.0 / res64;
+    int hits[COST_MANY_PW] = {0, 0, 0, 0};
+    static_assert(COST_MANY_PW == 4, "hits initialiser");
+    for (int i = lane; i < job.n_src; i += 64) {
+        const float2 q = job.src[i];
+#pragma unroll
+        for (int k = 0; k < COST_MANY_PW; ++k) {
+            bool inside;
+            int r, c;
+            if (F64) {
+                const double x = __dadd_rn(__dadd_rn(__dmul_rn((double)q.x, (double)t[k][0]), __dmul_rn((double)q.y, (double)t[k][1])), (double)t[k][2]);
+                const double y = __dadd_rn(__dadd_rn(__dmul_rn((double)q.x, (double)t[k][3]), __dmul_rn((double)q.y, (double)t[k][4])), (double)t[k][5]);
+                const double fc = cost_cell_f64(__dadd_rn(x, -(double)xmin), res64, rinv), fr = cost_cell_f64(__dadd_rn(y, -(double)ymin), res64, rinv);
+                inside = fr >= 0.0 && fr < (double)rows && fc >= 0.0 && fc < (double)cols; // NaN fails
+                r = inside ? (int)fr : 0;
+                c = inside ? (int)fc : 0;
+            } else {
+                const float x = __fadd_rn(__fmaf_rn(q.y, t[k][1], __fmul_rn(q.x, t[k][0])), t[k][2]);
+                const float y = __fadd_rn(__fmaf_rn(q.y, t[k][4], __fmul_rn(q.x, t[k][3])), t[k][5]);
+                const float fc = rintf(__fdiv_rn(__fadd_rn(x, -xmin), res32)), fr = rintf(__fdiv_rn(__fadd_rn(y, -ymin), res32));
+                inside = fr >= 0.0f && fr < (float)rows && fc >= 0.0f && fc < (float)cols;
+                r = inside ? (int)fr : 0;
+                c = inside ? (int)fc : 0;
+            }
+            if (inside)
+                hits[k] += (s_bits[r * wpr + (c >> 5)] >> (c & 31)) & 1u;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < COST_MANY_PW; ++k) {
+        int h = hits[k];
+#pragma unroll
+        for (int dd = 32; dd >= 1; dd >>= 1)
+            h += __shfl_down(h, dd);
+        if (lane == 0 && p0 + k < n_poses)
+            cost[(size_t)blockIdx.y * n_poses + p0 + k] = -h;
+    }
+}
+
 // cv2.getStructuringElement(MORPH_ELLIPSE, (2h+1, 2h+1), (h, h)) row spans
 static std::vector<int32_t> cost_ellipse_spans(int dilate_hs)
 {
@@ -303,10 +389,21 @@ static int cost_launch(sfe_ctx *ctx, sfe_costgrid *g, const CostJob *d_jobs, int
                     : (lds ? matching_cost_kernel<false, true> : matching_cost_kernel<false, false>);
     if (lds)
         SFE_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    const dim3 grid((unsigned)((n_poses + COST_POSES_PER_BLOCK - 1) / COST_POSES_PER_BLOCK), (unsigned)n_jobs);
-    hipLaunchKernelGGL(kern, grid, dim3(COST_THREADS), smem, ctx->stream, (const uint32_t *)g->d_bits,
-                       (const CostGridDesc *)g->d_desc, d_jobs, d_T, n_poses, (float)resolution, resolution, use_desc_origin,
-                       xmin, ymin, d_cost);
+    const bool no_many = getenv("SFE_COST_NO_MANY") != nullptr; // A/B (read per call): the 8-poses-per-workgroup kernel for every launch
+    if (lds && n_poses >= 32 && !no_many) {
+        // many poses per job: 64 per workgroup of 16 waves around one staged grid
+        auto many = f64 ? matching_cost_many_kernel<true> : matching_cost_many_kernel<false>;
+        SFE_HIP(ctx, hipFuncSetAttribute((const void *)many, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        const int ppb = (COST_MANY_THREADS / 64) * COST_MANY_PW;
+        hipLaunchKernelGGL(many, dim3((unsigned)((n_poses + ppb - 1) / ppb), (unsigned)n_jobs), dim3(COST_MANY_THREADS), smem,
+                           ctx->stream, (const uint32_t *)g->d_bits, (const CostGridDesc *)g->d_desc, d_jobs, d_T, n_poses,
+                           (float)resolution, resolution, use_desc_origin, xmin, ymin, d_cost);
+    } else {
+        const dim3 grid((unsigned)((n_poses + COST_POSES_PER_BLOCK - 1) / COST_POSES_PER_BLOCK), (unsigned)n_jobs);
+        hipLaunchKernelGGL(kern, grid, dim3(COST_THREADS), smem, ctx->stream, (const uint32_t *)g->d_bits,
+                           (const CostGridDesc *)g->d_desc, d_jobs, d_T, n_poses, (float)resolution, resolution, use_desc_origin,
+                           xmin, ymin, d_cost);
+    }
     SFE_LAUNCH_CHECK(ctx);
     SFE_HIP(ctx, hipMemcpyAsync(h_cost, d_cost, sizeof(int32_t) * n_out, hipMemcpyDeviceToHost, ctx->stream));
     SFE_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -95,6 +95,50 @@ def test_gpu_grid_and_costs_bit_exact(ctx, seed, noise):
 
 
 @pytest.mark.gpu
+def test_gpu_many_poses_per_launch_equal_the_oracle_and_the_small_kernel(ctx):
+    """launches of >= 32 poses go through matching_cost_many_kernel (16 waves around one staged grid; the float64 body finds the
+    cell from a multiplication and divides only next to a half-way point): the same costs as the oracle and as the kernel of the
+    small launches, in both dtypes, for pose counts that fill waves and workgroups unevenly -- and on a grid whose resolution is a
+    power of two with points ON the half-way points between cells (np.round's half-to-even decides every one of them)"""
+    import os
+    src, sp, tgt, tp, _ = _scene(3, n=2500)
+    rng = np.random.default_rng(8)
+    for f64 in (True, False):
+        cloud = src.astype(np.float64) if f64 else src
+        sub, _ = mc.get_matching_cost_subroutine1(cloud, sp, tgt, tp, None, point_noise=0.5, ctx=ctx)
+        geo = sub.geometry
+        grid = sub.grid.download()
+        for P in (32, 33, 64, 65, 244, 300):
+            X = np.c_[rng.uniform(-1, 1, P), rng.uniform(-1, 1, P), rng.uniform(-0.2, 0.2, P)]
+            T6 = np.array([np.asarray(tp.between(sp.compose(mc.Pose2(*x))).matrix()).astype(np.float32)[:2].reshape(-1) for x in X])
+            want = oracle.matching_cost(grid, src, T6, geo["xmin"], geo["ymin"], 0.05, f64_points=f64)
+            got = sub.batch(X)
+            os.environ["SFE_COST_NO_MANY"] = "1"
+            try:
+                small = sub.batch(X)
+            finally:
+                del os.environ["SFE_COST_NO_MANY"]
+            assert np.array_equal(got, want) and np.array_equal(small, want) and (want < -200).any(), (f64, P)
+        sub.grid.close()
+    # ties: resolution 2^-4, the source points on k + 0.5 cells of the target's grid, the identity as one of the poses
+    tgt2 = (np.round(tgt * 16) / 16).astype(np.float32)
+    sub, _ = mc.get_matching_cost_subroutine1(np.zeros((4, 2)), tp, tgt2, tp, None, point_noise=0.625, ctx=ctx)
+    geo = sub.geometry
+    assert float(geo["resolution"]) == 0.0625
+    k = rng.integers(0, min(geo["rows"], geo["cols"]) - 1, (3000, 2))
+    half = (np.array([geo["xmin"], geo["ymin"]], np.float64) + (k + 0.5) * 0.0625)
+    assert np.array_equal(half.astype(np.float32).astype(np.float64), half)
+    sub.grid.close()
+    sub, _ = mc.get_matching_cost_subroutine1(half, tp, tgt2, tp, None, point_noise=0.625, ctx=ctx)
+    X = np.r_[np.zeros((1, 3)), np.c_[rng.uniform(-1, 1, 40), rng.uniform(-1, 1, 40), rng.uniform(-0.2, 0.2, 40)]]
+    T6 = np.array([np.asarray(tp.between(tp.compose(mc.Pose2(*x))).matrix()).astype(np.float32)[:2].reshape(-1) for x in X])
+    want = oracle.matching_cost(sub.grid.download(), half.astype(np.float32), T6, sub.geometry["xmin"], sub.geometry["ymin"], 0.0625,
+                                f64_points=True)
+    assert np.array_equal(sub.batch(X), want) and want[0] < 0
+    sub.grid.close()
+
+
+@pytest.mark.gpu
 def test_gpu_large_grid_is_read_through_l2(ctx):
     """a grid too large for LDS (point_noise 0.05 m -> 5 mm cells)"""
     src, sp, tgt, tp, X = _scene(6, n=800)

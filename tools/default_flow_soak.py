@@ -117,7 +117,7 @@ def main():
         # ---- cost grids over handles: several (source, target) pairs in one launch, both dtypes ----
         pairs = [(i, j) for i in range(m) for j in range(m) if sizes[i] >= 1 and sizes[j] >= 2 and sizes[j] <= 3000][:6]
         if pairs:
-            P = int(rng.integers(1, 20))
+            P = int(rng.choice([rng.integers(1, 20), rng.integers(32, 90)]))     # (>= 32: the many-poses kernel)
             for f64 in (True, False):
                 T6 = rng.normal(0, 1, (len(pairs), P, 6)).astype(np.float32)
                 T6[:, :, [0, 4]] += 1.0
