@@ -1224,8 +1224,12 @@ static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_f
             const long long nwords = (long long)g->polar_rows * (g->polar_cols >> 5);
             // (record path: twice the workgroups per frame -- a workgroup's table of 1024 canvas words is its record region, and
             // at 8 workgroups per frame the densest bands of the bench's frames filled it: 77 spilled words per frame, each a
-            // returning atomic, 2 % of the frames handed back; profiles/r05_extract_records_stats.txt)
-            int slices = sg_slices > 0 ? sg_slices : std::max(2, std::min(64, (records ? 16384 : 8192) / std::max(nf, 1)));
+            // returning atomic, 2 % of the frames handed back; profiles/r05_extract_records_stats.txt.
+            // Measured: 256 frames per launch 59.1 us with 32 workgroups per frame, 72.7 with 64; 512 frames 0.147 ms with 16, 0.165
+            // with 32; 1024 frames 0.256 ms with 16.  So: 8192 workgroups per launch, but between 16 and 32 per frame for batches.)
+            int slices = sg_slices > 0 ? sg_slices : std::max(2, std::min(64, 8192 / std::max(nf, 1)));
+            if (sg_slices <= 0 && records && nf >= 64)
+                slices = std::max(16, std::min(32, slices));
             slices = (int)std::max<long long>(1, std::min<long long>(slices, (nwords + 63) / 64));
             int sg_piece = sg_piece_env >= 0 ? sg_piece_env : 4;
             while (sg_piece_env < 0 && sg_piece > 0 && (nwords >> (6 + sg_piece)) < slices)

@@ -29,7 +29,9 @@ kb.upload_frames(frames)
 kb.run_cfar()
 kb.run_extract()
 ctx.sync()
-slices = max(2, min(64, 16384 // B))
+slices = max(2, min(64, 8192 // B))
+if B >= 64:
+    slices = max(16, min(32, slices))
 raw = np.zeros(B * (slices + 2), np.int32)
 ctx._check(ctx.lib.sfe_debug_read_scratch(ctx.handle, 62, raw.ctypes.data, raw.nbytes))
 cnt = raw[:B * (slices + 1)].reshape(B, slices + 1)

@@ -21,6 +21,7 @@ run() {
   db=$(find /tmp/prof_$name -name '*.db' | head -1)
   if [ -n "$db" ]; then
     python $R/tools/rocpd_summary.py $db > $R/gpurun_out/${tag}_$name.txt 2>&1
+    cp $db $R/gpurun_out/${tag}_$name.db
   else
     tail -5 /tmp/prof_$name.log
   fi
@@ -29,6 +30,7 @@ run extract_kernels -- python $R/tools/extract_times.py 256
 run extract_fetch FETCH_SIZE -- python $R/tools/extract_times.py 256
 run extract_write WRITE_SIZE -- python $R/tools/extract_times.py 256
 cd $R
+for B in 512 1024; do for v in 0 2; do EXTRACT_VARIANT=$v timeout 300 python tools/extract_times.py $B; done; done 2>&1 | tee gpurun_out/${tag}_extract_records_ab2.txt
 grep -i "extract" gpurun_out/${tag}_extract_kernels.txt | head -12
 grep -i "extract" gpurun_out/${tag}_extract_fetch.txt | head -12
 grep -i "extract" gpurun_out/${tag}_extract_write.txt | head -12
