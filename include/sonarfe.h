@@ -165,9 +165,10 @@ int sfe_remap_u8_colormap_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_src, i
  */
 int sfe_extract_points(sfe_ctx *ctx, sfe_geom *g, const uint8_t *mask, int64_t cap,
                        int64_t *rc_out, double *pts_out, int64_t *n_out);
-/* A-B knob of the extraction: 0 = binary masks go through the inverse map (walk the set polar pixels,
- * evaluate only the canvas pixels that tap them; default), 1 = dense pass over the whole canvas for every frame
- * (what non-binary masks take anyway).  Identical results. */
+/* A-B knob of the extraction: 0 = binary masks go through the inverse map (walk the set polar pixels, evaluate only the
+ * canvas pixels that tap them; default) -- bit-stream batches without a canvas bitmap in HBM (records merged in LDS), frames
+ * beyond that path's capacities and byte masks through the canvas bitmap; 1 = dense pass over the whole canvas for every
+ * frame (what non-binary masks take anyway); 2 = inverse map through the canvas bitmap for every frame.  Identical results. */
 int sfe_extract_set_tuning(sfe_ctx *ctx, int variant);
 /* device-resident batch: per frame f, points go to d_pts + f*cap*2 (float64), count to d_counts[f]
  * (count is the true number even if it exceeds cap; only the first cap points are stored) */
