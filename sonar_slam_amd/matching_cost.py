@@ -48,6 +48,34 @@ def _like(pose, x):
     return type(pose)(float(x[0]), float(x[1]), float(x[2]))
 
 
+def _sample_poses(lib, source_pose, target_pose, X):
+    """-> (T6 [n x 6] float32 of target_pose.between(source_pose.compose(n2g(x))).matrix() (slam.py:548-550), sample source poses
+    [n x 3] = g2n(source_pose.compose(n2g(x)))) for the deltas X [n x 3].  This package's Pose2: the library's host routine and
+    vector arithmetic with Pose2's own expressions (cos / sin / atan2 through ``math``); any other pose class (gtsam.Pose2): its
+    own methods, pose by pose."""
+    import math
+    X = np.asarray(X, np.float64).reshape(-1, 3)
+    n = len(X)
+    if type(source_pose) is Pose2 and type(target_pose) is Pose2 and n:
+        from .chained import Pose2Batch, sample_transforms
+        tb = Pose2Batch([target_pose._x], [target_pose._y], cs=([target_pose._c], [target_pose._s]))
+        sb = Pose2Batch([source_pose._x], [source_pose._y], cs=([source_pose._c], [source_pose._s]))
+        T6 = sample_transforms(lib, tb, sb, X)[0]
+        c = np.array([math.cos(t) for t in X[:, 2]])
+        sn = np.array([math.sin(t) for t in X[:, 2]])
+        one = np.zeros(n, np.int64)
+        sp = sb.take(one).compose(Pose2Batch(X[:, 0], X[:, 1], cs=(c, sn)))
+        return T6, sp.xytheta()
+    T6 = np.zeros((n, 6), np.float32)
+    poses = np.zeros((n, 3))
+    for i, x in enumerate(X):
+        sample_source_pose = source_pose.compose(_like(source_pose, x))
+        T = np.asarray(target_pose.between(sample_source_pose).matrix()).astype(np.float32)   # Keyframe.transform_points (slam_objects.py:193)
+        T6[i] = (T[0, 0], T[0, 1], T[0, 2], T[1, 0], T[1, 1], T[1, 2])
+        poses[i] = (sample_source_pose.x(), sample_source_pose.y(), sample_source_pose.theta())
+    return T6, poses
+
+
 def get_matching_cost_subroutine1(source_points, source_pose, target_points, target_pose, source_pose_cov=None,
                                   point_noise=0.5, ctx=None):
     """-> (subroutine, pose_samples), as slam.py:461-570.  ``point_noise`` is ``self.point_noise``
@@ -89,30 +117,32 @@ def get_matching_cost_subroutine1(source_points, source_pose, target_points, tar
         raise ValueError("float64 source clouds must hold float32 values (slam_ros.py:169-170); cast the cloud to float32 first")
     x0, y0, res32 = f32(xmin), f32(ymin), f32(resolution)
 
-    def batch(X):
+    def batch(X, record=True):
+        """costs of the deltas X [n x 3] in one launch; record=False: the evaluations are not entered into pose_samples (the caller
+        enters those the reference would have made: ``subroutine.record``)"""
         X = np.asarray(X, np.float64).reshape(-1, 3)
-        T6 = np.zeros((len(X), 6), f32)
-        sample_poses = []
-        for i, x in enumerate(X):
-            delta = _like(source_pose, x)                       # n2g(x, "Pose2")
-            sample_source_pose = source_pose.compose(delta)
-            sample_transform = target_pose.between(sample_source_pose)
-            T = np.asarray(sample_transform.matrix()).astype(f32)   # Keyframe.transform_points (slam_objects.py:193)
-            T6[i] = (T[0, 0], T[0, 1], T[0, 2], T[1, 0], T[1, 1], T[1, 2])
-            sample_poses.append(sample_source_pose)
+        T6, poses = _sample_poses(ctx.lib, source_pose, target_pose, X)
         cost = np.zeros(len(X), np.int32)
-        with ctx.lock:
-            ctx._check(ctx.lib.sfe_matching_cost_batch(ctx.handle, grid.handle, _L.ptr(src32, _C.c_float), len(src32),
-                                                       _L.ptr(T6, _C.c_float), len(T6), x0, y0, float(resolution), flags,
-                                                       _L.ptr(cost, _C.c_int32)))
-        for sp, cst in zip(sample_poses, cost):
-            pose_samples.append(np.r_[[sp.x(), sp.y(), sp.theta()], cst])   # np.r_[g2n(pose), cost]
+        if len(X):
+            with ctx.lock:
+                ctx._check(ctx.lib.sfe_matching_cost_batch(ctx.handle, grid.handle, _L.ptr(src32, _C.c_float), len(src32),
+                                                           _L.ptr(T6, _C.c_float), len(T6), x0, y0, float(resolution), flags,
+                                                           _L.ptr(cost, _C.c_int32)))
+        if record:
+            for sp, cst in zip(poses, cost):
+                pose_samples.append(np.r_[sp, cst])                         # np.r_[g2n(pose), cost]
         return cost
+
+    def record(X, costs):
+        _, poses = _sample_poses(ctx.lib, source_pose, target_pose, X)
+        for sp, cst in zip(poses, costs):
+            pose_samples.append(np.r_[sp, cst])
 
     def subroutine(x):
         return batch([x])[0]
 
     subroutine.batch = batch
+    subroutine.record = record
     subroutine.grid = grid            # keeps the device grid alive as long as the closure
     subroutine.geometry = dict(xmin=x0, ymin=y0, resolution=res32, rows=rows, cols=cols, dilate_hs=dilate_hs,
                                target_r=r, target_c=c)
@@ -264,24 +294,25 @@ def get_matching_cost_subroutine1_store(store, source_handle, source_pose, targe
     pose_samples = []
     f32 = np.float32
 
-    def batch(X):
+    def batch(X, record=True):
         X = np.asarray(X, np.float64).reshape(-1, 3)
-        T6 = np.zeros((len(X), 6), f32)
-        sample_poses = []
-        for i, x in enumerate(X):
-            sample_source_pose = source_pose.compose(_like(source_pose, x))
-            T = np.asarray(target_pose.between(sample_source_pose).matrix()).astype(f32)
-            T6[i] = (T[0, 0], T[0, 1], T[0, 2], T[1, 0], T[1, 1], T[1, 2])
-            sample_poses.append(sample_source_pose)
+        T6, poses = _sample_poses(store.ctx.lib, source_pose, target_pose, X)
         cost = grids.cost([source_handle], T6[None], f64_points)[0] if len(X) else np.zeros(0, np.int32)
-        for sp, cst in zip(sample_poses, cost):
-            pose_samples.append(np.r_[[sp.x(), sp.y(), sp.theta()], cst])
+        if record:
+            for sp, cst in zip(poses, cost):
+                pose_samples.append(np.r_[sp, cst])
         return cost
+
+    def record(X, costs):
+        _, poses = _sample_poses(store.ctx.lib, source_pose, target_pose, X)
+        for sp, cst in zip(poses, costs):
+            pose_samples.append(np.r_[sp, cst])
 
     def subroutine(x):
         return batch([x])[0]
 
     subroutine.batch = batch
+    subroutine.record = record
     subroutine.grid = grids
     subroutine.geometry = dict(xmin=grids.xmin[0], ymin=grids.ymin[0], resolution=f32(grids.resolution), rows=int(grids.rows[0]),
                                cols=int(grids.cols[0]), dilate_hs=grids.dilate_hs)

@@ -297,6 +297,23 @@ class FrontEnd(object):
                 if st == shgo_fast.FAILED:
                     return OptimizeResult(x=x, fun=np.int64(fun), success=False, nfev=plan.V, replayed=True,
                                           message="Failed to find a feasible minimizer point. Lowest sampling point = %s" % fun)
+        elif replay and hasattr(subroutine, "record") and shgo_fast.multi_checked(params[0], params[1], params[2]):
+            # several iterations (the loop-closure search): every point that can become a vertex + its finite-difference points in
+            # ONE launch, the iterations replayed on the host (shgo_fast.replay_multi); the evaluations the reference's run makes --
+            # the vertices shgo creates, four per local minimisation -- are the ones entered into the subroutine's pose_samples
+            draws, cand, fd = shgo_fast.multi_candidates(pose_bounds, params[0], params[1])
+            M = len(cand)
+            costs = np.asarray(subroutine.batch(np.concatenate([cand, fd.reshape(-1, 3)]), record=False), np.int64)
+            cost, fd_cost = costs[:M], costs[M:].reshape(M, 3)
+            st, x, fun, vertices, minimised = shgo_fast.replay_multi(pose_bounds, params[0], params[1], draws, cand, cost, fd_cost)
+            if st != shgo_fast.FALLBACK:
+                X = np.concatenate([cand[vertices], cand[minimised], fd[minimised].reshape(-1, 3)])
+                subroutine.record(X, np.concatenate([cost[vertices], cost[minimised], fd_cost[minimised].reshape(-1)]))
+                if st == shgo_fast.OK:
+                    return OptimizeResult(x=x, fun=np.int64(fun), success=True, message="Optimization terminated successfully.",
+                                          nfev=len(X), replayed=True)
+                return OptimizeResult(x=x, fun=np.int64(fun), success=False, nfev=len(vertices), replayed=True,
+                                      message="Failed to find a feasible minimizer point. Lowest sampling point = %s" % fun)
 
         def pool(_fn, xs):
             xs = [np.asarray(x, np.float64) for x in xs]
@@ -480,7 +497,8 @@ class FrontEnd(object):
             subroutine, pose_samples = self.matching_cost_subroutine(source_points, source_pose, target_local, target_pose, cov,
                                                                      f64_source=False)
             try:
-                result = self.shgo(subroutine, pose_bounds, self.nssm_initialization_params)
+                result = self.shgo(subroutine, pose_bounds, self.nssm_initialization_params, replay=self.shgo_replay)
+                rec["init_replayed"] = bool(result.get("replayed", False))
             finally:
                 subroutine.grid.close()
             if not result.success:

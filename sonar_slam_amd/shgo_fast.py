@@ -173,3 +173,158 @@ def plan_for(bounds, n, ftol):
     if p is None:
         p = _PLANS[key] = SobolPlan(bounds, n, ftol)
     return p
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# several iterations (the loop-closure search: shgo(n=100, iters=5), slam.py:952-961)
+# ---------------------------------------------------------------------------------------------------------------------------------
+# With iters > 1 the triangulation is no longer a function of (bounds, n): every iteration draws 128 k NEW Sobol points, appends the
+# local results found so far (duplicates of vertices), and hands `Tri.add_points` the rows behind the previous iteration's row count
+# -- so which of the new points enter depends on how many minimisers earlier iterations found.  What stays true for a piecewise-constant
+# cost: every point that CAN become a vertex is known beforehand (the rows [128 (k - 1), 128 k) of draw k: 640 points for (100, 5)),
+# so their costs and those of their finite-difference points are taken in ONE launch, and the iterations are then replayed on the
+# host: scipy.spatial.Delaunay itself for the incremental triangulation (the same calls on the same arrays), the vertex-vertex
+# graph, the vertex-cache order, the minimiser pool and its order, the local results and the final argsort restated from
+# scipy/optimize/_shgo.py -- vectorised where shgo walks Python objects (its `minimizers` and `vf_to_vv` are 85 % of a 150 ms call).
+FD_STEP = 1.4901161193847656e-08        # SLSQP's forward-difference step (scipy/optimize/_slsqp_py.py: _epsilon = sqrt(eps))
+_DRAWS = {}
+
+
+def _sobol_draws(n, iters, dim=3):
+    """the unit-cube points draw k of shgo's engine returns (draw k has n2 * k rows; the sequence continues over the draws)"""
+    from scipy.stats import qmc
+    key = (int(n), int(iters), int(dim))
+    if key not in _DRAWS:
+        n2 = int(2 ** np.ceil(np.log2(n)))
+        engine = qmc.Sobol(d=dim, scramble=False, seed=0)
+        _DRAWS[key] = (n2, [engine.random(n2 * (k + 1)) for k in range(iters)])
+    return _DRAWS[key]
+
+
+def multi_candidates(bounds, n, iters):
+    """-> (draws: the scaled sample arrays of every iteration, cand [M x 3]: every point that can become a vertex, fd [M x 3 x 3])"""
+    bounds = np.array(bounds, float)
+    n2, units = _sobol_draws(n, iters, len(bounds))
+    draws = []
+    for U in units:
+        C = U.copy()
+        for i in range(len(bounds)):                                   # SHGO.sampling_custom, operation for operation
+            C[:, i] = (C[:, i] * (bounds[i][1] - bounds[i][0]) + bounds[i][0])
+        draws.append(C)
+    cand = np.concatenate([C[n2 * k:] for k, C in enumerate(draws)])
+    fd = np.repeat(cand[:, None, :], 3, axis=1)
+    for i in range(3):
+        fd[:, i, i] = cand[:, i] + FD_STEP
+    return draws, cand, fd
+
+
+def replay_multi(bounds, n, iters, draws, cand, cost, fd_cost):
+    """shgo(sobol, iters) after the evaluations: cand / cost [M] / fd_cost [M x 3] as multi_candidates laid them out.
+    -> (status, x, fun, vertices: indices into cand of the vertices shgo creates, minimised: indices of the starts it minimises, in
+    order).  FALLBACK: a start whose finite-difference points cost something else, a distance tie, a point too close to a bound."""
+    from scipy import spatial
+    bounds = np.array(bounds, float)
+    n2 = len(draws[0])
+    cost = np.asarray(cost, np.int64)
+    if np.any(bounds[:, 1] - cand.max(axis=0) <= 4 * FD_STEP):
+        return FALLBACK, None, None, None, None          # (SLSQP would difference backwards there)
+    index = {row.tobytes(): i for i, row in enumerate(cand)}
+    M = len(cand)
+    created = np.zeros(M, bool)
+    cache = []                                           # vertex-cache order (indices into cand)
+    nbr_min = np.full(M, np.iinfo(np.int64).max, np.int64)   # lowest cost among a vertex's neighbours (edges only ever add up)
+    xl, fl = [], []                                      # local results in the order they were found (indices, costs)
+    done = np.zeros(M, bool)                             # vertices that are local results already (SHGO.minimizers skips them)
+    tri, n_prc, pid = None, 0, np.zeros(0, np.int64)
+    for k in range(iters):
+        C = draws[k]
+        if xl:
+            C = np.vstack((C, cand[xl]))
+        if tri is None:
+            tri = spatial.Delaunay(C, incremental=True)
+        else:
+            tri.add_points(C[n_prc:, :])
+        n_prc = C.shape[0]
+        pts = tri.points
+        if len(pts) > len(pid):                          # cand index of every row of the triangulation
+            new = [index.get(row.tobytes(), -1) for row in pts[len(pid):]]
+            pid = np.concatenate([pid, np.array(new, np.int64)])
+            if (pid < 0).any():
+                return FALLBACK, None, None, None, None  # a triangulated point outside the candidate set: not this restatement's case
+        s = pid[tri.simplices[:, :3]]                    # vf_to_vv touches vertices 0, 1, 2 of a simplex, never the fourth
+        flat = s.reshape(-1)
+        uniq, first = np.unique(flat, return_index=True)
+        fresh = uniq[~created[uniq]]
+        fresh = fresh[np.argsort(first[~created[uniq]], kind="stable")]
+        created[fresh] = True
+        cache.extend(int(v) for v in fresh)
+        for a, b in ((0, 1), (0, 2), (1, 2)):
+            u, v = s[:, a], s[:, b]
+            ok = u != v
+            np.minimum.at(nbr_min, u[ok], cost[v[ok]])
+            np.minimum.at(nbr_min, v[ok], cost[u[ok]])
+        # SHGO.minimizers: vertices strictly below all their neighbours, in cache order, local results skipped
+        order = np.array(cache, np.int64)
+        is_min = (cost[order] < nbr_min[order]) & ~done[order]
+        pool = [int(v) for v in order[is_min]]
+        if not pool:
+            continue
+        if any((fd_cost[v] != cost[v]).any() for v in pool):
+            return FALLBACK, None, None, None, None
+        seq = [pool[0]]
+        rest = pool[1:]
+        while rest:
+            d = np.sqrt(((cand[rest] - cand[seq[-1]]) ** 2).sum(axis=1))
+            far = np.nonzero(d == d.max())[0]
+            if len(far) > 1:
+                return FALLBACK, None, None, None, None
+            seq.append(rest.pop(int(far[0])))
+        for v in seq:
+            xl.append(v)
+            fl.append(cost[v])
+            done[v] = True
+    vertices = np.array(cache, np.int64)
+    if not xl:
+        v = int(vertices[np.argmin(cost[vertices])])     # find_lowest_vertex: the first lowest in cache order
+        return FAILED, cand[v].copy(), cost[v], vertices, np.zeros(0, np.int64)
+    v = xl[lowest_result(np.array(fl, np.int64))]
+    return OK, cand[v].copy(), cost[v], vertices, np.array(xl, np.int64)
+
+
+_MULTI_OK = {}
+
+
+def multi_checked(n, iters, ftol, rounds=3, seed=5):
+    """replay_multi against the installed scipy.optimize.shgo on a few random step functions, once per process and (n, iters):
+    result, value, success and the multiset of evaluated points must agree (problems the replay hands back do not count)"""
+    key = (int(n), int(iters), float(ftol))
+    if key not in _MULTI_OK:
+        from scipy.optimize import shgo
+        rng = np.random.default_rng(seed)
+        good, decided = True, 0
+        for r in range(rounds + 3):
+            if decided >= rounds:
+                break
+            stds = np.array([[rng.uniform(0.2, 3), rng.uniform(0.2, 3), rng.uniform(0.01, 0.3)]]).T
+            bounds = 5.0 * np.c_[-stds, stds]
+            f = piecewise_constant(rng, bounds[:, 1] - bounds[:, 0], coarse=(r == 1))
+            draws, cand, fd = multi_candidates(bounds, n, iters)
+            cost = np.array([f(p) for p in cand])
+            fd_cost = np.array([[f(p) for p in row] for row in fd])
+            st, x, fun, vertices, minimised = replay_multi(bounds, n, iters, draws, cand, cost, fd_cost)
+            if st == FALLBACK:
+                continue
+            asked = []
+
+            def g(p):
+                asked.append(tuple(np.asarray(p, float)))
+                return f(p)
+            res = shgo(func=g, bounds=bounds, n=n, iters=iters, sampling_method="sobol", minimizer_kwargs={"options": {"ftol": ftol}})
+            mine = [tuple(cand[v]) for v in vertices]
+            for v in minimised:
+                mine.append(tuple(cand[v]))
+                mine.extend(tuple(p) for p in fd[v])
+            good &= bool(res.success) == (st == OK) and np.array_equal(res.x, x) and res.fun == fun and sorted(mine) == sorted(asked)
+            decided += 1
+        _MULTI_OK[key] = bool(good and decided >= 1)
+    return _MULTI_OK[key]

@@ -142,6 +142,76 @@ def test_front_end_shgo_replay_on_the_matching_cost():
     assert n_replayed >= 4
 
 
+def test_shgo_replay_of_several_iterations_equals_scipy():
+    """shgo_fast.replay_multi (the loop-closure search's shgo(100, 5): every possible vertex and its finite-difference points scored
+    beforehand, the iterations replayed with scipy's own incremental Delaunay) against scipy.optimize.shgo: result, value, success
+    and the multiset of evaluated points -- random bounds, ordinary / plateau / finer-than-the-step functions, three (n, iters)"""
+    from scipy.optimize import shgo
+    from sonar_slam_amd import shgo_fast as sf
+    rng = np.random.default_rng(77)
+    seen = {sf.OK: 0, sf.FAILED: 0, sf.FALLBACK: 0}
+    for r, (n, iters) in enumerate([(100, 5), (100, 5), (50, 2), (100, 3), (100, 5), (64, 4), (100, 5), (30, 2)]):
+        stds = np.array([[rng.uniform(0.2, 3), rng.uniform(0.2, 3), rng.uniform(0.01, 0.3)]]).T
+        bounds = 5.0 * np.c_[-stds, stds]
+        span = bounds[:, 1] - bounds[:, 0]
+        f = sf.piecewise_constant(rng, span * (1e-6 if r == 4 else 1.0), coarse=(r == 1), n_planes=(1 if r == 7 else 24))
+        if r == 7:
+            f = lambda x: np.int64(-3)          # a plateau: no strict minimiser in any iteration -> shgo fails
+        draws, cand, fd = sf.multi_candidates(bounds, n, iters)
+        cost = np.array([f(p) for p in cand])
+        fd_cost = np.array([[f(p) for p in row] for row in fd])
+        st, x, fun, vertices, minimised = sf.replay_multi(bounds, n, iters, draws, cand, cost, fd_cost)
+        seen[st] += 1
+        if st == sf.FALLBACK:
+            continue
+        asked = []
+
+        def g(p, f=f):
+            asked.append(tuple(np.asarray(p, float)))
+            return f(p)
+        res = shgo(func=g, bounds=bounds, n=n, iters=iters, sampling_method="sobol", minimizer_kwargs={"options": {"ftol": 0.01}})
+        assert bool(res.success) == (st == sf.OK) and np.array_equal(res.x, x) and res.fun == fun, (r, n, iters)
+        mine = [tuple(cand[v]) for v in vertices]
+        for v in minimised:
+            mine.append(tuple(cand[v]))
+            mine.extend(tuple(p) for p in fd[v])
+        assert sorted(mine) == sorted(asked), (r, len(mine), len(asked))
+    assert seen[sf.OK] >= 4 and seen[sf.FAILED] >= 1 and seen[sf.FALLBACK] >= 1, seen
+    assert sf.multi_checked(100, 5, 0.01)
+
+
+def test_front_end_shgo_replay_of_the_loop_closure_parameters():
+    """FrontEnd.shgo with (100, 5, 0.01) on the oracle's matching cost == the reference's call (chain.run_shgo): result, value,
+    success, and the pose samples the subroutine has collected afterwards (what initial_transforms draws its <= 30 guesses from)"""
+    from sonar_slam_amd.replay import FrontEnd
+    n_replayed = 0
+    for seed in range(3):
+        src, tgt, guess, _ = synth.scan_pair(seed=60 + seed, n_src=350, n_tgt=400)
+        sp, tp = chain.pose(*synth.pose_of(guess)), chain.pose(0.0, 0.0, 0.0)
+        pose_stds = np.array([[0.4 + 0.2 * seed, 0.5, 0.05]]).T
+        bounds = 5.0 * np.c_[-pose_stds, pose_stds]
+        sub_a, samples_a = chain.matching_cost_subroutine(src, sp, tgt, tp, 0.5, f64_points=False)
+        sub_b, samples_b = chain.matching_cost_subroutine(src, sp, tgt, tp, 0.5, f64_points=False)
+
+        def batch(X, record=True, sub_b=sub_b, samples_b=samples_b):
+            n0 = len(samples_b)
+            out = [sub_b(x) for x in X]
+            if not record:
+                del samples_b[n0:]
+            return out
+        sub_b.batch = batch
+        sub_b.record = lambda X, costs, sub_b=sub_b: [sub_b(x) for x in X]
+        ra = chain.run_shgo(sub_a, bounds, (100, 5, 0.01))
+        rb = FrontEnd.shgo(sub_b, bounds, (100, 5, 0.01))
+        n_replayed += bool(rb.get("replayed"))
+        assert bool(ra.success) == bool(rb.success) and np.array_equal(ra.x, rb.x) and ra.fun == rb.fun
+        key = lambda L: sorted(tuple(np.asarray(r, float)) for r in L)
+        assert key(samples_a) == key(samples_b) and len(samples_a) > 500
+        ga, gb = chain.initial_transforms(samples_a, tp), chain.initial_transforms(samples_b, tp)
+        assert [tuple(g) for g in ga] == [tuple(g) for g in gb]
+    assert n_replayed >= 2
+
+
 def test_sample_transforms_of_many_sessions_equal_pose2():
     """chained.sample_transforms (the library's host routine sfe_pose2_sample_transforms) == the float32 matrix rows of
     target.between(source.compose(Pose2(*x))) computed with the scalar Pose2, bit for bit -- rotations that need the
@@ -622,3 +692,19 @@ def test_front_end_loop_closure_search_equals_the_oracle_chain(ctx):
             assert _same(na["cov"], no["cov"], 1e-9)
         n_ok += na["status"] == "SUCCESS"
     assert n_ok >= 1 and len(logs[0][1]) == len(logs[1][1]) == n_ok
+    # the searches' shgo(100, 5) was replayed (shgo_fast.replay_multi); with scipy.optimize.shgo itself: the same records
+    searches = [r["nssm"] for r in logs[0][0] if r.get("nssm") is not None and "init_replayed" in r["nssm"]]
+    assert searches and sum(n["init_replayed"] for n in searches) >= len(searches) - 1
+    _, log_scipy = _replay_session(ctx, pings, bearings, dr, rows, None, ssm_min_points=20, nssm_enable=True, nssm_min_points=30,
+                                   mcd_random_state=0, shgo_replay=False)
+    for a, b in zip(logs[0][0], log_scipy):
+        na, nb = a.get("nssm"), b.get("nssm")
+        assert (na is None) == (nb is None)
+        if na is not None:
+            na, nb = dict(na), dict(nb)
+            na.pop("init_replayed", None)
+            nb.pop("init_replayed", None)
+            assert set(na) == set(nb)
+            for key in na:
+                assert _same(na[key], nb[key]), (key, na[key], nb[key])
+        assert a["status"] == b["status"] and a["pose"] == b["pose"]

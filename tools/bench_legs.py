@@ -638,8 +638,10 @@ def loop_closure(ctx, det, threads, n_keyframes=14, rows=1024, beams=512, world_
     """The loop-closure search of slam.py:839-1087 over the device-resident keyframe store (VERDICT r4 missing 3): one
     session on a closed trajectory (13 keyframes per lap), replay.FrontEnd(store, nssm_enable=True): after every keyframe the
     aggregated source cloud, the keyed global target cloud of every keyframe older than k - 8 (descriptor overload of
-    pcl.downsample), the field-of-view gate, shgo (100 x 5) on the device cost function, the target-key refinement, <= 30 ICPs on
-    one pair in one launch, MinCovDet, the gates.  Parity: the whole session through oracle/chain.py (initialization + nssm)."""
+    pcl.downsample), the field-of-view gate, shgo (100 x 5) on the device cost function -- its decisions replayed from ONE launch
+    over every point that can become a vertex (shgo_fast.replay_multi) -- the target-key refinement, <= 30 ICPs on one pair in
+    one launch, MinCovDet, the gates.  Parity: the whole session through oracle/chain.py (initialization + nssm, scipy's shgo),
+    and against the same front end with scipy.optimize.shgo in the loop."""
     import oracle
     from oracle import chain
     from sonar_slam_amd import icp_config, synth
@@ -657,15 +659,32 @@ def loop_closure(ctx, det, threads, n_keyframes=14, rows=1024, beams=512, world_
     pings = [SonarPing(f, bearings, 30.0 / rows, ping_id=k) for k, f in enumerate(frames)]
     fe.generate_map_xy(pings[0])
 
-    def run():
+    def run(shgo_replay):
         s = st.CloudStore(ctx, capacity_points=1 << 20, max_clouds=1024)
-        front = FrontEnd(ctx, keyframe_translation=1.5, keyframe_duration=0.5, store=s, nssm_enable=True, mcd_random_state=0)
+        front = FrontEnd(ctx, keyframe_translation=1.5, keyframe_duration=0.5, store=s, nssm_enable=True, mcd_random_state=0,
+                         shgo_replay=shgo_replay)
         t0 = time.perf_counter()
         log, t_fe, t_slam = replay(pings, np.arange(n_keyframes, dtype=float), dr, fe, front)
         dt = time.perf_counter() - t0
         s.close()
         return front, log, dt, t_fe, t_slam
-    front, log, dt, t_fe, t_slam = run()    # (one run: a search is seconds of scipy's shgo (100 x 5) on the host)
+    # the replays of shgo's decisions are checked against the installed scipy once per process: not part of the timed session
+    from sonar_slam_amd import shgo_fast
+    pose_stds = np.array([[0.2, 0.2, 0.02]]).T
+    plan = shgo_fast.plan_for(5.0 * np.c_[-pose_stds, pose_stds], 50, 0.01)
+    if plan.checked is None:
+        plan.self_check()
+    shgo_fast.multi_checked(100, 5, 0.01)
+    front, log, dt, t_fe, t_slam = run(True)
+    _, log_scipy, dt_scipy, _, t_slam_scipy = run(False)       # scipy.optimize.shgo for every initialisation: the same records
+    for a, b in zip(log, log_scipy):
+        na, nb = dict(a.get("nssm") or {}), dict(b.get("nssm") or {})
+        na.pop("init_replayed", None)
+        nb.pop("init_replayed", None)
+        same = a["status"] == b["status"] and a["pose"] == b["pose"] and set(na) == set(nb) and all(
+            np.array_equal(np.asarray(na[k]), np.asarray(nb[k])) for k in na)
+        if not same:
+            raise AssertionError("loop_closure: keyframe %d differs between the replayed shgo and scipy.optimize.shgo" % a["source_key"])
     searches = [r["nssm"] for r in log if r.get("nssm") is not None]
     clouds = [chain.slam_cloud(chain.feature_cloud(f, det.params["SOCA"], "SOCA", 65, fe)[1]) for f in frames]
     oracle.set_kdtree(1)
@@ -700,6 +719,10 @@ def loop_closure(ctx, det, threads, n_keyframes=14, rows=1024, beams=512, world_
             "searches": len(searches), "status_counts": status, "accepted_loops": status.get("SUCCESS", 0),
             "seconds_per_session": dt, "ms_per_keyframe_front_end": 1e3 * t_fe / n_keyframes,
             "ms_per_keyframe_slam_side": 1e3 * t_slam / n_keyframes, "ms_per_search_incl_ssm": 1e3 * t_slam / max(1, len(searches)),
+            "searches_whose_shgo_was_replayed": sum(bool(n.get("init_replayed")) for n in searches),
+            "scipy_only": {"seconds_per_session": dt_scipy, "ms_per_search_incl_ssm": 1e3 * t_slam_scipy / max(1, len(searches)),
+                           "note": "scipy.optimize.shgo itself for every initialisation (FrontEnd(shgo_replay=False)): the records "
+                                   "of the two runs are compared field by field"},
             "largest_global_target_points": max([n.get("n_target_global", 0) for n in searches] + [0]),
             "largest_icp_target_points": max([n.get("n_target", 0) for n in searches] + [0]),
             "oracle_chain_seconds": t_oracle,
