@@ -129,14 +129,12 @@ def get_matching_cost_subroutine1(source_points, source_pose, target_points, tar
                                                            _L.ptr(T6, _C.c_float), len(T6), x0, y0, float(resolution), flags,
                                                            _L.ptr(cost, _C.c_int32)))
         if record:
-            for sp, cst in zip(poses, cost):
-                pose_samples.append(np.r_[sp, cst])                         # np.r_[g2n(pose), cost]
+            pose_samples.extend(np.c_[poses, np.asarray(cost, np.float64)])     # np.r_[g2n(pose), cost] per evaluation
         return cost
 
     def record(X, costs):
         _, poses = _sample_poses(ctx.lib, source_pose, target_pose, X)
-        for sp, cst in zip(poses, costs):
-            pose_samples.append(np.r_[sp, cst])
+        pose_samples.extend(np.c_[poses, np.asarray(costs, np.float64)])
 
     def subroutine(x):
         return batch([x])[0]
@@ -299,14 +297,12 @@ def get_matching_cost_subroutine1_store(store, source_handle, source_pose, targe
         T6, poses = _sample_poses(store.ctx.lib, source_pose, target_pose, X)
         cost = grids.cost([source_handle], T6[None], f64_points)[0] if len(X) else np.zeros(0, np.int32)
         if record:
-            for sp, cst in zip(poses, cost):
-                pose_samples.append(np.r_[sp, cst])
+            pose_samples.extend(np.c_[poses, np.asarray(cost, np.float64)])
         return cost
 
     def record(X, costs):
         _, poses = _sample_poses(store.ctx.lib, source_pose, target_pose, X)
-        for sp, cst in zip(poses, costs):
-            pose_samples.append(np.r_[sp, cst])
+        pose_samples.extend(np.c_[poses, np.asarray(costs, np.float64)])
 
     def subroutine(x):
         return batch([x])[0]

@@ -528,7 +528,7 @@ class FrontEnd(object):
         initial_transform = target_pose.between(estimated_source_pose)
         use_samples = self.nssm_cov_samples > 0 and pose_samples is not None
         if self.nssm_initialization and self.nssm_cov_samples > 0:
-            guesses = self.initial_transforms(pose_samples, target_pose)[:self.nssm_cov_samples] if use_samples else []
+            guesses = self.initial_transforms(pose_samples, target_pose, limit=self.nssm_cov_samples) if use_samples else []
             rec["n_guesses"] = len(guesses)
             message, odom, cov_icp, samples = self.compute_icp_with_cov(source_points, target_local, guesses)
             rec["icp"] = message
@@ -559,21 +559,25 @@ class FrontEnd(object):
         self.backend.add_loop(target_key, source_key, odom, cov_icp)           # -> PCM + ISAM2 (slam.py:1089-1130): back end
 
     @staticmethod
-    def initial_transforms(pose_samples, target_pose, sample_eps=0.01):
+    def initial_transforms(pose_samples, target_pose, sample_eps=0.01, limit=None):
         """ICPResult.__init__ (slam_objects.py:287-300): the sampled source poses by ascending cost, as transforms from
         the target, near-duplicates dropped.  The reference sorts with ``np.argsort(cost)`` -- an unstable sort of integer
         costs full of ties, over samples whose order is the iteration order of a Python set inside shgo -- so its order
         among equal costs changes from run to run; here ties go by (x, y, theta): one of the orders the reference can
-        produce, the same on every run."""
+        produce, the same on every run.  ``limit``: stop after that many kept transforms (the caller uses the first
+        cov_samples only, slam.py:346: the filter looks at the last kept one alone, so the head of the list is the same)."""
         ps = np.asarray(pose_samples, np.float64)
         idx = np.lexsort((ps[:, 2], ps[:, 1], ps[:, 0], ps[:, 3]))
-        transforms = [target_pose.between(Pose2(*g)) for g in ps[idx, :3]]
-        filtered = [transforms[0]]
-        for b in transforms[1:]:
-            d = filtered[-1].between(b)
-            if np.linalg.norm([d.x(), d.y(), d.theta()]) < sample_eps:
-                continue
+        filtered = []
+        for g in ps[idx, :3]:
+            b = target_pose.between(Pose2(*g))
+            if filtered:
+                d = filtered[-1].between(b)
+                if np.linalg.norm([d.x(), d.y(), d.theta()]) < sample_eps:
+                    continue
             filtered.append(b)
+            if limit is not None and len(filtered) >= limit:
+                break
         return filtered
 
     def _release(self, ref):
