@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256, 3) void cfar_u8_ring(const uint8_t *__restrict
                                                     int n_frames, int groups_per_tile,
                                                     int tiles_per_frame, int chunks_per_row,
                                                     long long out_frame_bytes, CfarLut lut, float *__restrict__ thr = nullptr,
-                                                    CfarThrArith ta = CfarThrArith{0.0, 0.0, 1.0, 0})
+                                                    CfarThrArith ta = CfarThrArith{0.0, 0.0, 1.0, 0}, int full_last_tile = 0)
 {
     static_assert(!(THR && BITS), "the threshold map goes with the byte mask");
     constexpr int H = T + G;
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256, 3) void cfar_u8_ring(const uint8_t *__restrict
     // rows were computed twice, 9 % of the launch)
     const int full_rows = groups_per_tile * R;       // <= rows
     const bool last_tile = t == tiles_per_frame - 1;
-    const int my_groups = last_tile ? (rows - t * full_rows + R - 1) / R : groups_per_tile;
+    const int my_groups = (last_tile && !full_last_tile) ? (rows - t * full_rows + R - 1) / R : groups_per_tile;
     const int tile_rows = my_groups * R;
     const int r0 = last_tile ? rows - tile_rows : t * full_rows;
 
@@ -920,15 +920,16 @@ static void launch_ring(sfe_ctx *ctx, int alg, const uint8_t *d_img, uint8_t *d_
     const int chunks = ((cols >> 2) + 63) / 64;
     const long long bpf = ((long long)tiles * chunks + 3) / 4;             // workgroups per frame
     const unsigned blocks = (unsigned)((((long long)n_frames + 7) / 8) * 8 * bpf); // frames padded to the 8 XCDs
+    static const int full_last = getenv("SFE_CFAR_FULL_LAST_TILE") ? 1 : 0; // A/B: the last tile as long as the others (rounds 1-4)
     if (alg == SFE_CFAR_SOCA)
         hipLaunchKernelGGL((cfar_u8_ring<T, G, SFE_CFAR_SOCA, D, BITS, THR>), dim3(blocks), dim3(256), 0, ctx->stream,
-                           d_img, d_mask, rows, cols, n_frames, groups, tiles, chunks, out_frame_bytes, lut, d_thr, ta);
+                           d_img, d_mask, rows, cols, n_frames, groups, tiles, chunks, out_frame_bytes, lut, d_thr, ta, full_last);
     else if (alg == SFE_CFAR_GOCA)
         hipLaunchKernelGGL((cfar_u8_ring<T, G, SFE_CFAR_GOCA, D, BITS, THR>), dim3(blocks), dim3(256), 0, ctx->stream,
-                           d_img, d_mask, rows, cols, n_frames, groups, tiles, chunks, out_frame_bytes, lut, d_thr, ta);
+                           d_img, d_mask, rows, cols, n_frames, groups, tiles, chunks, out_frame_bytes, lut, d_thr, ta, full_last);
     else
         hipLaunchKernelGGL((cfar_u8_ring<T, G, SFE_CFAR_CA, D, BITS, THR>), dim3(blocks), dim3(256), 0, ctx->stream,
-                           d_img, d_mask, rows, cols, n_frames, groups, tiles, chunks, out_frame_bytes, lut, d_thr, ta);
+                           d_img, d_mask, rows, cols, n_frames, groups, tiles, chunks, out_frame_bytes, lut, d_thr, ta, full_last);
 }
 
 // cfar_thr_arith checked against the reference expression for every window sum of (alg, T, tau): on = 1 when each of them

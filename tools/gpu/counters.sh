@@ -31,7 +31,7 @@ run() { # name, pmc args..., -- command
     tail -5 /tmp/prof_$name.log
   fi
 }
-run cfar_bits_kernels -- python $R/tools/cfar_sweep.py --only --bits
+run cfar_bits_kernels -- python $R/tools/cfar_sweep.py --only --bits --reps 120   # (363 launches: the device's sustained clocks, profiles/r05_cfar_series.txt)
 run cfar_bits_fetch FETCH_SIZE -- python $R/tools/cfar_sweep.py --only --bits
 run cfar_bits_write WRITE_SIZE -- python $R/tools/cfar_sweep.py --only --bits
 run extract_fetch FETCH_SIZE -- python $R/tools/extract_times.py 256

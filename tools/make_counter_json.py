@@ -36,6 +36,13 @@ def kernel_us(name):
             db.execute("select name, count(*), avg(duration), min(duration), max(duration) from kernels group by name")}
 
 
+def kernel_series_us(name, kernel):
+    """durations (us) of every dispatch of `kernel`, in start order"""
+    db = sqlite3.connect(os.path.join(G, "%s_%s.db" % (tag, name)))
+    return [d / 1e3 for n, d in db.execute("select name, duration from kernels order by start")
+            if n.split("(")[0].replace("void ", "") == kernel]
+
+
 def have(name):
     return os.path.exists(os.path.join(G, "%s_%s.db" % (tag, name)))
 
@@ -95,6 +102,14 @@ def main():
            "launches": us[k][0], "avg_us_per_launch": us[k][1], "min_us_per_launch": us[k][2], "max_us_per_launch": us[k][3]}
     out["traffic_over_algorithmic"] = out["traffic_bytes_per_launch"] / out["algorithmic_bytes_per_launch"]
     out["frac_of_hbm_peak_rocprof"] = out["algorithmic_bytes_per_launch"] / (out["avg_us_per_launch"] * 1e-6) / 8e12
+    # the device reaches its sustained clocks after ~100 launches (profiles/r05_cfar_series.txt): the launches of the second half
+    # of the pass are what the bench line's `roofline.ms_per_launch` (timed after the launch time has settled) compares with
+    ser = kernel_series_us("cfar_bits_kernels", k)
+    if len(ser) >= 40:
+        half = ser[len(ser) // 2:]
+        out["avg_us_per_launch_second_half_of_the_pass"] = sum(half) / len(half)
+        out["avg_us_per_launch_first_20"] = sum(ser[:20]) / 20.0
+        out["frac_of_hbm_peak_rocprof_sustained"] = out["algorithmic_bytes_per_launch"] / (out["avg_us_per_launch_second_half_of_the_pass"] * 1e-6) / 8e12
     json.dump(out, open(os.path.join(ROOT, "profiles", "cfar_bits_pmc.json"), "w"), indent=1)
     # ---- extraction ----
     f, du = counters("extract_fetch")
