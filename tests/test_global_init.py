@@ -212,6 +212,39 @@ def test_front_end_shgo_replay_of_the_loop_closure_parameters():
     assert n_replayed >= 2
 
 
+def test_grid_geometry_of_many_boxes_equals_the_scalar_numpy():
+    """matching_cost.grid_geometry_many (float32 array arithmetic for np.arange's length) == grid_geometry (slam.py:506-511 on
+    numpy scalars) for thousands of bounding boxes and several point noises; the self check that guards it stays armed"""
+    from sonar_slam_amd import matching_cost as mc
+    rng = np.random.default_rng(4)
+    n = 3000
+    mn = rng.uniform(-40, 5, (n, 2)).astype(np.float32)
+    mx = (mn + rng.uniform(0.0, 60, (n, 2))).astype(np.float32)
+    mx[:30] = mn[:30]                                        # degenerate boxes: one point
+    bbox = np.c_[mn, mx]
+    for noise in (0.5, 0.25, 0.3, 0.625):
+        mc._MANY_OK = None
+        got = mc.grid_geometry_many(bbox, noise)
+        assert mc._MANY_OK is True
+        again = mc.grid_geometry_many(bbox[::-1], noise)     # (later calls probe eight boxes only)
+        for i in range(0, n, 7):
+            want = mc.grid_geometry(bbox[i], noise)
+            assert (got[0][i], got[1][i], got[2], got[3][i], got[4][i], got[5]) == want
+            j = n - 1 - i
+            assert (again[0][j], again[1][j], again[3][j], again[4][j]) == (want[0], want[1], want[3], want[4])
+    assert mc.grid_geometry_many(np.zeros((0, 4)), 0.5)[3].shape == (0,)
+
+
+def test_lowest_result_asks_numpy_among_equal_costs():
+    """shgo reports np.argsort(costs)[0] of its local results; among equal lowest costs that is the sort kernel's choice, so
+    shgo_fast asks numpy itself -- and takes the short cut only when the minimum is unique"""
+    from sonar_slam_amd import shgo_fast as sf
+    rng = np.random.default_rng(2)
+    for _ in range(300):
+        c = rng.integers(-5, 0, int(rng.integers(1, 40))).astype(np.int64)
+        assert sf.lowest_result(c) == int(np.argsort(c)[0])
+
+
 def test_sample_transforms_of_many_sessions_equal_pose2():
     """chained.sample_transforms (the library's host routine sfe_pose2_sample_transforms) == the float32 matrix rows of
     target.between(source.compose(Pose2(*x))) computed with the scalar Pose2, bit for bit -- rotations that need the
