@@ -171,8 +171,24 @@ def plan_for(bounds, n, ftol):
     key = (np.asarray(bounds, float).tobytes(), int(n), float(ftol))
     p = _PLANS.get(key)
     if p is None:
-        p = _PLANS[key] = SobolPlan(bounds, n, ftol)
+        try:
+            p = SobolPlan(bounds, n, ftol)
+        except Exception as e:       # a scipy without these internals, or one whose SLSQP behaves differently: no replay, shgo itself
+            p = _NoPlan(repr(e))
+        _PLANS[key] = p
     return p
+
+
+class _NoPlan:
+    """what plan_for hands out when the plan cannot be taken from the installed scipy: never `checked`, so every caller runs
+    scipy.optimize.shgo itself"""
+    checked = False
+
+    def __init__(self, why):
+        self.why = why
+
+    def self_check(self, *a, **k):
+        return False
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -299,32 +315,39 @@ def multi_checked(n, iters, ftol, rounds=3, seed=5):
     result, value, success and the multiset of evaluated points must agree (problems the replay hands back do not count)"""
     key = (int(n), int(iters), float(ftol))
     if key not in _MULTI_OK:
-        from scipy.optimize import shgo
-        rng = np.random.default_rng(seed)
-        good, decided = True, 0
-        for r in range(rounds + 3):
-            if decided >= rounds:
-                break
-            stds = np.array([[rng.uniform(0.2, 3), rng.uniform(0.2, 3), rng.uniform(0.01, 0.3)]]).T
-            bounds = 5.0 * np.c_[-stds, stds]
-            f = piecewise_constant(rng, bounds[:, 1] - bounds[:, 0], coarse=(r == 1))
-            draws, cand, fd = multi_candidates(bounds, n, iters)
-            cost = np.array([f(p) for p in cand])
-            fd_cost = np.array([[f(p) for p in row] for row in fd])
-            st, x, fun, vertices, minimised = replay_multi(bounds, n, iters, draws, cand, cost, fd_cost)
-            if st == FALLBACK:
-                continue
-            asked = []
-
-            def g(p):
-                asked.append(tuple(np.asarray(p, float)))
-                return f(p)
-            res = shgo(func=g, bounds=bounds, n=n, iters=iters, sampling_method="sobol", minimizer_kwargs={"options": {"ftol": ftol}})
-            mine = [tuple(cand[v]) for v in vertices]
-            for v in minimised:
-                mine.append(tuple(cand[v]))
-                mine.extend(tuple(p) for p in fd[v])
-            good &= bool(res.success) == (st == OK) and np.array_equal(res.x, x) and res.fun == fun and sorted(mine) == sorted(asked)
-            decided += 1
-        _MULTI_OK[key] = bool(good and decided >= 1)
+        try:
+            _MULTI_OK[key] = _multi_check(n, iters, ftol, rounds, seed)
+        except Exception:            # (a scipy without the pieces the replay leans on: shgo itself)
+            _MULTI_OK[key] = False
     return _MULTI_OK[key]
+
+
+def _multi_check(n, iters, ftol, rounds, seed):
+    from scipy.optimize import shgo
+    rng = np.random.default_rng(seed)
+    good, decided = True, 0
+    for r in range(rounds + 3):
+        if decided >= rounds:
+            break
+        stds = np.array([[rng.uniform(0.2, 3), rng.uniform(0.2, 3), rng.uniform(0.01, 0.3)]]).T
+        bounds = 5.0 * np.c_[-stds, stds]
+        f = piecewise_constant(rng, bounds[:, 1] - bounds[:, 0], coarse=(r == 1))
+        draws, cand, fd = multi_candidates(bounds, n, iters)
+        cost = np.array([f(p) for p in cand])
+        fd_cost = np.array([[f(p) for p in row] for row in fd])
+        st, x, fun, vertices, minimised = replay_multi(bounds, n, iters, draws, cand, cost, fd_cost)
+        if st == FALLBACK:
+            continue
+        asked = []
+
+        def g(p):
+            asked.append(tuple(np.asarray(p, float)))
+            return f(p)
+        res = shgo(func=g, bounds=bounds, n=n, iters=iters, sampling_method="sobol", minimizer_kwargs={"options": {"ftol": ftol}})
+        mine = [tuple(cand[v]) for v in vertices]
+        for v in minimised:
+            mine.append(tuple(cand[v]))
+            mine.extend(tuple(p) for p in fd[v])
+        good &= bool(res.success) == (st == OK) and np.array_equal(res.x, x) and res.fun == fun and sorted(mine) == sorted(asked)
+        decided += 1
+    return bool(good and decided >= 1)
