@@ -466,8 +466,9 @@ int sfe_matching_cost_store_samples(sfe_ctx *ctx, sfe_costgrid *g, sfe_cloud_sto
  * status_out: SFE_SHGO_OK (result = vertex_out), SFE_SHGO_OK_TIED (several local results share the lowest cost: the caller asks
  * np.argsort over the costs of order_out[.. n_order_out], as shgo does -- its sort kernel is not stable), SFE_SHGO_FAILED (no
  * vertex strictly below all its neighbours: shgo's success = False, vertex_out = the lowest vertex), SFE_SHGO_FALLBACK (a
- * finite-difference point costs something else than its vertex, two pool members equally far from the last result, or more
- * than SFE_SHGO_MAX_POOL minimisers: run scipy.optimize.shgo itself).  order_out [n_problems x SFE_SHGO_MAX_POOL]: the
+ * finite-difference point costs something else than its vertex or more than SFE_SHGO_MAX_POOL minimisers: run
+ * scipy.optimize.shgo itself; two pool members equally far from the last result: the order is numpy's sort kernel's choice,
+ * shgo_fast.py asks it).  order_out [n_problems x SFE_SHGO_MAX_POOL]: the
  * vertices in the order shgo minimises them. */
 #define SFE_SHGO_OK 0
 #define SFE_SHGO_FAILED 1

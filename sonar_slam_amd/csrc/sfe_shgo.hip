@@ -79,7 +79,7 @@ int sfe_shgo_sobol_replay(int n_vertices, const int32_t *nn_off, const int32_t *
                     ++n_far;
             }
             if (n_far > 1) {
-                tie = true; // np.argsort's last among equal distances is the sort kernel's choice
+                tie = true; // np.argsort's last among equal distances is the sort kernel's choice: the caller asks numpy (shgo_fast.farthest)
                 break;
             }
             order[n_order++] = rest[far];

@@ -17,9 +17,9 @@ function of the cost at a fixed set of points that depends on (bounds, n) only:
 `SobolPlan` takes all of that from ONE run of the installed scipy on a constant function (so the qhull triangulation, the graph quirks,
 the vertex order and the finite-difference points are scipy's own, whatever its version), and `solve` / `solve_many` replay the rest on
 a table of costs [n_vertices x 4] that the caller fills in one launch (`plan.points`).  What the replay cannot decide the way scipy
-would -- a finite-difference point whose cost differs from its vertex's (SLSQP then moves), two pool members exactly equally far from
-the last result (np.argsort's choice among equal keys is the sort kernel's) -- is REPORTED (`FALLBACK`) and the caller runs
-scipy.optimize.shgo itself for that problem; equal lowest costs among the local results are resolved by asking np.argsort itself.  `SobolPlan.self_check` compares the replay with
+would -- a finite-difference point whose cost differs from its vertex's (SLSQP then moves) -- is REPORTED (`FALLBACK`) and the caller
+runs scipy.optimize.shgo itself for that problem.  Where shgo's own choice is numpy's sort kernel's -- equal lowest costs among the
+local results, pool members exactly equally far from the last result -- numpy is asked with the same call on the same numbers.  `SobolPlan.self_check` compares the replay with
 scipy.optimize.shgo on random piecewise-constant functions; the callers run it once per plan and use shgo for everything if it fails.
 """
 import ctypes as _C
@@ -36,6 +36,14 @@ def lowest_result(costs):
     stable), so numpy itself is asked whenever there is a tie."""
     low = np.nonzero(costs == costs.min())[0]
     return int(low[0]) if len(low) == 1 else int(np.argsort(costs)[0])
+
+
+def farthest(x, rest_points):
+    """`SHGO.g_topograph`: which of the remaining minimisers is minimised next -- the LAST entry of np.argsort over
+    scipy.spatial.distance.cdist from the last local result.  Among exactly equal distances (Sobol points are dyadic: it happens)
+    the last one is the sort kernel's choice, so the same two calls are made on the same numbers."""
+    from scipy.spatial.distance import cdist
+    return int(np.argsort(cdist(np.array([x]), rest_points, "euclidean"), axis=-1)[0, -1])
 
 
 class SobolPlan:
@@ -94,11 +102,7 @@ class SobolPlan:
         order = [pool[0]]
         rest = pool[1:]
         while rest:
-            d = np.sqrt(((self.X[rest] - self.X[order[-1]]) ** 2).sum(axis=1))   # decided by exact ties only: see below
-            far = np.nonzero(d == d.max())[0]
-            if len(far) > 1:
-                return FALLBACK, None, None, 0               # np.argsort's choice among equal distances is the platform's
-            order.append(rest.pop(int(far[0])))
+            order.append(rest.pop(farthest(self.X[order[-1]], self.X[rest])))
         v = order[lowest_result(np.array([f[v] for v in order], np.int64))]
         return OK, self.X[v].copy(), f[v], len(order)
 
@@ -124,6 +128,12 @@ class SobolPlan:
             o = order[s, :n_order[s]]
             vertex[s] = o[lowest_result(tables[s, o, 0].astype(np.int64))]
             status[s] = OK
+        # the C routine also hands back exact distance ties: the Python definition decides those with numpy's own argsort
+        for s in np.nonzero(status == FALLBACK)[0]:
+            st, x, _ = self.solve(tables[s])
+            if st != FALLBACK:
+                status[s] = st
+                vertex[s] = int(np.nonzero((self.X == x).all(axis=1))[0][0])
         return status, vertex
 
     # ---- the replay against the installed scipy ----
@@ -237,7 +247,7 @@ def multi_candidates(bounds, n, iters):
 def replay_multi(bounds, n, iters, draws, cand, cost, fd_cost):
     """shgo(sobol, iters) after the evaluations: cand / cost [M] / fd_cost [M x 3] as multi_candidates laid them out.
     -> (status, x, fun, vertices: indices into cand of the vertices shgo creates, minimised: indices of the starts it minimises, in
-    order).  FALLBACK: a start whose finite-difference points cost something else, a distance tie, a point too close to a bound."""
+    order).  FALLBACK: a start whose finite-difference points cost something else, a point too close to a bound."""
     from scipy import spatial
     bounds = np.array(bounds, float)
     n2 = len(draws[0])
@@ -290,11 +300,7 @@ def replay_multi(bounds, n, iters, draws, cand, cost, fd_cost):
         seq = [pool[0]]
         rest = pool[1:]
         while rest:
-            d = np.sqrt(((cand[rest] - cand[seq[-1]]) ** 2).sum(axis=1))
-            far = np.nonzero(d == d.max())[0]
-            if len(far) > 1:
-                return FALLBACK, None, None, None, None
-            seq.append(rest.pop(int(far[0])))
+            seq.append(rest.pop(farthest(cand[seq[-1]], cand[rest])))
         for v in seq:
             xl.append(v)
             fl.append(cost[v])
