@@ -61,8 +61,8 @@ int sfe_shgo_sobol_replay(int n_vertices, const int32_t *nn_off, const int32_t *
         bool tie = false;
         while (n_rest > 0 && !tie) {
             const double *a = x + 3 * (size_t)order[n_order - 1];
-            int far = -1, n_far = 0;
-            double d_far = -1.0;
+            int far = -1;
+            double d_far = -1.0, d_second = -1.0;
             for (int i = 0; i < n_rest; ++i) { // scipy.spatial.distance.cdist "euclidean": sqrt of the running sum of squares
                 const double *b = x + 3 * (size_t)rest[i];
                 double acc = 0.0;
@@ -72,12 +72,14 @@ int sfe_shgo_sobol_replay(int n_vertices, const int32_t *nn_off, const int32_t *
                 }
                 const double d = std::sqrt(acc);
                 if (d > d_far) {
+                    d_second = d_far;
                     d_far = d;
                     far = i;
-                    n_far = 1;
-                } else if (d == d_far)
-                    ++n_far;
+                } else if (d > d_second)
+                    d_second = d;
             }
+            // equal -- or within what a fused multiply-add inside scipy's build of cdist could move them -- : not decided here
+            const int n_far = (n_rest > 1 && d_far - d_second <= 1e-12 * d_far) ? 2 : 1;
             if (n_far > 1) {
                 tie = true; // np.argsort's last among equal distances is the sort kernel's choice: the caller asks numpy (shgo_fast.farthest)
                 break;
