@@ -143,6 +143,25 @@ def initial_transforms(pose_samples, target_pose, sample_eps=0.01):
 
 
 # ---- loop-closure search (slam.py:839-1087) ----
+def fov_gate(target_points, poses, covs, source_frames, max_range, horizontal_aperture):
+    """slam.py:877-895: the points of the global target cloud (float32) that some source frame can have in its field of view, the
+    bounds widened by five standard deviations of that frame's pose.  Pinned to the reference's own lines by
+    tests/golden/nssm_pieces.npz."""
+    sel = np.zeros(len(target_points), bool)
+    for f in source_frames:
+        cov = covs[f]
+        translation_std = np.sqrt(np.max(np.linalg.eigvals(cov[:2, :2])))
+        rotation_std = np.sqrt(cov[2, 2])
+        range_bound = translation_std * 5.0 + max_range
+        bearing_bound = rotation_std * 5.0 + horizontal_aperture * 0.5
+        local_points = _tp32(target_points, matrix(inverse(poses[f])))
+        ranges = np.linalg.norm(local_points, axis=1)
+        bearings = np.arctan2(local_points[:, 1], local_points[:, 0])
+        sel |= (ranges < range_bound) & (abs(bearings) < bearing_bound)
+    return sel
+
+
+
 NSSM_DEFAULTS = dict(initialization=True, initialization_params=(100, 5, 0.01), min_st_sep=8, min_points=50, max_translation=10.0,
                      max_rotation=np.deg2rad(60), source_frames=5, cov_samples=30, oculus_max_range=30.0,
                      oculus_horizontal_aperture=np.radians(130.0), icp_odom_sigmas=(0.1, 0.1, 0.01), mcd_random_state=None)
@@ -182,17 +201,7 @@ def nssm_search(clouds, poses, covs, current_frame_pose, icp_params, point_resol
         target_keys = allk[idx]
     else:
         target_points, target_keys = allp, allk
-    sel = np.zeros(len(target_points), bool)
-    for f in source_frames:                                                     # slam.py:878-895
-        cov = covs[f]
-        translation_std = np.sqrt(np.max(np.linalg.eigvals(cov[:2, :2])))
-        rotation_std = np.sqrt(cov[2, 2])
-        range_bound = translation_std * 5.0 + P["oculus_max_range"]
-        bearing_bound = rotation_std * 5.0 + P["oculus_horizontal_aperture"] * 0.5
-        local_points = _tp32(target_points, matrix(inverse(poses[f])))
-        ranges = np.linalg.norm(local_points, axis=1)
-        bearings = np.arctan2(local_points[:, 1], local_points[:, 0])
-        sel |= (ranges < range_bound) & (abs(bearings) < bearing_bound)
+    sel = fov_gate(target_points, poses, covs, source_frames, P["oculus_max_range"], P["oculus_horizontal_aperture"])
     target_points, target_keys = target_points[sel], target_keys[sel]
     rec["n_target_global"] = len(target_points)
     frames1, counts = np.unique(np.int32(target_keys), return_counts=True)

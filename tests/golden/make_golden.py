@@ -26,6 +26,11 @@ are executed straight from the reference sources:
     (bounds, np.arange lengths, rounding, clipping, BLAS dot of transform_points, inside test, sum)
     is the reference's own code on this image's numpy.
 
+  * (round 5) two pieces of the loop-closure search: the field-of-view gate and the per-keyframe counts of
+    ``initialize_nonsequential_scan_matching`` (slam.py:875-904: a block inside a long method, cut out by its first and last
+    source lines and exec'd on prepared locals) and ``ICPResult.__init__`` (slam_objects.py:247-300: which pose samples become
+    ICP guesses, in which order) -> ``nssm_pieces.npz``.  `python tests/golden/make_golden.py nssm` writes that file alone.
+
 Nothing of the reference is copied into the repository: only the numbers it produces.
 """
 import ast
@@ -170,6 +175,82 @@ class _Ping(object):
         self.num_ranges = num_ranges
 
 
+def _cut_block(path, first_marker, last_marker):
+    """the source lines of a block inside a function, from the line containing first_marker to the one containing last_marker,
+    dedented (for code that is not a function of its own in the reference)"""
+    import textwrap
+    lines = open(os.path.join(REF, path)).read().split("\n")
+    a = next(i for i, l in enumerate(lines) if first_marker in l)
+    b = next(i for i, l in enumerate(lines) if last_marker in l and i >= a)
+    return textwrap.dedent("\n".join(lines[a:b + 1])), (a + 1, b + 1)
+
+
+def make_nssm_pieces():
+    """-> nssm_pieces.npz: the reference's own lines of the loop-closure search that decide WHICH points and WHICH guesses are used"""
+    import textwrap
+    out = {}
+    _, Keyframe, _ = reference_matching_cost()
+    # ---- field-of-view gate + counts per keyframe (slam.py:875-904) ----
+    block, span = _cut_block("slam.py", "sel = np.zeros(len(target_points), np.bool)", "counts = counts[counts > 10]")
+    np_ns = types.SimpleNamespace(**{k: getattr(np, k) for k in dir(np) if not k.startswith("__")})
+    np_ns.bool = bool                        # (np.bool is gone from numpy 2: the alias the reference's numpy had)
+    rng = np.random.default_rng(11)
+    n_kf = 14
+    poses = [Pose2(20.0 * np.cos(a) + rng.normal(0, 0.2), 20.0 * np.sin(a) + rng.normal(0, 0.2), a + np.pi / 2 + rng.normal(0, 0.05))
+             for a in np.linspace(0, 2 * np.pi * 14 / 13, n_kf)]
+    covs = []
+    for k in range(n_kf):
+        A = rng.normal(0, 0.2, (3, 3))
+        covs.append(A @ A.T + np.diag([0.01, 0.01, 1e-4]) * (k + 1))
+    keyframes = [types.SimpleNamespace(pose=p, cov=c) for p, c in zip(poses, covs)]
+    target_points = np.c_[rng.uniform(-45, 45, 6000), rng.uniform(-45, 45, 6000)].astype(np.float32)
+    target_keys = rng.integers(0, 6, 6000).astype(np.float32)          # (keys travel as a float descriptor row: pcl.cpp:143-159)
+    target_keys[rng.random(6000) < 0.004] = 5.0                          # a keyframe with a handful of points: dropped by counts > 10
+    target_keys[(target_keys == 5.0) & (rng.random(6000) < 0.995)] = 4.0
+    source_frames = [13, 12, 11, 10, 9]
+    ns = {"np": np_ns, "Keyframe": Keyframe, "source_frames": source_frames, "target_points": target_points.copy(),
+          "target_keys": target_keys.copy(),
+          "self": types.SimpleNamespace(keyframes=keyframes, oculus=types.SimpleNamespace(max_range=30.0, horizontal_aperture=np.radians(130.0)))}
+    exec(compile(block, "reference:slam.py:%d-%d" % span, "exec"), ns)
+    out.update(fov_poses=np.array([[p.x(), p.y(), p.theta()] for p in poses]), fov_covs=np.array(covs),
+               fov_source_frames=np.array(source_frames), fov_max_range=30.0, fov_aperture=np.radians(130.0),
+               fov_target_points=target_points, fov_target_keys=target_keys, fov_sel=np.asarray(ns["sel"], bool),
+               fov_kept_points=np.asarray(ns["target_points"]), fov_kept_keys=np.asarray(ns["target_keys"]),
+               fov_frames=np.asarray(ns["target_frames"]), fov_counts=np.asarray(ns["counts"]),
+               fov_lines=np.array("slam.py:%d-%d" % span))
+    # ---- ICPResult.__init__ (slam_objects.py:247-300): initial transform and the filtered list of sampled transforms ----
+    src = open(os.path.join(REF, "slam_objects.py")).read()
+    cls = next(n for n in ast.walk(ast.parse(src)) if isinstance(n, ast.ClassDef) and n.name == "ICPResult")
+    init = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "__init__")
+    fn_src = textwrap.dedent(ast.get_source_segment(src, init))
+    ns2 = {"np": np, "InitializationResult": object, "n2g": lambda g, kind: Pose2(*g),
+           "g2n": lambda p: np.array([p.x(), p.y(), p.theta()])}
+    exec(compile(fn_src, "reference:slam_objects.py", "exec"), ns2)
+    source_pose, target_pose = Pose2(3.0, -1.0, 0.4), Pose2(2.2, -0.7, 0.1)
+    est = source_pose.compose(Pose2(0.31, -0.12, 0.02))
+    base = rng.normal(0, [0.6, 0.6, 0.05], (60, 3))
+    deltas, costs = [], []
+    for i, b in enumerate(base):                  # near-duplicates NEXT to their original in cost order: the filter's business
+        for j in range(int(rng.integers(1, 6))):
+            deltas.append(b + (rng.normal(0, [0.003, 0.003, 0.0005]) if j else 0.0))
+            costs.append(-1000.0 + 10 * i + j)                                         # distinct costs: argsort has one answer
+    order = rng.permutation(len(deltas))          # (the list itself comes in evaluation order, not in cost order)
+    deltas, costs = np.array(deltas)[order], np.array(costs)[order]
+    sample_poses = [source_pose.compose(Pose2(*d)) for d in deltas]
+    samples = np.array([[p.x(), p.y(), p.theta(), c] for p, c in zip(sample_poses, costs)])
+    init_ret = types.SimpleNamespace(source_points=None, target_points=None, source_key=13, target_key=2, source_pose=source_pose,
+                                     target_pose=target_pose, status=None, estimated_source_pose=est, source_pose_samples=samples)
+    res = types.SimpleNamespace()
+    ns2["__init__"](res, init_ret, True, 0.01)
+    g = lambda p: [p.x(), p.y(), p.theta()]
+    out.update(icp_samples=samples, icp_source_pose=np.array(g(source_pose)), icp_target_pose=np.array(g(target_pose)),
+               icp_estimated_source_pose=np.array(g(est)), icp_initial_transform=np.array(g(res.initial_transform)),
+               icp_initial_transforms=np.array([g(t) for t in res.initial_transforms]), icp_sample_eps=0.01)
+    np.savez_compressed(os.path.join(HERE, "nssm_pieces.npz"), **out)
+    print("wrote nssm_pieces.npz (field-of-view gate of %s: %d of %d points kept, keyframes %r; ICPResult: %d of %d sampled transforms kept)"
+          % (span, int(ns["sel"].sum()), len(target_points), list(np.asarray(ns["target_frames"])), len(res.initial_transforms), len(samples)))
+
+
 def bearings_for(n, aperture_deg=130.0):
     half = aperture_deg * 50.0
     return np.round(np.linspace(-half, half, n)).astype(np.int16)
@@ -178,6 +259,9 @@ def bearings_for(n, aperture_deg=130.0):
 def main():
     if not os.path.isdir(REF):
         sys.exit("reference tree not present; fixtures are committed, nothing to do")
+    if sys.argv[1:] == ["nssm"]:
+        make_nssm_pieces()
+        return
 
     # ---- tau ----
     CFAR = reference_cfar_class()
@@ -290,6 +374,7 @@ def main():
     out["index"] = np.array(json.dumps(index))
     np.savez_compressed(os.path.join(HERE, "cfar_ref.npz"), **out)
     print("wrote cfar_tau.json, maps_small.npz, maps_digest.json, matching_cost.npz, transform_points.npz, cfar_ref.npz")
+    make_nssm_pieces()
 
 
 if __name__ == "__main__":

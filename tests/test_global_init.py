@@ -647,6 +647,34 @@ def test_loop_closure_primitives_over_the_store(ctx):
 
 
 @pytest.mark.gpu
+def test_device_fov_gate_equals_the_reference_lines(ctx):
+    """sfe_cloud_store_fov_select / compact_selected on the inputs of tests/golden/nssm_pieces.npz == what the reference's own
+    lines (slam.py:877-904, exec'd by tests/golden/make_golden.py) select and count"""
+    import os
+    from types import SimpleNamespace
+    from sonar_slam_amd import store as st
+    from sonar_slam_amd.replay import FrontEnd
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nssm_pieces.npz"))
+    tp, tk, sel = z["fov_target_points"], np.int32(z["fov_target_keys"]), z["fov_sel"]
+    K = int(tk.max()) + 1
+    me = SimpleNamespace(keyframes=[SimpleNamespace(pose=Pose2(*p), cov=c) for p, c in zip(z["fov_poses"], z["fov_covs"])],
+                         oculus_max_range=float(z["fov_max_range"]), oculus_horizontal_aperture=float(z["fov_aperture"]))
+    Tinv, rb, bb = FrontEnd._fov_bounds(me, [int(f) for f in z["fov_source_frames"]])
+    s = st.CloudStore(ctx, capacity_points=1 << 16, max_clouds=64)
+    hs = [s.put(tp[tk == k]) for k in range(K)]                       # the global target cloud, keyframe by keyframe
+    g = s.get_points_keys(hs, [st.pose_T6(Pose2(0, 0, 0))] * K, list(range(K)), 0.0)
+    hist, n_sel, n_amb = s.fov_select(g, [st.pose_T6(t) for t in Tinv], rb, bb, K)
+    assert n_amb == 0 and n_sel == int(sel.sum())
+    assert np.array_equal(hist, np.bincount(tk[sel], minlength=K))
+    frames = np.nonzero(hist)[0]
+    assert np.array_equal(frames[hist[frames] > 10], z["fov_frames"]) and np.array_equal(hist[frames][hist[frames] > 10], z["fov_counts"])
+    c = s.compact_selected(g)
+    assert np.array_equal(s.read(c), np.concatenate([tp[(tk == k) & sel] for k in range(K)]))
+    assert np.array_equal(s.read_keys(c), np.concatenate([tk[(tk == k) & sel] for k in range(K)]))
+    s.close()
+
+
+@pytest.mark.gpu
 def test_fov_gate_ranges_on_their_bound(ctx):
     """points on circles around the frames, each range bound placed ON a float32 value those ranges take: a point whose range
     is that value is outside (slam.py:892 `ranges < range_bound`), one ulp less is inside -- so a device range that is not the

@@ -101,3 +101,47 @@ def test_transform_points_and_get_points_match_the_reference_functions():
     a = np.concatenate([z["f64_ref4_moved%d" % k] for k in (1, 2, 3)])
     b = np.concatenate([z["f32_ref4_moved%d" % k] for k in (1, 2, 3)])
     assert a.shape == b.shape and not np.array_equal(a, b)
+
+
+def test_field_of_view_gate_and_guess_selection_match_the_reference_lines():
+    """round 5: two pieces of the loop-closure search pinned to the reference's own code (tests/golden/nssm_pieces.npz, made by
+    exec'ing slam.py:877-904 and ICPResult.__init__ of slam_objects.py on prepared inputs): the field-of-view gate with the
+    per-keyframe counts, and which sampled poses become ICP guesses in which order -- for the product's host code
+    (replay.FrontEnd) and for the oracle chain"""
+    from types import SimpleNamespace
+    from oracle import chain
+    from sonar_slam_amd.pose2 import Pose2
+    from sonar_slam_amd.replay import FrontEnd
+    z = np.load(os.path.join(G, "nssm_pieces.npz"))
+    poses = [Pose2(*p) for p in z["fov_poses"]]
+    covs = list(z["fov_covs"])
+    source_frames = [int(f) for f in z["fov_source_frames"]]
+    tp, tk = z["fov_target_points"], z["fov_target_keys"]
+    assert tp.dtype == np.float32 and 1000 < z["fov_sel"].sum() < len(tp)
+    # product: the bounds and the numpy gate of the host path (the device gate is compared with it on the GPU)
+    me = SimpleNamespace(keyframes=[SimpleNamespace(pose=p, cov=c) for p, c in zip(poses, covs)],
+                         oculus_max_range=float(z["fov_max_range"]), oculus_horizontal_aperture=float(z["fov_aperture"]))
+    Tinv, rb, bb = FrontEnd._fov_bounds(me, source_frames)
+    sel = FrontEnd._fov_numpy(tp, Tinv, rb, bb)
+    assert np.array_equal(sel, z["fov_sel"])
+    frames, counts = np.unique(np.int32(tk[sel]), return_counts=True)
+    assert np.array_equal(frames[counts > 10], z["fov_frames"]) and np.array_equal(counts[counts > 10], z["fov_counts"])
+    assert len(z["fov_frames"]) < len(frames)                     # (a keyframe with <= 10 points in view is dropped)
+    assert np.array_equal(tp[sel], z["fov_kept_points"]) and np.array_equal(tk[sel], z["fov_kept_keys"])
+    # oracle chain
+    sel_o = chain.fov_gate(tp, [chain.pose(*p) for p in z["fov_poses"]], covs, source_frames, float(z["fov_max_range"]),
+                           float(z["fov_aperture"]))
+    assert np.array_equal(sel_o, z["fov_sel"])
+    # ICPResult.__init__: initial transform and the filtered list of sampled transforms
+    target, est = Pose2(*z["icp_target_pose"]), Pose2(*z["icp_estimated_source_pose"])
+    it = target.between(est)
+    assert np.allclose([it.x(), it.y(), it.theta()], z["icp_initial_transform"], rtol=0, atol=1e-15)
+    want = z["icp_initial_transforms"]
+    got = FrontEnd.initial_transforms(z["icp_samples"], target, sample_eps=float(z["icp_sample_eps"]))
+    assert len(got) == len(want) and 20 < len(want) < len(z["icp_samples"])
+    assert np.allclose([[g.x(), g.y(), g.theta()] for g in got], want, rtol=0, atol=1e-15)
+    head = FrontEnd.initial_transforms(z["icp_samples"], target, sample_eps=float(z["icp_sample_eps"]), limit=30)
+    assert np.allclose([[g.x(), g.y(), g.theta()] for g in head], want[:30], rtol=0, atol=1e-15)
+    got_o = chain.initial_transforms(z["icp_samples"], chain.pose(*z["icp_target_pose"]), sample_eps=float(z["icp_sample_eps"]))
+    assert len(got_o) == len(want)
+    assert np.allclose([[g[0], g[1], chain.theta(g)] for g in got_o], want, rtol=0, atol=1e-15)
