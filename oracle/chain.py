@@ -143,6 +143,36 @@ def initial_transforms(pose_samples, target_pose, sample_eps=0.01):
 
 
 # ---- loop-closure search (slam.py:839-1087) ----
+def icp_with_cov(source_points, target_points, guesses, icp_params, icp_odom_sigmas, random_state=None):
+    """slam.py:325-387 (compute_icp_with_cov): ICP from every guess, the converged transforms' robust centre and covariance
+    (MinCovDet, the reference's arguments), the covariance turned into the centre's frame the way the reference does it (in place,
+    rows first), never below the configured sigmas -> (message, centre pose, cov, converged transforms [n x 3], (status,
+    iterations) per guess).  Pinned to the reference's own function by tests/golden/nssm_pieces.npz."""
+    from sklearn.covariance import MinCovDet
+    xyt, icp_recs = [], []
+    for g in guesses:
+        st, T, it = oracle.icp(source_points, target_points, matrix(g).astype(np.float32), icp_params)
+        icp_recs.append((st, it))
+        if st == 0:
+            xyt.append((T[0, 2], T[1, 2], np.arctan2(T[1, 0], T[0, 0])))
+    xyt = np.array(xyt, np.float32).reshape(-1, 3)      # (tuples of np.float32 scalars: the reference's np.array keeps float32)
+    if len(xyt) < 5:
+        return "Too few samples for covariance computation", None, None, xyt, icp_recs
+    try:
+        est = MinCovDet(store_precision=False, support_fraction=0.8, random_state=random_state).fit(xyt)
+    except ValueError:
+        return "Failed to calculate covariance", None, None, xyt, icp_recs
+    odom = pose(*est.location_)
+    cov = est.covariance_
+    R = matrix(odom)[:2, :2]
+    cov[:2, :] = R.T.dot(cov[:2, :])
+    cov[:, :2] = cov[:, :2].dot(R)
+    floor = np.diag(icp_odom_sigmas) ** 2
+    if np.linalg.det(cov) < np.linalg.det(floor):
+        cov = floor
+    return "success", odom, cov, xyt, icp_recs
+
+
 def fov_gate(target_points, poses, covs, source_frames, max_range, horizontal_aperture):
     """slam.py:877-895: the points of the global target cloud (float32) that some source frame can have in its field of view, the
     bounds widened by five standard deviations of that frame's pose.  Pinned to the reference's own lines by
@@ -245,30 +275,12 @@ def nssm_search(clouds, poses, covs, current_frame_pose, icp_params, point_resol
     if P["initialization"] and P["cov_samples"] > 0:
         guesses = initial_transforms(pose_samples, target_pose)[:P["cov_samples"]]
         rec["n_guesses"] = len(guesses)
-        xyt, icp_recs = [], []
-        for g in guesses:
-            st, T, it = oracle.icp(source_points, target_local, matrix(g).astype(np.float32), icp_params)
-            icp_recs.append((st, it))
-            if st == 0:
-                xyt.append((T[0, 2], T[1, 2], np.arctan2(T[1, 0], T[0, 0])))
+        message, odom, cov, xyt, icp_recs = icp_with_cov(source_points, target_local, guesses, icp_params, P["icp_odom_sigmas"],
+                                                         P["mcd_random_state"])
         rec["icp_runs"] = icp_recs
-        xyt = np.array(xyt, np.float64).reshape(-1, 3)
-        if len(xyt) < 5:
-            rec["icp"], rec["status"] = "Too few samples for covariance computation", "NOT_CONVERGED"
+        if message != "success":
+            rec["icp"], rec["status"] = message, "NOT_CONVERGED"
             return rec
-        try:
-            est = MinCovDet(store_precision=False, support_fraction=0.8, random_state=P["mcd_random_state"]).fit(xyt)
-        except ValueError:
-            rec["icp"], rec["status"] = "Failed to calculate covariance", "NOT_CONVERGED"
-            return rec
-        odom = pose(*est.location_)
-        cov = est.covariance_
-        R = matrix(odom)[:2, :2]
-        cov[:2, :] = R.T.dot(cov[:2, :])
-        cov[:, :2] = cov[:, :2].dot(R)
-        floor = np.diag(P["icp_odom_sigmas"]) ** 2
-        if np.linalg.det(cov) < np.linalg.det(floor):
-            cov = floor
         rec["icp"], rec["n_converged"], rec["sample_transforms"], rec["cov"] = "success", len(xyt), xyt, cov
     else:
         st, T, it = oracle.icp(source_points, target_local, matrix(initial).astype(np.float32), icp_params)

@@ -232,8 +232,10 @@ class FrontEnd(object):
                                                  [g.matrix() for g in guesses])
             ok = np.array([m == "success" for m in msgs], bool)
         Ts = np.asarray(Ts, np.float32)[ok]
-        # x, y = T[:2, 2]; theta = np.arctan2(T[1, 0], T[0, 0]) on the float32 matrix; np.array of the tuples -> float64
-        xyt = np.c_[Ts[:, 0, 2], Ts[:, 1, 2], np.arctan2(Ts[:, 1, 0], Ts[:, 0, 0])].astype(np.float64) if len(Ts) else np.zeros((0, 3))
+        # x, y = T[:2, 2]; theta = np.arctan2(T[1, 0], T[0, 0]) on the float32 matrix; np.array of tuples of np.float32 scalars
+        # STAYS float32 (slam.py:352-361), and MinCovDet then takes its location as a float32 mean (its covariance in double):
+        # pinned by tests/golden/nssm_pieces.npz -- rounds 1-5 cast to float64 here and were 6e-8 off the reference's centre
+        xyt = np.c_[Ts[:, 0, 2], Ts[:, 1, 2], np.arctan2(Ts[:, 1, 0], Ts[:, 0, 0])].astype(np.float32) if len(Ts) else np.zeros((0, 3), np.float32)
         if len(xyt) < 5:
             return "Too few samples for covariance computation", None, None, None
         try:

@@ -28,8 +28,10 @@ are executed straight from the reference sources:
 
   * (round 5) two pieces of the loop-closure search: the field-of-view gate and the per-keyframe counts of
     ``initialize_nonsequential_scan_matching`` (slam.py:875-904: a block inside a long method, cut out by its first and last
-    source lines and exec'd on prepared locals) and ``ICPResult.__init__`` (slam_objects.py:247-300: which pose samples become
-    ICP guesses, in which order) -> ``nssm_pieces.npz``.  `python tests/golden/make_golden.py nssm` writes that file alone.
+    source lines and exec'd on prepared locals), ``ICPResult.__init__`` (slam_objects.py:247-300: which pose samples become
+    ICP guesses, in which order), ``get_points(frames, None, return_keys=True)`` (slam.py:229-292: the keyed global target cloud),
+    ``get_overlap`` (slam.py:389-424) and ``compute_icp_with_cov`` (slam.py:325-387) with the oracle standing in for pcl.downsample /
+    pcl.match / pcl.ICP.compute and sklearn's own MinCovDet -> ``nssm_pieces.npz``.  `python tests/golden/make_golden.py nssm` writes that file alone.
 
 Nothing of the reference is copied into the repository: only the numbers it produces.
 """
@@ -79,6 +81,9 @@ class Pose2(object):
 
     def matrix(self):
         return np.array([[self._c, -self._s, self._x], [self._s, self._c, self._y], [0.0, 0.0, 1.0]])
+
+    def rotation(self):
+        return types.SimpleNamespace(matrix=lambda: np.array([[self._c, -self._s], [self._s, self._c]]))
 
 
 def reference_cfar_class():
@@ -246,9 +251,78 @@ def make_nssm_pieces():
     out.update(icp_samples=samples, icp_source_pose=np.array(g(source_pose)), icp_target_pose=np.array(g(target_pose)),
                icp_estimated_source_pose=np.array(g(est)), icp_initial_transform=np.array(g(res.initial_transform)),
                icp_initial_transforms=np.array([g(t) for t in res.initial_transforms]), icp_sample_eps=0.01)
+    # ---- get_points(frames, None, return_keys=True) (slam.py:229-292): the keyed global target cloud of the search ----
+    # pcl.downsample(points, keys, res) = the oracle's octree with the index of every leaf's medoid (that one stays unpinned); the
+    # transform to the SLAM frame, the key column, the concatenation order and the float32 rounding at the pybind boundary are the
+    # reference's own code.  pcl.match = the oracle's exact nearest neighbour; pcl.ICP.compute = the oracle's chain.
+    import oracle as _orc
+    from typing import Any, Union
+    from sonar_slam_amd import synth
+
+    def ds_keys(pts, keys, res):
+        p32 = np.asarray(pts, np.float32)                                  # (pybind: Matrix = fp32)
+        out_p, idx = _orc.downsample(p32, res, return_index=True)
+        return out_p, np.asarray(keys, np.float32)[idx]
+    gp_src = _cut("slam.py", "get_points")
+    ns_gp = {"np": np, "gtsam": types.SimpleNamespace(Pose2=Pose2), "Keyframe": Keyframe, "Any": Any,
+             "pcl": types.SimpleNamespace(downsample=lambda *a: ds_keys(*a) if len(a) == 3 else _orc.downsample(np.asarray(a[0], np.float32), a[1]))}
+    exec(compile(gp_src, "reference:slam.py", "exec"), ns_gp)
+    rng = np.random.default_rng(23)
+    kf_clouds = [np.c_[rng.uniform(1, 29, n), rng.uniform(-20, 20, n)].astype(np.float32).astype(np.float64) for n in (900, 1, 1400, 0, 650, 1100)]
+    kf_poses = [(0.0, 0.0, 0.0), (1.7, -0.2, 0.05), (3.1, 0.4, 0.13), (4.9, 0.1, 0.2), (6.2, -0.7, 0.31), (7.0, -1.6, 0.52)]
+    kfs = [types.SimpleNamespace(points=c, pose=Pose2(*q)) for c, q in zip(kf_clouds, kf_poses)]
+    for k in kfs:
+        k.transf_points = Keyframe.transform_points(k.points, k.pose)          # Keyframe.update (slam_objects.py:160)
+    slam = types.SimpleNamespace(keyframes=kfs, current_key=len(kfs), point_resolution=0.5)
+    frames_k = [0, 1, 2, 3, 4]
+    gpts, gkeys = ns_gp["get_points"](slam, frames_k, None, True)
+    out.update({"keyed_cloud%d" % i: c for i, c in enumerate(kf_clouds)})
+    out.update(keyed_poses=np.array(kf_poses), keyed_frames=np.array(frames_k), keyed_points=np.asarray(gpts, np.float32),
+               keyed_keys=np.asarray(gkeys, np.float32).reshape(-1), keyed_resolution=0.5)
+    # ---- get_overlap (slam.py:389-424) ----
+    ov_src = _cut("slam.py", "get_overlap")
+    ns_ov = {"np": np, "gtsam": types.SimpleNamespace(Pose2=Pose2), "Keyframe": Keyframe,
+             "pcl": types.SimpleNamespace(match=lambda tgt, src, k, r: _orc.match(np.asarray(tgt, np.float32), np.asarray(src, np.float32), r))}
+    exec(compile(ov_src, "reference:slam.py", "exec"), ns_ov)
+    src_o, tgt_o, guess_o, truth_o = synth.scan_pair(seed=33, n_src=800, n_tgt=900)
+    me = types.SimpleNamespace(point_noise=0.5)
+    pose_o = Pose2(*synth.pose_of(truth_o))
+    n64, idx64 = ns_ov["get_overlap"](me, src_o.astype(np.float64), tgt_o, pose_o, None, True)       # keyframe cloud: float64
+    n32 = ns_ov["get_overlap"](me, src_o, tgt_o, pose_o)                                             # aggregated cloud: float32
+    n_none = ns_ov["get_overlap"](me, src_o, tgt_o)
+    out.update(ov_source=src_o, ov_target=tgt_o, ov_pose=np.array(synth.pose_of(truth_o)), ov_count_f64=int(n64),
+               ov_indices_f64=np.asarray(idx64).reshape(-1), ov_count_f32=int(n32), ov_count_no_pose=int(n_none), ov_point_noise=0.5)
+    # ---- compute_icp_with_cov (slam.py:325-387): many guesses on one pair, MinCovDet, the covariance in the centre's frame ----
+    cov_src = _cut("slam.py", "compute_icp_with_cov")
+    import time as time_pkg
+    from sklearn.covariance import MinCovDet
+    prm = _orc.shipped_icp_params(precision=1)
+
+    def icp_compute(src, tgt, g):
+        st, T, _ = _orc.icp(src, tgt, np.asarray(g, np.float32), prm)
+        return ("success", T) if st == 0 else ("failure", np.asarray(g, np.float32))
+    ns_cv = {"np": np, "Union": Union, "time_pkg": time_pkg, "MinCovDet": MinCovDet, "n2g": lambda g, kind: Pose2(*g)}
+    exec(compile(cov_src, "reference:slam.py", "exec"), ns_cv)
+    src_c, tgt_c, guess_c, truth_c = synth.scan_pair(seed=9, n_src=1500, n_tgt=1500)
+    gx, gy, gt = synth.pose_of(guess_c)
+    rng = np.random.default_rng(1)
+    gs = np.array([[gx + dx, gy + dy, gt + dt] for dx, dy, dt in rng.normal(0, [0.2, 0.2, 0.02], (30, 3))])
+    me = types.SimpleNamespace(icp=types.SimpleNamespace(compute=icp_compute), icp_odom_sigmas=np.array([0.1, 0.1, 0.01]))
+    np.random.seed(0)                       # MinCovDet(random_state=None) draws from numpy's global generator
+    msg, m, cov, samples_c = ns_cv["compute_icp_with_cov"](me, src_c, tgt_c, [Pose2(*g) for g in gs])
+    np.random.seed(0)
+    msg_few, *_ = ns_cv["compute_icp_with_cov"](me, src_c, tgt_c, [Pose2(*g) for g in gs[:3]])
+    tiny = types.SimpleNamespace(icp=types.SimpleNamespace(compute=icp_compute), icp_odom_sigmas=np.array([1e-4, 1e-4, 1e-5]))
+    np.random.seed(0)
+    _, m2, cov2, _ = ns_cv["compute_icp_with_cov"](tiny, src_c, tgt_c, [Pose2(*g) for g in gs])    # sigmas below the scatter: MinCovDet's own
+    out.update(cov_source=src_c, cov_target=tgt_c, cov_guesses=gs, cov_message=np.array(msg), cov_message_3_guesses=np.array(msg_few),
+               cov_centre=np.array([m.x(), m.y(), m.theta()]), cov_cov=np.asarray(cov), cov_samples=np.asarray(samples_c),
+               cov_cov_small_sigmas=np.asarray(cov2), cov_sigmas=np.array([0.1, 0.1, 0.01]), cov_small_sigmas=np.array([1e-4, 1e-4, 1e-5]))
     np.savez_compressed(os.path.join(HERE, "nssm_pieces.npz"), **out)
-    print("wrote nssm_pieces.npz (field-of-view gate of %s: %d of %d points kept, keyframes %r; ICPResult: %d of %d sampled transforms kept)"
-          % (span, int(ns["sel"].sum()), len(target_points), list(np.asarray(ns["target_frames"])), len(res.initial_transforms), len(samples)))
+    print("wrote nssm_pieces.npz (field-of-view gate of %s: %d of %d points kept, keyframes %r; ICPResult: %d of %d sampled transforms kept; "
+          "keyed target cloud: %d points from %d; overlap %d / %d / %d; compute_icp_with_cov: %s, %d of 30 guesses converged, det(cov) %.3g / %.3g)"
+          % (span, int(ns["sel"].sum()), len(target_points), list(np.asarray(ns["target_frames"])), len(res.initial_transforms), len(samples),
+             len(gpts), sum(len(c) for c in kf_clouds[:5]), n64, n32, n_none, msg, len(samples_c), np.linalg.det(cov), np.linalg.det(cov2)))
 
 
 def bearings_for(n, aperture_deg=130.0):

@@ -675,6 +675,50 @@ def test_device_fov_gate_equals_the_reference_lines(ctx):
 
 
 @pytest.mark.gpu
+def test_device_loop_closure_pieces_equal_the_reference_functions(ctx):
+    """the product against the outputs of the reference's own functions (tests/golden/nssm_pieces.npz: get_points with keys,
+    get_overlap, compute_icp_with_cov run by make_golden.py with the oracle as pcl): keyed global target cloud over the store,
+    overlap over handles and on host arrays in both cloud dtypes, many guesses on one pair with MinCovDet on float32 samples"""
+    import os
+    from sonar_slam_amd import store as st
+    from sonar_slam_amd.replay import FrontEnd
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nssm_pieces.npz"))
+    s = st.CloudStore(ctx, capacity_points=1 << 17, max_clouds=64)
+    # keyed target cloud
+    frames = [int(f) for f in z["keyed_frames"]]
+    hs = [s.put(z["keyed_cloud%d" % f].astype(np.float32)) for f in frames]
+    g = s.get_points_keys(hs, [st.pose_T6(Pose2(*z["keyed_poses"][f])) for f in frames], frames, float(z["keyed_resolution"]))
+    assert np.array_equal(s.read(g), z["keyed_points"]) and np.array_equal(s.read_keys(g), np.int32(z["keyed_keys"]))
+    # overlap: handles (keyframe cloud = float64 semantics, aggregated cloud = float32) and host arrays
+    front = FrontEnd(ctx, store=s, mcd_random_state=0, nssm_enable=False)
+    from sonar_slam_amd.replay import CloudRef
+    hsrc, htgt = s.put(z["ov_source"]), s.put(z["ov_target"])
+    pose = Pose2(*z["ov_pose"])
+    a, b = CloudRef(hsrc, len(z["ov_source"])), CloudRef(htgt, len(z["ov_target"]))
+    assert front.get_overlap(a, b, pose) == int(z["ov_count_f64"])
+    assert front.get_overlap(a, b, pose, f32_source=True) == int(z["ov_count_f32"])
+    host = FrontEnd(ctx, mcd_random_state=0, nssm_enable=False)
+    assert host.get_overlap(z["ov_source"].astype(np.float64), z["ov_target"], pose) == int(z["ov_count_f64"])
+    assert host.get_overlap(z["ov_source"], z["ov_target"], pose) == int(z["ov_count_f32"])
+    # many guesses on one pair: the reference's function ran the oracle's ICP; the device's transforms agree to 1e-6, MinCovDet
+    # (random_state 0 here = numpy's global generator seeded with 0 there) then picks the same support
+    guesses = [Pose2(*gg) for gg in z["cov_guesses"]]
+    for fe_, src, tgt in ((host, z["cov_source"], z["cov_target"]),
+                          (front, CloudRef(s.put(z["cov_source"]), len(z["cov_source"])), CloudRef(s.put(z["cov_target"]), len(z["cov_target"])))):
+        msg, centre, cov, xyt = fe_.compute_icp_with_cov(src, tgt, guesses)
+        assert msg == str(z["cov_message"]) and xyt.dtype == np.float32 and xyt.shape == z["cov_samples"].shape
+        assert np.abs(xyt - z["cov_samples"]).max() <= 1e-6
+        assert np.abs(np.array([centre.x(), centre.y(), centre.theta()]) - z["cov_centre"]).max() <= 1e-6
+        assert np.array_equal(cov, z["cov_cov"])                      # (the floor of the configured sigmas)
+        fe_.icp_odom_sigmas = z["cov_small_sigmas"]
+        _, _, cov2, _ = fe_.compute_icp_with_cov(src, tgt, guesses)
+        fe_.icp_odom_sigmas = z["cov_sigmas"]
+        assert np.allclose(cov2, z["cov_cov_small_sigmas"], rtol=2e-2, atol=1e-12) and cov2[0, 0] > 1e-8
+        assert fe_.compute_icp_with_cov(src, tgt, guesses[:3])[0] == str(z["cov_message_3_guesses"])
+    s.close()
+
+
+@pytest.mark.gpu
 def test_fov_gate_ranges_on_their_bound(ctx):
     """points on circles around the frames, each range bound placed ON a float32 value those ranges take: a point whose range
     is that value is outside (slam.py:892 `ranges < range_bound`), one ulp less is inside -- so a device range that is not the

@@ -145,3 +145,38 @@ def test_field_of_view_gate_and_guess_selection_match_the_reference_lines():
     got_o = chain.initial_transforms(z["icp_samples"], chain.pose(*z["icp_target_pose"]), sample_eps=float(z["icp_sample_eps"]))
     assert len(got_o) == len(want)
     assert np.allclose([[g[0], g[1], chain.theta(g)] for g in got_o], want, rtol=0, atol=1e-15)
+
+
+def test_oracle_loop_closure_pieces_match_the_reference_functions():
+    """round 5: the oracle chain's restatements against the reference's own functions run with the oracle standing in for pcl
+    (tests/golden/nssm_pieces.npz): the keyed global target cloud (slam.py:229-292 with return_keys), get_overlap (slam.py:389-424,
+    both cloud dtypes) and compute_icp_with_cov (slam.py:325-387: converged transforms, MinCovDet's centre, the covariance turned
+    into the centre's frame in place, the floor of the configured sigmas)"""
+    import oracle
+    from oracle import chain
+    z = np.load(os.path.join(G, "nssm_pieces.npz"))
+    # keyed target cloud: every keyframe under its own pose (float64 arithmetic on float32 values), key column, one downsample
+    frames = [int(f) for f in z["keyed_frames"]]
+    moved = [oracle.transform_points(z["keyed_cloud%d" % f], chain.matrix(chain.pose(*z["keyed_poses"][f])), f64_points=True) for f in frames]
+    allp = np.concatenate(moved)
+    allk = np.concatenate([np.full(len(m), f, np.float32) for m, f in zip(moved, frames)])
+    pts, idx = oracle.downsample(allp, float(z["keyed_resolution"]), return_index=True)
+    assert np.array_equal(pts, z["keyed_points"]) and np.array_equal(allk[idx], z["keyed_keys"]) and 2000 < len(pts) < len(allp)
+    # overlap
+    T = chain.matrix(chain.pose(*z["ov_pose"]))
+    src, tgt, noise = z["ov_source"], z["ov_target"], float(z["ov_point_noise"])
+    assert oracle.overlap(src, tgt, T, noise, f64_points=True) == int(z["ov_count_f64"]) > 100
+    assert oracle.overlap(src, tgt, T, noise, f64_points=False) == int(z["ov_count_f32"])
+    ids = oracle.match(tgt, oracle.transform_points(src, T, f64_points=True), noise)[0].reshape(-1)
+    assert np.array_equal(ids, z["ov_indices_f64"])
+    assert int(np.sum(oracle.match(tgt, src, noise)[0] != -1)) == int(z["ov_count_no_pose"])
+    # many guesses on one pair
+    prm = oracle.shipped_icp_params(precision=1)
+    guesses = [chain.pose(*g) for g in z["cov_guesses"]]
+    msg, odom, cov, xyt, runs = chain.icp_with_cov(z["cov_source"], z["cov_target"], guesses, prm, z["cov_sigmas"], random_state=0)
+    assert msg == str(z["cov_message"]) == "success" and len(runs) == 30
+    assert np.array_equal(xyt, z["cov_samples"]) and np.array_equal(cov, z["cov_cov"])
+    assert np.allclose([odom[0], odom[1], chain.theta(odom)], z["cov_centre"], rtol=0, atol=1e-15)
+    _, _, cov2, _, _ = chain.icp_with_cov(z["cov_source"], z["cov_target"], guesses, prm, z["cov_small_sigmas"], random_state=0)
+    assert np.allclose(cov2, z["cov_cov_small_sigmas"], rtol=1e-12, atol=0) and not np.array_equal(cov2, np.diag(z["cov_small_sigmas"]) ** 2)
+    assert chain.icp_with_cov(z["cov_source"], z["cov_target"], guesses[:3], prm, z["cov_sigmas"], 0)[0] == str(z["cov_message_3_guesses"])
