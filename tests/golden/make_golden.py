@@ -85,6 +85,9 @@ class Pose2(object):
     def rotation(self):
         return types.SimpleNamespace(matrix=lambda: np.array([[self._c, -self._s], [self._s, self._c]]))
 
+    def translation(self):
+        return np.array([self._x, self._y])
+
 
 def reference_cfar_class():
     src = open(os.path.join(REF, "CFAR.py")).read()
@@ -325,6 +328,172 @@ def make_nssm_pieces():
              len(gpts), sum(len(c) for c in kf_clouds[:5]), n64, n32, n_none, msg, len(samples_c), np.linalg.det(cov), np.linalg.det(cov2)))
 
 
+def _cut_class(path, name):
+    import textwrap
+    src = open(os.path.join(REF, path)).read()
+    for node in ast.walk(ast.parse(src)):
+        if isinstance(node, ast.ClassDef) and node.name == name:
+            return textwrap.dedent(ast.get_source_segment(src, node))
+    raise RuntimeError("class %s not found in %s" % (name, path))
+
+
+def make_ssm_session():
+    """-> ssm_session.npz: the reference's OWN sequential-scan-matching methods (slam.py: initialize_sequential_scan_matching,
+    add_sequential_scan_matching, add_odometry, get_points, get_matching_cost_subroutine1, compute_icp, get_overlap; slam_objects.py:
+    STATUS, InitializationResult, ICPResult, Keyframe.transform_points) run on a synthetic session of keyframe clouds, by the
+    reference's defaults (global initialisation with scipy's shgo ON), with stand-ins only for what is not in this image: pcl
+    (downsample / match / ICP.compute = the oracle), cv2 (element / dilate = the oracle), gtsam (Pose2 = the class above; factors and
+    noise models = records) and ISAM2 (the new keyframe keeps the initial value its factor was inserted with -- what a chain of
+    between factors optimises to).  Recorded per keyframe: status, its description, shgo's estimated source pose, the ICP transform,
+    the overlap, whether a scan-matching factor went in, and the pose the keyframe ends with."""
+    import contextlib
+    from enum import Enum
+    from typing import Any, Union
+    from scipy.optimize import shgo
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    import oracle as _orc
+    from oracle import chain
+    from sonar_slam_amd import synth
+    from sonar_slam_amd.CFAR import CFAR
+    from sonar_slam_amd.feature_extraction import build_maps, oculus_bearings
+    cost_fn, Keyframe, _ = reference_matching_cost()
+    n2g = lambda g, kind: Pose2(*g)
+    g2n = lambda p: np.array([p.x(), p.y(), p.theta()])
+    ns_o = {"np": np, "Enum": Enum, "Any": Any, "Union": Union, "n2g": n2g, "g2n": g2n, "gtsam": types.SimpleNamespace(Pose2=Pose2)}
+    for cls in ("STATUS", "InitializationResult", "ICPResult"):
+        exec(compile(_cut_class("slam_objects.py", cls), "reference:slam_objects.py", "exec"), ns_o)
+    STATUS = ns_o["STATUS"]
+    prm = _orc.shipped_icp_params(precision=1)
+
+    def icp_compute(src, tgt, g):
+        st, T, _ = _orc.icp(np.asarray(src, np.float32), np.asarray(tgt, np.float32), np.asarray(g, np.float32), prm)
+        return ("success", T) if st == 0 else ("failure", np.asarray(g, np.float32))
+    factors = []
+    gt = types.SimpleNamespace(Pose2=Pose2, BetweenFactorPose2=lambda a, b, t, model: factors.append(("between", a, b, t, model)) or ("between", a, b),
+                               PriorFactorPose2=lambda a, p, model: ("prior", a))
+
+    @contextlib.contextmanager
+    def CodeTimer(name):
+        yield
+    ns = {"np": np, "gtsam": gt, "shgo": shgo, "CodeTimer": CodeTimer, "n2g": n2g, "g2n": g2n, "X": lambda k: k, "STATUS": STATUS,
+          "InitializationResult": ns_o["InitializationResult"], "ICPResult": ns_o["ICPResult"], "Keyframe": Keyframe, "Any": Any,
+          "Union": Union,
+          "pcl": types.SimpleNamespace(downsample=lambda pts, res: _orc.downsample(np.asarray(pts, np.float32), res),
+                                       match=lambda tgt, src, k, r: _orc.match(np.asarray(tgt, np.float32), np.asarray(src, np.float32), r))}
+    for name in ("initialize_sequential_scan_matching", "add_sequential_scan_matching", "add_odometry", "get_points", "compute_icp",
+                 "get_overlap"):
+        exec(compile(_cut("slam.py", name), "reference:slam.py", "exec"), ns)
+
+    class Stamp(float):
+        def __sub__(self, o):
+            return types.SimpleNamespace(to_sec=lambda d=float(self) - float(o): d)
+
+    class Slam(object):
+        current_key = property(lambda self: len(self.keyframes))
+        current_keyframe = property(lambda self: self.keyframes[-1])
+    S = Slam()
+    S.keyframes, S.graph, S.values = [], [], {}
+    S.graph = types.SimpleNamespace(add=lambda f: None)
+    S.values = types.SimpleNamespace(insert=lambda k, p: inserted.__setitem__(k, p))
+    inserted = {}
+    S.ssm_params = types.SimpleNamespace(enable=True, min_points=20, max_translation=3.0, max_rotation=np.pi / 6, target_frames=3,
+                                         initialization=True, initialization_params=(50, 1, 0.01), cov_samples=0)
+    S.odom_sigmas, S.point_resolution, S.point_noise = np.array([0.2, 0.2, 0.02]), 0.5, 0.5
+    S.icp = types.SimpleNamespace(compute=icp_compute)
+    S.odom_model, S.icp_odom_model = "odometry", "icp"
+    S.save_data = S.save_fig = False
+    S.create_full_noise_model = lambda cov: ("cov", cov)
+    for name in ("initialize_sequential_scan_matching", "add_sequential_scan_matching", "add_odometry", "get_points", "compute_icp",
+                 "get_overlap"):
+        setattr(S, name, types.MethodType(ns[name], S))
+    S.get_matching_cost_subroutine1 = types.MethodType(cost_fn, S)
+    last_init = {}
+    inner = S.initialize_sequential_scan_matching
+
+    def spy(keyframe):
+        ret = inner(keyframe)
+        last_init["ret"] = ret
+        last_init["status"] = (ret.status.name, ret.status.description)
+        return ret
+    S.initialize_sequential_scan_matching = spy
+    # ---- the session: pings of a synthetic scene -> SLAM-node clouds (oracle feature extraction), drifting odometry ----
+    K, rows, beams = 7, 256, 128
+    bearings = oculus_bearings(beams)
+    res, height, _, width, cols, mx, my = build_maps(bearings, 30.0 / rows, rows)
+    fe = types.SimpleNamespace(map_x=mx, map_y=my, rows=rows, cols=cols, width=width, height=height)
+    world = synth.world_structure(seed=2, n=5000)
+    true, dr = synth.trajectory(n=K, step=1.7, turn=0.04, seed=11, start=(2.0, 0.0, 0.0))
+    det = CFAR(40, 10, 0.1, 10)
+    clouds = []
+    for k in range(K):
+        img = synth.render_ping(world, true[k], bearings, rows=rows, seed=k)
+        # (float64 arrays of float32 values: ros_numpy's pointcloud2_to_xyz_array hands the SLAM node doubles, slam_ros.py:169-170)
+        clouds.append(chain.slam_cloud(chain.feature_cloud(img, det.params["SOCA"], "SOCA", 65, fe)[1]).astype(np.float64))
+    clouds[4] = clouds[4][:12]                       # a keyframe with too few points: the odometry factor goes in
+    out = {"K": K, "dr": np.array(dr)}
+    for k, c in enumerate(clouds):
+        out["cloud%d" % k] = c
+    summary = []
+    for tag, min_points, max_translation in (("a", 20, 3.0), ("b", 20, 0.05), ("c", 600, 3.0)):
+        S.keyframes = []
+        S.ssm_params.min_points, S.ssm_params.max_translation = min_points, max_translation
+        out[tag + "_min_points"], out[tag + "_max_translation"] = min_points, max_translation
+        recs = []
+        for k in range(K):
+            frame = types.SimpleNamespace(time=Stamp(k), dr_pose=Pose2(*dr[k]), points=clouds[k], pose=Pose2(*dr[k]))
+            if S.keyframes:                               # slam_ros.py:181-184
+                frame.pose = S.current_keyframe.pose.compose(S.current_keyframe.dr_pose.between(frame.dr_pose))
+            inserted.clear()
+            del factors[:]
+            last_init.clear()
+            for m in STATUS:                              # (the members carry the description of whoever used them last)
+                m.description = None
+            overlaps = []
+            rec = {"k": k}
+            if not S.keyframes:
+                inserted[0] = frame.pose                  # add_prior (slam.py:426-436)
+                rec["status"] = "PRIOR"
+            else:
+                S.add_sequential_scan_matching(frame)
+                ret = last_init["ret"]
+                f = factors[-1]
+                rec["init_status"], rec["init_description"] = last_init["status"]
+                rec["estimated_source_pose"] = g2n(ret.estimated_source_pose) if ret.estimated_source_pose is not None else None
+                rec["n_source"], rec["n_target"] = len(ret.source_points), len(ret.target_points)
+                rec["target_points"] = np.asarray(ret.target_points)
+                # what went into the graph: the last between factor of this keyframe (scan match or odometry: both run target -> source)
+                rec["factor_transform"] = g2n(f[3])
+                rec["factor_is_odometry"] = f[4] == "odometry"
+                touched = {m.name: m.description for m in STATUS if m.description is not None}
+                failed = [n for n in touched if n != "SUCCESS"]
+                rec["status"] = failed[0] if rec["factor_is_odometry"] and failed else ("SUCCESS" if not rec["factor_is_odometry"] else rec["init_status"])
+                rec["description"] = touched.get(rec["status"])
+            # update_factor_graph with a chain of between factors: the keyframe takes the value inserted for it
+            frame.pose = inserted[k]
+            S.keyframes.append(frame)
+            rec["pose"] = g2n(frame.pose)
+            recs.append(rec)
+        for r in recs:
+            k = r["k"]
+            out["%s_pose%d" % (tag, k)] = r["pose"]
+            if k:
+                out["%s_init_status%d" % (tag, k)] = np.array(r["init_status"])
+                out["%s_init_description%d" % (tag, k)] = np.array(str(r["init_description"]))
+                out["%s_factor_transform%d" % (tag, k)] = r["factor_transform"]
+                out["%s_factor_is_odometry%d" % (tag, k)] = r["factor_is_odometry"]
+                out["%s_status%d" % (tag, k)] = np.array(r["status"])
+                out["%s_description%d" % (tag, k)] = np.array(str(r["description"]))
+                out["%s_n_source%d" % (tag, k)], out["%s_n_target%d" % (tag, k)] = r["n_source"], r["n_target"]
+                out["%s_target_points%d" % (tag, k)] = r["target_points"]
+                if r["estimated_source_pose"] is not None:
+                    out["%s_estimated_source_pose%d" % (tag, k)] = r["estimated_source_pose"]
+        summary.append((tag, [(r["k"], r.get("status"), r.get("description")) for r in recs]))
+    np.savez_compressed(os.path.join(HERE, "ssm_session.npz"), **out)
+    print("wrote ssm_session.npz:")
+    for t in summary:
+        print("  ", t)
+
+
 def bearings_for(n, aperture_deg=130.0):
     half = aperture_deg * 50.0
     return np.round(np.linspace(-half, half, n)).astype(np.int16)
@@ -335,6 +504,9 @@ def main():
         sys.exit("reference tree not present; fixtures are committed, nothing to do")
     if sys.argv[1:] == ["nssm"]:
         make_nssm_pieces()
+        return
+    if sys.argv[1:] == ["ssm"]:
+        make_ssm_session()
         return
 
     # ---- tau ----
@@ -449,6 +621,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "cfar_ref.npz"), **out)
     print("wrote cfar_tau.json, maps_small.npz, maps_digest.json, matching_cost.npz, transform_points.npz, cfar_ref.npz")
     make_nssm_pieces()
+    make_ssm_session()
 
 
 if __name__ == "__main__":

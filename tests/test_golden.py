@@ -180,3 +180,50 @@ def test_oracle_loop_closure_pieces_match_the_reference_functions():
     _, _, cov2, _, _ = chain.icp_with_cov(z["cov_source"], z["cov_target"], guesses, prm, z["cov_small_sigmas"], random_state=0)
     assert np.allclose(cov2, z["cov_cov_small_sigmas"], rtol=1e-12, atol=0) and not np.array_equal(cov2, np.diag(z["cov_small_sigmas"]) ** 2)
     assert chain.icp_with_cov(z["cov_source"], z["cov_target"], guesses[:3], prm, z["cov_sigmas"], 0)[0] == str(z["cov_message_3_guesses"])
+
+
+def test_oracle_chain_equals_the_reference_sequential_scan_matching_methods():
+    """round 5: oracle/chain.py::run_session(initialization=True) against sessions run by the reference's OWN methods
+    (tests/golden/ssm_session.npz: initialize_sequential_scan_matching + add_sequential_scan_matching + add_odometry + get_points +
+    get_matching_cost_subroutine1 + compute_icp + get_overlap of slam.py, STATUS / InitializationResult / ICPResult of
+    slam_objects.py, exec'd by make_golden.py with the oracle as pcl / cv2 and scipy's shgo) -- three parameter sets, so that every
+    status the flow can end in but INITIALIZATION_FAILURE / NOT_CONVERGED occurs: per keyframe the status and its description, the
+    cloud sizes, the aggregated target cloud, shgo's cost, the overlap, the transform of the factor that went into the graph and
+    the pose the keyframe ends with"""
+    import oracle
+    from oracle import chain
+    z = np.load(os.path.join(G, "ssm_session.npz"))
+    K = int(z["K"])
+    clouds = [z["cloud%d" % k] for k in range(K)]
+    assert clouds[0].dtype == np.float64                     # (the SLAM node's keyframe clouds: doubles holding float32 values)
+    seen = set()
+    for tag in "abc":
+        recs = chain.run_session(clouds, z["dr"], oracle.shipped_icp_params(precision=1), ssm_min_points=int(z[tag + "_min_points"]),
+                                 ssm_max_translation=float(z[tag + "_max_translation"]), initialization=True)
+        assert len(recs) == K and recs[0]["status"] == "PRIOR" and np.array_equal(recs[0]["pose"], z[tag + "_pose0"])
+        poses = [chain.pose(*z["%s_pose%d" % (tag, k)]) for k in range(K)]
+        for k in range(1, K):
+            r, g = recs[k], lambda name: z["%s_%s%d" % (tag, name, k)]
+            status, description = str(g("status")), str(g("description"))
+            seen.add(status)
+            assert r["status"] == status, (tag, k, r["status"], status)
+            assert (r["n_source"], r["n_target"]) == (int(g("n_source")), int(g("n_target")))
+            frames = list(range(k))[-3:]
+            target = oracle.get_points([clouds[f] for f in frames], [chain.matrix(chain.between(poses[k - 1], poses[f])) for f in frames],
+                                       0.5, f64_points=True)
+            assert np.array_equal(target, g("target_points"))
+            if "init_cost" in r:
+                assert str(g("init_description")) == "matching cost {:.2f}".format(r["init_cost"])
+            if status in ("SUCCESS", "NOT_ENOUGH_OVERLAP"):
+                assert description == "overlap {}".format(r["overlap"])
+            if status == "LARGE_TRANSFORMATION":
+                initial = chain.between(poses[k - 1], chain.pose(*g("estimated_source_pose")))
+                d = chain.between(initial, chain.pose(*r["transform"]))
+                assert description == "trans {:.2f} rot {:.2f}".format(float(np.hypot(d[0], d[1])), abs(chain.theta(d)))
+            if status == "NOT_ENOUGH_POINTS":
+                assert description in ("source points {}".format(r["n_source"]), "target points {}".format(r["n_target"]))
+            assert bool(g("factor_is_odometry")) == (status != "SUCCESS")
+            if status == "SUCCESS":
+                assert np.allclose(r["transform"], g("factor_transform"), rtol=0, atol=1e-12), (tag, k)
+            assert np.allclose(r["pose"], g("pose"), rtol=0, atol=1e-12), (tag, k)
+    assert seen == {"SUCCESS", "NOT_ENOUGH_POINTS", "LARGE_TRANSFORMATION", "NOT_ENOUGH_OVERLAP"}
