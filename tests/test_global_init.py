@@ -675,6 +675,45 @@ def test_device_fov_gate_equals_the_reference_lines(ctx):
 
 
 @pytest.mark.gpu
+def test_front_end_equals_the_reference_sequential_scan_matching_methods(ctx):
+    """replay.FrontEnd (host arrays and over the store) fed the keyframe clouds of tests/golden/ssm_session.npz == the sessions the
+    reference's OWN methods ran there (initialize_sequential_scan_matching / add_sequential_scan_matching / ... exec'd from slam.py
+    with the oracle as pcl and scipy's shgo): every status of the three parameter sets, the cloud sizes, shgo's cost, the overlap,
+    the factor's transform and the keyframe poses to the 1e-6 of the device's ICP"""
+    import os
+    from sonar_slam_amd import store as st, wire
+    from sonar_slam_amd.replay import FrontEnd
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ssm_session.npz"))
+    K = int(z["K"])
+    seen = set()
+    for tag in "abc":
+        for use_store in (False, True):
+            s = st.CloudStore(ctx, capacity_points=1 << 17, max_clouds=64) if use_store else None
+            front = FrontEnd(ctx, keyframe_translation=1.5, keyframe_duration=0.5, store=s, nssm_enable=False,
+                             ssm_min_points=int(z[tag + "_min_points"]), ssm_max_translation=float(z[tag + "_max_translation"]))
+            for k in range(K):
+                c = z["cloud%d" % k]
+                rec = front.feed(wire.pack_features(np.c_[c[:, 0], -c[:, 1]]), float(k), Pose2(*z["dr"][k]))
+                assert rec is not None, k                       # (every ping of the fixture is a keyframe)
+                g = lambda name: z["%s_%s%d" % (tag, name, k)]
+                assert np.abs(np.array(rec["pose"]) - g("pose")).max() <= 1e-6, (tag, k)
+                if k == 0:
+                    continue
+                status = str(g("status"))
+                seen.add(status)
+                assert rec["status"] == status and (rec["n_source"], rec["n_target"]) == (int(g("n_source")), int(g("n_target"))), (tag, k)
+                if "init_cost" in rec:
+                    assert str(g("init_description")) == "matching cost {:.2f}".format(rec["init_cost"])
+                if status in ("SUCCESS", "NOT_ENOUGH_OVERLAP"):
+                    assert str(g("description")) == "overlap {}".format(rec["overlap"])
+                if status == "SUCCESS":
+                    assert np.abs(np.array(rec["transform"]) - g("factor_transform")).max() <= 1e-6
+            if s is not None:
+                s.close()
+    assert seen == {"SUCCESS", "NOT_ENOUGH_POINTS", "LARGE_TRANSFORMATION", "NOT_ENOUGH_OVERLAP"}
+
+
+@pytest.mark.gpu
 def test_device_loop_closure_pieces_equal_the_reference_functions(ctx):
     """the product against the outputs of the reference's own functions (tests/golden/nssm_pieces.npz: get_points with keys,
     get_overlap, compute_icp_with_cov run by make_golden.py with the oracle as pcl): keyed global target cloud over the store,
