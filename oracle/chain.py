@@ -275,6 +275,8 @@ def nssm_search(clouds, poses, covs, current_frame_pose, icp_params, point_resol
     if P["initialization"] and P["cov_samples"] > 0:
         guesses = initial_transforms(pose_samples, target_pose)[:P["cov_samples"]]
         rec["n_guesses"] = len(guesses)
+        ps = np.asarray(pose_samples, np.float64)
+        rec["pose_samples"] = ps[np.lexsort((ps[:, 2], ps[:, 1], ps[:, 0], ps[:, 3]))]     # every evaluation of the cost, canonical order
         message, odom, cov, xyt, icp_recs = icp_with_cov(source_points, target_local, guesses, icp_params, P["icp_odom_sigmas"],
                                                          P["mcd_random_state"])
         rec["icp_runs"] = icp_recs

@@ -494,6 +494,168 @@ def make_ssm_session():
         print("  ", t)
 
 
+def make_nssm_session():
+    """-> nssm_session.npz: one session on a closed trajectory run by the reference's OWN methods, the loop-closure search included:
+    initialize_nonsequential_scan_matching + add_nonsequential_scan_matching + compute_icp_with_cov next to the sequential-scan-
+    matching methods of make_ssm_session, by the reference's defaults (slam.yaml's nssm block; both global initialisations ON).
+    Stand-ins as there, plus: MinCovDet = sklearn's own with numpy's global generator seeded with 0 before every search (the
+    oracle / the product pass random_state=0), PCM = nothing passes (verify_pcm -> []: loop factors never reach the graph, as with
+    the chain back end), the marginal covariances of ISAM2 = oracle/chain.py::chain_covariance (an INPUT of the search), and
+    self.current_frame moving on only after the search (slam_ros.py:207-211)."""
+    import contextlib
+    import time as time_pkg
+    from enum import Enum
+    from typing import Any, Union
+    from scipy.optimize import shgo
+    from sklearn.covariance import MinCovDet
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    import oracle as _orc
+    from oracle import chain
+    from sonar_slam_amd import synth
+    from sonar_slam_amd.CFAR import CFAR
+    from sonar_slam_amd.feature_extraction import build_maps, oculus_bearings
+    cost_fn, Keyframe, _ = reference_matching_cost()
+    n2g = lambda g, kind: Pose2(*g)
+    g2n = lambda p: np.array([p.x(), p.y(), p.theta()])
+    ns_o = {"np": np, "Enum": Enum, "Any": Any, "Union": Union, "n2g": n2g, "g2n": g2n, "gtsam": types.SimpleNamespace(Pose2=Pose2)}
+    for cls in ("STATUS", "InitializationResult", "ICPResult"):
+        exec(compile(_cut_class("slam_objects.py", cls), "reference:slam_objects.py", "exec"), ns_o)
+    STATUS = ns_o["STATUS"]
+    prm = _orc.shipped_icp_params(precision=1)
+
+    def icp_compute(src, tgt, g):
+        st, T, _ = _orc.icp(np.asarray(src, np.float32), np.asarray(tgt, np.float32), np.asarray(g, np.float32), prm)
+        return ("success", T) if st == 0 else ("failure", np.asarray(g, np.float32))
+
+    def ds(*a):
+        if len(a) == 3:
+            out_p, idx = _orc.downsample(np.asarray(a[0], np.float32), a[2], return_index=True)
+            return out_p, np.asarray(a[1], np.float32)[idx]
+        return _orc.downsample(np.asarray(a[0], np.float32), a[1])
+    factors = []
+    gt = types.SimpleNamespace(Pose2=Pose2, BetweenFactorPose2=lambda a, b, t, model: factors.append(("between", a, b, t, model)) or ("between", a, b))
+
+    @contextlib.contextmanager
+    def CodeTimer(name):
+        yield
+    np_ns = types.SimpleNamespace(**{k: getattr(np, k) for k in dir(np) if not k.startswith("__")})
+    np_ns.bool = bool
+    ns = {"np": np_ns, "gtsam": gt, "shgo": shgo, "CodeTimer": CodeTimer, "n2g": n2g, "g2n": g2n, "X": lambda k: k, "STATUS": STATUS,
+          "InitializationResult": ns_o["InitializationResult"], "ICPResult": ns_o["ICPResult"], "Keyframe": Keyframe, "Any": Any,
+          "Union": Union, "MinCovDet": MinCovDet,
+          # (compute_icp_with_cov stops trying guesses after 2 s of wall clock, slam.py:356-358: a real-time guard that
+          #  libpointmatcher never reaches with 30 guesses, but the oracle's ICP on this CPU does -- the clock stands still here)
+          "time_pkg": types.SimpleNamespace(time=lambda: 0.0),
+          "pcl": types.SimpleNamespace(downsample=ds, match=lambda tgt, src, k, r: _orc.match(np.asarray(tgt, np.float32), np.asarray(src, np.float32), r))}
+    names = ("initialize_sequential_scan_matching", "add_sequential_scan_matching", "add_odometry", "get_points", "compute_icp",
+             "compute_icp_with_cov", "get_overlap", "initialize_nonsequential_scan_matching", "add_nonsequential_scan_matching")
+    for name in names:
+        exec(compile(_cut("slam.py", name), "reference:slam.py", "exec"), ns)
+
+    class Stamp(float):
+        def __sub__(self, o):
+            return types.SimpleNamespace(to_sec=lambda d=float(self) - float(o): d)
+
+    class Slam(object):
+        current_key = property(lambda self: len(self.keyframes))
+        current_keyframe = property(lambda self: self.keyframes[-1])
+    S = Slam()
+    inserted = {}
+    S.keyframes, S.current_frame, S.nssm_queue, S.pcm_queue_size, S.min_pcm = [], None, [], 5, 2
+    S.graph = types.SimpleNamespace(add=lambda f: None)
+    S.values = types.SimpleNamespace(insert=lambda k, p: inserted.__setitem__(k, p))
+    S.verify_pcm = lambda queue, min_pcm: []
+    S.ssm_params = types.SimpleNamespace(enable=True, min_points=20, max_translation=3.0, max_rotation=np.pi / 6, target_frames=3,
+                                         initialization=True, initialization_params=(50, 1, 0.01), cov_samples=0)
+    S.nssm_params = types.SimpleNamespace(enable=True, min_st_sep=8, min_points=30, max_translation=10.0, max_rotation=np.pi / 3,
+                                          source_frames=5, cov_samples=30, initialization=True, initialization_params=(100, 5, 0.01))
+    S.oculus = types.SimpleNamespace(max_range=30.0, horizontal_aperture=np.radians(130.0))
+    S.odom_sigmas, S.icp_odom_sigmas, S.point_resolution, S.point_noise = np.array([0.2, 0.2, 0.02]), np.array([0.1, 0.1, 0.01]), 0.5, 0.5
+    S.icp = types.SimpleNamespace(compute=icp_compute)
+    S.odom_model, S.icp_odom_model = "odometry", "icp"
+    S.save_data = S.save_fig = False
+    S.create_full_noise_model = lambda cov: ("cov", cov)
+    for name in names:
+        setattr(S, name, types.MethodType(ns[name], S))
+    S.get_matching_cost_subroutine1 = types.MethodType(cost_fn, S)
+    last = {}
+    inner = S.initialize_nonsequential_scan_matching
+
+    def spy():
+        ret = inner()
+        last["init"] = ret
+        last["init_status"] = (ret.status.name, ret.status.description)
+        return ret
+    S.initialize_nonsequential_scan_matching = spy
+    K, rows, beams = 15, 256, 128
+    bearings = oculus_bearings(beams)
+    res, height, _, width, cols, mx, my = build_maps(bearings, 30.0 / rows, rows)
+    fe = types.SimpleNamespace(map_x=mx, map_y=my, rows=rows, cols=cols, width=width, height=height)
+    world = synth.world_structure(seed=2, n=9000)
+    true, dr = synth.trajectory(n=K, step=1.7, turn=2 * np.pi / 13, seed=21, start=(20.0, 0.0, 0.0))
+    det = CFAR(40, 10, 0.1, 10)
+    clouds = []
+    for k in range(K):
+        img = synth.render_ping(world, true[k], bearings, rows=rows, seed=k)
+        clouds.append(chain.slam_cloud(chain.feature_cloud(img, det.params["SOCA"], "SOCA", 65, fe)[1]).astype(np.float64))
+    out = {"K": K, "dr": np.array(dr), "ssm_min_points": 20, "nssm_min_points": 30}
+    summary = []
+    for k in range(K):
+        out["cloud%d" % k] = clouds[k]
+        frame = types.SimpleNamespace(time=Stamp(k), dr_pose=Pose2(*dr[k]), points=clouds[k], pose=Pose2(*dr[k]), cov=None, constraints=[])
+        if S.keyframes:
+            frame.pose = S.current_keyframe.pose.compose(S.current_keyframe.dr_pose.between(frame.dr_pose))
+        inserted.clear()
+        del factors[:]
+        if not S.keyframes:
+            inserted[0] = frame.pose
+            kind = "prior"
+        else:
+            S.add_sequential_scan_matching(frame)
+            kind = "odometry" if factors[-1][4] == "odometry" else "icp"
+        frame.pose = inserted[k]
+        frame.cov = chain.chain_covariance(S.keyframes[-1].cov if S.keyframes else None, kind)
+        frame.transf_points = Keyframe.transform_points(frame.points, frame.pose)       # Keyframe.update (slam_objects.py:160)
+        S.keyframes.append(frame)
+        out["pose%d" % k] = g2n(frame.pose)
+        if S.current_frame is not None:                                                  # slam_ros.py:207
+            for m in STATUS:
+                m.description = None
+            last.clear()
+            np.random.seed(0)
+            ret2 = S.add_nonsequential_scan_matching()
+            if "init" in last:
+                ret = last["init"]
+                out["search%d" % k] = True
+                out["init_status%d" % k] = np.array(last["init_status"][0])
+                out["init_description%d" % k] = np.array(str(last["init_status"][1]))
+                out["n_source%d" % k] = len(ret.source_points)
+                if ret2 is not None:
+                    out["status%d" % k] = np.array(ret2.status.name)
+                    out["description%d" % k] = np.array(str(ret2.status.description))
+                    out["target_key%d" % k] = int(ret2.target_key)
+                    out["n_target%d" % k] = len(ret2.target_points)
+                    out["initial_transform%d" % k] = g2n(ret2.initial_transform)
+                    out["n_guesses%d" % k] = len(ret2.initial_transforms[:30])
+                    # the ICP inputs of the search and the guesses in the order THIS run tried them (among pose samples of equal cost
+                    # the reference's order is an unstable argsort over shgo's evaluation order: it differs from run to run)
+                    out["icp_source%d" % k] = np.asarray(ret2.source_points, np.float32)
+                    out["icp_target%d" % k] = np.asarray(ret2.target_points, np.float32)
+                    out["guesses%d" % k] = np.array([g2n(t) for t in ret2.initial_transforms[:30]])
+                    ps = np.asarray(ret.source_pose_samples)
+                    out["pose_samples%d" % k] = ps[np.lexsort((ps[:, 2], ps[:, 1], ps[:, 0], ps[:, 3]))]
+                    if ret2.estimated_transform is not None:
+                        out["transform%d" % k] = g2n(ret2.estimated_transform)
+                        out["cov%d" % k] = np.asarray(ret2.cov)
+                        out["sample_transforms%d" % k] = np.asarray(ret2.sample_transforms)
+                summary.append((k, last["init_status"], None if ret2 is None else (ret2.status.name, ret2.status.description, int(ret2.target_key))))
+        S.current_frame = frame
+    np.savez_compressed(os.path.join(HERE, "nssm_session.npz"), **out)
+    print("wrote nssm_session.npz:")
+    for t in summary:
+        print("  ", t)
+
+
 def bearings_for(n, aperture_deg=130.0):
     half = aperture_deg * 50.0
     return np.round(np.linspace(-half, half, n)).astype(np.int16)
@@ -507,6 +669,9 @@ def main():
         return
     if sys.argv[1:] == ["ssm"]:
         make_ssm_session()
+        return
+    if sys.argv[1:] == ["nssm_session"]:
+        make_nssm_session()
         return
 
     # ---- tau ----
@@ -622,6 +787,7 @@ def main():
     print("wrote cfar_tau.json, maps_small.npz, maps_digest.json, matching_cost.npz, transform_points.npz, cfar_ref.npz")
     make_nssm_pieces()
     make_ssm_session()
+    make_nssm_session()
 
 
 if __name__ == "__main__":

@@ -227,3 +227,53 @@ def test_oracle_chain_equals_the_reference_sequential_scan_matching_methods():
                 assert np.allclose(r["transform"], g("factor_transform"), rtol=0, atol=1e-12), (tag, k)
             assert np.allclose(r["pose"], g("pose"), rtol=0, atol=1e-12), (tag, k)
     assert seen == {"SUCCESS", "NOT_ENOUGH_POINTS", "LARGE_TRANSFORMATION", "NOT_ENOUGH_OVERLAP"}
+
+
+def test_oracle_chain_equals_the_reference_loop_closure_methods():
+    """round 5: oracle/chain.py::run_session(initialization=True, nssm=...) against a closed-trajectory session run by the
+    reference's OWN methods with the loop-closure search included (tests/golden/nssm_session.npz: initialize_nonsequential_scan_
+    matching, add_nonsequential_scan_matching, compute_icp_with_cov, ICPResult next to the sequential ones; oracle as pcl / cv2,
+    scipy's shgo (100 x 5), sklearn's MinCovDet).  Equal per search: both statuses, the aggregated source cloud's size, shgo's cost,
+    EVERY evaluation of the cost (the pose samples as a multiset), the refined target key, the ICP's clouds, the number of guesses.
+    The <= 30 guesses themselves are the head of a list sorted by an integer cost full of ties: the reference's order among equals is
+    an unstable argsort over shgo's evaluation order (a Python set: it changes from run to run), ours is (cost, x, y, theta) -- so the
+    converged transforms and MinCovDet's centre are compared (a) exactly, by giving the oracle the guesses of the reference's run, and
+    (b) loosely between the two orders (the centres differ by centimetres to decimetres: the reference's own run-to-run spread)"""
+    import oracle
+    from oracle import chain
+    z = np.load(os.path.join(G, "nssm_session.npz"))
+    K = int(z["K"])
+    clouds = [z["cloud%d" % k] for k in range(K)]
+    prm = oracle.shipped_icp_params(precision=1)
+    recs = chain.run_session(clouds, z["dr"], prm, ssm_min_points=int(z["ssm_min_points"]), initialization=True,
+                             nssm=dict(min_points=int(z["nssm_min_points"]), mcd_random_state=0))
+    n_searches = n_loops = 0
+    for k in range(K):
+        assert np.allclose(recs[k]["pose"], z["pose%d" % k], rtol=0, atol=1e-12), k
+        n = recs[k].get("nssm")
+        assert (n is not None) == ("search%d" % k in z.files), k
+        if n is None:
+            continue
+        n_searches += 1
+        g = lambda name: z["%s%d" % (name, k)]
+        assert n["n_source"] == int(g("n_source"))
+        if "status%d" % k not in z.files:              # the search ended in its initialisation (no ICPResult)
+            assert n["status"] == str(g("init_status")), (k, n["status"])
+            if n["status"] == "NOT_ENOUGH_POINTS":
+                assert str(g("init_description")) in ("source points {}".format(n["n_source"]), "target points {}".format(n.get("n_target_global", 0)))
+            continue
+        assert str(g("init_description")) == "matching cost {:.2f}".format(n["init_cost"])
+        assert np.array_equal(n["pose_samples"], g("pose_samples")) and len(g("pose_samples")) > 400
+        assert n["status"] == str(g("status")) and n["target_key"] == int(g("target_key")) and n["n_target"] == int(g("n_target")), k
+        assert n["n_guesses"] == int(g("n_guesses")) == len(g("guesses"))
+        # (a) the reference run's guesses through the oracle's compute_icp_with_cov: its converged transforms, centre, covariance
+        msg, odom, cov, xyt, _ = chain.icp_with_cov(g("icp_source"), g("icp_target"), [chain.pose(*q) for q in g("guesses")], prm,
+                                                    (0.1, 0.1, 0.01), random_state=0)
+        assert msg == "success" and np.array_equal(xyt, g("sample_transforms"))
+        assert np.allclose([odom[0], odom[1], chain.theta(odom)], g("transform"), rtol=0, atol=1e-12)
+        assert np.allclose(cov, g("cov"), rtol=1e-12, atol=0)
+        # (b) the canonical order against the order of that run
+        common = len(set(map(tuple, n["sample_transforms"])) & set(map(tuple, g("sample_transforms"))))
+        assert common >= 20 and np.abs(np.array(n["transform"]) - g("transform")).max() < 0.5, (k, common)
+        n_loops += n["status"] == "SUCCESS"
+    assert n_searches >= 7 and n_loops >= 4
