@@ -714,6 +714,45 @@ def test_front_end_equals_the_reference_sequential_scan_matching_methods(ctx):
 
 
 @pytest.mark.gpu
+def test_front_end_equals_the_reference_loop_closure_methods(ctx):
+    """replay.FrontEnd(nssm_enable=True) over the store, fed the keyframe clouds of tests/golden/nssm_session.npz == the session the
+    reference's OWN methods ran there (sequential scan matching + initialize_nonsequential_scan_matching / add_nonsequential_scan_
+    matching / compute_icp_with_cov exec'd from slam.py): keyframe poses, per search both statuses, the source cloud's size, shgo's
+    cost, the refined target key, the ICP target's size, the number of guesses; the loop transform loosely (the <= 30 guesses are the
+    head of a list sorted by a cost full of ties: tests/test_golden.py says what can and what cannot be equal there)"""
+    import os
+    from sonar_slam_amd import store as st, wire
+    from sonar_slam_amd.replay import FrontEnd
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nssm_session.npz"))
+    K = int(z["K"])
+    s = st.CloudStore(ctx, capacity_points=1 << 18, max_clouds=256)
+    front = FrontEnd(ctx, keyframe_translation=1.5, keyframe_duration=0.5, store=s, ssm_min_points=int(z["ssm_min_points"]),
+                     nssm_enable=True, nssm_min_points=int(z["nssm_min_points"]), mcd_random_state=0)
+    n_searches = n_loops = 0
+    for k in range(K):
+        c = z["cloud%d" % k]
+        rec = front.feed(wire.pack_features(np.c_[c[:, 0], -c[:, 1]]), float(k), Pose2(*z["dr"][k]))
+        assert rec is not None and np.abs(np.array(rec["pose"]) - z["pose%d" % k]).max() <= 1e-6, k
+        n = rec.get("nssm")
+        assert (n is not None) == ("search%d" % k in z.files), k
+        if n is None:
+            continue
+        n_searches += 1
+        g = lambda name: z["%s%d" % (name, k)]
+        assert n["n_source"] == int(g("n_source"))
+        if "status%d" % k not in z.files:
+            assert n["status"] == str(g("init_status"))
+            continue
+        assert str(g("init_description")) == "matching cost {:.2f}".format(n["init_cost"])
+        assert n["status"] == str(g("status")) and n["target_key"] == int(g("target_key")) and n["n_target"] == int(g("n_target")), k
+        assert n["n_guesses"] == int(g("n_guesses"))
+        assert np.abs(np.array(n["transform"]) - g("transform")).max() < 0.5
+        n_loops += n["status"] == "SUCCESS"
+    assert n_searches >= 7 and n_loops >= 4
+    s.close()
+
+
+@pytest.mark.gpu
 def test_device_loop_closure_pieces_equal_the_reference_functions(ctx):
     """the product against the outputs of the reference's own functions (tests/golden/nssm_pieces.npz: get_points with keys,
     get_overlap, compute_icp_with_cov run by make_golden.py with the oracle as pcl): keyed global target cloud over the store,
