@@ -656,6 +656,52 @@ def make_nssm_session():
         print("  ", t)
 
 
+def make_feature_callback():
+    """-> feature_callback.npz: the body of FeatureExtraction.callback from the detection to the filtered cloud (feature_extraction.py:
+    222-249, cut out by its first and last line) run on synthetic pings with the reference's own CFAR class calling the reference's
+    own compiled cfar.cpp (oracle/_ref), its own generate_map_xy maps, and the oracle standing in for cv2.remap and pcl: the intensity
+    gate, np.nonzero's order, the pixel -> metre arithmetic and the order of the two filters are the reference's lines."""
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    import oracle as _orc
+    from sonar_slam_amd import synth
+    if not _orc.have_ref_cfar():
+        sys.exit("oracle/_ref/libcfar_ref.so missing: run `make -C oracle ref` first")
+    block, span = _cut_block("feature_extraction.py", "peaks = self.detector.detect(img, self.alg)", "self.outlier_filter_radius, self.outlier_filter_min_points")
+    block += "\n    )\n"                     # (the call's closing parenthesis sits on the next source line)
+    CFAR = reference_cfar_class()
+    gen = reference_generate_map_xy()
+    out, summary = {}, []
+    for i, (rows, beams, n_blobs, thr, res, radius, min_pts) in enumerate([(256, 128, 10, 65, 0.5, 1.0, 5), (512, 256, 25, 65, 0.5, 1.0, 5),
+                                                                           (192, 64, 6, 40, 0.25, 0.5, 3), (256, 128, 10, 65, 0.0, 1.0, 1)]):
+        img = synth.sonar_frame(seed=90 + i, rows=rows, cols=beams, n_blobs=n_blobs)
+        det = CFAR(40, 10, 0.1, 10)
+        for alg in ("CA", "SOCA", "GOCA", "OS"):
+            det.detector[alg] = (lambda a: lambda mat, th, gh, tau, k=0: _orc.ref_cfar(mat, a, th, gh, tau, k))(alg)
+        me = _Self()
+        ping = _Ping(bearings_for(beams), 30.0 / rows, rows)
+        gen(me, ping)
+        me.detector, me.alg, me.threshold = det, "SOCA", thr
+        me.resolution, me.outlier_filter_radius, me.outlier_filter_min_points = res, radius, min_pts
+        me.feature_img_pub = types.SimpleNamespace(publish=lambda m: None)
+        ns = {"np": np, "self": me, "img": img.copy(), "sonar_msg": ping,
+              "cv2": types.SimpleNamespace(INTER_LINEAR=1, remap=lambda a, mx, my, interp: _orc.remap_u8(np.asarray(a, np.uint8), mx, my),
+                                           applyColorMap=lambda a, c: a),
+              "ros_numpy": types.SimpleNamespace(image=types.SimpleNamespace(numpy_to_image=lambda a, enc: a)),
+              "pcl": types.SimpleNamespace(downsample=lambda pts, r: _orc.downsample(np.asarray(pts, np.float32), r),
+                                           remove_outlier=lambda pts, r, k: _orc.remove_outlier(np.asarray(pts, np.float32), r, k))}
+        exec(compile(block, "reference:feature_extraction.py:%d-%d" % span, "exec"), ns)
+        out.update({"img%d" % i: img, "bearings%d" % i: np.asarray(ping.bearings, np.int16), "range_resolution%d" % i: ping.range_resolution,
+                    "threshold%d" % i: thr, "resolution%d" % i: res, "radius%d" % i: radius, "min_points%d" % i: min_pts,
+                    "locs%d" % i: np.asarray(ns["locs"]), "points%d" % i: np.asarray(ns["points"]),
+                    "points_dtype%d" % i: np.array(str(np.asarray(ns["points"]).dtype)),
+                    "raw_xy%d" % i: np.column_stack((ns["y"], ns["x"]))})
+        summary.append((rows, beams, len(ns["locs"]), len(ns["points"]), str(np.asarray(ns["points"]).dtype)))
+    out["n"] = len(summary)
+    out["lines"] = np.array("feature_extraction.py:%d-%d" % span)
+    np.savez_compressed(os.path.join(HERE, "feature_callback.npz"), **out)
+    print("wrote feature_callback.npz (%s):" % out["lines"], summary)
+
+
 def bearings_for(n, aperture_deg=130.0):
     half = aperture_deg * 50.0
     return np.round(np.linspace(-half, half, n)).astype(np.int16)
@@ -672,6 +718,9 @@ def main():
         return
     if sys.argv[1:] == ["nssm_session"]:
         make_nssm_session()
+        return
+    if sys.argv[1:] == ["callback"]:
+        make_feature_callback()
         return
 
     # ---- tau ----
@@ -788,6 +837,7 @@ def main():
     make_nssm_pieces()
     make_ssm_session()
     make_nssm_session()
+    make_feature_callback()
 
 
 if __name__ == "__main__":

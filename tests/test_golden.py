@@ -277,3 +277,29 @@ def test_oracle_chain_equals_the_reference_loop_closure_methods():
         assert common >= 20 and np.abs(np.array(n["transform"]) - g("transform")).max() < 0.5, (k, common)
         n_loops += n["status"] == "SUCCESS"
     assert n_searches >= 7 and n_loops >= 4
+
+
+def test_oracle_feature_cloud_equals_the_reference_callback_lines():
+    """round 5: the oracle's feature pipeline (oracle/chain.py::feature_cloud) against the body of FeatureExtraction.callback run
+    from the reference's own lines (tests/golden/feature_callback.npz: feature_extraction.py:223-248 exec'd with the reference's CFAR
+    class on its compiled cfar.cpp, its generate_map_xy maps, the oracle as cv2.remap / pcl): the gated detections' canvas pixels in
+    np.nonzero order, the pixel -> metre arithmetic bit for bit, the filtered cloud"""
+    from types import SimpleNamespace
+    import oracle
+    from oracle import chain
+    z = np.load(os.path.join(G, "feature_callback.npz"))
+    det = CFAR(40, 10, 0.1, 10)
+    for i in range(int(z["n"])):
+        img, bearings = z["img%d" % i], z["bearings%d" % i]
+        res, height, _, width, cols, mx, my = build_maps(bearings, float(z["range_resolution%d" % i]), img.shape[0])
+        fe = SimpleNamespace(map_x=mx, map_y=my, rows=img.shape[0], cols=cols, width=width, height=height)
+        th, gh, tau = det.params["SOCA"]
+        m = oracle.gate(img, oracle.cfar(img, "SOCA", th, gh, tau), int(z["threshold%d" % i]))
+        rc = oracle.nonzero(oracle.remap_u8(m, mx, my))
+        assert np.array_equal(rc, z["locs%d" % i]) and len(rc) > 1000
+        raw = oracle.px_to_m(rc, fe.rows, fe.cols, fe.width, fe.height)
+        assert raw.dtype == np.float64 and np.array_equal(raw, z["raw_xy%d" % i])
+        _, cloud = chain.feature_cloud(img, det.params["SOCA"], "SOCA", int(z["threshold%d" % i]), fe, float(z["resolution%d" % i]),
+                                       float(z["radius%d" % i]), int(z["min_points%d" % i]))
+        want = z["points%d" % i]
+        assert np.array_equal(cloud, want.astype(np.float32)) and len(want) > 400, i

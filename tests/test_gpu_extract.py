@@ -404,3 +404,21 @@ def test_vis_image_with_the_jet_colour_map_in_one_pass(ctx):
         fe.callback(ping)
         assert np.array_equal(fe.feature_img, want)
         s.close()
+
+
+def test_callback_equals_the_reference_callback_lines(ctx):
+    """FeatureExtraction.callback (fused one-call path and per-stage path) == the body of the reference's callback run from its own
+    lines (tests/golden/feature_callback.npz: feature_extraction.py:223-248 with the reference's CFAR class on its compiled cfar.cpp,
+    its own maps, the oracle as cv2.remap / pcl) -- the filtered cloud of every case, the unfiltered fp64 points of the last"""
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "feature_callback.npz"))
+    for i in range(int(z["n"])):
+        for fused in (True, False):
+            fe = FeatureExtraction(ctx)
+            fe.Ntc, fe.Ngc, fe.Pfa, fe.rank, fe.alg, fe.threshold = 40, 10, 0.1, 10, "SOCA", int(z["threshold%d" % i])
+            fe.resolution, fe.outlier_filter_radius, fe.outlier_filter_min_points, fe.skip = (
+                float(z["resolution%d" % i]), float(z["radius%d" % i]), int(z["min_points%d" % i]), 1)
+            fe.fused = fused
+            fe.configure()
+            pts = fe.callback(SonarPing(z["img%d" % i], z["bearings%d" % i], float(z["range_resolution%d" % i])))
+            want = z["points%d" % i]
+            assert np.array_equal(np.asarray(pts, want.dtype), want) and len(want) > 400, (i, fused, len(pts), len(want))
