@@ -421,4 +421,8 @@ def test_callback_equals_the_reference_callback_lines(ctx):
             fe.configure()
             pts = fe.callback(SonarPing(z["img%d" % i], z["bearings%d" % i], float(z["range_resolution%d" % i])))
             want = z["points%d" % i]
-            assert np.array_equal(np.asarray(pts, want.dtype), want) and len(want) > 400, (i, fused, len(pts), len(want))
+            # (float32: what the filters return and what the feature message carries, feature_extraction.py:182-185; with both
+            #  filters off the reference's array is still float64 at this point and the one-call path hands back float32)
+            assert np.array_equal(np.asarray(pts, np.float32), want.astype(np.float32)) and len(want) > 400, (i, fused, len(pts), len(want))
+            if not fused and want.dtype == np.float64:
+                assert np.asarray(pts).dtype == np.float64 and np.array_equal(pts, want)
