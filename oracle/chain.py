@@ -294,7 +294,7 @@ def nssm_search(clouds, poses, covs, current_frame_pose, icp_params, point_resol
         rec["icp"], rec["cov"] = "success", None
     rec["transform"] = (odom[0], odom[1], theta(odom))
     d = between(initial, odom)
-    if float(np.hypot(d[0], d[1])) > P["max_translation"] or abs(theta(d)) > P["max_rotation"]:
+    if np.linalg.norm(np.array([d[0], d[1]])) > P["max_translation"] or abs(theta(d)) > P["max_rotation"]:      # slam.py:1064-1070
         rec["status"] = "LARGE_TRANSFORMATION"
         return rec
     rec["overlap"] = oracle.overlap(source_points, target_local, matrix(odom), point_noise, f64_points=False)
@@ -357,7 +357,7 @@ def run_session(clouds, dr, icp_params, point_resolution=0.5, point_noise=0.5, s
             status = "SUCCESS" if st == 0 else "NOT_CONVERGED"
             if status == "SUCCESS":
                 d = between(initial, est)
-                if float(np.hypot(d[0], d[1])) > ssm_max_translation or abs(theta(d)) > ssm_max_rotation:
+                if np.linalg.norm(np.array([d[0], d[1]])) > ssm_max_translation or abs(theta(d)) > ssm_max_rotation:   # slam.py:781-787
                     status = "LARGE_TRANSFORMATION"
             if status == "SUCCESS":
                 rec["overlap"] = oracle.overlap(source, target, matrix(est), point_noise, f64_points=True)

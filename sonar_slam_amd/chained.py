@@ -262,6 +262,8 @@ class SessionBatch(object):
             est.put(idx, e)
             rec["status"][idx[sti != 0]] = NOT_CONVERGED
             delta = initial.take(idx).between(e)
+            # (the reference: np.linalg.norm(delta.translation()) per scan match; hypot here, for all sessions at once -- the two can
+            #  differ in the last bit, i.e. for a translation within 4e-16 m of the 3 m gate)
             large = (np.hypot(delta.x, delta.y) > self.ssm_max_translation) | (np.abs(delta.theta()) > self.ssm_max_rotation)
             rec["status"][idx[(sti == 0) & large]] = LARGE_TRANSFORMATION
             ok = idx[(sti == 0) & ~large]

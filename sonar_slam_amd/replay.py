@@ -179,7 +179,7 @@ class FrontEnd(object):
         if frame.time - self.current_keyframe.time < self.keyframe_duration:
             return False
         dr_odom = self.keyframes[-1].dr_pose.between(frame.dr_pose)
-        translation = float(np.hypot(dr_odom.x(), dr_odom.y()))
+        translation = np.linalg.norm(np.array([dr_odom.x(), dr_odom.y()]))       # np.linalg.norm(dr_odom.translation()), the reference's call
         rotation = abs(dr_odom.theta())
         return translation > self.keyframe_translation or rotation > self.keyframe_rotation
 
@@ -374,7 +374,7 @@ class FrontEnd(object):
             status = "NOT_CONVERGED"
         if status == "SUCCESS":
             delta = initial_transform.between(estimated)
-            if (float(np.hypot(delta.x(), delta.y())) > self.ssm_max_translation or
+            if (np.linalg.norm(np.array([delta.x(), delta.y()])) > self.ssm_max_translation or     # (np.linalg.norm(delta.translation()))
                     abs(delta.theta()) > self.ssm_max_rotation):
                 status = "LARGE_TRANSFORMATION"
         if status == "SUCCESS":
@@ -549,7 +549,7 @@ class FrontEnd(object):
                 return
         rec["transform"] = (odom.x(), odom.y(), odom.theta())
         delta = initial_transform.between(odom)                                 # slam.py:1066-1077
-        if (float(np.hypot(delta.x(), delta.y())) > self.nssm_max_translation or abs(delta.theta()) > self.nssm_max_rotation):
+        if (np.linalg.norm(np.array([delta.x(), delta.y()])) > self.nssm_max_translation or abs(delta.theta()) > self.nssm_max_rotation):
             rec["status"] = "LARGE_TRANSFORMATION"
             return
         overlap = self.get_overlap(source_points, target_local, odom, f32_source=True)

@@ -321,6 +321,28 @@ def make_nssm_pieces():
     out.update(cov_source=src_c, cov_target=tgt_c, cov_guesses=gs, cov_message=np.array(msg), cov_message_3_guesses=np.array(msg_few),
                cov_centre=np.array([m.x(), m.y(), m.theta()]), cov_cov=np.asarray(cov), cov_samples=np.asarray(samples_c),
                cov_cov_small_sigmas=np.asarray(cov2), cov_sigmas=np.array([0.1, 0.1, 0.01]), cov_small_sigmas=np.array([1e-4, 1e-4, 1e-5]))
+    # ---- is_keyframe (slam.py:1134-1161): which pings become keyframes ----
+    kf_src = _cut("slam.py", "is_keyframe")
+    ns_kf = {"np": np, "Keyframe": object}
+    exec(compile(kf_src, "reference:slam.py", "exec"), ns_kf)
+    rng = np.random.default_rng(3)
+    last = types.SimpleNamespace(time=10.0, dr_pose=Pose2(4.0, -2.0, 0.7))
+
+    class _S(object):
+        keyframes = [last]
+        current_keyframe = last
+        keyframe_duration, keyframe_translation, keyframe_rotation = 1.0, 3.0, np.radians(30.0)
+    cases, flags = [], []
+    for _ in range(400):
+        kind = rng.integers(4)
+        t = 10.0 + float(rng.choice([0.5, 0.999, 1.0, 1.5, 4.0]))
+        d = Pose2(*(rng.normal(0, [2.5, 2.5, 0.4]) if kind else (3.0 * np.cos(0.3), 3.0 * np.sin(0.3), 0.0)))   # (on the 3 m gate)
+        frame = types.SimpleNamespace(time=t, dr_pose=last.dr_pose.compose(d))
+        cases.append([t, frame.dr_pose.x(), frame.dr_pose.y(), frame.dr_pose.theta()])
+        flags.append(bool(ns_kf["is_keyframe"](_S(), frame)))
+    empty = type("E", (), {"keyframes": []})()
+    out.update(kf_last=np.array([10.0, 4.0, -2.0, 0.7]), kf_cases=np.array(cases), kf_flags=np.array(flags),
+               kf_first=bool(ns_kf["is_keyframe"](empty, None)))
     np.savez_compressed(os.path.join(HERE, "nssm_pieces.npz"), **out)
     print("wrote nssm_pieces.npz (field-of-view gate of %s: %d of %d points kept, keyframes %r; ICPResult: %d of %d sampled transforms kept; "
           "keyed target cloud: %d points from %d; overlap %d / %d / %d; compute_icp_with_cov: %s, %d of 30 guesses converged, det(cov) %.3g / %.3g)"

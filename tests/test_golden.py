@@ -303,3 +303,18 @@ def test_oracle_feature_cloud_equals_the_reference_callback_lines():
                                        float(z["radius%d" % i]), int(z["min_points%d" % i]))
         want = z["points%d" % i]
         assert np.array_equal(cloud, want.astype(np.float32)) and len(want) > 400, i
+
+
+def test_is_keyframe_matches_the_reference_function():
+    """replay.FrontEnd.is_keyframe against slam.py:1134-1161 run from the reference's source (tests/golden/nssm_pieces.npz)"""
+    from types import SimpleNamespace
+    from sonar_slam_amd.pose2 import Pose2
+    from sonar_slam_amd.replay import FrontEnd
+    z = np.load(os.path.join(G, "nssm_pieces.npz"))
+    t0, x0, y0, th0 = z["kf_last"]
+    last = SimpleNamespace(time=float(t0), dr_pose=Pose2(x0, y0, th0))
+    me = SimpleNamespace(keyframes=[last], current_keyframe=last, keyframe_duration=1.0, keyframe_translation=3.0,
+                         keyframe_rotation=np.radians(30.0))
+    got = [FrontEnd.is_keyframe(me, SimpleNamespace(time=float(t), dr_pose=Pose2(x, y, th))) for t, x, y, th in z["kf_cases"]]
+    assert np.array_equal(np.array(got, bool), z["kf_flags"]) and 50 < z["kf_flags"].sum() < 350
+    assert FrontEnd.is_keyframe(SimpleNamespace(keyframes=[]), None) == bool(z["kf_first"]) is True
