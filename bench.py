@@ -281,7 +281,8 @@ def parity_check(kb, res, frames, srcs, tgts, guesses, det, fe, icp_mode, filter
             if int(res["status"][j]) != st64 or int(res["iters"][j]) != it64:
                 raise AssertionError("parity: ICP job %d status/iterations (%d, %d) vs oracle (%d, %d)"
                                      % (j, res["status"][j], res["iters"][j], st64, it64))
-            return pose_diff(res["T"][j], To), pose_diff(res["T"][j], To64)
+            # (third figure: how far the float oracle is from its OWN fp64-sum version on this job -- the bound below)
+            return pose_diff(res["T"][j], To), pose_diff(res["T"][j], To64), pose_diff(To, To64)
         from multiprocessing.pool import ThreadPool
         with ThreadPool(max(1, usable_cores())) as tp:
             diffs = tp.map(one, picks, chunksize=1)
@@ -296,13 +297,23 @@ def parity_check(kb, res, frames, srcs, tgts, guesses, det, fe, icp_mode, filter
     worst = float(d32.max())
     if not worst64 <= 1e-6:
         raise AssertionError("parity: ICP pose differs from the oracle (fp64 sums) by %.3e (> 1e-6)" % worst64)
-    if not worst <= 1e-3:
-        raise AssertionError("parity: ICP pose differs from the oracle in float by %.3e" % worst)
+    # Against the float oracle there is no absolute bar to enforce: sequential float sums leave the fp64-sum version of the
+    # same chain by 1e-4 .. 6e-3 on 5000-point pairs, job by job (profiles/r05_oracle_soak_seed2828.json).  What must hold
+    # is that the HIP pose is no further from the float oracle than the float oracle is from its own fp64-sum version on
+    # that job (+ 1e-6, the bar enforced against the fp64-sum version): a difference beyond that is the kernel's.
+    self32 = np.array([d[2] for d in diffs])
+    excess = float((d32 - self32).max())
+    if not excess <= 1e-6:
+        j = int(np.argmax(d32 - self32))
+        raise AssertionError("parity: ICP job %d is %.3e from the float oracle, which is only %.3e from its own fp64-sum "
+                             "version" % (picks[j], d32[j], self32[j]))
     return {"jobs": len(picks), "frames_bit_exact": bit_exact, "icp_max_pose_diff": worst,
             "icp_float_oracle_beyond_1e-4": "%d / %d" % (beyond, len(picks)),
             "icp_max_pose_diff_vs_f64_sums": worst64,
             # what this function ENFORCES (it raises beyond them) and what north_star asks for, kept apart:
-            "icp_tolerance_enforced_f64_sums": 1e-6, "icp_tolerance_enforced_float_oracle": 1e-3,
+            "icp_tolerance_enforced_f64_sums": 1e-6,
+            "icp_tolerance_enforced_float_oracle": "per job: <= |float oracle - its own fp64-sum version| + 1e-6",
+            "float_oracle_max_distance_from_its_f64_version": float(self32.max()),
             "icp_tolerance_north_star": 1e-4, "north_star_1e-4_met_vs_float_oracle": beyond == 0,
             "north_star_1e-4_met_vs_f64_sum_oracle": worst64 <= 1e-4,
             "icp_tolerance_note": "the float (PointMatcher<float>-style, sequential float sums) oracle leaves its OWN fp64-sum "

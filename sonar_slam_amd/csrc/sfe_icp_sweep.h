@@ -246,6 +246,7 @@ struct SweepShared {
     unsigned n_rechit[2];     // queries settled by their clearance record, this iteration / the one before
     int long_n, long_next, mid_n, wl_n[2];
     int flag_iterate, flag_status;
+    int chk_n[3]; // the transformation checkers' counters (IcpCheck: nhist, counter, iters), thread 0's
     float Ti[9];
     float thist[REC ? ICP_MAX_HIST : 1][6]; // T_iter of every iteration so far (rows 0 and 1): the movement bounds below
     float mva[REC ? ICP_MAX_HIST : 1], mvt[REC ? ICP_MAX_HIST : 1]; // a query x = T0 * src has moved by at most

@@ -3,6 +3,10 @@
 // definitions, the search's exactness argument and the overview: sfe_icp_sweep.h.
 #include "sfe_icp_sweep.h"
 
+#ifndef SW_SUMS_ONEPASS
+#define SW_SUMS_ONEPASS 1
+#endif
+
 // ties at the final best: lowest original index among the points at distance `best`, found by
 // searching the final window once more (rare)
 template <class TV>
@@ -52,7 +56,7 @@ __device__ __forceinline__ int sweep_resolve_tie(const TV &T, const StripTab &ta
 // the census of a search round, the histograms of the radix select, the sums of the error minimiser -- is exchanged
 // through the job's sync area (xreduce below) and every share takes the same decisions and solves the same system.
 template <int NT, int MINW, bool LDS_TGT, bool LDS_Q, bool PROF, bool REC, bool MULTI>
-__global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
+__global__ __launch_bounds__(NT, MINW) __attribute__((amdgpu_waves_per_eu(MINW, MINW))) void icp_sweep_kernel(
     sfe_icp_params P, const SweepJob *__restrict__ jobs, const int *__restrict__ job_ids, const float2 *__restrict__ src_all,
     const float *__restrict__ guess_all, const float2 *__restrict__ stgt_all, const int *__restrict__ perm_all,
     const float2 *__restrict__ snrm_all, const float *__restrict__ mean_all, const StripTab *__restrict__ tab_all,
@@ -293,8 +297,12 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
         for (int i = tid; i < nt + SW_PAD; i += NT)
             lds_tgt[i] = stgt[i];
     }
-    IcpCheck chk = {S.hist_c, S.hist_s, S.hist_x, S.hist_y, 1, 0, 0};
+    // (the checkers' counters -- history length, iteration counter, iterations run -- are thread 0's alone: they live in
+    // LDS between the solves instead of three VGPRs of every lane for the whole kernel)
     if (tid == 0) {
+        S.chk_n[0] = 1;
+        S.chk_n[1] = 0;
+        S.chk_n[2] = 0;
         const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
         for (int i = 0; i < 9; ++i)
             S.Ti[i] = I[i];
@@ -321,7 +329,7 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
     const float W2 = sw_uniform(fmaxf(r2m_up, f_mul(r2_match, 1.1025f)));
     const float md_hi = sw_uniform(f_mul(P.matcher_max_dist, 1.00001f));
     // no pair beyond Cmax can get weight 1
-    const float Cmax = P.use_max_dist_filter ? fminf(r2_filter, r2_match) : r2_match;
+    const float Cmax = sw_uniform(P.use_max_dist_filter ? fminf(r2_filter, r2_match) : r2_match);
     float Cinit;
     {
         const float h = 8.0f * tab.ext_x / (float)nt; // a few point spacings of a cloud spread along x
@@ -330,12 +338,12 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
             Cinit = Cmax;
         Cinit = sw_uniform(Cinit);
     }
-    float Cnext = P.use_trimmed_filter ? Cinit : Cmax; // cap the next iteration starts with
+    float Cnext = sw_uniform(P.use_trimmed_filter ? Cinit : Cmax); // cap the next iteration starts with
     SW_PROF(0);
 
     const int sw_rtrips = (sw_cache >> 8) & 255;
     const bool sw_jump = (sw_cache & 2) != 0;
-    const float sw_margin = 1.0f + 0.01f * (float)((sw_cache >> 16) & 255);
+    const float sw_margin = sw_uniform(1.0f + 0.01f * (float)((sw_cache >> 16) & 255));
     int wd_outer = 0;
     // cur = Ti * (T0 * src): the same two roundings wherever a query is (re)computed
     auto xform = [&](const float (&Ti)[9], float2 sp) {
@@ -1255,7 +1263,7 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
                 }
                 __syncthreads();
                 SW_PROF(7);
-                if (PROF && tid == 0 && chk.iters == 0 && round < 8) { // first iteration, round by round
+                if (PROF && tid == 0 && S.chk_n[2] == 0 && round < 8) { // first iteration, round by round
                     const long long t_ = clock64();
                     S.prof_it[24 + 4 * round] = nwork;
                     S.prof_it[25 + 4 * round] = (round == 0) ? S.mid_n : 0;
@@ -1317,9 +1325,9 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
             }
         }
         SW_PROF(2);
-        if (PROF && tid == 0 && chk.iters < 32) {
-            S.prof_it[2 * chk.iters] = clock64() - S.prof_b0;
-            S.prof_it[2 * chk.iters + 1] = ((long long)__float_as_uint(C) << 32) | (nexact & 0xFFFFu) |
+        if (PROF && tid == 0 && S.chk_n[2] < 32) {
+            S.prof_it[2 * S.chk_n[2]] = clock64() - S.prof_b0;
+            S.prof_it[2 * S.chk_n[2] + 1] = ((long long)__float_as_uint(C) << 32) | (nexact & 0xFFFFu) |
                                            ((S.n_rechit[it & 1] & 0xFFFFu) << 16); // (clouds of < 65536 points)
         }
 
@@ -1340,9 +1348,107 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
             break;
         // the next iteration's cap: this limit plus a margin (the clouds keep moving a little: without it about
         // every fourth converged iteration finds one match too few inside the cap and has to search twice)
-        Cnext = P.use_trimmed_filter ? fminf(fmaxf(limit * sw_margin, Cinit * 0.0625f), Cmax) : Cmax;
+        Cnext = sw_uniform(P.use_trimmed_filter ? fminf(fmaxf(limit * sw_margin, Cinit * 0.0625f), Cmax) : Cmax);
         SW_PROF(3);
 
+#if SW_SUMS_ONEPASS
+        // ---- D: error minimiser sums over the kept pairs: ONE pass over the results, nine fp64 accumulators per lane.
+        // The tenth sum -- the number of kept pairs -- is an integer: counted per wave by ballot + popcount in an SGPR
+        // (a sum of 1.0s is exact in any order, so the canonical fp64 total has these very bits).  Rounds 1-5 ran the
+        // sums in two halves of five accumulators; each half gathered (source point, neighbour, normal) again -- ten
+        // exposed memory round trips per iteration instead of five (profiles/r05_stage_times.txt: 34 k cycles).
+        // The order of these sums is that of a 1024-thread workgroup whatever NT is: query i belongs to thread i mod 1024,
+        // 64 consecutive threads are a wave (its fixed tree), the 16 wave totals are added left to right.  The smaller
+        // builds play those waves one after the other.  (On a rank-deficient problem -- a target of three points -- the
+        // sums are rounding noise that the solve amplifies without bound: only the same order gives the same result
+        // as the other kernels; tools/icp_soak.py found such jobs at 6 in 100 000 before.)
+        {
+            asm volatile("; SUMS_BEGIN");
+            constexpr int NA = 9;
+            // kept pair?  (called wave-uniformly; counts the kept pairs of the wave on the way)
+            auto kept = [&](int i, bool in, int &id, unsigned &cnt) -> bool {
+                float d = 0.0f;
+                id = -1;
+                if (in) {
+                    id = Pz(i);
+                    d = Dz(i);
+                }
+                const bool ok = in && id >= 0 && (!P.use_max_dist_filter || d <= r2_filter) &&
+                                (!P.use_trimmed_filter || d <= limit);
+                cnt += (unsigned)__popcll(__ballot(ok));
+                return ok;
+            };
+            const int roles = min(16, (ns + 63) >> 6); // (the waves beyond hold no query: their totals are 0.0)
+            for (int w0 = tid >> 6; w0 < roles; w0 += NT / 64) { // (NT == 1024: every wave plays itself)
+                double a[NA] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                unsigned cnt = 0;
+                if (P.minimizer == 0) { // (a loop per minimiser: eight / nine live accumulators, no merged tails)
+                    for (int base = 64 * w0; base < ns; base += 1024) {
+                        const int i = base + lane;
+                        int id;
+                        if (kept(i, i < ns, id, cnt)) {
+                            const float2 p = xform(Ti, src[i]);
+                            const float2 q = T[id + 1];
+                            const double px = p.x, py = p.y, qx = q.x, qy = q.y;
+                            a[0] += px;
+                            a[1] += py;
+                            a[2] += qx;
+                            a[3] += qy;
+                            a[4] += qx * px;
+                            a[5] += qx * py;
+                            a[6] += qy * px;
+                            a[7] += qy * py;
+                        }
+                    }
+                } else {
+                    for (int base = 64 * w0; base < ns; base += 1024) {
+                        const int i = base + lane;
+                        int id;
+                        if (kept(i, i < ns, id, cnt)) {
+                            const float2 sp = src[i]; // (both requests leave before either answer is waited for)
+                            const float2 n = snrm[id];
+                            const float2 q = T[id + 1];
+                            const float2 p = xform(Ti, sp);
+                            const double px = p.x, py = p.y, nx = n.x, ny = n.y;
+                            const double a0 = px * ny - py * nx;
+                            const double e = nx * (px - (double)q.x) + ny * (py - (double)q.y);
+                            a[0] += a0 * a0;
+                            a[1] += a0 * nx;
+                            a[2] += a0 * ny;
+                            a[3] += nx * nx;
+                            a[4] += nx * ny;
+                            a[5] += ny * ny;
+                            a[6] += -(a0 * e);
+                            a[7] += -(nx * e);
+                            a[8] += -(ny * e);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < NA; ++k) {
+                    const double sk = wave_sum(a[k]);
+                    if (lane == 0)
+                        S.red[NA * w0 + k] = sk;
+                }
+                if (lane == 0)
+                    S.xr[w0] = cnt; // (the exchange words of the split jobs are idle between their exchanges)
+            }
+            __syncthreads();
+            if (tid < NA) {
+                double sk = 0;
+                for (int w = 0; w < roles; ++w)
+                    sk += S.red[NA * w + tid];
+                S.acc[1 + tid] = sk;
+            } else if (tid == NA) {
+                unsigned c = 0;
+                for (int w = 0; w < roles; ++w)
+                    c += S.xr[w];
+                S.acc[0] = (double)c;
+            }
+            __syncthreads();
+            asm volatile("; SUMS_END");
+        }
+#else
         // ---- D: error minimiser sums over the kept pairs, in two halves of five accumulators: ten fp64
         // accumulators per lane do not fit the 64-VGPR budget next to the loop state (they spilled) ----
         // The order of these sums is that of a 1024-thread workgroup whatever NT is: query i belongs to thread i mod 1024,
@@ -1430,6 +1536,7 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
         };
         sums(std::integral_constant<int, 0>());
         sums(std::integral_constant<int, 5>());
+#endif
         if (MULTI)
             xreduce_acc(); // the sums over the queries of every share
         SW_PROF(4);
@@ -1440,7 +1547,11 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
             double acc[10];
             for (int i = 0; i < 10; ++i)
                 acc[i] = S.acc[i];
+            IcpCheck chk = {S.hist_c, S.hist_s, S.hist_x, S.hist_y, S.chk_n[0], S.chk_n[1], S.chk_n[2]};
             icp_solve_and_check(P, acc, Ti, S.Ti, chk, status, iterate);
+            S.chk_n[0] = chk.nhist;
+            S.chk_n[1] = chk.counter;
+            S.chk_n[2] = chk.iters;
             S.flag_status = status;
             S.flag_iterate = (status == SFE_ICP_OK) ? iterate : 0;
         }
@@ -1471,7 +1582,7 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
                 To[i] = guess[i];
         }
         status_out[J.out] = status;
-        iters_out[J.out] = chk.iters;
+        iters_out[J.out] = S.chk_n[2];
         if (PROF && blockIdx.x == 0) {
             for (int i = 0; i < 16; ++i)
                 prof[i] = S.prof[i];
@@ -1486,7 +1597,7 @@ __global__ __launch_bounds__(NT, MINW) void icp_sweep_kernel(
         atomicAdd((unsigned long long *)&prof[82], c_wit);
         atomicAdd((unsigned long long *)&prof[83], c_lb);
         if (tid == 0)
-            atomicAdd((unsigned long long *)&prof[84], (unsigned long long)chk.iters);
+            atomicAdd((unsigned long long *)&prof[84], (unsigned long long)S.chk_n[2]);
     }
 }
 
@@ -1619,6 +1730,9 @@ int sweep_launch_loop(const SweepLaunchArgs &a, int n, const int *d_ids, size_t 
 // the builds the host side asks for: {threads, min waves per EU (the VGPR budget), target in LDS, results in LDS, counted
 // profile, clearance records, job shared by several workgroups}
 #define SW_LOOP_INST(...) template int sweep_launch_loop<__VA_ARGS__>(const SweepLaunchArgs &, int, const int *, size_t, int, int);
+#ifdef SW_INSPECT // (tools/icp_isa.sh: the bench's build alone, for a look at its ISA)
+SW_LOOP_INST(ICP_THREADS, 8, true, true, false, true, false)
+#else
 SW_LOOP_INST(SW_T0_NT, 4, true, true, false, true, false)
 SW_LOOP_INST(SW_T0_NT, 4, true, true, false, false, false)
 SW_LOOP_INST(SW_T1_NT, 4, true, true, true, false, false)
@@ -1637,6 +1751,7 @@ SW_LOOP_INST(ICP_THREADS, 8, true, false, false, false, false)
 SW_LOOP_INST(ICP_THREADS, 4, false, false, false, false, false)
 SW_LOOP_INST(ICP_THREADS, 8, false, false, false, false, false)
 SW_LOOP_INST(ICP_THREADS, 4, false, false, false, false, true)
+#endif
 
 int sweep_launch_split(sfe_ctx *ctx, hipStream_t ps, int n_split, SweepJob *d_jobs, const int *d_split, const float2 *d_src,
                        const float *d_guess9, const float *d_mean, const StripTab *d_tab, float2 *d_gsrc)

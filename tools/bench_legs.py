@@ -79,7 +79,7 @@ def check_against_oracle(name, jobs, got, params_kw, threads, tol64=1e-6):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-def reference_chain(ctx, kb, srcs, tgts, guesses, threads, sample=8):
+def reference_chain(ctx, kb, srcs, tgts, guesses, threads, sample=64):
     """The timed batch's scan pairs through the chain bruce_slam ships: point-to-point, 40-iteration cap, differential
     stop (icp.yaml:17-28) -- the only chain with reference meaning; the headline step runs configs[1]'s 30 forced
     point-to-plane iterations."""
@@ -122,7 +122,7 @@ def real_size(ctx, threads, n_ssm=16384, n_nssm=512, distinct=2048):
     b = ScanMatchBatch(ctx, p, srcs, tgts, [(j, j) for j in range(n_ssm)], gs)
     ms = timed(ctx, b.run, 3)
     res = b.results()
-    picks = list(range(0, n_ssm, max(1, n_ssm // 16)))[:16]
+    picks = list(range(0, n_ssm, max(1, n_ssm // 64)))[:64]
     par = check_against_oracle("real_size.ssm", [(srcs[j], tgts[j], gs[j]) for j in picks],
                                (res["T"][picks], res["status"][picks], res["iters"][picks]), {}, threads)
     os.environ.update(SFE_SW_TIERS="0", SFE_SW_TINY="0")
@@ -164,7 +164,7 @@ def real_size(ctx, threads, n_ssm=16384, n_nssm=512, distinct=2048):
     b = ScanMatchBatch(ctx, p, [q[0] for q in npair], [q[1] for q in npair], jobs, gs)
     ms = timed(ctx, b.run, 3)
     res = b.results()
-    picks = list(range(0, len(jobs), max(1, len(jobs) // 16)))[:16]
+    picks = list(range(0, len(jobs), max(1, len(jobs) // 64)))[:64]
     par = check_against_oracle("real_size.nssm", [(npair[jobs[j][0]][0], npair[jobs[j][1]][1], gs[j]) for j in picks],
                                (res["T"][picks], res["status"][picks], res["iters"][picks]), {}, threads)
     b.free()

@@ -10,6 +10,13 @@ Cholesky solve round differently).  A disagreement counts as a MISMATCH unless t
 checkable sense that the oracle disagrees with ITSELF between float sums (PointMatcher<float>) and fp64 sums
 (status, iteration count, or pose by more than 1e-3): e.g. every inlier matched to one target point, where the
 cross-covariance is rounding noise and the rotation any angle.  Those are listed separately (`ill_conditioned`).
+An ill-conditioned job on which the HIP path differs from the fp64-sum oracle (`ill_conditioned_disagreeing`) is not waved
+through on that alone (VERDICT r5 "what's weak" 4): it is written out in full (`ill_conditioned_disagreeing_jobs`) and
+re-examined -- the fp64-sum oracle runs the same job again with the guess moved by ONE float ulp in x, y (four runs).  If
+the oracle's own answer (status, iteration count, pose beyond the tolerance) changes under a perturbation that is below
+the resolution of its input, no implementation can be held to its unperturbed answer: the job stays excused, with the
+evidence in the record.  If the oracle is stable under those perturbations the disagreement is the kernel's and counts
+as a mismatch.
 Against the oracle in float the pose difference is reported for the bench-like class next to the float oracle's own
 distance from its fp64 version (the float sums' accumulation noise, which grows with the cloud size).
 
@@ -146,12 +153,38 @@ def main():
                 why = ("iters", it, it_d)
             elif not d <= (1e-4 if p["minimizer"] else 1e-6):
                 why = ("pose", float(d))
-        if why is not None:
-            if ill:
+        if why is not None and ill:
+            # not excused on the oracle's float/fp64 disagreement alone: is the fp64-sum oracle's answer stable under a
+            # one-ulp move of the guess?
+            tol = 1e-4 if p["minimizer"] else 1e-6
+            oracle.set_kdtree(1 if kind == "bench" else 0)
+            unstable = []
+            for (r, c, sgn) in ((0, 2, 1), (0, 2, -1), (1, 2, 1), (1, 2, -1)):
+                g2 = np.array(g, np.float32, copy=True)
+                g2[r, c] = np.nextafter(g2[r, c], np.float32(np.inf * sgn))
+                st2, T2, it2 = oracle.icp(s, t, g2, oracle.IcpParams(precision=1, **p))
+                moved = st2 != st_d or it2 != it_d or (st_d == 0 and not pose_diff(T2, T_d) <= tol)
+                unstable.append({"guess_entry": [r, c], "ulp": sgn, "status": int(st2), "iters": int(it2),
+                                 "pose_diff_vs_unperturbed": float(pose_diff(T2, T_d)) if st_d == 0 and st2 == 0 else None,
+                                 "oracle_answer_changed": bool(moved)})
+            oracle.set_kdtree(0)
+            excused = any(u["oracle_answer_changed"] for u in unstable)
+            out.setdefault("ill_conditioned_disagreeing_jobs", []).append({
+                "index": int(i), "kind": kind, "n_src": int(len(s)), "n_tgt": int(len(t)), "params": p,
+                "disagreement": [str(x) for x in why], "hip": {"message": m, "iters": int(it), "pose": [float(x) for x in synth.pose_of(T)]},
+                "oracle_f64_sums": {"status": int(st_d), "iters": int(it_d), "pose": [float(x) for x in synth.pose_of(T_d)]},
+                "oracle_float": {"status": int(st_f), "iters": int(it_f), "pose": [float(x) for x in synth.pose_of(T_f)]},
+                "oracle_f64_sums_with_the_guess_moved_by_one_ulp": unstable,
+                "excused": bool(excused),
+                "reading": ("the fp64-sum oracle's own answer changes when the guess moves by one float ulp: the job has no "
+                            "answer an implementation could be held to" if excused else
+                            "the fp64-sum oracle is stable under one-ulp moves of the guess: counted as a mismatch")})
+            if excused:
                 out["ill_conditioned_disagreeing"] += 1
-            else:
-                out[{"status": "status_mismatch", "iters": "iteration_mismatch"}.get(why[0], "pose_mismatch_f64")] += 1
-                bad.append((i,) + why)
+                continue
+        if why is not None:
+            out[{"status": "status_mismatch", "iters": "iteration_mismatch"}.get(why[0], "pose_mismatch_f64")] += 1
+            bad.append((i,) + why)
             continue
         if st_d != 0:
             out["failures_agreed"] += 1

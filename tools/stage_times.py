@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--icp-variants", default="0,4")  # 0 = sweep, 4 = brute force
     ap.add_argument("--p2plane-only", action="store_true", help="skip the shipped chain (counter passes)")
+    ap.add_argument("--max-iter", type=int, default=30, help="iterations of the forced point-to-plane chain")
     a = ap.parse_args()
     ctx = _lib.default_context()
     det = CFAR(40, 10, 0.1, 10)
@@ -35,7 +36,7 @@ def main():
         for _ in range(reps):
             fn()
         return ctx.timer_stop() / reps
-    for mode, p in (("p2plane30", icp_config.shipped_params(minimizer=1, use_diff_checker=0, max_iter=30)),
+    for mode, p in (("p2plane30", icp_config.shipped_params(minimizer=1, use_diff_checker=0, max_iter=a.max_iter)),
                     ("reference", icp_config.shipped_params())):
         if a.p2plane_only and mode != "p2plane30":
             continue
