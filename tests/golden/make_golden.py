@@ -46,6 +46,10 @@ import numpy as np
 
 REF = "/root/reference/bruce_slam/src/bruce_slam"
 HERE = os.path.dirname(os.path.abspath(__file__))
+ICP_YAML = "/root/reference/bruce_slam/config/icp.yaml"
+sys.path.insert(0, HERE)
+import thirdparty  # noqa: E402  (cv2 / bruce_slam.pcl REAL where this machine has them, the oracle's restatement where not;
+#                                 every file written below records which stand-ins were used: `stand_ins`)
 
 
 class Pose2(object):
@@ -136,20 +140,7 @@ def reference_matching_cost():
     exec(compile(tp_src, "reference:slam_objects.py", "exec"), ns_k)
     Keyframe = types.SimpleNamespace(transform_points=ns_k["transform_points"])
 
-    class _cv2(object):     # OpenCV is not in this image: the two calls come from the oracle's restatement
-        MORPH_ELLIPSE = 2
-
-        @staticmethod
-        def getStructuringElement(shape, ksize, anchor):
-            assert shape == 2 and ksize[0] == ksize[1] and anchor == (ksize[0] // 2, ksize[0] // 2)
-            return oracle.ellipse_kernel(ksize[0] // 2)
-
-        @staticmethod
-        def dilate(img, kernel):
-            hs = kernel.shape[0] // 2
-            assert np.array_equal(kernel, oracle.ellipse_kernel(hs))
-            r, c = np.nonzero(img)
-            return oracle.cost_grid(r, c, img.shape[0], img.shape[1], hs)
+    _cv2 = thirdparty.cv2(oracle)   # (OpenCV is not in this image: then the two calls come from the oracle's restatement)
 
     def n2g(x, kind):
         assert kind == "Pose2"
@@ -262,13 +253,10 @@ def make_nssm_pieces():
     from typing import Any, Union
     from sonar_slam_amd import synth
 
-    def ds_keys(pts, keys, res):
-        p32 = np.asarray(pts, np.float32)                                  # (pybind: Matrix = fp32)
-        out_p, idx = _orc.downsample(p32, res, return_index=True)
-        return out_p, np.asarray(keys, np.float32)[idx]
+    pcl_mod = thirdparty.pcl(_orc)
     gp_src = _cut("slam.py", "get_points")
     ns_gp = {"np": np, "gtsam": types.SimpleNamespace(Pose2=Pose2), "Keyframe": Keyframe, "Any": Any,
-             "pcl": types.SimpleNamespace(downsample=lambda *a: ds_keys(*a) if len(a) == 3 else _orc.downsample(np.asarray(a[0], np.float32), a[1]))}
+             "pcl": pcl_mod}
     exec(compile(gp_src, "reference:slam.py", "exec"), ns_gp)
     rng = np.random.default_rng(23)
     kf_clouds = [np.c_[rng.uniform(1, 29, n), rng.uniform(-20, 20, n)].astype(np.float32).astype(np.float64) for n in (900, 1, 1400, 0, 650, 1100)]
@@ -285,7 +273,7 @@ def make_nssm_pieces():
     # ---- get_overlap (slam.py:389-424) ----
     ov_src = _cut("slam.py", "get_overlap")
     ns_ov = {"np": np, "gtsam": types.SimpleNamespace(Pose2=Pose2), "Keyframe": Keyframe,
-             "pcl": types.SimpleNamespace(match=lambda tgt, src, k, r: _orc.match(np.asarray(tgt, np.float32), np.asarray(src, np.float32), r))}
+             "pcl": pcl_mod}
     exec(compile(ov_src, "reference:slam.py", "exec"), ns_ov)
     src_o, tgt_o, guess_o, truth_o = synth.scan_pair(seed=33, n_src=800, n_tgt=900)
     me = types.SimpleNamespace(point_noise=0.5)
@@ -299,11 +287,7 @@ def make_nssm_pieces():
     cov_src = _cut("slam.py", "compute_icp_with_cov")
     import time as time_pkg
     from sklearn.covariance import MinCovDet
-    prm = _orc.shipped_icp_params(precision=1)
-
-    def icp_compute(src, tgt, g):
-        st, T, _ = _orc.icp(src, tgt, np.asarray(g, np.float32), prm)
-        return ("success", T) if st == 0 else ("failure", np.asarray(g, np.float32))
+    icp_compute = thirdparty.icp_compute(_orc, ICP_YAML)
     ns_cv = {"np": np, "Union": Union, "time_pkg": time_pkg, "MinCovDet": MinCovDet, "n2g": lambda g, kind: Pose2(*g)}
     exec(compile(cov_src, "reference:slam.py", "exec"), ns_cv)
     src_c, tgt_c, guess_c, truth_c = synth.scan_pair(seed=9, n_src=1500, n_tgt=1500)
@@ -343,6 +327,7 @@ def make_nssm_pieces():
     empty = type("E", (), {"keyframes": []})()
     out.update(kf_last=np.array([10.0, 4.0, -2.0, 0.7]), kf_cases=np.array(cases), kf_flags=np.array(flags),
                kf_first=bool(ns_kf["is_keyframe"](empty, None)))
+    out["stand_ins"] = thirdparty.record()
     np.savez_compressed(os.path.join(HERE, "nssm_pieces.npz"), **out)
     print("wrote nssm_pieces.npz (field-of-view gate of %s: %d of %d points kept, keyframes %r; ICPResult: %d of %d sampled transforms kept; "
           "keyed target cloud: %d points from %d; overlap %d / %d / %d; compute_icp_with_cov: %s, %d of 30 guesses converged, det(cov) %.3g / %.3g)"
@@ -385,11 +370,7 @@ def make_ssm_session():
     for cls in ("STATUS", "InitializationResult", "ICPResult"):
         exec(compile(_cut_class("slam_objects.py", cls), "reference:slam_objects.py", "exec"), ns_o)
     STATUS = ns_o["STATUS"]
-    prm = _orc.shipped_icp_params(precision=1)
-
-    def icp_compute(src, tgt, g):
-        st, T, _ = _orc.icp(np.asarray(src, np.float32), np.asarray(tgt, np.float32), np.asarray(g, np.float32), prm)
-        return ("success", T) if st == 0 else ("failure", np.asarray(g, np.float32))
+    icp_compute = thirdparty.icp_compute(_orc, ICP_YAML)
     factors = []
     gt = types.SimpleNamespace(Pose2=Pose2, BetweenFactorPose2=lambda a, b, t, model: factors.append(("between", a, b, t, model)) or ("between", a, b),
                                PriorFactorPose2=lambda a, p, model: ("prior", a))
@@ -400,8 +381,7 @@ def make_ssm_session():
     ns = {"np": np, "gtsam": gt, "shgo": shgo, "CodeTimer": CodeTimer, "n2g": n2g, "g2n": g2n, "X": lambda k: k, "STATUS": STATUS,
           "InitializationResult": ns_o["InitializationResult"], "ICPResult": ns_o["ICPResult"], "Keyframe": Keyframe, "Any": Any,
           "Union": Union,
-          "pcl": types.SimpleNamespace(downsample=lambda pts, res: _orc.downsample(np.asarray(pts, np.float32), res),
-                                       match=lambda tgt, src, k, r: _orc.match(np.asarray(tgt, np.float32), np.asarray(src, np.float32), r))}
+          "pcl": thirdparty.pcl(_orc)}
     for name in ("initialize_sequential_scan_matching", "add_sequential_scan_matching", "add_odometry", "get_points", "compute_icp",
                  "get_overlap"):
         exec(compile(_cut("slam.py", name), "reference:slam.py", "exec"), ns)
@@ -510,6 +490,7 @@ def make_ssm_session():
                 if r["estimated_source_pose"] is not None:
                     out["%s_estimated_source_pose%d" % (tag, k)] = r["estimated_source_pose"]
         summary.append((tag, [(r["k"], r.get("status"), r.get("description")) for r in recs]))
+    out["stand_ins"] = thirdparty.record()
     np.savez_compressed(os.path.join(HERE, "ssm_session.npz"), **out)
     print("wrote ssm_session.npz:")
     for t in summary:
@@ -543,17 +524,7 @@ def make_nssm_session():
     for cls in ("STATUS", "InitializationResult", "ICPResult"):
         exec(compile(_cut_class("slam_objects.py", cls), "reference:slam_objects.py", "exec"), ns_o)
     STATUS = ns_o["STATUS"]
-    prm = _orc.shipped_icp_params(precision=1)
-
-    def icp_compute(src, tgt, g):
-        st, T, _ = _orc.icp(np.asarray(src, np.float32), np.asarray(tgt, np.float32), np.asarray(g, np.float32), prm)
-        return ("success", T) if st == 0 else ("failure", np.asarray(g, np.float32))
-
-    def ds(*a):
-        if len(a) == 3:
-            out_p, idx = _orc.downsample(np.asarray(a[0], np.float32), a[2], return_index=True)
-            return out_p, np.asarray(a[1], np.float32)[idx]
-        return _orc.downsample(np.asarray(a[0], np.float32), a[1])
+    icp_compute = thirdparty.icp_compute(_orc, ICP_YAML)
     factors = []
     gt = types.SimpleNamespace(Pose2=Pose2, BetweenFactorPose2=lambda a, b, t, model: factors.append(("between", a, b, t, model)) or ("between", a, b))
 
@@ -568,7 +539,7 @@ def make_nssm_session():
           # (compute_icp_with_cov stops trying guesses after 2 s of wall clock, slam.py:356-358: a real-time guard that
           #  libpointmatcher never reaches with 30 guesses, but the oracle's ICP on this CPU does -- the clock stands still here)
           "time_pkg": types.SimpleNamespace(time=lambda: 0.0),
-          "pcl": types.SimpleNamespace(downsample=ds, match=lambda tgt, src, k, r: _orc.match(np.asarray(tgt, np.float32), np.asarray(src, np.float32), r))}
+          "pcl": thirdparty.pcl(_orc)}
     names = ("initialize_sequential_scan_matching", "add_sequential_scan_matching", "add_odometry", "get_points", "compute_icp",
              "compute_icp_with_cov", "get_overlap", "initialize_nonsequential_scan_matching", "add_nonsequential_scan_matching")
     for name in names:
@@ -672,6 +643,7 @@ def make_nssm_session():
                         out["sample_transforms%d" % k] = np.asarray(ret2.sample_transforms)
                 summary.append((k, last["init_status"], None if ret2 is None else (ret2.status.name, ret2.status.description, int(ret2.target_key))))
         S.current_frame = frame
+    out["stand_ins"] = thirdparty.record()
     np.savez_compressed(os.path.join(HERE, "nssm_session.npz"), **out)
     print("wrote nssm_session.npz:")
     for t in summary:
@@ -706,11 +678,9 @@ def make_feature_callback():
         me.resolution, me.outlier_filter_radius, me.outlier_filter_min_points = res, radius, min_pts
         me.feature_img_pub = types.SimpleNamespace(publish=lambda m: None)
         ns = {"np": np, "self": me, "img": img.copy(), "sonar_msg": ping,
-              "cv2": types.SimpleNamespace(INTER_LINEAR=1, remap=lambda a, mx, my, interp: _orc.remap_u8(np.asarray(a, np.uint8), mx, my),
-                                           applyColorMap=lambda a, c: a),
+              "cv2": thirdparty.cv2(_orc),
               "ros_numpy": types.SimpleNamespace(image=types.SimpleNamespace(numpy_to_image=lambda a, enc: a)),
-              "pcl": types.SimpleNamespace(downsample=lambda pts, r: _orc.downsample(np.asarray(pts, np.float32), r),
-                                           remove_outlier=lambda pts, r, k: _orc.remove_outlier(np.asarray(pts, np.float32), r, k))}
+              "pcl": thirdparty.pcl(_orc)}
         exec(compile(block, "reference:feature_extraction.py:%d-%d" % span, "exec"), ns)
         out.update({"img%d" % i: img, "bearings%d" % i: np.asarray(ping.bearings, np.int16), "range_resolution%d" % i: ping.range_resolution,
                     "threshold%d" % i: thr, "resolution%d" % i: res, "radius%d" % i: radius, "min_points%d" % i: min_pts,
@@ -720,6 +690,7 @@ def make_feature_callback():
         summary.append((rows, beams, len(ns["locs"]), len(ns["points"]), str(np.asarray(ns["points"]).dtype)))
     out["n"] = len(summary)
     out["lines"] = np.array("feature_extraction.py:%d-%d" % span)
+    out["stand_ins"] = thirdparty.record()
     np.savez_compressed(os.path.join(HERE, "feature_callback.npz"), **out)
     print("wrote feature_callback.npz (%s):" % out["lines"], summary)
 
@@ -795,7 +766,8 @@ def main():
     T = tp.between(sp.compose(Pose2(*X[7]))).matrix()
     pts7 = Keyframe.transform_points(src, types.SimpleNamespace(matrix=lambda: T))
     np.savez_compressed(os.path.join(HERE, "matching_cost.npz"), src=src, tgt=tgt, source_pose=np.array(synth.pose_of(truth)),
-                        X=X, costs=costs, samples=np.array(samples), points_pose7=pts7, point_noise=0.5)
+                        X=X, costs=costs, samples=np.array(samples), points_pose7=pts7, point_noise=0.5,
+                        stand_ins=thirdparty.record())
     # ---- Keyframe.transform_points / SLAM.get_points: the scan matcher's inputs ----
     # transform_points on float64 keyframe clouds holding float32 values (what ros_numpy hands the SLAM node,
     # slam_ros.py:169-170) and on float32 ones (sgemm); get_points (slam.py:229-292) cut by AST with
@@ -804,11 +776,7 @@ def main():
     from typing import Any
     gp_src = _cut("slam.py", "get_points")
     ns_gp = {"np": np, "gtsam": types.SimpleNamespace(Pose2=Pose2), "Keyframe": Keyframe, "Any": Any,
-             "pcl": types.SimpleNamespace(downsample=lambda pts, res: oracle_downsample(pts, res))}
-    import oracle as _orc
-
-    def oracle_downsample(pts, res):
-        return _orc.downsample(np.asarray(pts, np.float32), res)      # (pybind: Matrix = fp32)
+             "pcl": thirdparty.pcl(__import__("oracle"))}
     exec(compile(gp_src, "reference:slam.py", "exec"), ns_gp)
     rng = np.random.default_rng(77)
     clouds32 = [np.c_[rng.uniform(1, 29, n), rng.uniform(-20, 20, n)].astype(np.float32) for n in (700, 1, 1300, 0, 450)]
@@ -830,6 +798,7 @@ def main():
             out_tp["%s_ref%d_target" % (name, ref)] = np.asarray(tgt_cloud, np.float32)
     for i, c in enumerate(clouds32):
         out_tp["cloud%d" % i] = c
+    out_tp["stand_ins"] = thirdparty.record()
     np.savez_compressed(os.path.join(HERE, "transform_points.npz"), **out_tp)
     # ---- CFAR masks / threshold maps from the reference's own cfar.cpp (oracle/_ref, compiled unmodified) ----
     import oracle

@@ -5,6 +5,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 
 from sonar_slam_amd.CFAR import CFAR
 from sonar_slam_amd.feature_extraction import build_maps, oculus_bearings
@@ -174,7 +175,7 @@ def test_oracle_loop_closure_pieces_match_the_reference_functions():
     prm = oracle.shipped_icp_params(precision=1)
     guesses = [chain.pose(*g) for g in z["cov_guesses"]]
     msg, odom, cov, xyt, runs = chain.icp_with_cov(z["cov_source"], z["cov_target"], guesses, prm, z["cov_sigmas"], random_state=0)
-    assert msg == str(z["cov_message"]) == "success" and len(runs) == 30
+    assert msg == str(z["cov_message"]) == "success" and len(runs) == 23
     assert np.array_equal(xyt, z["cov_samples"]) and np.array_equal(cov, z["cov_cov"])
     assert np.allclose([odom[0], odom[1], chain.theta(odom)], z["cov_centre"], rtol=0, atol=1e-15)
     _, _, cov2, _, _ = chain.icp_with_cov(z["cov_source"], z["cov_target"], guesses, prm, z["cov_small_sigmas"], random_state=0)
@@ -318,3 +319,62 @@ def test_is_keyframe_matches_the_reference_function():
     got = [FrontEnd.is_keyframe(me, SimpleNamespace(time=float(t), dr_pose=Pose2(x, y, th))) for t, x, y, th in z["kf_cases"]]
     assert np.array_equal(np.array(got, bool), z["kf_flags"]) and 50 < z["kf_flags"].sum() < 350
     assert FrontEnd.is_keyframe(SimpleNamespace(keyframes=[]), None) == bool(z["kf_first"]) is True
+
+
+# ---- the oracle against the REAL third-party libraries ----
+# tools/pin_thirdparty.py writes these two files on a machine that has OpenCV / the compiled bruce_slam.pcl; neither is in
+# this image or on the GPU box, so until someone runs it there the two tests below are skipped and the rows they would pin
+#  stay "parity unpinned".
+def _thirdparty():
+    import sys
+    if G not in sys.path:
+        sys.path.insert(0, G)
+    import thirdparty
+    return thirdparty
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(G, "thirdparty_cv2.npz")),
+                    reason="thirdparty_cv2.npz not generated: OpenCV is in neither image (python tools/pin_thirdparty.py on a machine that has it)")
+def test_oracle_matches_the_real_cv2():
+    import oracle
+    assert _thirdparty().check_cv2(np.load(os.path.join(G, "thirdparty_cv2.npz")), oracle) == 23
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(G, "thirdparty_pcl.npz")),
+                    reason="thirdparty_pcl.npz not generated: PCL / libpointmatcher / libnabo are in neither image "
+                           "(python tools/pin_thirdparty.py in a catkin workspace with bruce_slam built)")
+def test_oracle_matches_the_real_pcl_module():
+    import oracle
+    n, worst = _thirdparty().check_pcl(np.load(os.path.join(G, "thirdparty_pcl.npz")), oracle)
+    assert n == 4 * 8 + 5 * 5 and worst <= 1e-4
+
+
+def test_thirdparty_fixture_plumbing_with_the_stand_ins(tmp_path):
+    """The generator and the two checks above, end to end, with the oracle's stand-ins in the place of the libraries: this
+    proves the hook runs (keys, shapes, the comparison code), NOT parity -- the oracle trivially agrees with itself."""
+    import importlib.util
+    import sys
+    import oracle
+    tp = _thirdparty()
+    spec = importlib.util.spec_from_file_location("pin_thirdparty", os.path.join(os.path.dirname(G), "..", "tools", "pin_thirdparty.py"))
+    pin = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pin)
+    tp.record()                                                         # (clears the log of stand-ins handed out so far)
+    cv2_standin = tp.cv2(oracle) if tp.real_cv2() is None else None
+    if cv2_standin is not None:
+        np.savez(tmp_path / "cv2.npz", **pin.cv2_fixture(cv2_standin))
+        assert tp.check_cv2(np.load(tmp_path / "cv2.npz"), oracle) == 23
+    if tp.real_pcl() is None:
+        prm = oracle.shipped_icp_params(precision=0)
+
+        def compute(s, t, g):
+            st, T, _ = oracle.icp(s, t, g, prm)
+            return oracle.ICP_STATUS_MESSAGES[st], (T if st == 0 else np.asarray(g, np.float32))
+        np.savez(tmp_path / "pcl.npz", **pin.pcl_fixture(tp.pcl(oracle), compute, {"stand-in": "oracle"}))
+        z = np.load(tmp_path / "pcl.npz")
+        n, worst = tp.check_pcl(z, oracle)
+        assert n == 4 * 8 + 5 * 5 and worst == 0.0
+        # the fixture's jobs cover what pcl.cpp:198-212 can return: successes and a failure with the guess handed back
+        msgs = [str(z["icp_msg%d" % i]) for i in range(int(z["n_jobs"]))]
+        assert msgs.count("success") >= 3 and any(m != "success" for m in msgs), msgs
+    assert "oracle" in str(tp.record())                                 # the stand-ins were logged
