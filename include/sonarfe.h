@@ -177,6 +177,17 @@ int sfe_extract_points_batch_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mas
 /* the same from the bit streams of sfe_cfar_u8_bits_batch_dev (polar_cols % 32 == 0 required) */
 int sfe_extract_points_bits_batch_dev(sfe_ctx *ctx, sfe_geom *g, const uint32_t *d_bits, int n_frames,
                                       int64_t cap, double *d_pts, int32_t *d_counts);
+/* The same, handing the clouds to the resident cloud filters without the float64 round trip (round 6): next to d_counts the
+ * call leaves every frame's points as float32 pairs -- the float64 metres of feature_extraction.py:235-238 rounded once, the
+ * cast pybind makes when `points` enters pcl.downsample (pcl.cpp:128-131) -- and the frame's bounding box in the context's
+ * staging area, where sfe_cloud_filter_staged_dev (below) picks them up; it must be the next filter call on this context with
+ * the same n_frames and cap (anything else that stages clouds in between makes it fail with SFE_ERR_ARG, never run on stale
+ * data).  d_pts [n_frames][cap][2] float64 is still required: with want_points64 != 0 it receives every frame's points like
+ * sfe_extract_points_bits_batch_dev; with 0 only the frames that leave the fast path land there (dense frames beyond its
+ * per-frame capacities; their float32 form is made from it) and the rest of it is left untouched -- 8 instead of 24 bytes
+ * written per point.  cap <= 65536 (the filters' limit).  Enqueue only. */
+int sfe_extract_points_bits_staged_dev(sfe_ctx *ctx, sfe_geom *g, const uint32_t *d_bits, int n_frames,
+                                       int64_t cap, double *d_pts, int want_points64, int32_t *d_counts);
 
 /* ---- point clouds: replaces bruce_slam.pcl (pcl.cpp:54-74,161-212) ------ */
 typedef struct sfe_icp_params {
@@ -286,6 +297,11 @@ int sfe_icp_jobs_dev(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_src, 
 int sfe_cloud_filter_batch_dev(sfe_ctx *ctx, const double *d_pts, const int32_t *d_counts, int n_frames,
                                int64_t cap, float resolution, double radius, int min_points,
                                float *d_out, int32_t *d_out_counts);
+/* The same filters (feature_extraction.py:241-249; pcl.cpp:128-141, 54-74) on the clouds sfe_extract_points_bits_staged_dev
+ * left staged on this context: same arguments minus the float64 points, same outputs, bit for bit (the float32 points are
+ * those the cast of the call above produces; a bounding box does not depend on the order it is taken in). */
+int sfe_cloud_filter_staged_dev(sfe_ctx *ctx, int n_frames, int64_t cap, float resolution, double radius,
+                                int min_points, float *d_out, int32_t *d_out_counts);
 
 /*
  * ONE ping through the whole of FeatureExtraction.callback (feature_extraction.py:223-249) in one call, for the live

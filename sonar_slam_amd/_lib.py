@@ -106,6 +106,7 @@ SIGNATURES = {
     "sfe_extract_set_tuning": (C.c_int, [_vp, C.c_int]),
     "sfe_extract_points_batch_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int64, _vp, _vp]),
     "sfe_extract_points_bits_batch_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int64, _vp, _vp]),
+    "sfe_extract_points_bits_staged_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int64, _vp, C.c_int, _vp]),
     "sfe_match": (C.c_int, [_vp, _f32p, C.c_int, _f32p, C.c_int, C.c_float, _i32p, _f32p]),
     "sfe_match_knn": (C.c_int, [_vp, _f32p, C.c_int, _f32p, C.c_int, C.c_int, C.c_float, _i32p, _f32p]),
     "sfe_knn_density": (C.c_int, [_vp, _f32p, C.c_int, C.c_int, _f32p]),
@@ -127,6 +128,7 @@ SIGNATURES = {
     "sfe_icp_jobs_dev": (C.c_int, [_vp, C.POINTER(IcpParams), _vp, _vp, _i32p, _vp, C.c_int, _vp, _vp, _vp]),
     "sfe_cloud_filter_batch_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_int,
                                              _vp, _vp]),
+    "sfe_cloud_filter_staged_dev": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_int, _vp, _vp]),
     "sfe_cloud_store_create": (C.c_int, [_vp, C.c_int64, C.c_int32, C.POINTER(_vp)]),
     "sfe_cloud_store_destroy": (None, [_vp]),
     "sfe_cloud_store_count": (C.c_int, [_vp]),

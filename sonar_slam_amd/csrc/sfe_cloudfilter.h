@@ -51,3 +51,12 @@ int sfe_cf_run_staged(sfe_ctx *ctx, int n_frames, int64_t cap, float resolution,
 float sfe_cf_max_size(float resolution);
 #define CF_SLOT_P32 25
 #define CF_SLOT_HDR 27
+// Staged hand-over from the extraction (round 6): sfe_extract_points_bits_staged_dev leaves every frame's points as float2 in
+// slot CF_SLOT_P32 -- the fp64 metres rounded to float32, the cast pybind makes at pcl.cpp's boundary -- and the frame's
+// bounding box + point count here; sfe_cloud_filter_staged_dev turns the boxes into headers and runs the filters.  The
+// float64 staging copy of rounds 2-5 (cf_cast_bbox_kernel: 16 B read + 8 B written per point) is gone from that path.
+struct CfBBox {
+    float mnx, mny, mxx, mxy; // over (float)y, (float)x of the frame's stored points (+-inf when it has none)
+    int n;                    // stored points (the frame's count clamped to the capacity)
+};
+#define CF_SLOT_BBOX 63

@@ -610,6 +610,17 @@ __global__ __launch_bounds__(1024) void cf_radius_filter_kernel(const float2 *__
     }
 }
 
+// staged hand-over from the extraction: bounding box + count -> octree root and depth (what cf_cast_bbox_kernel's last thread does)
+__global__ __launch_bounds__(256) void cf_header_from_bbox_kernel(const CfBBox *__restrict__ bbox, int n_frames, float max_size,
+                                                                  CfHeader *__restrict__ hdrs)
+{
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f < n_frames) {
+        const CfBBox b = bbox[f];
+        hdrs[f] = cf_make_header(b.mnx, b.mny, b.mxx, b.mxy, max_size, b.n);
+    }
+}
+
 float sfe_cf_max_size(float resolution)
 {
     char buf[64];
@@ -630,12 +641,34 @@ extern "C" int sfe_cloud_filter_batch_dev(sfe_ctx *ctx, const double *d_pts, con
         return sfe_set_err(ctx, SFE_ERR_ARG, "sfe_cloud_filter_batch_dev: cap %lld exceeds %d points per frame",
                            (long long)cap, CF_MAX_CAP);
     const size_t per = (size_t)std::max<int64_t>(cap, 1);
+    ctx->staged_frames = -1; // (the staging slots are rewritten)
     float2 *d_p32 = (float2 *)sfe_scratch(ctx, CF_SLOT_P32, sizeof(float2) * per * (size_t)n_frames);
     CfHeader *d_hdr = (CfHeader *)sfe_scratch(ctx, CF_SLOT_HDR, sizeof(CfHeader) * (size_t)n_frames);
     if (!d_p32 || !d_hdr)
         return SFE_ERR_HIP;
     hipLaunchKernelGGL(cf_cast_bbox_kernel, dim3(n_frames), dim3(1024), 0, ctx->stream, d_pts, d_counts, (long long)cap,
                        sfe_cf_max_size(resolution), d_p32, d_hdr);
+    return sfe_cf_run_staged(ctx, n_frames, cap, resolution, radius, min_points, d_out, d_out_counts);
+}
+
+extern "C" int sfe_cloud_filter_staged_dev(sfe_ctx *ctx, int n_frames, int64_t cap, float resolution, double radius, int min_points,
+                                           float *d_out, int32_t *d_out_counts)
+{
+    if (int rc = sfe_use(ctx))
+        return rc;
+    SFE_ARG(ctx, n_frames >= 0 && cap > 0 && (n_frames == 0 || (d_out && d_out_counts)));
+    if (ctx->staged_frames != n_frames || ctx->staged_cap != (long long)cap)
+        return sfe_set_err(ctx, SFE_ERR_ARG, "sfe_cloud_filter_staged_dev: no staged clouds of %d frames x %lld points on this context "
+                           "(sfe_extract_points_bits_staged_dev must precede it; found %d x %lld)", n_frames, (long long)cap,
+                           ctx->staged_frames, ctx->staged_cap);
+    if (n_frames == 0)
+        return 0;
+    CfBBox *d_bbox = (CfBBox *)sfe_scratch(ctx, CF_SLOT_BBOX, sizeof(CfBBox) * (size_t)n_frames);
+    CfHeader *d_hdr = (CfHeader *)sfe_scratch(ctx, CF_SLOT_HDR, sizeof(CfHeader) * (size_t)n_frames);
+    if (!d_bbox || !d_hdr)
+        return SFE_ERR_HIP;
+    hipLaunchKernelGGL(cf_header_from_bbox_kernel, dim3((unsigned)((n_frames + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const CfBBox *)d_bbox, n_frames, sfe_cf_max_size(resolution), d_hdr);
     return sfe_cf_run_staged(ctx, n_frames, cap, resolution, radius, min_points, d_out, d_out_counts);
 }
 

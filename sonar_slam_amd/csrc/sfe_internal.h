@@ -58,6 +58,10 @@ struct sfe_ctx {
     int icp_prof = 0;            // debug: per-phase cycle counts of workgroup 0 of the sweep kernel
     long long icp_prof_host[SFE_ICP_PROF_N] = {0};
     int n_cu = 256;
+    // clouds left in the staging slots by sfe_extract_points_bits_staged_dev, waiting for sfe_cloud_filter_staged_dev
+    // (-1: none; anything else that writes those slots resets it)
+    int staged_frames = -1;
+    long long staged_cap = 0;
 };
 
 struct sfe_geom {

@@ -13,6 +13,7 @@
 // image.  That halves the per-frame map traffic (4 B instead of 8 B per Cartesian pixel), and a
 // per-row [first,last) span skips the pixels outside the sonar fan.
 #include "sfe_internal.h"
+#include "sfe_cloudfilter.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -924,8 +925,12 @@ __global__ __launch_bounds__(ME_THREADS) void extract_merge_expand_kernel(const 
                                                                           int32_t *__restrict__ ovf_flag, long long *__restrict__ rc_out,
                                                                           double *__restrict__ pts_out, long long cap, int crows,
                                                                           int ccols, int wpr, int capw, const double *__restrict__ ytab,
-                                                                          const double *__restrict__ xtab)
+                                                                          const double *__restrict__ xtab, float2 *__restrict__ p32_out,
+                                                                          CfBBox *__restrict__ bbox_out)
 {
+    // p32_out / bbox_out (staged hand-over to the resident cloud filters, round 6): the frame's points once more as float2 --
+    // the fp64 metres rounded to float32, what pybind does at pcl.cpp's boundary -- and their bounding box + count, so that the
+    // filters start from here instead of reading the float64 points back (cf_cast_bbox_kernel); pts_out may then be null.
     extern __shared__ __attribute__((aligned(16))) unsigned char me_raw[];
     __shared__ int s_wsum[ME_THREADS / 64];
     __shared__ int s_total;
@@ -982,7 +987,7 @@ __global__ __launch_bounds__(ME_THREADS) void extract_merge_expand_kernel(const 
         pres[i] = 0u;
     for (int i = tid; i < capw; i += ME_THREADS)
         w_bits[i] = 0ull;
-    if (pts_out) {
+    if (pts_out || p32_out) {
         for (int i = tid; i < crows; i += ME_THREADS)
             s_y[i] = ytab[i];
         for (int i = tid; i < ccols; i += ME_THREADS)
@@ -1061,6 +1066,7 @@ __global__ __launch_bounds__(ME_THREADS) void extract_merge_expand_kernel(const 
     __syncthreads();
     if (cap <= 0)
         return;
+    float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY; // (staged: bounding box of this thread's points)
     for (int b = wave * 64; b < nW; b += (ME_THREADS / 64) * 64) { // a wave takes 64 consecutive words
         const int hi0 = min(b + 63, nW - 1);
         const int first = (int)w_off[b], npts = (int)w_off[hi0 + 1] - first;
@@ -1101,6 +1107,91 @@ __global__ __launch_bounds__(ME_THREADS) void extract_merge_expand_kernel(const 
                 reinterpret_cast<longlong2 *>(rc_out)[o] = make_longlong2(row, col);
             if (pts_out)
                 reinterpret_cast<double2 *>(pts_out)[o] = make_double2(s_y[row], s_x[col]);
+            if (p32_out) {
+                const float2 p = make_float2((float)s_y[row], (float)s_x[col]);
+                p32_out[o] = p;
+                mnx = fminf(mnx, p.x);
+                mxx = fmaxf(mxx, p.x);
+                mny = fminf(mny, p.y);
+                mxy = fmaxf(mxy, p.y);
+            }
+        }
+    }
+    if (bbox_out) { // (min / max do not depend on the order they are taken in: the same box as cf_cast_bbox_kernel's)
+        __shared__ float s_bb[4][ME_THREADS / 64];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            mnx = fminf(mnx, __shfl_down(mnx, d));
+            mxx = fmaxf(mxx, __shfl_down(mxx, d));
+            mny = fminf(mny, __shfl_down(mny, d));
+            mxy = fmaxf(mxy, __shfl_down(mxy, d));
+        }
+        if (lane == 0) {
+            s_bb[0][wave] = mnx;
+            s_bb[1][wave] = mny;
+            s_bb[2][wave] = mxx;
+            s_bb[3][wave] = mxy;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < ME_THREADS / 64; ++w) {
+                mnx = fminf(mnx, s_bb[0][w]);
+                mny = fminf(mny, s_bb[1][w]);
+                mxx = fmaxf(mxx, s_bb[2][w]);
+                mxy = fmaxf(mxy, s_bb[3][w]);
+            }
+            CfBBox bb;
+            bb.mnx = mnx;
+            bb.mny = mny;
+            bb.mxx = mxx;
+            bb.mxy = mxy;
+            bb.n = total;
+            bbox_out[f] = bb;
+        }
+    }
+}
+
+// staged hand-over, the frames the record path handed back to the canvas kernels (flagged; or every frame when `flags` is
+// null: the record path was not taken): float64 points -> float2 + bounding box, what cf_cast_bbox_kernel does for all frames
+// on the unstaged path.  A fixed, small grid whose WAVES stride over the frames: a wave looks at a frame's flag and moves on
+// (one workgroup per frame cost 0.03 ms per 4096 frames in launches that almost always return at once); a flagged frame --
+// rare -- is cast by the one wave that meets it.
+__global__ __launch_bounds__(256) void extract_stage_fallback_kernel(const double *__restrict__ pts64, const int32_t *__restrict__ counts,
+                                                                     long long cap, const int32_t *__restrict__ flags,
+                                                                     float2 *__restrict__ p32, CfBBox *__restrict__ bbox, int n_frames)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+    for (int f = wave; f < n_frames; f += n_waves) {
+        if (flags && !flags[f])
+            continue;
+        const int n = (int)min((long long)max(counts[f], 0), cap);
+        const double *src = pts64 + (size_t)f * cap * 2;
+        float2 *dst = p32 + (size_t)f * cap;
+        float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
+        for (int i = lane; i < n; i += 64) {
+            const float2 p = make_float2((float)src[2 * i], (float)src[2 * i + 1]);
+            dst[i] = p;
+            mnx = fminf(mnx, p.x);
+            mxx = fmaxf(mxx, p.x);
+            mny = fminf(mny, p.y);
+            mxy = fmaxf(mxy, p.y);
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            mnx = fminf(mnx, __shfl_down(mnx, d));
+            mxx = fmaxf(mxx, __shfl_down(mxx, d));
+            mny = fminf(mny, __shfl_down(mny, d));
+            mxy = fmaxf(mxy, __shfl_down(mxy, d));
+        }
+        if (lane == 0) {
+            CfBBox bb;
+            bb.mnx = mnx;
+            bb.mny = mny;
+            bb.mxx = mxx;
+            bb.mxy = mxy;
+            bb.n = n;
+            bbox[f] = bb;
         }
     }
 }
@@ -1127,8 +1218,11 @@ int sfe_mask_pack(sfe_ctx *ctx, const uint8_t *d_mask, int n_frames, long long p
 
 // d_bits_in != nullptr: the frames arrive as bit streams (sfe_cfar_u8_bits_batch_dev: binary by construction) and
 // d_mask is not read
+// d_p32 / d_bbox != nullptr: the staged hand-over to the resident cloud filters (float2 points + bounding boxes, see CfBBox);
+// want64 = 0 then leaves d_pts unwritten for the frames the record path handles (the others still land there first)
 static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_frames, long long cap,
-                       long long *d_rc, double *d_pts, int32_t *d_counts, const uint32_t *d_bits_in = nullptr)
+                       long long *d_rc, double *d_pts, int32_t *d_counts, const uint32_t *d_bits_in = nullptr,
+                       float2 *d_p32 = nullptr, CfBBox *d_bbox = nullptr, bool want64 = true)
 {
     const int crows = g->cart_rows, wpr = g->words_per_row;
     static const int chunk = getenv("SFE_EXTRACT_CHUNK") ? std::max(1, atoi(getenv("SFE_EXTRACT_CHUNK"))) : 1024; // frames per pass: bounds the bitmap scratch (0.25 MB per frame), fewer passes = fewer launches
@@ -1257,15 +1351,17 @@ static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_f
                                        d_bits, d_nonbin, p_off, p_ent, d_bm, g->polar_rows, g->polar_cols, crows, wpr, wpf, sg_piece,
                                        d_rec, d_rec_n, rec_cap, (const int32_t *)nullptr);
                 long long *rc_f = d_rc ? d_rc + (size_t)f0 * cap * 2 : nullptr;
-                double *pts_f = d_pts ? d_pts + (size_t)f0 * cap * 2 : nullptr;
+                double *pts_f = (d_pts && (want64 || !d_p32)) ? d_pts + (size_t)f0 * cap * 2 : nullptr;
+                float2 *p32_f = d_p32 ? d_p32 + (size_t)f0 * cap : nullptr;
+                CfBBox *bb_f = d_bbox ? d_bbox + f0 : nullptr;
                 if (me_narrow)
                     hipLaunchKernelGGL(extract_merge_expand_kernel<uint16_t>, dim3(nf), dim3(ME_THREADS), me_lds, ctx->stream, d_rec,
                                        d_rec_n, rec_cap, slices, d_counts + f0, d_ovf_flag, rc_f, pts_f, cap, crows, g->cart_cols, wpr,
-                                       capw, g->d_ytab, g->d_xtab);
+                                       capw, g->d_ytab, g->d_xtab, p32_f, bb_f);
                 else
                     hipLaunchKernelGGL(extract_merge_expand_kernel<uint32_t>, dim3(nf), dim3(ME_THREADS), me_lds, ctx->stream, d_rec,
                                        d_rec_n, rec_cap, slices, d_counts + f0, d_ovf_flag, rc_f, pts_f, cap, crows, g->cart_cols, wpr,
-                                       capw, g->d_ytab, g->d_xtab);
+                                       capw, g->d_ytab, g->d_xtab, p32_f, bb_f);
             }
             if (c4)
                 hipLaunchKernelGGL((extract_gather_kernel<true, false>), dim3((unsigned)slices, nf), dim3(256), 0, ctx->stream, d_bits,
@@ -1314,6 +1410,10 @@ static int extract_dev(sfe_ctx *ctx, sfe_geom *g, const uint8_t *d_mask, int n_f
                                    crows, g->cart_cols, wpr, g->width, g->height, (const int32_t *)nullptr,
                                    (const int32_t *)nullptr);
             }
+            if (d_p32) // staged: the frames the canvas kernels just expanded (flagged by the record path, or all of them)
+                hipLaunchKernelGGL(extract_stage_fallback_kernel, dim3((unsigned)std::min(256, (nf + 3) / 4)), dim3(256), 0, ctx->stream,
+                                   (const double *)pts_f, (const int32_t *)(d_counts + f0), cap, (const int32_t *)d_ovf_flag,
+                                   d_p32 + (size_t)f0 * cap, d_bbox + f0, nf);
         }
     }
     SFE_LAUNCH_CHECK(ctx);
@@ -1751,6 +1851,31 @@ int sfe_extract_points_bits_batch_dev(sfe_ctx *ctx, sfe_geom *g, const uint32_t 
     if (n_frames == 0)
         return 0;
     return extract_dev(ctx, g, nullptr, n_frames, cap, nullptr, d_pts, d_counts, d_bits);
+}
+
+int sfe_extract_points_bits_staged_dev(sfe_ctx *ctx, sfe_geom *g, const uint32_t *d_bits, int n_frames, int64_t cap,
+                                       double *d_pts, int want_points64, int32_t *d_counts)
+{
+    if (int rc = sfe_use(ctx))
+        return rc;
+    SFE_ARG(ctx, g && d_bits && d_pts && d_counts && g->ctx == ctx && n_frames >= 0 && cap > 0);
+    if ((g->polar_cols & 31) != 0)
+        return sfe_set_err(ctx, SFE_ERR_ARG, "bit-stream extraction needs polar_cols %% 32 == 0 (got %d)", g->polar_cols);
+    if (cap > CF_MAX_CAP)
+        return sfe_set_err(ctx, SFE_ERR_ARG, "sfe_extract_points_bits_staged_dev: cap %lld exceeds %d points per frame",
+                           (long long)cap, CF_MAX_CAP);
+    ctx->staged_frames = -1;
+    if (n_frames == 0)
+        return 0;
+    float2 *d_p32 = (float2 *)sfe_scratch(ctx, CF_SLOT_P32, sizeof(float2) * (size_t)cap * (size_t)n_frames);
+    CfBBox *d_bbox = (CfBBox *)sfe_scratch(ctx, CF_SLOT_BBOX, sizeof(CfBBox) * (size_t)n_frames);
+    if (!d_p32 || !d_bbox)
+        return SFE_ERR_HIP;
+    if (int rc = extract_dev(ctx, g, nullptr, n_frames, cap, nullptr, d_pts, d_counts, d_bits, d_p32, d_bbox, want_points64 != 0))
+        return rc;
+    ctx->staged_frames = n_frames;
+    ctx->staged_cap = cap;
+    return 0;
 }
 
 int sfe_extract_points(sfe_ctx *ctx, sfe_geom *g, const uint8_t *mask, int64_t cap, int64_t *rc_out,

@@ -831,6 +831,7 @@ int sfe_cloud_store_get_points(sfe_ctx *ctx, sfe_cloud_store *s, const int32_t *
     const size_t b_tab = nh * (sizeof(int32_t) + 6 * sizeof(float));
     char *h_tab = (char *)sfe_pinned_begin(ctx, b_tab);
     char *d_tab = (char *)sfe_scratch(ctx, 48, b_tab);
+    ctx->staged_frames = -1; // (the staging slots are rewritten)
     float2 *d_p32 = (float2 *)sfe_scratch(ctx, CF_SLOT_P32, sizeof(float2) * (size_t)cap * (size_t)n_jobs);
     CfHeader *d_hdr = (CfHeader *)sfe_scratch(ctx, CF_SLOT_HDR, sizeof(CfHeader) * (size_t)n_jobs);
     float *d_out = (float *)sfe_scratch(ctx, 49, sizeof(float2) * (size_t)cap * (size_t)n_jobs);

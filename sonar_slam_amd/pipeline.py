@@ -7,6 +7,7 @@ kernels on the context's stream (no host round trip between the stages) and ``re
 downloads the small per-job outputs.  This is the unit bench.py times and the farm shards.
 """
 import ctypes as _C
+import os
 
 import numpy as np
 
@@ -16,10 +17,15 @@ from .cfar import _gate_u8
 
 class KeyframeBatch(object):
     def __init__(self, ctx, geometry, cfar_params, alg, intensity_thr, icp_params, n_jobs,
-                 max_points=16384, bit_masks=None):
+                 max_points=16384, bit_masks=None, staged=None, points64=False):
         """bit_masks: the detections go from CFAR to the extraction as bit streams
         (sfe_cfar_u8_bits_batch_dev -> sfe_extract_points_bits_batch_dev) instead of 0/1 bytes; default:
-        whenever the geometry allows it (polar_cols % 32 == 0).  Same points either way."""
+        whenever the geometry allows it (polar_cols % 32 == 0).  Same points either way.
+        staged: the extraction hands its clouds to the filters as float32 pairs + bounding boxes
+        (sfe_extract_points_bits_staged_dev -> sfe_cloud_filter_staged_dev) instead of float64 points that the
+        filters read back and cast; default: with bit masks and max_points <= 65536.  Same clouds either way.
+        points64 (staged only): the float64 points (feature_extraction.py:238) are written too; without them
+        points(j) extracts frame j again on demand."""
         self.ctx, self.geom = ctx, geometry
         self.alg = _L.ALG[alg]
         if alg == "OS":
@@ -37,6 +43,13 @@ class KeyframeBatch(object):
         if self.bit_masks and self.cols % 32:
             raise ValueError("bit_masks needs polar_cols % 32 == 0")
         self.wpf = (self.rows * self.cols + 31) // 32 + 1      # SFE_BITS_WORDS
+        if staged is None and os.environ.get("SONARFE_STAGED") == "0":     # A/B inside one GPU call (tools/ab_stage.sh)
+            staged = False
+        self.staged = (self.bit_masks and self.cap <= 65536) if staged is None else bool(staged)
+        if self.staged and not (self.bit_masks and self.cap <= 65536):
+            raise ValueError("staged needs bit masks and max_points <= 65536")
+        self.points64 = bool(points64) or not self.staged
+        self._staged_ready = False                  # run_extract has left clouds for run_filter on the context
         self.d_img = ctx.alloc(fb)
         self.d_mask = ctx.alloc(self.n * self.wpf * 4 if self.bit_masks else fb)
         self.d_pts = ctx.alloc(self.n * self.cap * 16)
@@ -86,6 +99,11 @@ class KeyframeBatch(object):
 
     def run_extract(self):
         c = self.ctx
+        if self.staged:
+            c._check(c.lib.sfe_extract_points_bits_staged_dev(c.handle, self.geom.handle, self.d_mask.ptr, self.n, self.cap,
+                                                              self.d_pts.ptr, 1 if self.points64 else 0, self.d_cnt.ptr))
+            self._staged_ready = True
+            return
         fn = c.lib.sfe_extract_points_bits_batch_dev if self.bit_masks else c.lib.sfe_extract_points_batch_dev
         c._check(fn(c.handle, self.geom.handle, self.d_mask.ptr, self.n, self.cap, self.d_pts.ptr, self.d_cnt.ptr))
 
@@ -96,6 +114,21 @@ class KeyframeBatch(object):
         if self.d_cloud is None:
             self.d_cloud = c.alloc(self.n * self.cap * 8)
             self.d_cloud_cnt = c.alloc(self.n * 4)
+        if self.staged:
+            # the staged clouds stay valid until something else on this context stages clouds (another batch, a per-cloud
+            # pcl.downsample, the keyframe store): run_filter may repeat; the library refuses stale data (SFE_ERR_ARG),
+            # and then the extraction is simply enqueued again in front
+            for attempt in (0, 1):
+                if not self._staged_ready:
+                    self.run_extract()
+                rc = c.lib.sfe_cloud_filter_staged_dev(c.handle, self.n, self.cap, float(resolution), float(radius),
+                                                       int(min_points), self.d_cloud.ptr, self.d_cloud_cnt.ptr)
+                if rc < 0 and attempt == 0 and b"no staged clouds" in c.lib.sfe_last_error(c.handle):
+                    self._staged_ready = False
+                    continue
+                c._check(rc)
+                break
+            return
         c._check(c.lib.sfe_cloud_filter_batch_dev(c.handle, self.d_pts.ptr, self.d_cnt.ptr, self.n, self.cap,
                                                   float(resolution), float(radius), int(min_points),
                                                   self.d_cloud.ptr, self.d_cloud_cnt.ptr))
@@ -167,7 +200,22 @@ class KeyframeBatch(object):
         }
 
     def points(self, j):
+        """the float64 points of frame j (feature_extraction.py:235-238), np.nonzero order"""
         n = self._check_frame(j)
+        if not self.points64:
+            # the staged step keeps float32 pairs only: frame j's bit stream goes through the float64 extraction once more
+            c = self.ctx
+            tmp_p, tmp_n = c.alloc(self.cap * 16), c.alloc(4)
+            try:
+                c._check(c.lib.sfe_extract_points_bits_batch_dev(c.handle, self.geom.handle,
+                                                                 _C.c_void_p(self.d_mask.ptr.value + j * self.wpf * 4),
+                                                                 1, self.cap, tmp_p.ptr, tmp_n.ptr))
+                c.sync()
+                assert int(tmp_n.download(np.int32, 1)[0]) == n
+                return tmp_p.download(np.float64, 2 * n).reshape(n, 2)
+            finally:
+                tmp_p.free()
+                tmp_n.free()
         return self.d_pts.download(np.float64, 2 * n, offset=j * self.cap * 16).reshape(n, 2)
 
     def mask(self, j):

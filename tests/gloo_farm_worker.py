@@ -1,4 +1,4 @@
-"""Helper of test_host.test_two_rank_gloo_farm: one rank of a 2-process gloo job farm."""
+"""Helper of test_host.test_gloo_farm: one rank of a W-process gloo job farm (W = 2 and the target machine's 8)."""
 import os
 import sys
 
@@ -18,11 +18,13 @@ def job(j):
 
 def main():
     dist.init_process_group("gloo")
-    n_jobs = 7
+    w = dist.get_world_size()
+    n_jobs = 7 if w == 2 else 2 * w + 3          # (not a multiple of the world size: the shards differ in length)
     res = farm.run_sharded(job, n_jobs)
     serial = [job(j) for j in range(n_jobs)]
     assert res == serial, "sharded results differ from serial ones"
-    assert len(farm.shard(n_jobs, dist.get_rank(), dist.get_world_size())) in (3, 4)
+    mine = farm.shard(n_jobs, dist.get_rank(), w)
+    assert mine == list(range(dist.get_rank(), n_jobs, w)) and len(mine) in (n_jobs // w, n_jobs // w + 1)  # job j -> rank j mod W
     dist.barrier()
     dist.destroy_process_group()
     print("FARM_OK rank", os.environ["RANK"])

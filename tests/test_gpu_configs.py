@@ -199,3 +199,18 @@ def test_bench_two_ranks_on_one_device():
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert abs(out["value"] - 2 * 16 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
     assert out["parity_check"]["frames_bit_exact"] == 2
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_on_one_device():
+    """the same launch at the target machine's width: eight ranks, all pinned to this box's only device,
+    a tiny batch each -- rendezvous on 127.0.0.1, barrier, max-over-ranks time, the aggregate value over 8 ranks and rank 0's
+    one JSON line; the legs that measure one device stay off in a multi-rank launch"""
+    port = 29500 + (os.getpid() + 77) % 1000
+    out = _bench(["--gpus", "8", "--batch", "8", "--parity-jobs", "2", "--steps", "2", "--warmup", "1"],
+                 env={"SONARFE_BENCH_DEVICE": "0"},
+                 launcher=["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+                           "127.0.0.1", "--master-port", str(port)])
+    assert out["n_gpus"] == 8 and out["scaling"] == "weak" and out["value"] > 0 and out["steps"] == 2
+    assert abs(out["value"] - 8 * 8 / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
+    assert out["parity_check"]["frames_bit_exact"] == 2

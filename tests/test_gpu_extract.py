@@ -102,10 +102,13 @@ def test_batched_extract_device_path(ctx, shipped_cfar):
         assert np.array_equal(pts[f, :cnt[f]], oracle.px_to_m(rc, ranges, mx.shape[1], width, height))
 
 
-def test_resident_cloud_filters_equal_the_per_cloud_api_and_the_oracle(ctx, shipped_cfar):
+@pytest.mark.parametrize("staged", [True, False])
+def test_resident_cloud_filters_equal_the_per_cloud_api_and_the_oracle(ctx, shipped_cfar, staged):
     """sfe_cloud_filter_batch_dev (downsample + remove_outlier, device to device, the tail of
     FeatureExtraction.callback) against pcl.downsample / pcl.remove_outlier on the same clouds and
-    against the oracle; also with either stage switched off like feature_extraction.py:241,245."""
+    against the oracle; also with either stage switched off like feature_extraction.py:241,245.
+    staged: the round-6 hand-over (sfe_extract_points_bits_staged_dev -> sfe_cloud_filter_staged_dev: float32 pairs +
+    bounding boxes instead of float64 points read back and cast) -- the same clouds bit for bit."""
     import oracle
     from sonar_slam_amd import pcl
     from sonar_slam_amd.pipeline import KeyframeBatch
@@ -116,7 +119,8 @@ def test_resident_cloud_filters_equal_the_per_cloud_api_and_the_oracle(ctx, ship
     frames = np.stack([synth.sonar_frame(seed=70 + s, rows=512, cols=256, n_blobs=25) for s in range(5)])
     frames[3] = 0                                             # a frame without detections
     fe.generate_map_xy(SonarPing(frames[0], oculus_bearings(256), 30.0 / 512))
-    kb = KeyframeBatch(ctx, fe.geometry, (th, gh, tau), "SOCA", 65, None, len(frames), max_points=8192)
+    kb = KeyframeBatch(ctx, fe.geometry, (th, gh, tau), "SOCA", 65, None, len(frames), max_points=8192, staged=staged)
+    assert kb.staged == staged and kb.points64 == (not staged)
     kb.upload_frames(frames)
     kb.run_cfar()
     kb.run_extract()
@@ -142,6 +146,72 @@ def test_resident_cloud_filters_equal_the_per_cloud_api_and_the_oracle(ctx, ship
             assert got.dtype == np.float32 and np.array_equal(got, want.reshape(-1, 2)), (res, rad, mp, j)
             assert np.array_equal(got, np.asarray(want_o, np.float32).reshape(-1, 2))
     kb.free()
+
+
+@pytest.mark.parametrize("points64", [False, True])
+def test_staged_hand_over_with_frames_that_leave_the_record_path(ctx, shipped_cfar, points64, monkeypatch):
+    """The staged extraction when frames do not fit the record path's per-frame capacities (forced here by shrinking them:
+    SFE_EXTRACT_REC_CAP / SFE_EXTRACT_CAPW are read per call): those frames go through the canvas kernels, land as float64
+    and are cast by extract_stage_fallback_kernel; the others are staged by the merge kernel itself.  Same clouds as the
+    unstaged path and the oracle either way, and points(j) is the float64 cloud in both modes."""
+    import oracle
+    from sonar_slam_amd.pipeline import KeyframeBatch
+    th, gh, tau = shipped_cfar.params["SOCA"]
+    fe = FeatureExtraction(ctx)
+    fe.Ntc, fe.Ngc, fe.Pfa, fe.rank, fe.alg, fe.threshold = 40, 10, 0.1, 10, "SOCA", 65
+    fe.configure()
+    # frames of very different density: with a record capacity of 1500 some fit and some do not
+    frames = np.stack([synth.sonar_frame(seed=170 + s, rows=512, cols=256, n_blobs=nb) for s, nb in enumerate((2, 25, 4, 40, 0, 12))])
+    frames[4] = 0
+    fe.generate_map_xy(SonarPing(frames[0], oculus_bearings(256), 30.0 / 512))
+    ref = KeyframeBatch(ctx, fe.geometry, (th, gh, tau), "SOCA", 65, None, len(frames), max_points=16384, staged=False)
+    ref.upload_frames(frames)
+    ref.run_cfar()
+    ref.run_extract()
+    ref.run_filter(0.5, 1.0, 5)
+    ctx.sync()
+    want_pts = [ref.points(j) for j in range(len(frames))]
+    want_cl = [ref.cloud(j) for j in range(len(frames))]
+    ref.free()
+    n_rec = sorted(len(p) for p in want_pts)
+    for env in ({}, {"SFE_EXTRACT_REC_CAP": "1500"}, {"SFE_EXTRACT_CAPW": "200"}, {"SFE_EXTRACT_REC_CAP": "1"}):
+        for k in ("SFE_EXTRACT_REC_CAP", "SFE_EXTRACT_CAPW"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        kb = KeyframeBatch(ctx, fe.geometry, (th, gh, tau), "SOCA", 65, None, len(frames), max_points=16384, staged=True,
+                           points64=points64)
+        kb.upload_frames(frames)
+        kb.run_cfar()
+        kb.run_extract()
+        kb.run_filter(0.5, 1.0, 5)
+        ctx.sync()
+        for j in range(len(frames)):
+            assert np.array_equal(kb.cloud(j), want_cl[j]), (env, j)
+            assert np.array_equal(kb.points(j), want_pts[j]), (env, j)
+            o = oracle.remove_outlier(oracle.downsample(want_pts[j].astype(np.float32), 0.5), 1.0, 5) if len(want_pts[j]) else want_cl[j]
+            assert np.array_equal(kb.cloud(j), np.asarray(o, np.float32).reshape(-1, 2)), (env, j)
+        kb.run_filter(0.25, 0.6, 3)                  # the staged clouds serve a second filter call
+        ctx.sync()
+        for j in (1, 3):
+            o = oracle.remove_outlier(oracle.downsample(want_pts[j].astype(np.float32), 0.25), 0.6, 3)
+            assert np.array_equal(kb.cloud(j), o), (env, j)
+        kb.free()
+    assert n_rec[0] == 0 and n_rec[-1] > 3000
+
+
+def test_staged_filter_call_without_staged_clouds_is_refused(ctx):
+    """sfe_cloud_filter_staged_dev checks that the context holds staged clouds of that shape: never stale data"""
+    out, cnt = ctx.alloc(4 * 64 * 8), ctx.alloc(4 * 4)
+    try:
+        ctx.lib.sfe_cloud_filter_batch_dev(ctx.handle, None, None, 0, 64, 0.5, 1.0, 5, None, None)   # (resets nothing: 0 frames)
+        rc = ctx.lib.sfe_cloud_filter_staged_dev(ctx.handle, 4, 63, 0.5, 1.0, 5, out.ptr, cnt.ptr)
+        assert rc != 0
+        with pytest.raises(Exception, match="no staged clouds"):
+            ctx._check(rc)
+    finally:
+        out.free()
+        cnt.free()
 
 
 def test_resident_cloud_filters_hires_frame(ctx, shipped_cfar):

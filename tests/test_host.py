@@ -123,15 +123,17 @@ def test_shard_and_scatter_back():
         farm.shard(4, 2, 2)
 
 
-def test_two_rank_gloo_farm():
-    """world_size 2 over gloo on CPU: each rank matches its shard of ICP jobs (with the oracle as
-    the stand-in compute, tests may use it) and every rank ends up with all poses in job order."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_gloo_farm(world):
+    """world_size 2 and 8 (the target node: 8 x MI355X) over gloo on CPU: each rank matches its shard of ICP jobs (with
+    the oracle as the stand-in compute, tests may use it) and every rank ends up with all poses in job order --
+    rendezvous, shard arithmetic (job j -> rank j mod W) and the gather, with no collective on the data path."""
     script = os.path.join(ROOT, "tests", "gloo_farm_worker.py")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2",
-               PYTHONPATH=ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29533 + world), WORLD_SIZE=str(world),
+               PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
     procs = [subprocess.Popen([sys.executable, script], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
-    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
         assert "FARM_OK" in o, o
@@ -191,6 +193,28 @@ def test_persistent_two_worker_farm_over_shared_memory():
     with farm.IcpFarm(p, devices=[0], _backend="farm_backend:failing_compute") as f:
         with pytest.raises(RuntimeError, match="boom"):
             f.run(batch(2))
+
+
+def test_persistent_eight_worker_farm_over_shared_memory():
+    """the farm at the target machine's width: eight persistent workers (CPU-backend stand-ins for the eight devices), jobs
+    dealt j mod 8 through eight shared-memory blocks with distinct names, fewer jobs than workers and more, results in job
+    order -- so that the first 8-GPU run cannot fail on process start-up, block naming or shard arithmetic."""
+    import oracle
+    from sonar_slam_amd import farm, icp_config, synth
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    p = icp_config.shipped_params()
+    pairs = [synth.scan_pair(seed=40 + s, n_src=120 + 7 * s, n_tgt=130) for s in range(5)]
+    with farm.IcpFarm(p, devices=list(range(8)), chunk=4, _backend="farm_backend:oracle_compute") as f:
+        assert len(f._workers) == 8 and len(set(w.name for w in f._workers)) == 8
+        for n in (3, 8, 21):
+            jobs = [(pairs[j % 5][0], pairs[j % 5][1], [pairs[j % 5][2]]) for j in range(n)]
+            out = f.run(jobs)
+            assert len(out) == n
+            for (s, t, gs), (msgs, T, it) in zip(jobs, out):
+                st, To, ito = oracle.icp(s, t, gs[0], oracle.IcpParams(precision=1, **p.as_dict()))
+                assert msgs[0] == oracle.ICP_STATUS_MESSAGES[st] and it[0] == ito and np.array_equal(T[0], To)
+        assert [farm.shard(21, r, 8) for r in range(8)] == [list(range(r, 21, 8)) for r in range(8)]
+    assert f._workers == []
 
 
 def test_farm_bad_job_leaves_no_request_in_flight():
