@@ -50,6 +50,10 @@ def parse():
                     help="CPU-baseline keyframes per host core (0 = about 10 s of work per core)")
     ap.add_argument("--icp-mode", choices=["p2plane30", "reference"], default="p2plane30")
     ap.add_argument("--no-filters", action="store_true", help="leave pcl.downsample / remove_outlier out of the step")
+    ap.add_argument("--max-points", type=int, default=32768,
+                    help="point capacity per frame.  The synthetic frames of some ranks hold pings of > 16384 detections (seed 3002: "
+                         "19 122): the 8-rank launch of round 6 found rank 3 raising at the 16384 of rounds 1-5.  The resident "
+                         "filters pick their sort per frame, so the capacity only sizes buffers")
     ap.add_argument("--parity-jobs", type=int, default=64,
                     help="keyframes of the timed batch re-computed by the oracle after the timed region (0 = skip)")
     ap.add_argument("--no-farm", action="store_true", help="skip the BASELINE configs[3] leg (job farm on this device)")
@@ -372,7 +376,7 @@ def main():
         f.Ntc, f.Ngc, f.Pfa, f.rank, f.alg, f.threshold = 40, 10, 0.1, 10, "SOCA", 65
         f.configure()
         f.generate_map_xy(SonarPing(frames[0], oculus_bearings(COLS), 30.0 / ROWS))
-        b = KeyframeBatch(c, f.geometry, det.params["SOCA"], "SOCA", 65, icp_p, args.batch)
+        b = KeyframeBatch(c, f.geometry, det.params["SOCA"], "SOCA", 65, icp_p, args.batch, max_points=args.max_points)
         b.upload_frames(frames)
         b.upload_scan_pairs(srcs, tgts, guesses)
         if not args.serial_prep:

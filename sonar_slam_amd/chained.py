@@ -316,6 +316,14 @@ class SessionBatch(object):
                 self._plan.self_check()
         return self._plan if self._plan.checked else None
 
+    def warm_up(self):
+        """Build and self-check the shgo replay NOW instead of inside the first step (a few seconds of scipy.optimize.shgo on
+        random step functions), and say in the log whether it is active for the installed scipy.  -> shgo_fast.status()"""
+        from . import shgo_fast
+        pose_stds = np.array([self.odom_sigmas]).T
+        self._replay_plan(5.0 * np.c_[-pose_stds, pose_stds])
+        return shgo_fast.status()
+
     def _global_init(self, idx, src_h, tgt_h, pose, prev):
         """-> (success [n], estimated source poses Pose2Batch [n], result.x [n x 3], result.fun [n]) for sessions idx"""
         import time

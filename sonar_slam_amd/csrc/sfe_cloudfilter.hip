@@ -90,6 +90,10 @@ __device__ __forceinline__ unsigned long long cf_path_key(float2 p, const CfHead
 // itself CF_NEEDS_WIDE and is taken by the uint64 instantiation, which is launched behind it for those
 // frames only.
 #define CF_NEEDS_WIDE (-2)
+// ... and a frame with more points than the launch's LDS holds (capacities beyond CF_SORT_CAP: round 6) marks itself
+// CF_NEEDS_GLOBAL: the instantiation that sorts in HBM scratch, launched last, takes whatever is still marked.  The sort
+// is chosen per FRAME, not per batch: one dense ping among thousands no longer sends every frame of the batch to the slow path.
+#define CF_NEEDS_GLOBAL (-3)
 template <bool IN_LDS, typename K>
 __global__ __launch_bounds__(1024) void cf_downsample_kernel(const float2 *__restrict__ p32, long long cap,
                                                              CfHeader *__restrict__ hdrs, float2 *__restrict__ ds_out,
@@ -102,13 +106,18 @@ __global__ __launch_bounds__(1024) void cf_downsample_kernel(const float2 *__res
     K *s_keys = IN_LDS ? reinterpret_cast<K *>(lds_raw) : gkeys_all + (size_t)blockIdx.x * n2cap;
     const int f = blockIdx.x, tid = threadIdx.x;
     const CfHeader h = hdrs[f];
-    if (only_marked && h.n_seg != CF_NEEDS_WIDE)
+    if (only_marked && h.n_seg != CF_NEEDS_WIDE && h.n_seg != CF_NEEDS_GLOBAL)
         return;
     const int n = h.n;
     const float2 *pts = p32 + (size_t)f * cap;
     float2 *out = ds_out + (size_t)f * cap;
     if (n == 0)
         return;
+    if (IN_LDS && n2cap > 0 && n > n2cap) { // more points than this launch's LDS holds: left to the HBM-scratch instantiation
+        if (tid == 0)
+            hdrs[f].n_seg = CF_NEEDS_GLOBAL;
+        return;
+    }
     constexpr int KEY_BITS = (int)sizeof(K) * 8 - 16;
     if (2 * h.levels > KEY_BITS) {
         // (key << 16 | index) holds KEY_BITS key bits: narrow keys hand the frame to the wide instantiation,
@@ -268,6 +277,11 @@ __global__ __launch_bounds__(1024) void cf_downsample_radix_kernel(const float2 
     float2 *out = ds_out + (size_t)f * cap;
     if (n == 0)
         return;
+    if (n > n2cap) { // more points than the LDS of this launch holds: the HBM-scratch sort launched last takes the frame
+        if (tid == 0)
+            hdrs[f].n_seg = CF_NEEDS_GLOBAL;
+        return;
+    }
     if (2 * h.levels > 16) { // deeper tree: the 64-bit bitonic instantiation launched behind takes the frame
         if (tid == 0)
             hdrs[f].n_seg = CF_NEEDS_WIDE;
@@ -698,9 +712,12 @@ int sfe_cf_run_staged(sfe_ctx *ctx, int n_frames, int64_t cap, float resolution,
         float2 *d_spts = (float2 *)sfe_scratch(ctx, 40, sizeof(float2) * per * (size_t)n_frames);
         if (!d_seg || !d_lkeys || !d_spts)
             return SFE_ERR_HIP;
-        if (cap <= CF_SORT_CAP) {
-            // trees of <= 8 levels (every frame of a sonar fan at 0.5 m): radix sort of the indices; then the bitonic
-            // sort with 64-bit keys for the frames that marked themselves
+        {
+            // Per FRAME (round 6): frames of <= CF_SORT_CAP points sort in LDS whatever the batch's capacity is -- trees of <= 8
+            // levels (every frame of a sonar fan at 0.5 m) by the radix sort of the indices, deeper ones by the bitonic sort with
+            // 64-bit keys; a frame with more points (a capacity beyond CF_SORT_CAP allows them) marks itself and is sorted in HBM
+            // scratch by the last launch.  (Rounds 2-5 chose by the batch's capacity: one dense ping sent all frames to HBM.)
+            const size_t n2l = std::min<size_t>(n2, CF_SORT_CAP); // LDS slots of the first two launches
             {
                 // indices + keys + counters for the sort, then (same bytes) every point of the frame in sorted order.
                 // (The LDS is sized by the CAPACITY: 128 KB = one frame per CU at 16 384 points, 64 KB = two per CU at 8 192.
@@ -710,26 +727,27 @@ int sfe_cf_run_staged(sfe_ctx *ctx, int n_frames, int64_t cap, float resolution,
                 // whose pings are small passes a smaller capacity instead: chained.SessionBatch sizes it from its warm-up.)
                 // (digit counters: one column of 16 per sorting thread -- 1024 of them, 512 at capacities of <= 8192 points so
                 // that indices + keys + counters stay inside the 64 KB that let two frames share a CU)
-                const int sort_cols = n2 <= 8192 ? 512 : 1024;
+                const int sort_cols = n2l <= 8192 ? 512 : 1024;
                 const size_t n_cnt = CF_RDX_DIGITS * (size_t)sort_cols;
-                const size_t rdx_smem = std::max<size_t>(3 * 2 * n2 + 2 * (n_cnt + n_cnt / 16), sizeof(float2) * n2);
+                const size_t rdx_smem = std::max<size_t>(3 * 2 * n2l + 2 * (n_cnt + n_cnt / 16), sizeof(float2) * n2l);
                 SFE_HIP(ctx, hipFuncSetAttribute((const void *)cf_downsample_radix_kernel,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)rdx_smem));
                 hipLaunchKernelGGL(cf_downsample_radix_kernel, dim3(n_frames), dim3(1024), rdx_smem, ctx->stream, d_p32,
-                                   (long long)cap, d_hdr, d_ds, d_seg, (int)n2, d_lkeys, d_spts, (int)rdx_smem, sort_cols);
+                                   (long long)cap, d_hdr, d_ds, d_seg, (int)n2l, d_lkeys, d_spts, (int)rdx_smem, sort_cols);
             }
             SFE_HIP(ctx, hipFuncSetAttribute((const void *)cf_downsample_kernel<true, unsigned long long>,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(8 * n2)));
-            hipLaunchKernelGGL((cf_downsample_kernel<true, unsigned long long>), dim3(n_frames), dim3(1024), 8 * n2,
-                               ctx->stream, d_p32, (long long)cap, d_hdr, d_ds, d_seg, (unsigned long long *)nullptr, 0LL, 1,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(8 * n2l)));
+            hipLaunchKernelGGL((cf_downsample_kernel<true, unsigned long long>), dim3(n_frames), dim3(1024), 8 * n2l,
+                               ctx->stream, d_p32, (long long)cap, d_hdr, d_ds, d_seg, (unsigned long long *)nullptr, (long long)n2l, 1,
                                (unsigned *)nullptr);
-        } else {
-            unsigned long long *d_gk = (unsigned long long *)sfe_scratch(ctx, 29, 8 * n2 * (size_t)n_frames);
-            if (!d_gk)
-                return SFE_ERR_HIP;
-            hipLaunchKernelGGL((cf_downsample_kernel<false, unsigned long long>), dim3(n_frames), dim3(1024), 0,
-                               ctx->stream, d_p32, (long long)cap, d_hdr, d_ds, d_seg, d_gk, (long long)n2, 0,
-                               (unsigned *)nullptr);
+            if (cap > CF_SORT_CAP) {
+                unsigned long long *d_gk = (unsigned long long *)sfe_scratch(ctx, 29, 8 * n2 * (size_t)n_frames);
+                if (!d_gk)
+                    return SFE_ERR_HIP;
+                hipLaunchKernelGGL((cf_downsample_kernel<false, unsigned long long>), dim3(n_frames), dim3(1024), 0,
+                                   ctx->stream, d_p32, (long long)cap, d_hdr, d_ds, d_seg, d_gk, (long long)n2, 1,
+                                   (unsigned *)nullptr);
+            }
         }
         stage = d_ds;
     }

@@ -291,8 +291,17 @@ class FrontEnd(object):
             if plan.checked is None:
                 plan.self_check()
             if plan.checked:
-                table = np.array(subroutine.batch(list(plan.points.reshape(-1, 3))), np.int64).reshape(plan.V, 4)
-                st, x, fun, n_local = plan.solve(table, return_pool=True)
+                # (the costs are taken without entering them into the subroutine's pose samples; what the reference's own run
+                #  evaluates -- every vertex, then four points per local minimisation -- is entered below: ADVICE r5.  When the
+                #  problem goes to scipy instead, scipy's own calls enter theirs.)
+                can_record = hasattr(subroutine, "record")
+                pts = list(plan.points.reshape(-1, 3))
+                table = np.array(subroutine.batch(pts, record=False) if can_record else subroutine.batch(pts), np.int64).reshape(plan.V, 4)
+                st, x, fun, order = plan.solve_order(table)
+                n_local = len(order)
+                if st != shgo_fast.FALLBACK and can_record:
+                    subroutine.record(np.concatenate([plan.X, plan.points[order].reshape(-1, 3)]),
+                                      np.concatenate([table[:, 0], table[order].reshape(-1)]))
                 if st == shgo_fast.OK:
                     return OptimizeResult(x=x, fun=np.int64(fun), success=True, message="Optimization terminated successfully.",
                                           nfev=plan.V + 4 * n_local, nlfev=4 * n_local, replayed=True)
@@ -322,6 +331,22 @@ class FrontEnd(object):
             return [np.int64(c) for c in subroutine.batch(xs)] if xs else []
         return shgo(func=subroutine, bounds=pose_bounds, n=params[0], iters=params[1], sampling_method="sobol",
                     minimizer_kwargs={"options": {"ftol": params[2]}}, workers=pool)
+
+    def warm_up(self):
+        """Build and self-check the shgo replays this front end will use NOW (tens of scipy.optimize.shgo runs on random step
+        functions, a few seconds) instead of inside the first keyframe / loop-closure callback of a live node, and
+        say in the log whether they are active for the installed scipy (shgo_fast.status()).  -> shgo_fast.status()"""
+        from . import shgo_fast
+        if self.shgo_replay:
+            if self.ssm_initialization and self.ssm_initialization_params[1] == 1:
+                pose_stds = np.array([self.odom_sigmas]).T
+                plan = shgo_fast.plan_for(5.0 * np.c_[-pose_stds, pose_stds], self.ssm_initialization_params[0],
+                                          self.ssm_initialization_params[2])
+                if plan.checked is None:
+                    plan.self_check()
+            if self.nssm_enable and self.nssm_initialization and self.nssm_initialization_params[1] > 1:
+                shgo_fast.multi_checked(*self.nssm_initialization_params)
+        return shgo_fast.status()
 
     def add_sequential_scan_matching(self, keyframe):
         """slam.py:607-832: initialize_sequential_scan_matching (target cloud, the point-count tests, the global

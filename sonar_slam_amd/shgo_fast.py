@@ -22,11 +22,39 @@ runs scipy.optimize.shgo itself for that problem.  Where shgo's own choice is nu
 local results, pool members exactly equally far from the last result -- numpy is asked with the same call on the same numbers.  `SobolPlan.self_check` compares the replay with
 scipy.optimize.shgo on random piecewise-constant functions; the callers run it once per plan and use shgo for everything if it fails.
 """
+import collections
 import ctypes as _C
+import logging
 
 import numpy as np
 
 OK, FAILED, FALLBACK, OK_TIED = 0, 1, 2, 3     # SFE_SHGO_* of sonarfe.h
+DEVELOPED_AGAINST = "1.15.3"   # the scipy whose shgo / SLSQP internals the replays were written against
+
+# ---- what a maintainer must be able to SEE (VERDICT r5 item 7): the replays lean on scipy internals and switch themselves off
+# when the installed scipy does not reproduce them -- correct, but ~100 x slower, and silent until round 6.  Every self-check now
+# ends in one log line (WARNING when a replay is off, INFO when it is on) and in `status()`, which bench.py prints into its line.
+_LOG = logging.getLogger("sonar_slam_amd.shgo_fast")
+_STATUS = {}
+
+
+def _announce(kind, key, ok, why=""):
+    import scipy
+    _STATUS["%s %s" % (kind, key)] = {"active": bool(ok), "why": why}
+    if ok:
+        _LOG.info("shgo replay (%s, %s) ACTIVE: reproduces scipy %s's shgo on random step functions (developed against %s)",
+                  kind, key, scipy.__version__, DEVELOPED_AGAINST)
+    else:
+        _LOG.warning("shgo replay (%s, %s) OFF -- scipy %s does not reproduce what shgo_fast.py was written against (%s)%s: every "
+                     "global initialisation goes through scipy.optimize.shgo itself (same results, ~100 x slower)",
+                     kind, key, scipy.__version__, DEVELOPED_AGAINST, (": " + why) if why else "")
+
+
+def status():
+    """-> {"scipy": installed version, "developed_against": ..., "replays": {name: {"active": bool, "why": str}}} for every replay
+    this process has checked so far (none yet: nothing has asked for one)"""
+    import scipy
+    return {"scipy": scipy.__version__, "developed_against": DEVELOPED_AGAINST, "replays": dict(_STATUS)}
 MAX_POOL = 32                 # the C routine's bound on the minimiser pool (beyond: FALLBACK)
 
 
@@ -87,7 +115,13 @@ class SobolPlan:
         find a feasible minimizer point" (no vertex strictly below all its neighbours): x / fun are the lowest vertex like
         shgo's result then."""
         r = self._solve(table)
-        return r if return_pool else r[:3]
+        return r[:4] if return_pool else r[:3]
+
+    def solve_order(self, table):
+        """-> (status, x, fun, the vertices shgo minimises from, in its order) -- what the caller needs to enter the evaluations
+        of the reference's run into its pose samples: every vertex once, four points per local minimisation"""
+        st, x, fun, _, order = self._solve(table)
+        return st, x, fun, order
 
     def _solve(self, table):
         table = np.asarray(table)
@@ -96,15 +130,15 @@ class SobolPlan:
                 if all(f[v] < f[j] for j in self.nn_idx[self.nn_off[v]:self.nn_off[v + 1]])]
         if not pool:
             v = int(np.argmin(f))                            # first lowest in cache order (find_lowest_vertex: strict <)
-            return FAILED, self.X[v].copy(), f[v], 0
+            return FAILED, self.X[v].copy(), f[v], 0, []
         if any((table[v, 1:] != f[v]).any() for v in pool):
-            return FALLBACK, None, None, 0
+            return FALLBACK, None, None, 0, []
         order = [pool[0]]
         rest = pool[1:]
         while rest:
             order.append(rest.pop(farthest(self.X[order[-1]], self.X[rest])))
         v = order[lowest_result(np.array([f[v] for v in order], np.int64))]
-        return OK, self.X[v].copy(), f[v], len(order)
+        return OK, self.X[v].copy(), f[v], len(order), order
 
     # ---- many problems at once (C: sfe_shgo_sobol_replay) ----
     def solve_many(self, lib, tables):
@@ -157,6 +191,8 @@ class SobolPlan:
             else:
                 good &= (not res.success) and np.array_equal(res.x, x) and res.fun == fun
         self.checked = bool(good and decided >= rounds // 2)
+        _announce("one iteration", "n=%d bounds=%s" % (self.n, np.array2string(self.bounds[:, 1], precision=4)), self.checked,
+                  "" if self.checked else "%d of %d random problems decided, agreement %s" % (decided, rounds, good))
         return self.checked
 
 
@@ -173,11 +209,13 @@ def piecewise_constant(rng, span, coarse=False, n_planes=24):
     return f
 
 
-_PLANS = {}
+_PLANS = collections.OrderedDict()
+MAX_PLANS = 8   # (a caller whose bounds change from call to call -- the loop-closure search with (n, 1) parameters takes them from a
+#                 keyframe's covariance -- would otherwise keep every plan it ever built: ADVICE r5)
 
 
 def plan_for(bounds, n, ftol):
-    """plans are a function of (bounds, n, ftol): one per process"""
+    """plans are a function of (bounds, n, ftol): the most recently used MAX_PLANS of them are kept per process"""
     key = (np.asarray(bounds, float).tobytes(), int(n), float(ftol))
     p = _PLANS.get(key)
     if p is None:
@@ -185,7 +223,12 @@ def plan_for(bounds, n, ftol):
             p = SobolPlan(bounds, n, ftol)
         except Exception as e:       # a scipy without these internals, or one whose SLSQP behaves differently: no replay, shgo itself
             p = _NoPlan(repr(e))
+            _announce("one iteration", "n=%d" % int(n), False, p.why)
         _PLANS[key] = p
+    else:
+        _PLANS.move_to_end(key)
+    while len(_PLANS) > MAX_PLANS:
+        _PLANS.popitem(last=False)
     return p
 
 
@@ -321,10 +364,13 @@ def multi_checked(n, iters, ftol, rounds=3, seed=5):
     result, value, success and the multiset of evaluated points must agree (problems the replay hands back do not count)"""
     key = (int(n), int(iters), float(ftol))
     if key not in _MULTI_OK:
+        why = ""
         try:
             _MULTI_OK[key] = _multi_check(n, iters, ftol, rounds, seed)
-        except Exception:            # (a scipy without the pieces the replay leans on: shgo itself)
+        except Exception as e:       # (a scipy without the pieces the replay leans on: shgo itself)
             _MULTI_OK[key] = False
+            why = repr(e)
+        _announce("%d iterations" % int(iters), "n=%d" % int(n), _MULTI_OK[key], why)
     return _MULTI_OK[key]
 
 

@@ -142,6 +142,62 @@ def test_front_end_shgo_replay_on_the_matching_cost():
     assert n_replayed >= 4
 
 
+def test_one_iteration_replay_enters_the_reference_runs_evaluations_and_says_what_it_is(caplog):
+    """ADVICE r5 / VERDICT r5 item 7.  (i) A subroutine with `record` (the product's matching cost) gets exactly the evaluations of
+    the reference's own shgo run entered into its pose samples -- every vertex once, four points per local minimisation -- not
+    the whole V x 4 table the replay scores.  (ii) The self-check of a replay ends in a log line and in shgo_fast.status();
+    (iii) the plan cache is bounded."""
+    import logging
+    from sonar_slam_amd import shgo_fast
+    from sonar_slam_amd.replay import FrontEnd
+    pose_stds = np.array([[0.2, 0.2, 0.02]]).T
+    bounds = 5.0 * np.c_[-pose_stds, pose_stds]
+    src, tgt, guess, _ = synth.scan_pair(seed=21, n_src=340, n_tgt=350)
+    sp, tp = chain.pose(*synth.pose_of(guess)), chain.pose(0.0, 0.0, 0.0)
+    # the reference's run: scipy calls the cost function point by point; every call is a pose sample (slam.py:549-566)
+    sub_ref, _ = chain.matching_cost_subroutine(src, sp, tgt, tp, 0.5, f64_points=True)
+    seen = []
+
+    def counted(x):
+        seen.append(np.array(x, float))
+        return sub_ref(x)
+    ra = chain.run_shgo(counted, bounds, (50, 1, 0.01))
+
+    class Sub(object):                       # the product subroutine's interface over the same cost
+        def __init__(self):
+            self.samples = []
+
+        def __call__(self, x):
+            return self.batch([x])[0]
+
+        def batch(self, X, record=True):
+            c = [sub_ref(x) for x in X]
+            if record:
+                self.record(X, c)
+            return c
+
+        def record(self, X, costs):
+            self.samples.extend(np.c_[np.asarray(X, float).reshape(-1, 3), np.asarray(costs, float)])
+    sub = Sub()
+    with caplog.at_level(logging.INFO, logger="sonar_slam_amd.shgo_fast"):
+        shgo_fast._PLANS.clear()
+        rb = FrontEnd.shgo(sub, bounds, (50, 1, 0.01))
+    assert rb.get("replayed") and np.array_equal(ra.x, rb.x) and ra.fun == rb.fun
+    got = np.array(sub.samples)
+    assert len(got) == ra.nfev == len(seen)                                  # not V x 4 = 244
+    assert sorted(map(tuple, got[:, :3])) == sorted(map(tuple, np.array(seen)))
+    st = shgo_fast.status()
+    assert st["developed_against"] == shgo_fast.DEVELOPED_AGAINST and any(v["active"] for v in st["replays"].values())
+    assert any("shgo replay" in r.getMessage() and "ACTIVE" in r.getMessage() for r in caplog.records)
+    for k in range(shgo_fast.MAX_PLANS + 3):                                 # bounds that change from call to call
+        shgo_fast._PLANS[("fake", k)] = object()
+    shgo_fast.plan_for(bounds, 50, 0.01)
+    assert len(shgo_fast._PLANS) <= shgo_fast.MAX_PLANS
+    for k in list(shgo_fast._PLANS):
+        if isinstance(k, tuple) and k[0] == "fake":
+            del shgo_fast._PLANS[k]
+
+
 def test_shgo_replay_of_several_iterations_equals_scipy():
     """shgo_fast.replay_multi (the loop-closure search's shgo(100, 5): every possible vertex and its finite-difference points scored
     beforehand, the iterations replayed with scipy's own incremental Delaunay) against scipy.optimize.shgo: result, value, success

@@ -200,6 +200,33 @@ def test_staged_hand_over_with_frames_that_leave_the_record_path(ctx, shipped_cf
     assert n_rec[0] == 0 and n_rec[-1] > 3000
 
 
+@pytest.mark.parametrize("staged", [True, False])
+def test_resident_filters_choose_the_sort_per_frame(ctx, shipped_cfar, staged):
+    """A batch whose capacity is beyond the LDS sort (32768 > CF_SORT_CAP) with ONE ping of more than 16384 detections among
+    ordinary ones (bench seed 3002: 19 122 points -- the frame that made rank 3 of the 8-rank bench launch raise at the old
+    capacity): the dense frame is sorted in HBM scratch, the others in LDS as before; every cloud equals the oracle's."""
+    import oracle
+    from sonar_slam_amd.pipeline import KeyframeBatch
+    th, gh, tau = shipped_cfar.params["SOCA"]
+    fe = FeatureExtraction(ctx)
+    fe.Ntc, fe.Ngc, fe.Pfa, fe.rank, fe.alg, fe.threshold = 40, 10, 0.1, 10, "SOCA", 65
+    fe.configure()
+    frames = np.stack([synth.sonar_frame(seed=s) for s in (3001, 3002, 3003)])
+    fe.generate_map_xy(SonarPing(frames[0], oculus_bearings(frames.shape[2]), 30.0 / frames.shape[1]))
+    kb = KeyframeBatch(ctx, fe.geometry, (th, gh, tau), "SOCA", 65, None, len(frames), max_points=32768, staged=staged)
+    kb.upload_frames(frames)
+    kb.run_cfar()
+    kb.run_extract()
+    kb.run_filter(0.5, 1.0, 5)
+    counts = kb.results()["counts"]
+    assert counts[1] > 16384 and counts[0] <= 16384 and counts[2] <= 16384, counts
+    for j in range(len(frames)):
+        pts = kb.points(j)
+        want = oracle.remove_outlier(oracle.downsample(pts.astype(np.float32), 0.5), 1.0, 5)
+        assert np.array_equal(kb.cloud(j), want), j
+    kb.free()
+
+
 def test_staged_filter_call_without_staged_clouds_is_refused(ctx):
     """sfe_cloud_filter_staged_dev checks that the context holds staged clouds of that shape: never stale data"""
     out, cnt = ctx.alloc(4 * 64 * 8), ctx.alloc(4 * 4)

@@ -582,7 +582,16 @@ def chained(ctx, det, threads, n_sessions=4096, n_steps=8, n_distinct=64, parity
                     raise AssertionError("chained/with_initialization: step %d session %d: %s differs between the replayed shgo and "
                                          "scipy.optimize.shgo: %r vs %r" % (r["k"], bad, key, r[key][bad], r0[key][bad]))
             n_same += S0 if "init_x" in r0 else 0
+        # the figure under this key is the rate WITH the replays: a scipy that switched them off must not print the scipy-only
+        # rate in its place
+        from sonar_slam_amd import shgo_fast
+        replay_status = shgo_fast.status()
+        if sbi.init_stats["replayed"] == 0 or not any(v["active"] for v in replay_status["replays"].values()):
+            raise AssertionError("chained/with_initialization: the shgo replays are OFF for scipy %s (shgo_fast.py was developed "
+                                 "against %s): %r -- this leg would report the scipy-only rate under the replay's key"
+                                 % (replay_status["scipy"], replay_status["developed_against"], replay_status["replays"]))
         leg = {"sessions": S, "seconds_per_run": dt, "keyframes_per_s": S * n_steps / dt,
+               "shgo_replays": replay_status,
                "ms_per_scan_match": 1e3 * dt / (S * (n_steps - 1)),
                "host_seconds_after_the_cost_table": sbi.init_stats["shgo_s"], "host_share": sbi.init_stats["shgo_s"] / dt,
                "seconds_sample_transforms_on_the_host": sbi.init_stats["transforms_s"],
