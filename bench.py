@@ -460,7 +460,9 @@ def main():
         ms_cfar_b = timed(kb.run_cfar, 5)
         ms_extract_b = timed(kb.run_extract, 5)
         ms_filter_b = 0.0 if args.no_filters else timed(kb.run_filter, 5)
-        extract_bytes = float(args.batch) * ROWS * COLS / (8.0 if kb.bit_masks else 1.0) + 16.0 * float(res["counts"].sum())
+        # (staged hand-over, round 6: the extraction writes one float32 pair per point for the filters instead of a float64 pair)
+        pt_bytes = 8.0 if (kb.staged and not kb.points64) else 16.0
+        extract_bytes = float(args.batch) * ROWS * COLS / (8.0 if kb.bit_masks else 1.0) + pt_bytes * float(res["counts"].sum())
         ms_icp_b = timed(kb.run_icp, 2)
         iters_total = int(res["iters"].sum())
         icp_kernel = icp_utilisation(ctx, kb, ms_icp_b, iters_total, args.batch)
@@ -502,6 +504,13 @@ def main():
         bits = kb.bit_masks
         ms_cfar, ms_cfar_first, cfar_warm = timed_steady(cfar_big_bits, args.cfar_launches) if bits else (ms_cfar_bytes, ms_cfar_bytes_first, 0)
         cfar_moved = (1.125 if bits else 2.0) * ROWS * COLS * nf
+        # ... and the SAME kernel in the shape the timed step launches it (args.batch frames per launch, the batch's own
+        # resident frames), under the same warm-up protocol: this is what `roofline.frac` reports from round 6 on (VERDICT r5
+        # item 4).  Rounds 1-5 timed this shape over 5 launches after ONE warm-up call and read 0.44 against 0.49 at 1024
+        # frames: the difference was the device's clock ramp, not the shape -- at sustained clocks the larger launch is the
+        # faster one per frame (profiles/r06_cfar_series.txt: 0.1503 / 0.1476 / 0.1413 us per frame at 1024 / 2048 / 4096).
+        ms_cfar_step, ms_cfar_step_first, cfar_step_warm = timed_steady(kb.run_cfar, args.cfar_launches)
+        cfar_step_moved = (1.125 if bits else 2.0) * ROWS * COLS * args.batch
         cfar_gbs = cfar_bytes / (ms_cfar * 1e-3) / 1e9
         big.free()
         bigm.free()
@@ -513,7 +522,7 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
                 pmc = json.load(f)
-            if (pmc["frames_per_launch"], pmc["rows"], pmc["cols"]) == (nf, ROWS, COLS):
+            if (pmc["frames_per_launch"], pmc["rows"], pmc["cols"]) == (args.batch, ROWS, COLS):
                 traffic = pmc["traffic_bytes_per_launch"]
                 pmc_source = pmc.get("source_files")
         except (OSError, KeyError, ValueError):
@@ -528,10 +537,11 @@ def main():
         except (OSError, KeyError, ValueError):
             pass
 
-        # the cloud filters: 16 B in (the float64 point of the extraction) + 8 B out (the float32 point that survives)
+        # the cloud filters: the extraction's point in (8 B float32 pair staged by the extraction; 16 B float64 on the unstaged
+        # path of rounds 2-5) + 8 B out (the float32 point that survives)
         filters_bytes = filters_traffic = None
         if not args.no_filters:
-            filters_bytes = 16.0 * float(res["counts"].sum()) + 8.0 * float(res["cloud_counts"].sum())
+            filters_bytes = (8.0 if kb.staged else 16.0) * float(res["counts"].sum()) + 8.0 * float(res["cloud_counts"].sum())
             try:
                 with open(os.path.join(ROOT, "profiles", "filters_pmc.json")) as f:
                     filters_traffic = json.load(f)["traffic_bytes_per_frame"] * args.batch
@@ -564,19 +574,25 @@ def main():
                          "limiter_note": ("27 VALU instructions per 256-pixel row and wave, 3 waves per SIMD (168 VGPRs: the ring): ~370 cycles per "
                                           "row against 324 of VALU issue; LDS table latency and the 4-deep load FIFO within 15 % (DESIGN 5.1); "
                                           "round 5: the last tile of a frame runs only the rows it needs (6 % fewer row steps, no change in time)") if bits else "",
-                         "achieved": cfar_moved / (ms_cfar * 1e-3) / 1e9,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cfar_moved / (ms_cfar * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         # achieved / frac: the launch shape of the timed step (args.batch frames per launch, kb.run_cfar), at
+                         # sustained clocks: after `warmup_launches` launches whose time had settled within 1 %
+                         "achieved": cfar_step_moved / (ms_cfar_step * 1e-3) / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cfar_step_moved / (ms_cfar_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "traffic": traffic,
-                         "traffic_note": "bytes/launch = 2*FETCH_SIZE + WRITE_SIZE from profiles/%s" % pmc_file,
-                         "bytes_per_launch": cfar_moved, "ms_per_launch": ms_cfar, "frames_per_launch": nf,
-                         # (ms_per_launch: at sustained clocks, after `warmup_launches` launches whose time had settled within 1 %;
-                         #  the first launches after host work run ~12 % slower: what rounds 1-4 put into `frac`)
-                         "warmup_launches": cfar_warm, "ms_per_launch_first_launches": ms_cfar_first,
-                         "frac_first_launches": cfar_moved / (ms_cfar_first * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         # the same kernel at the launch shape of the timed step (args.batch frames per launch: HIP events
-                         # around kb.run_cfar): fewer launch ramps per byte
-                         "frac_at_step_launch_shape": (1.125 if bits else 2.0) * ROWS * COLS * args.batch / (ms_cfar_b * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "traffic_note": "bytes/launch = 2*FETCH_SIZE + WRITE_SIZE from profiles/%s (quoted when that pass ran at "
+                                         "this launch shape)" % pmc_file,
+                         "bytes_per_launch": cfar_step_moved, "ms_per_launch": ms_cfar_step, "frames_per_launch": args.batch,
                          "frames_per_launch_in_the_step": args.batch,
+                         "warmup_launches": cfar_step_warm, "ms_per_launch_first_launches": ms_cfar_step_first,
+                         # (the first launches after host work run ~12 % slower -- the clock ramp: what rounds 1-4 put into `frac`)
+                         "frac_first_launches": cfar_step_moved / (ms_cfar_step_first * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         # 5 launches after one warm-up call, as the per-stage times below are taken (and as rounds 1-5 reported
+                         # `frac_at_step_launch_shape`): mid-ramp
+                         "frac_at_step_launch_shape_five_launches_after_one": cfar_step_moved / (ms_cfar_b * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         # the shape rounds 1-5 reported as `frac`: %d frames per launch on a buffer of its own
+                         "frac_at_%d_frames_per_launch" % nf: cfar_moved / (ms_cfar * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "ms_per_launch_at_%d_frames" % nf: ms_cfar, "warmup_launches_at_%d_frames" % nf: cfar_warm,
+                         "frac_first_launches_at_%d_frames" % nf: cfar_moved / (ms_cfar_first * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "bytes_note": "1 B read + %s written per pixel" % ("1 bit" if bits else "1 B"),
                          "achieved_survey_bytes": cfar_gbs, "frac_survey_bytes": cfar_gbs / HBM_PEAK_GBS,
                          "survey_bytes_per_launch": cfar_bytes,
@@ -592,7 +608,7 @@ def main():
             "stage_ms_per_512_keyframes": {k: v * 512.0 / args.batch for k, v in
                                            (("cfar", ms_cfar_b), ("extract", ms_extract_b), ("filters", ms_filter_b),
                                             ("icp", ms_icp_b))},
-            # SURVEY 8d, on-the-fly form: R*B bytes of mask in + 16 B per extracted point out
+            # SURVEY 8d, on-the-fly form: R*B bytes of mask in + 16 B per extracted point out (8 B on the staged path: float32 pairs)
             "roofline_extract": {"kernel": ("extract_gather<records> + extract_merge_expand (no canvas bitmap in HBM; round 5)" if kb.bit_masks
                                             else "mask_pack + extract_gather + extract_scan + extract_expand_words"), "bound": "hbm",
                                  "limiter": "scattered reads of the inverse-map entries (L1 tag rate: one line per lane and load) and load latency",
@@ -601,7 +617,8 @@ def main():
                                  "bytes_per_launch": extract_bytes, "ms_per_launch": ms_extract_b, "traffic": extract_traffic,
                                  "traffic_note": "bytes/launch from the committed PMC passes (profiles/extract_pmc.json: per-frame "
                                                  "FETCH_SIZE x 2 + WRITE_SIZE of the stage's kernels, scaled to this launch's frames)",
-                                 "note": "algorithmic bytes = the R*B detections (bits when CFAR hands over bit streams) + 16 B per point per frame; the kernels are "
+                                 "point_bytes": pt_bytes,
+                                 "note": "algorithmic bytes = the R*B detections (bits when CFAR hands over bit streams) + `point_bytes` per point per frame (16: float64 pairs; 8: the float32 pairs of the staged hand-over to the filters); the kernels are "
                                          "bound by gathers into the inverse remap table (10 MB of 4-byte entries, four candidates per 16-byte read), not "
                                          "by streaming"},
         }
@@ -610,13 +627,14 @@ def main():
             out["roofline"]["filters_frac"] = filters_bytes / (ms_filter_b * 1e-3) / 1e9 / HBM_PEAK_GBS
             out["roofline"]["filters_ms_per_launch"] = ms_filter_b
             out["roofline_filters"] = {
-                "kernel": "cf_cast_bbox + cf_downsample_radix + cf_radius_filter", "bound": "hbm",
+                "kernel": ("cf_header_from_bbox + cf_downsample_radix + cf_radius_filter (staged float32 input: no cast pass)" if kb.staged
+                           else "cf_cast_bbox + cf_downsample_radix + cf_radius_filter"), "bound": "hbm",
                 "limiter": "LDS radix sort and per-leaf medoid loops of the octree downsample: one 1024-thread workgroup and 132 KB of "
                            "LDS per frame (instruction issue at ~55 % VALU-active; profiles/filters_pmc.json)",
                 "achieved": filters_bytes / (ms_filter_b * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": filters_bytes / (ms_filter_b * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": filters_bytes,
                 "ms_per_launch": ms_filter_b, "traffic": filters_traffic,
-                "bytes_note": "16 B per extracted point in + 8 B per filtered point out (SURVEY 8 f1 / pcl.cpp:128-141,54-74)",
+                "bytes_note": "%d B per extracted point in + 8 B per filtered point out (SURVEY 8 f1 / pcl.cpp:128-141,54-74)" % (8 if kb.staged else 16),
                 "traffic_note": "bytes/launch from the committed PMC passes (profiles/filters_pmc.json), scaled to this launch's frames"}
         try:  # committed SQ counter pass of the ICP loop kernel (rocprofv3 cannot run inside the timed process)
             with open(os.path.join(ROOT, "profiles", "icp_sq.json")) as f:

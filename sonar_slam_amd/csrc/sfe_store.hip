@@ -37,7 +37,9 @@ struct sfe_cloud_store {
     int32_t *d_key = nullptr; // [capacity], allocated on first use
     uint8_t *d_sel = nullptr;
     size_t sel_cap = 0;
-    int32_t sel_handle = -1;
+    int32_t sel_handle = -1, sel_count = 0; // the cloud the selection was made for, and its size then (a handle alone can
+                                            // be reused by a larger cloud after a truncate)
+    std::vector<uint8_t> keyed;             // per slot: built by a keyed entry point (the key pool holds ITS keys)
     // host mirror of the slot table: entries < n_synced are valid
     std::vector<int64_t> stamp, off;
     std::vector<int32_t> cnt;
@@ -641,6 +643,11 @@ static int store_get_points_big(sfe_cloud_store *s, const int32_t *handles, cons
                            (const int32_t *)s->d_cnt, (int)h_new, s->d_key);
         SFE_LAUNCH_CHECK(ctx);
     }
+    if (keys && h_new >= 0) { // (an empty keyed cloud is keyed too: it has no keys to be wrong about)
+        if ((int32_t)s->keyed.size() <= h_new)
+            s->keyed.resize((size_t)h_new + 1, 0);
+        s->keyed[(size_t)h_new] = 1;
+    }
     *handle_out = h_new;
     return 0;
 }
@@ -788,6 +795,10 @@ int sfe_cloud_store_truncate(sfe_ctx *ctx, sfe_cloud_store *s, int32_t n_slots)
     SFE_LAUNCH_CHECK(ctx);
     s->n_slots = n_slots;
     s->n_synced = std::min(s->n_synced, n_slots);
+    if (s->sel_handle >= n_slots) // the cloud the selection belonged to is gone: its slot may come back as another cloud
+        s->sel_handle = -1;
+    if ((int32_t)s->keyed.size() > n_slots)
+        s->keyed.resize((size_t)n_slots);
     return 0;
 }
 
@@ -875,8 +886,8 @@ static int store_keyed_cloud(sfe_cloud_store *s, int32_t handle, const char *wha
     if (handle < 0 || handle >= s->n_slots || s->cnt[handle] < 0)
         return sfe_set_err(ctx, SFE_ERR_ARG, "%s: cloud %d (the store holds %d) does not exist or was not stored", what, handle,
                            s->n_slots);
-    if (!s->d_key)
-        return sfe_set_err(ctx, SFE_ERR_ARG, "%s: cloud %d has no keys (no keyed cloud was built yet)", what, handle);
+    if (!s->d_key || handle >= (int32_t)s->keyed.size() || !s->keyed[(size_t)handle])
+        return sfe_set_err(ctx, SFE_ERR_ARG, "%s: cloud %d has no keys (it was not built by a keyed entry point)", what, handle);
     return 0;
 }
 
@@ -931,6 +942,7 @@ int sfe_cloud_store_fov_select(sfe_ctx *ctx, sfe_cloud_store *s, int32_t handle,
     if (int rc = store_sel_buffer(s, (size_t)std::max(n, 1)))
         return rc;
     s->sel_handle = handle;
+    s->sel_count = n;
     const size_t b_fr = sizeof(FovFrame) * (size_t)std::max(n_frames, 1), b_out = sizeof(int32_t) * ((size_t)n_keys + 2);
     FovFrame *h_fr = (FovFrame *)sfe_pinned_begin(ctx, b_fr);
     FovFrame *d_fr = (FovFrame *)sfe_scratch(ctx, 59, b_fr);
@@ -974,6 +986,7 @@ int sfe_cloud_store_set_selection(sfe_ctx *ctx, sfe_cloud_store *s, int32_t hand
     if (int rc = store_sel_buffer(s, (size_t)std::max(n, 1)))
         return rc;
     s->sel_handle = handle;
+    s->sel_count = n;
     if (n) {
         SFE_HIP(ctx, hipMemcpyAsync(s->d_sel, sel, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
         SFE_HIP(ctx, hipStreamSynchronize(ctx->stream)); // (pageable source)
@@ -989,9 +1002,9 @@ int sfe_cloud_store_compact_selected(sfe_ctx *ctx, sfe_cloud_store *s, int32_t h
     SFE_ARG(ctx, s && s->ctx == ctx && handle_out);
     if (int rc = store_keyed_cloud(s, handle, "compact_selected"))
         return rc;
-    if (s->sel_handle != handle)
-        return sfe_set_err(ctx, SFE_ERR_ARG, "compact_selected: cloud %d has no selection (the last one was made for cloud %d)",
-                           handle, s->sel_handle);
+    if (s->sel_handle != handle || s->sel_count != s->cnt[handle])
+        return sfe_set_err(ctx, SFE_ERR_ARG, "compact_selected: cloud %d has no selection (the last one was made for cloud %d of %d "
+                           "points)", handle, s->sel_handle, s->sel_count);
     const int n = s->cnt[handle];
     const size_t cap = (size_t)std::max(n, 1);
     float2 *d_out = (float2 *)sfe_scratch(ctx, 55, sizeof(float2) * cap);
@@ -1008,6 +1021,11 @@ int sfe_cloud_store_compact_selected(sfe_ctx *ctx, sfe_cloud_store *s, int32_t h
     hipLaunchKernelGGL(store_commit_keys_kernel, dim3(64), dim3(256), 0, ctx->stream, (const int32_t *)d_okey,
                        (const int64_t *)s->d_off, (const int32_t *)s->d_cnt, (int)h_new, s->d_key);
     SFE_LAUNCH_CHECK(ctx);
+    if (h_new >= 0) {
+        if ((int32_t)s->keyed.size() <= h_new)
+            s->keyed.resize((size_t)h_new + 1, 0);
+        s->keyed[(size_t)h_new] = 1;
+    }
     *handle_out = h_new;
     return 0;
 }

@@ -180,6 +180,11 @@ def grid_geometry_many(bbox, point_noise):
         geo = [grid_geometry(b, point_noise) for b in bbox]
         return (np.array([g[0] for g in geo], np.float32), np.array([g[1] for g in geo], np.float32), float(geo[0][2]),
                 np.array([g[3] for g in geo], np.int32), np.array([g[4] for g in geo], np.int32), int(geo[0][5]))
+    if _MANY_OK is None and np.result_type(np.float32(1), 1.0) != np.float32:
+        # legacy promotion (numpy < 2, or NPY_PROMOTION_STATE=legacy): `float32 scalar / Python float` is a double division there,
+        # and the two forms differ only for near-integer quotients -- too rare for a sampled check to catch.
+        # Decided once from the promotion rule itself: the scalar loop, which IS numpy's own np.arange on that numpy.
+        _MANY_OK = False
     if _MANY_OK is False or n == 0:
         return loop() if n else (np.zeros(0, np.float32), np.zeros(0, np.float32), point_noise / 10.0, np.zeros(0, np.int32),
                                  np.zeros(0, np.int32), int(np.ceil(point_noise / (point_noise / 10.0))))

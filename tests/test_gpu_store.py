@@ -339,3 +339,33 @@ def test_large_targets_and_many_guesses_over_handles(ctx):
     assert np.array_equal(T, Tb) and np.array_equal(iters, itb)
     assert [_lib.ICP_STATUS_MESSAGES[int(x)] for x in status] == list(msgs)
     s.close()
+
+
+def test_selection_and_keys_belong_to_the_cloud_they_were_made_for(ctx):
+    """(i) a selection is bound to the cloud AND its size -- after a truncate the slot number can come back as a
+    larger cloud, and compact_selected on it used to read a stale (and too short) selection buffer; (ii) the keyed entry
+    points refuse a cloud that was not built with keys instead of reading whatever the key pool holds at its offset."""
+    from sonar_slam_amd import _lib
+    from sonar_slam_amd.store import CloudStore, pose_T6
+    rng = np.random.default_rng(3)
+    st = CloudStore(ctx, capacity_points=1 << 16, max_clouds=64)
+    a = st.put(rng.uniform(-20, 20, (500, 2)).astype(np.float32))
+    b = st.put(rng.uniform(-20, 20, (700, 2)).astype(np.float32))
+    T = np.stack([pose_T6(np.eye(3)), pose_T6(np.eye(3))])
+    with pytest.raises(_lib.SonarFEError, match="no keys"):
+        st.read_keys(a)                                            # a plain cloud, no keyed cloud built yet
+    h = st.get_points_keys([a, b], T, [0, 1], 0.5)
+    n_h = int(st.counts([h])[0])
+    assert len(st.read_keys(h)) == n_h
+    with pytest.raises(_lib.SonarFEError, match="no keys"):
+        st.read_keys(a)                                            # still a plain cloud: the pool exists now, its keys do not
+    st.set_selection(h, np.ones(n_h, np.uint8))
+    st.truncate(2)                                                 # the keyed cloud is dropped ...
+    big = st.get_points_keys([a, b, a], np.stack([pose_T6(np.eye(3))] * 3), [0, 1, 2], 0.25)   # ... its slot comes back, larger
+    assert big == h and int(st.counts([big])[0]) > n_h
+    with pytest.raises(_lib.SonarFEError, match="no selection"):
+        st.compact_selected(big)
+    st.set_selection(big, np.ones(int(st.counts([big])[0]), np.uint8))
+    c = st.compact_selected(big)
+    assert int(st.counts([c])[0]) == int(st.counts([big])[0]) and len(st.read_keys(c)) == int(st.counts([c])[0])
+    st.close()

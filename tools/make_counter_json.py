@@ -10,7 +10,8 @@ import sqlite3
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
+CFAR_FRAMES = int(sys.argv[2]) if len(sys.argv) > 2 else 4096   # frames per CFAR launch of the passes (counters.sh)
 G = os.path.join(ROOT, "gpurun_out")
 
 
@@ -90,9 +91,9 @@ def main():
     us = kernel_us("cfar_bits_kernels")
     k = [x for x in f if x.startswith("cfar_u8_ring")][0]
     fetch, write = f[k]["FETCH_SIZE"], w[k]["WRITE_SIZE"]
-    rows, cols, frames = 1024, 512, 1024
+    rows, cols, frames = 1024, 512, CFAR_FRAMES
     out = {"kernel": k, "source": "tools/gpu/counters.sh %s: rocprofv3 --kernel-trace [--pmc FETCH_SIZE | --pmc WRITE_SIZE], "
-                                  "one pass each, on `python tools/cfar_sweep.py --only --bits` (1024 frames per launch)" % tag,
+                                  "one pass each, on `python tools/cfar_sweep.py --only --bits --frames %d`" % (tag, frames),
            "source_files": [files % "cfar_bits_kernels", files % "cfar_bits_fetch", files % "cfar_bits_write"],
            "frames_per_launch": frames, "rows": rows, "cols": cols, "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
            "correction": "fetch bytes = 2 * FETCH_SIZE, write bytes = WRITE_SIZE (profiles/r01_run3_pmc_calibration.txt)",
