@@ -612,18 +612,37 @@ __global__ __launch_bounds__(64) void cfar_u8_os(const uint8_t *__restrict__ img
 struct CfarOsGateTab {
     int16_t L[256]; // pixel value x -> largest v with x > tau * v and x above the gate; -1: never fires
     int xc;         // smallest x with L[x] >= 0 (L grows with x: "can fire at all" is one threshold); 257: none
+    // PREF (no gate, or a low one: round 6): the level l0 of the pre-filter and what the kernel needs of it
+    int x_hi;       // smallest x with L[x] > l0 (257: none)
+    int c0;         // l0 + 1: a training cell counts as "above" when it is >= c0
+    int m_le;       // 2T - (k + 1): at most that many cells above l0 <=> at least k + 1 cells <= l0
 };
 
-template <bool V16> // V16: rows and pointers are 16-byte aligned -- the tile streams through in 16-byte pieces
+// cfar.os() WITHOUT the gate (the drop-in's plain `cfar.os`, `feature.yaml alg: OS` with a low threshold): rounds 2-5 ran the
+// sliding 256-bin histogram for every pixel (cfar_u8_os: 4 % of HBM).  PREF turns the image's own statistics into the gate:
+//     x fires  <=>  at least k + 1 training cells are <= L[x]  =>  (L[x] > l0)  or  (at least k + 1 cells are <= l0)
+// for ANY level l0 (counts grow with the level), so a pixel is a candidate iff x >= x_hi, or x can fire at all and its window
+// holds k + 1 cells <= l0.  The second test is one sliding COUNT per column against a constant -- four columns per lane in
+// packed bytes (~9 VALU operations per pixel) -- and on sonar images with l0 = L[80] it passes one window in ten thousand
+// (background cells are Rayleigh around 20; a cell <= 8 is rare, eleven of them in one window rarer).  Candidates then take
+// the exact per-candidate count of the gated kernel.  Exact for every image: a pixel the pre-filter drops cannot fire.
+// PREF: 0 = gate only; 1 = pre-filter, any window (the count slides down the column: 16 dependent LDS round trips per thread);
+// 2 = pre-filter for train_hs = 20 (the shipped Ntc = 40): the 35 + 35 rows a thread's 16 pixels need are read at once and
+// the 16 window counts are differences of two running sums kept in registers -- no dependent chain (the kernel's occupancy is
+// set by its LDS, two waves per SIMD: registers are free)
+template <bool V16, int PREF> // V16: rows and pointers are 16-byte aligned -- the tile streams through in 16-byte pieces
 __global__ __launch_bounds__(256) void cfar_u8_os_gated(const uint8_t *__restrict__ img, uint8_t *__restrict__ mask, int rows,
                                                         int cols, int n_frames, int T, int G, int k, int tiles_y, int tiles_x,
                                                         CfarOsGateTab tab)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t osg_raw[];
     const int H = T + G, SR = OSG_TR + 2 * H; // staged rows
+    // (round 6: the tile's output and the pre-filter's flags are BITS in LDS -- 2 KB each instead of 16 KB of bytes: the staged
+    //  input alone decides how many workgroups share a CU, 5 instead of 3 for the shipped window)
     uint8_t *s_in = osg_raw;                                  // [SR][OSG_TC]
-    uint8_t *s_out = s_in + (size_t)SR * OSG_TC;              // [OSG_TR][OSG_TC]
-    unsigned short *s_list = reinterpret_cast<unsigned short *>(s_out + (size_t)OSG_TR * OSG_TC); // [4][OSG_LIST + 64 * 4]
+    uint32_t *s_obits = reinterpret_cast<uint32_t *>(s_in + (size_t)SR * OSG_TC);            // [OSG_TR][OSG_TC / 32]: the mask
+    unsigned short *s_list = reinterpret_cast<unsigned short *>(s_obits + OSG_TR * (OSG_TC / 32)); // [4][OSG_LIST + 64 * 4]
+    uint32_t *s_flag = reinterpret_cast<uint32_t *>(s_list + 4 * (OSG_LIST + 256)); // PREF: [8 row groups][32 column words][2]: a nibble per row
     __shared__ short s_L[256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tpf = tiles_y * tiles_x;
@@ -657,8 +676,6 @@ __global__ __launch_bounds__(256) void cfar_u8_os_gated(const uint8_t *__restric
                 if (i0 + u * 256 < n16)
                     reinterpret_cast<uint4 *>(s_in)[i0 + u * 256] = v[u];
         }
-        for (int i = tid; i < OSG_TR * QPR; i += 256)
-            reinterpret_cast<uint4 *>(s_out)[i] = make_uint4(0u, 0u, 0u, 0u);
     } else {
         for (int i = tid; i < (tr + 2 * H) * wpr; i += 256) {
             const int rr = i / wpr, cw = i - rr * wpr;
@@ -668,10 +685,68 @@ __global__ __launch_bounds__(256) void cfar_u8_os_gated(const uint8_t *__restric
                 v = *reinterpret_cast<const uint32_t *>(in + (size_t)gr * cols + c0 + 4 * cw);
             reinterpret_cast<uint32_t *>(s_in)[rr * wpr + cw] = v;
         }
-        for (int i = tid; i < OSG_TR * wpr; i += 256)
-            reinterpret_cast<uint32_t *>(s_out)[i] = 0u;
     }
+    for (int i = tid; i < OSG_TR * (OSG_TC / 32); i += 256)
+        s_obits[i] = 0u;
     __syncthreads();
+    if constexpr (PREF != 0) {
+        // per pixel: do at least k + 1 of its 2T training cells lie at or below l0?  Thread = (4 columns, 16 rows): the count
+        // of cells ABOVE l0 (>= c0) is built once from the 2T rows of its first pixel and then slides down -- four cells in,
+        // four out per row, every test on four packed bytes.  Byte-wise v >= c without a carry between bytes: the low
+        // seven bits by an addition that cannot leave the byte, bit 7 of the cell decides the rest.
+        const int c0 = tab.c0;                                 // 1 .. 255
+        const bool hi = c0 > 128;
+        const uint32_t kadd = (uint32_t)(128 - (hi ? c0 - 128 : c0)) * 0x01010101u; // low7(v) + kadd has bit 7 <=> low7(v) >= low7(c)
+        auto above = [&](uint32_t v) -> uint32_t {             // 0x01 per byte that is >= c0
+            const uint32_t g7 = (v & 0x7F7F7F7Fu) + kadd;
+            const uint32_t ge = hi ? (g7 & v) : (g7 | v);      // (c0 == 128: kadd = 0, g7 has no bit 7, ge = bit 7 of v)
+            return (ge >> 7) & 0x01010101u;
+        };
+        const int cw = tid & 31, sg = tid >> 5, rr0 = 16 * sg;
+        const uint32_t madd = (uint32_t)(127 - min(tab.m_le, 127)) * 0x01010101u; // cnt + madd has bit 7 <=> cnt > m_le
+        if constexpr (PREF == 2) {
+            if (4 * cw < tc && rr0 < tr) {
+                constexpr int TT = 20, NR = 16 + TT - 1;
+                const uint32_t *lead = reinterpret_cast<const uint32_t *>(s_in) + rr0 * wpr + cw;   // staged rows rr0 ..
+                const uint32_t *lag = lead + (H + G + 1) * wpr;                                     // ... and rr0 + H + G + 1 ..
+                uint32_t pl[NR + 1], pg[NR + 1]; // running sums of `above` down the two row ranges (<= 35 per byte)
+                pl[0] = pg[0] = 0u;
+#pragma unroll
+                for (int i = 0; i < NR; ++i) {
+                    pl[i + 1] = pl[i] + above(lead[i * wpr]);
+                    pg[i + 1] = pg[i] + above(lag[i * wpr]);
+                }
+                uint32_t fw[2] = {0u, 0u}; // a nibble per row: bit b = column 4 cw + b holds k + 1 cells <= l0
+#pragma unroll
+                for (int d = 0; d < 16; ++d) {
+                    const uint32_t cnt = (pl[d + TT] - pl[d]) + (pg[d + TT] - pg[d]); // (per byte: no borrow, the sums grow)
+                    const uint32_t f7 = ~(cnt + madd) & 0x80808080u;
+                    fw[d >> 3] |= ((((f7 >> 7) * 0x01020408u) >> 24) & 15u) << (4 * (d & 7));
+                }
+                s_flag[(sg * 32 + cw) * 2] = fw[0];
+                s_flag[(sg * 32 + cw) * 2 + 1] = fw[1];
+            }
+        } else
+        if (4 * cw < tc && rr0 < tr) {
+            const uint32_t *col = reinterpret_cast<const uint32_t *>(s_in) + cw; // staged row q: col[q * wpr]
+            uint32_t cnt = 0u;                                  // per byte: training cells above l0 (<= 2T <= 255)
+            for (int i = 0; i < T; ++i)
+                cnt += above(col[(rr0 + i) * wpr]) + above(col[(rr0 + H + G + 1 + i) * wpr]);
+            const int rr1 = min(rr0 + 16, tr);
+            uint32_t fw[2] = {0u, 0u};
+            for (int rr = rr0; rr < rr1; ++rr) {
+                // (2T <= 127 on this path: the launcher keeps taller windows on the histogram kernel)
+                const uint32_t f7 = ~(cnt + madd) & 0x80808080u; // bit 7: at most m_le cells above l0
+                const int d = rr - rr0;
+                fw[d >> 3] |= ((((f7 >> 7) * 0x01020408u) >> 24) & 15u) << (4 * (d & 7));
+                cnt += above(col[(rr + T) * wpr]) - above(col[rr * wpr]) + above(col[(rr + 2 * H + 1) * wpr]) -
+                       above(col[(rr + H + G + 1) * wpr]);
+            }
+            s_flag[(sg * 32 + cw) * 2] = fw[0];
+            s_flag[(sg * 32 + cw) * 2 + 1] = fw[1];
+        }
+        __syncthreads();
+    }
     unsigned short *wl = s_list + wave * (OSG_LIST + 256);
     int nl = 0; // candidates in this wave's list (wave-uniform)
     auto take = [&](int n_take) { // one lane per candidate, the last n_take of the list: count its window
@@ -686,7 +761,7 @@ __global__ __launch_bounds__(256) void cfar_u8_os_gated(const uint8_t *__restric
             cnt += (int)col[(size_t)(H + G + 1 + i) * OSG_TC] <= Lx;     // lag:  rows r + G + 1 .. r + H
         }
         if (on && cnt > k)
-            s_out[rr * OSG_TC + cc] = 1;
+            atomicOr(&s_obits[rr * (OSG_TC / 32) + (cc >> 5)], 1u << (cc & 31));
         nl -= n_take;
     };
     const int xc = tab.xc; // "x can fire at all" is one threshold: x >= xc
@@ -698,7 +773,16 @@ __global__ __launch_bounds__(256) void cfar_u8_os_gated(const uint8_t *__restric
         // per byte: x >= xc.  Low seven bits by a borrow-free subtraction, bit 7 of the pixel decides the rest
         const uint32_t t7 = ((px | 0x80808080u) - c7) & 0x80808080u; // bit 7 of a byte: its low seven bits are >= xc's
         const uint32_t ge = (xc >= 128) ? (px & t7) : ((px | t7) & 0x80808080u);
-        const unsigned cand = valid ? ((((ge >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 15u : 0u; // bit b: column 4 cw + b
+        unsigned cand = valid ? ((((ge >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 15u : 0u; // bit b: column 4 cw + b
+        if constexpr (PREF != 0) { // x >= x_hi, or x >= xc and the window holds k + 1 cells <= l0
+            const int xh = tab.x_hi;
+            const uint32_t h7 = (uint32_t)(xh & 127) * 0x01010101u;
+            const uint32_t u7 = ((px | 0x80808080u) - h7) & 0x80808080u;
+            const uint32_t geh = xh > 255 ? 0u : ((xh >= 128) ? (px & u7) : ((px | u7) & 0x80808080u));
+            const unsigned hi_n = ((((geh >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 15u;
+            const unsigned fl_n = valid ? (s_flag[((rr >> 4) * 32 + cw) * 2 + ((rr >> 3) & 1)] >> (4 * (rr & 7))) & 15u : 0u;
+            cand = valid ? (hi_n | (cand & fl_n)) : 0u;
+        }
         const int pc = __popc(cand);
         if (!__ballot(pc != 0))
             continue;
@@ -728,14 +812,20 @@ __global__ __launch_bounds__(256) void cfar_u8_os_gated(const uint8_t *__restric
         constexpr int QPR = OSG_TC / 16;
         for (int i = tid; i < tr * QPR; i += 256) {
             const int rr = i / QPR, cw = i - rr * QPR;
-            if (16 * cw < tc)
-                *reinterpret_cast<uint4 *>(out + (size_t)(r0 + rr) * cols + c0 + 16 * cw) = reinterpret_cast<const uint4 *>(s_out)[i];
+            if (16 * cw < tc) {
+                const uint32_t b16 = (s_obits[rr * (OSG_TC / 32) + (cw >> 1)] >> (16 * (cw & 1))) & 0xFFFFu; // 16 columns
+                auto spread = [](uint32_t n4) { return (n4 * 0x00204081u) & 0x01010101u; };                // nibble -> 4 bytes 0 / 1
+                *reinterpret_cast<uint4 *>(out + (size_t)(r0 + rr) * cols + c0 + 16 * cw) =
+                    make_uint4(spread(b16 & 15u), spread((b16 >> 4) & 15u), spread((b16 >> 8) & 15u), spread(b16 >> 12));
+            }
         }
     } else {
         for (int i = tid; i < tr * wpr; i += 256) {
             const int rr = i / wpr, cw = i - rr * wpr;
-            if (4 * cw < tc)
-                *reinterpret_cast<uint32_t *>(out + (size_t)(r0 + rr) * cols + c0 + 4 * cw) = reinterpret_cast<const uint32_t *>(s_out)[rr * wpr + cw];
+            if (4 * cw < tc) {
+                const uint32_t n4 = (s_obits[rr * (OSG_TC / 32) + (cw >> 3)] >> (4 * (cw & 7))) & 15u;
+                *reinterpret_cast<uint32_t *>(out + (size_t)(r0 + rr) * cols + c0 + 4 * cw) = (n4 * 0x00204081u) & 0x01010101u;
+            }
         }
     }
 }
@@ -990,8 +1080,10 @@ static int launch_os_hist(sfe_ctx *ctx, const uint8_t *d_img, int n_frames, int 
     return 0;
 }
 
+// pref: the pre-filtered form for a missing or low gate (see the kernel); *applied (nullable) = false when it does not apply
+// (no level to filter on, a window the packed counters do not hold) and nothing was launched
 static int launch_os_gated(sfe_ctx *ctx, const uint8_t *d_img, int n_frames, int rows, int cols, int T, int G, int k, double tau,
-                           int intensity_thr, uint8_t *d_mask)
+                           int intensity_thr, uint8_t *d_mask, bool pref = false, bool *applied = nullptr)
 {
     CfarOsGateTab tab;
     for (int x = 0; x < 256; ++x) {
@@ -1010,10 +1102,33 @@ static int launch_os_gated(sfe_ctx *ctx, const uint8_t *d_img, int n_frames, int
     for (int x = 255; x >= 0; --x)
         if (tab.L[x] >= 0)
             tab.xc = x;
+    tab.x_hi = 257;
+    tab.c0 = 1;
+    tab.m_le = 0;
+    if (pref) {
+        // the level: what a pixel of a third of full scale is compared with (L[80]; SFE_CFAR_OS_PREF_X moves it).  Any level is
+        // exact; this one keeps both kinds of candidates rare on sonar images
+        const int xs = std::min(255, std::max(tab.xc, getenv("SFE_CFAR_OS_PREF_X") ? atoi(getenv("SFE_CFAR_OS_PREF_X")) : 80));
+        const int l0 = xs <= 255 ? tab.L[xs] : -1;
+        const bool ok = l0 >= 0 && l0 < 255 && 2 * T <= 127 && k + 1 <= 2 * T;
+        if (applied)
+            *applied = ok;
+        if (!ok)
+            return 0;
+        tab.c0 = l0 + 1;
+        tab.m_le = 2 * T - (k + 1);
+        for (int x = 255; x >= 0; --x)
+            if (tab.L[x] > l0)
+                tab.x_hi = x;
+    }
     const int tiles_y = (rows + OSG_TR - 1) / OSG_TR, tiles_x = (cols + OSG_TC - 1) / OSG_TC;
-    const size_t smem = (size_t)(OSG_TR + 2 * (T + G)) * OSG_TC + (size_t)OSG_TR * OSG_TC + sizeof(unsigned short) * 4 * (OSG_LIST + 256);
+    const size_t smem = (size_t)(OSG_TR + 2 * (T + G)) * OSG_TC + (size_t)OSG_TR * (OSG_TC / 8) + sizeof(unsigned short) * 4 * (OSG_LIST + 256) +
+                        (pref ? (size_t)8 * 32 * 2 * 4 : 0);
     const bool v16 = cols % 16 == 0 && (((uintptr_t)d_img | (uintptr_t)d_mask) & 15) == 0 && !getenv("SFE_CFAR_OSG_V4");
-    auto kernel = v16 ? cfar_u8_os_gated<true> : cfar_u8_os_gated<false>;
+    const int pv = !pref ? 0 : (T == 20 && !getenv("SFE_CFAR_OS_PREF_SLIDE")) ? 2 : 1;
+    auto kernel = pv == 2 ? (v16 ? cfar_u8_os_gated<true, 2> : cfar_u8_os_gated<false, 2>)
+                  : pv == 1 ? (v16 ? cfar_u8_os_gated<true, 1> : cfar_u8_os_gated<false, 1>)
+                            : (v16 ? cfar_u8_os_gated<true, 0> : cfar_u8_os_gated<false, 0>);
     SFE_HIP(ctx, hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(kernel, dim3((unsigned)((long long)n_frames * tiles_y * tiles_x)), dim3(256), smem, ctx->stream,
                        d_img, d_mask, rows, cols, n_frames, T, G, k, tiles_y, tiles_x, tab);
@@ -1175,6 +1290,12 @@ static int cfar_u8_dev(sfe_ctx *ctx, const uint8_t *d_img, int n_frames, int row
         if (int rc = launch_os_gated(ctx, d_img, n_frames, rows, cols, T, G, k, tau, intensity_thr, d_mask))
             return rc;
     } else if (os_hist) {
+        // no gate, or a low one: the pre-filtered candidate kernel (round 6) where it applies, else the sliding histogram
+        bool done = false;
+        if (!d_thr && aligned && (size_t)(OSG_TR + 2 * (T + G)) * OSG_TC <= 96 * 1024 && !getenv("SFE_CFAR_NO_OS_PREF"))
+            if (int rc = launch_os_gated(ctx, d_img, n_frames, rows, cols, T, G, k, tau, intensity_thr, d_mask, true, &done))
+                return rc;
+        if (!done)
         if (int rc = launch_os_hist(ctx, d_img, n_frames, rows, cols, T, G, k, tau, intensity_thr, d_mask, d_thr))
             return rc;
     } else {

@@ -117,6 +117,42 @@ def test_os_behind_a_gate_counts_candidates_only(shape, monkeypatch):
                           oracle.gate(img, oracle.cfar(img, "OS", 20, 5, 9.137608674642355, 10), 65))
 
 
+@pytest.mark.parametrize("shape", [(1024, 512), (300, 260), (131, 128), (64, 516), (52, 4)])
+def test_os_without_a_gate_is_pre_filtered_by_a_window_count(shape, monkeypatch):
+    """cfar.os() with NO gate (the drop-in's plain call) and with low gates goes through the pre-filtered candidate kernel
+    (round 6: a pixel is looked at when x >= x_hi, or when it can fire at all and its window holds k + 1 cells <= l0).  Same
+    masks as the oracle for sonar frames, uniform noise (every pixel a candidate of one kind or the other), dark frames with
+    bright pixels (every window passes the count), all-255 / all-0 frames, levels l0 from 0 up (SFE_CFAR_OS_PREF_X), k at
+    both ends, odd windows -- and the same as the sliding-histogram kernel (SFE_CFAR_NO_OS_PREF)."""
+    rows, cols = shape
+    rng = np.random.default_rng(rows * 11 + cols)
+    first = (synth.sonar_frame(seed=rows + cols + 1, rows=rows, cols=cols, n_blobs=12) if rows > 61 and cols > 11
+             else rng.integers(40, 256, (rows, cols)).astype(np.uint8))
+    dark = rng.integers(0, 6, (rows, cols)).astype(np.uint8)          # windows full of cells <= l0 ...
+    dark[rng.random((rows, cols)) < 0.03] = 200                       # ... around pixels that can fire
+    steps = np.repeat(np.arange(rows, dtype=np.uint8)[:, None], cols, axis=1)   # a ramp: the count changes every row
+    imgs = [first, rng.integers(0, 256, (rows, cols)).astype(np.uint8), dark, steps, np.full((rows, cols), 255, np.uint8),
+            np.zeros((rows, cols), np.uint8)]
+    for (th, gh, k, tau) in ((20, 5, 10, 9.137608674642355), (6, 2, 0, 1.3), (6, 2, 11, 0.9), (3, 0, 5, 2.0), (20, 5, 39, 40.0)):
+        for px in (None, "1", "255"):                                  # the level's pixel value: default 80, lowest, highest
+            if px is None:
+                monkeypatch.delenv("SFE_CFAR_OS_PREF_X", raising=False)
+            else:
+                monkeypatch.setenv("SFE_CFAR_OS_PREF_X", px)
+            for gate in (None, 0, 20):
+                for img in imgs:
+                    want = oracle.cfar(img, "OS", th, gh, tau, k)
+                    if gate is None:
+                        got = cfar.os(img, th, gh, k, tau)
+                    else:
+                        want = oracle.gate(img, want, gate)
+                        got = cfar.detect_gated(img, "OS", (th, gh, k, tau), gate)
+                    assert np.array_equal(got, want), (shape, th, gh, k, tau, px, gate)
+    monkeypatch.delenv("SFE_CFAR_OS_PREF_X", raising=False)
+    monkeypatch.setenv("SFE_CFAR_NO_OS_PREF", "1")      # A/B: the histogram kernel gives the same
+    assert np.array_equal(cfar.os(imgs[0], 20, 5, 10, 9.137608674642355), oracle.cfar(imgs[0], "OS", 20, 5, 9.137608674642355, 10))
+
+
 def test_fused_intensity_gate(shipped_cfar):
     img = synth.sonar_frame(seed=2)
     for alg in ALGS:

@@ -56,6 +56,25 @@ def main():
                 gb = (6.0 if want_thr else 2.0) * fb * a.frames / ms / 1e6
                 print("%-10s %-5s %-8s %9.3f %9.0f %6.1f%%" % (w, alg, "mask+thr" if want_thr else "mask", ms, gb, gb / 80.0),
                       flush=True)
+                if alg == "OS" and not want_thr:
+                    # cfar.os() of the drop-in has NO gate (and feature.yaml's threshold can be low): the pre-filtered candidate
+                    # kernel of round 6 against the sliding histogram of rounds 2-5 (SFE_CFAR_NO_OS_PREF=1), same launch
+                    for gate in (-1, 20):
+                        for pref in (True, False):
+                            if pref:
+                                os.environ.pop("SFE_CFAR_NO_OS_PREF", None)
+                            else:
+                                os.environ["SFE_CFAR_NO_OS_PREF"] = "1"
+
+                            def launch_g():
+                                ctx._check(ctx.lib.sfe_cfar_u8_batch_dev(ctx.handle, d_in.ptr, a.frames, rows, cols, _lib.ALG[alg], th, gh,
+                                                                         k, float(tau), gate, d_out.ptr, None))
+                            ms = timed(launch_g)
+                            gb = 2.0 * fb * a.frames / ms / 1e6
+                            print("%-10s %-5s %-8s %9.3f %9.0f %6.1f%%   %s" % (
+                                w, alg, "gate %d" % gate, ms, gb, gb / 80.0,
+                                "pre-filtered candidates (cfar_u8_os_gated<PREF>)" if pref else "sliding histogram (cfar_u8_os)"), flush=True)
+                    os.environ.pop("SFE_CFAR_NO_OS_PREF", None)
 
 
 if __name__ == "__main__":
