@@ -241,6 +241,7 @@ struct SweepShared {
     double acc[10];  // the reduced error-minimiser sums (read by the solving lane)
     unsigned hist[256], hist0[256];
     unsigned sel_prefix, sel_k;
+    unsigned sel_below, sel_n; // predicted quantile: exact values below the window / inside it (their bit patterns: hist[0 .. sel_n))
     unsigned n_none, n_exact; // census of the iteration, tallied where a query is settled
     int grid_skips;           // first iteration: queries that took a grid witness instead of searching in round 0
     unsigned n_rechit[2];     // queries settled by their clearance record, this iteration / the one before
@@ -268,6 +269,15 @@ struct SweepShared {
             S.prof[SW_PI(k)] += t_ - S.prof_t;                                                          \
             S.prof_t = t_;                                                                       \
         }                                                                                        \
+    } while (0)
+
+// PROF builds: clock stamps of ONE steady-state iteration (SW_STAMP_ITER) of workgroup 0 -> prof[85 ..]: where an iteration
+// that the clearance records settle spends its cycles (tools/stage_times.py prints the differences)
+#define SW_STAMP_ITER 25
+#define SW_STAMP(k)                                                                              \
+    do {                                                                                         \
+        if (PROF && threadIdx.x == 0 && blockIdx.x == 0 && it == SW_STAMP_ITER)                  \
+            prof[85 + (k)] = clock64();                                                          \
     } while (0)
 
 // debug watchdog: a loop that exceeds its bound records a code instead of hanging the device

@@ -329,6 +329,7 @@ int sfe_icp_sweep_launch(sfe_ctx *ctx, const sfe_icp_params *p, const float *d_s
                          (env_int("SFE_SW_GRID_DEFER", 1) ? 64 : 0) | // bit 6: first iteration: queries without a witness wait for round 1
                          (env_int("SFE_SW_UNBOUNDED_COOP", 1) ? 128 : 0) | // bit 7: later passes: unbounded queries -> cooperative tier
                          (env_int("SFE_SW_LEAN_TRIAGE", 1) ? (1 << 25) : 0) |  // bit 25: the triage pass as a loop of its own
+                         (env_int("SFE_SW_PREDICT_Q", 1) ? (1 << 26) : 0) |    // bit 26: steady state: the trimmed quantile looked for around the previous one
                          (env_int("SFE_SW_JUMP", 1) ? 2 : 0) |
                          // bits 16..23: margin (percent) of the next iteration's cap over this iteration's limit
                          (std::max(0, std::min(255, env_int("SFE_SW_MARGIN", SW_CAP_MARGIN))) << 16) |

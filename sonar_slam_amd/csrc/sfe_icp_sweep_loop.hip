@@ -357,6 +357,7 @@ __global__ __launch_bounds__(NT, MINW) __attribute__((amdgpu_waves_per_eu(MINW, 
     int rec_epoch = 0;
     const float rmax = sw_uniform(f_mul(__uint_as_float(S.rmax_bits), 1.00001f));
     int it = 0; // iteration index (the records carry it in 6 bits: they are used while it < ICP_MAX_HIST = 64)
+    float limit_prev = INFINITY; // the trimmed quantile of the previous iteration (the prediction of this one's, below)
     while (true) {
         SW_WATCH(wd_outer, P.max_iter + 2, 0)
         float Ti[9];
@@ -396,7 +397,11 @@ __global__ __launch_bounds__(NT, MINW) __attribute__((amdgpu_waves_per_eu(MINW, 
         //   records older than rec_epoch are ignored (searches of iterations without rec_on did not maintain them);
         //   triage: the fresh pass only tests the records, the misses are searched as dense waves by the second pass --
         //     when most queries of the previous iteration hit (a miss among 64 lanes makes the whole wave search).
+        SW_STAMP(0);
         bool rec_on = false, triage = false;
+        // predict: the trimmed quantile is looked for in a narrow window around the previous iteration's first (steady state:
+        // the limit moves by a fraction of a percent per iteration) -- see "C" below; decided with `triage`
+        bool predict = false;
         const int sw_umax = (sw_cache2 >> 8) & 0xFFFF;           // most points of a wave's union window
         const bool union_on = it < (sw_cache2 & 255) && sw_umax > 0; // iterations that use the union scan
         float mu2 = 0.0f; // additive part of the records' margin (squared): searched window = M2 * bound + mu2
@@ -514,8 +519,10 @@ __global__ __launch_bounds__(NT, MINW) __attribute__((amdgpu_waves_per_eu(MINW, 
             S.n_exact = 0;
             S.grid_skips = 0;
             S.n_rechit[it & 1] = 0u;
+            S.sel_below = 0u;
+            S.sel_n = 0u;
         }
-        auto tally_settled = [&](bool is_none, bool is_exact, float best) { // called wave-uniformly
+        auto tally_settled = [&](bool is_none, bool is_exact, float best, bool with_hist = true) { // called wave-uniformly
             const unsigned long long mn = __ballot(is_none), me = __ballot(is_exact);
             if (lane == 0) {
                 if (mn)
@@ -523,6 +530,8 @@ __global__ __launch_bounds__(NT, MINW) __attribute__((amdgpu_waves_per_eu(MINW, 
                 if (me)
                     atomicAdd(&S.n_exact, (unsigned)__popcll(me));
             }
+            if (!with_hist) // (a predicted quantile does not need the top-byte histogram: its fallback tallies all four passes)
+                return;
             // wave-aggregated: the exponent byte is the same for nearly every point
             const unsigned bin = is_exact ? (__float_as_uint(best) >> 24) : 0xFFFFFFFFu;
             unsigned long long todo = me;
@@ -552,6 +561,8 @@ __global__ __launch_bounds__(NT, MINW) __attribute__((amdgpu_waves_per_eu(MINW, 
                     S.wl_n[cur ^ 1] = 0;
                 }
                 __syncthreads();
+                if (round == 0)
+                    SW_STAMP(1);
                 if (round == 0 && sw_rec && use_cache && it < ICP_MAX_HIST) { // (it >= 1: mvb[it - 1] = the last step)
                     const float mv_last = sw_uniform(f_add(f_mul(S.mva[it - 1], rmax), S.mvt[it - 1]));
                     const float mu = f_mul(sw_kappa, mv_last);
@@ -560,6 +571,8 @@ __global__ __launch_bounds__(NT, MINW) __attribute__((amdgpu_waves_per_eu(MINW, 
                     // (the first iteration with records has no count yet: the margin was sized for them to hold)
                     triage = rec_on && rec_epoch < it && (rec_epoch == it - 1 || 2u * rechit_prev >= (unsigned)ns) &&
                              (sw_cache & 32) != 0;
+                    predict = triage && (sw_cache & (1 << 25)) != 0 && (sw_cache & (1 << 26)) != 0 && P.use_trimmed_filter &&
+                              limit_prev < INFINITY && limit_prev > 0.0f;
                 }
                 const bool rec_use = rec_on && rec_epoch < it;
                 const int *wl = Q.wl[cur];
@@ -1053,7 +1066,7 @@ __global__ __launch_bounds__(NT, MINW) __attribute__((amdgpu_waves_per_eu(MINW, 
                             Q.st[q].z = __float_as_int(INFINITY);
                             Q.rec[slot] = 0u;
                         }
-                        tally_settled(is_none, is_exact, best);
+                        tally_settled(is_none, is_exact, best, !predict);
                         const unsigned long long ms = __ballot(is_susp), ml = __ballot(is_long);
                         const unsigned long long below = (1ull << lane) - 1ull;
                         if (ms) {
@@ -1074,6 +1087,12 @@ __global__ __launch_bounds__(NT, MINW) __attribute__((amdgpu_waves_per_eu(MINW, 
                         }
                     }
                 };
+                // (measured and dropped in round 6: the few dozen misses of a steady-state triage pass straight to the cooperative
+                //  tier -- one wave per miss instead of one wave walking them all while fifteen wait: later passes -130 k cycles,
+                //  cooperative tier +150 k, the launch unchanged at 26.3-26.4 ms per 4096 jobs (profiles/r06_icp_coop_direct_ab.txt);
+                //  and the triage pass's three words per query requested two slices ahead instead of one: 37 k -> 45 k cycles
+                //  per steady-state iteration -- the pass is bound by instruction issue next to the other workgroup, not by
+                //  those loads)
                 if (round == 0) {
                     if (REC && triage && (sw_cache & (1 << 25)) != 0)
                         triage_pass();
@@ -1081,6 +1100,7 @@ __global__ __launch_bounds__(NT, MINW) __attribute__((amdgpu_waves_per_eu(MINW, 
                         walk_pass(wl, nwork, true, sw_budget_a, false);
                     __syncthreads();
                     SW_PROF(1);
+                    SW_STAMP(2);
                     if (PROF && tid == 0)
                         S.prof[SW_PI(11)] += S.mid_n;
                     walk_pass(Q.mid, S.mid_n, false, sw_budget, true);
@@ -1089,6 +1109,7 @@ __global__ __launch_bounds__(NT, MINW) __attribute__((amdgpu_waves_per_eu(MINW, 
                 }
                 __syncthreads();
                 SW_PROF(6);
+                SW_STAMP(3);
                 const int nlong = S.long_n;
                 if (PROF && tid == 0) {
                     S.prof[SW_PI(9)] += 1;
@@ -1263,6 +1284,7 @@ __global__ __launch_bounds__(NT, MINW) __attribute__((amdgpu_waves_per_eu(MINW, 
                 }
                 __syncthreads();
                 SW_PROF(7);
+                SW_STAMP(4);
                 if (PROF && tid == 0 && S.chk_n[2] == 0 && round < 8) { // first iteration, round by round
                     const long long t_ = clock64();
                     S.prof_it[24 + 4 * round] = nwork;
@@ -1325,6 +1347,7 @@ __global__ __launch_bounds__(NT, MINW) __attribute__((amdgpu_waves_per_eu(MINW, 
             }
         }
         SW_PROF(2);
+        SW_STAMP(5);
         if (PROF && tid == 0 && S.chk_n[2] < 32) {
             S.prof_it[2 * S.chk_n[2]] = clock64() - S.prof_b0;
             S.prof_it[2 * S.chk_n[2] + 1] = ((long long)__float_as_uint(C) << 32) | (nexact & 0xFFFFu) |
@@ -1339,6 +1362,70 @@ __global__ __launch_bounds__(NT, MINW) __attribute__((amdgpu_waves_per_eu(MINW, 
                 fail = true; // "no outlier to filter"
                 if (tid == 0)
                     S.flag_status = SFE_ICP_NO_OUTLIER;
+            } else if (!limit_inf && predict) {
+                // Steady state (round 6): the k-th smallest exact d2 is almost where it was one iteration ago.  ONE pass over the
+                // results counts the values below a window of +-2^17 ulps (0.8 .. 1.6 %) around the previous limit and collects
+                // those inside it (a few dozen of 4000); when the rank falls into the window -- it does, once the clouds have
+                // converged -- one wave picks the value out of the list by counting.  Exact: the window's values are all there
+                // and everything below is counted; any other outcome (rank outside, list full) takes the radix select, all four
+                // passes (the top-byte histogram was not tallied in this iteration).  15-17 k -> ~6 k cycles per iteration.
+                const unsigned pb = __float_as_uint(limit_prev);
+                const unsigned w_lo = pb > (1u << 17) ? pb - (1u << 17) : 0u, w_hi = pb + (1u << 17);
+                unsigned n_lo = 0; // (wave-uniform)
+                for (int base = 0; base < ns; base += NT) {
+                    const int i = base + tid;
+                    unsigned u = 0xFFFFFFFFu;
+                    if (i < ns && Pz(i) >= 0)
+                        u = __float_as_uint(Dz(i));
+                    n_lo += (unsigned)__popcll(__ballot(u < w_lo));
+                    const bool in = u >= w_lo && u <= w_hi;
+                    const unsigned long long mi = __ballot(in);
+                    if (mi) {
+                        unsigned b0 = 0;
+                        if (lane == 0)
+                            b0 = atomicAdd(&S.sel_n, (unsigned)__popcll(mi));
+                        b0 = (unsigned)__builtin_amdgcn_readfirstlane((int)b0);
+                        const unsigned at = b0 + (unsigned)__popcll(mi & ((1ull << lane) - 1ull));
+                        if (in && at < 256u)
+                            S.hist[at] = u;
+                    }
+                }
+                if (lane == 0 && n_lo)
+                    atomicAdd(&S.sel_below, n_lo);
+                __syncthreads();
+                const unsigned n_below = S.sel_below, n_win = S.sel_n;
+                const bool hit = n_win <= 256u && ksel >= n_below && ksel - n_below < n_win; // (workgroup-uniform)
+                if (hit) {
+                    if (tid < 64) {
+                        const unsigned r = ksel - n_below;
+                        unsigned e[4], less[4] = {0, 0, 0, 0}, leq[4] = {0, 0, 0, 0};
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            e[c] = (unsigned)(64 * c + lane) < n_win ? S.hist[64 * c + lane] : 0xFFFFFFFFu;
+                        const int nc = (int)((n_win + 63u) >> 6); // chunks of 64 list entries (<= 4)
+                        for (int c = 0; c < nc; ++c) {
+                            const unsigned v = c == 0 ? e[0] : c == 1 ? e[1] : c == 2 ? e[2] : e[3]; // chunk c, one entry per lane
+                            const int nj = min(64, (int)n_win - 64 * c);
+                            for (int j = 0; j < nj; ++j) {
+                                const unsigned x = (unsigned)__builtin_amdgcn_readlane((int)v, j);
+#pragma unroll
+                                for (int k2 = 0; k2 < 4; ++k2)
+                                    if (k2 < nc) { // (uniform)
+                                        less[k2] += x < e[k2];
+                                        leq[k2] += x <= e[k2];
+                                    }
+                            }
+                        }
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if ((unsigned)(64 * c + lane) < n_win && less[c] <= r && r < leq[c])
+                                S.sel_prefix = e[c]; // (every lane that passes holds the same value)
+                    }
+                    __syncthreads();
+                    limit = sw_uniform(__uint_as_float(S.sel_prefix));
+                } else {
+                    limit = select_kth(ksel, false, false);
+                }
             } else if (!limit_inf) {
                 limit = select_kth(ksel, false, true);
             }
@@ -1346,10 +1433,12 @@ __global__ __launch_bounds__(NT, MINW) __attribute__((amdgpu_waves_per_eu(MINW, 
         __syncthreads();
         if (fail)
             break;
+        limit_prev = limit;
         // the next iteration's cap: this limit plus a margin (the clouds keep moving a little: without it about
         // every fourth converged iteration finds one match too few inside the cap and has to search twice)
         Cnext = sw_uniform(P.use_trimmed_filter ? fminf(fmaxf(limit * sw_margin, Cinit * 0.0625f), Cmax) : Cmax);
         SW_PROF(3);
+        SW_STAMP(6);
 
 #if SW_SUMS_ONEPASS
         // ---- D: error minimiser sums over the kept pairs: ONE pass over the results, nine fp64 accumulators per lane.
@@ -1540,6 +1629,7 @@ __global__ __launch_bounds__(NT, MINW) __attribute__((amdgpu_waves_per_eu(MINW, 
         if (MULTI)
             xreduce_acc(); // the sums over the queries of every share
         SW_PROF(4);
+        SW_STAMP(7);
 
         // ---- E: solve, compose, check (one lane) ----
         if (tid == 0) {
@@ -1557,6 +1647,7 @@ __global__ __launch_bounds__(NT, MINW) __attribute__((amdgpu_waves_per_eu(MINW, 
         }
         __syncthreads();
         SW_PROF(5);
+        SW_STAMP(8);
         if (!S.flag_iterate)
             break;
         use_cache = (sw_cache & 1) != 0;

@@ -69,6 +69,11 @@ def main():
                          (cyc[80] + cyc[81] + cyc[82]) / max(1.0, cyc[84] * float(bench.N_PTS))))
                 print("   tier 2: %d trips over %d walks; wave 0 of workgroup 0: fetch %d, walk %d, finish %d cycles"
                       % (cyc[12], cyc[10], cyc[13], cyc[14], cyc[15]))
+                if it > 25 and cyc[93] > cyc[85] > 0:
+                    st = [int(cyc[85 + k]) for k in range(9)]
+                    names2 = ["bounds+reset", "fresh/triage pass", "second pass", "cooperative tier", "census+rounds", "quantile", "sums", "solve"]
+                    print("   iteration 25 of workgroup 0, cycles by phase: " + ", ".join("%s %d" % (n, b - a_) for n, a_, b in zip(names2, st[:-1], st[1:]))
+                          + " = %d" % (st[8] - st[0]))
                 if it <= 10:
                     print("   first iteration by round (queries, second pass, long, kcycles since start): " + " ".join(
                         "%d/%d/%d/%d" % (cyc[16 + 24 + 4 * r], cyc[16 + 25 + 4 * r], cyc[16 + 26 + 4 * r], cyc[16 + 27 + 4 * r] // 1000)
