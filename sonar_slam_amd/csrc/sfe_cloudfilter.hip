@@ -94,17 +94,26 @@ __device__ __forceinline__ unsigned long long cf_path_key(float2 p, const CfHead
 // CF_NEEDS_GLOBAL: the instantiation that sorts in HBM scratch, launched last, takes whatever is still marked.  The sort
 // is chosen per FRAME, not per batch: one dense ping among thousands no longer sends every frame of the batch to the slow path.
 #define CF_NEEDS_GLOBAL (-3)
+// frames that marked themselves CF_NEEDS_GLOBAL, for the HBM-scratch launch: a list + its length (the marking thread appends)
+__device__ __forceinline__ void cf_mark_global(CfHeader *hdrs, int f, int *marked, int *n_marked)
+{
+    hdrs[f].n_seg = CF_NEEDS_GLOBAL;
+    if (marked)
+        marked[atomicAdd(n_marked, 1)] = f;
+}
+
+// one frame (the whole workgroup); key_slot: which slice of the HBM key scratch this workgroup sorts in (!IN_LDS)
 template <bool IN_LDS, typename K>
-__global__ __launch_bounds__(1024) void cf_downsample_kernel(const float2 *__restrict__ p32, long long cap,
-                                                             CfHeader *__restrict__ hdrs, float2 *__restrict__ ds_out,
-                                                             int *__restrict__ seg_all, K *__restrict__ gkeys_all,
-                                                             long long n2cap, int only_marked,
-                                                             unsigned *__restrict__ leaf_keys_all)
+__device__ __forceinline__ void cf_downsample_frame(const int f, const int key_slot, const float2 *__restrict__ p32, long long cap,
+                                                    CfHeader *__restrict__ hdrs, float2 *__restrict__ ds_out,
+                                                    int *__restrict__ seg_all, K *__restrict__ gkeys_all, long long n2cap,
+                                                    int only_marked, unsigned *__restrict__ leaf_keys_all, int *marked,
+                                                    int *n_marked)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[]; // n2 sort keys (IN_LDS)
     __shared__ int s_scan[1024];
-    K *s_keys = IN_LDS ? reinterpret_cast<K *>(lds_raw) : gkeys_all + (size_t)blockIdx.x * n2cap;
-    const int f = blockIdx.x, tid = threadIdx.x;
+    K *s_keys = IN_LDS ? reinterpret_cast<K *>(lds_raw) : gkeys_all + (size_t)key_slot * n2cap;
+    const int tid = threadIdx.x;
     const CfHeader h = hdrs[f];
     if (only_marked && h.n_seg != CF_NEEDS_WIDE && h.n_seg != CF_NEEDS_GLOBAL)
         return;
@@ -114,8 +123,8 @@ __global__ __launch_bounds__(1024) void cf_downsample_kernel(const float2 *__res
     if (n == 0)
         return;
     if (IN_LDS && n2cap > 0 && n > n2cap) { // more points than this launch's LDS holds: left to the HBM-scratch instantiation
-        if (tid == 0)
-            hdrs[f].n_seg = CF_NEEDS_GLOBAL;
+        if (tid == 0 && h.n_seg != CF_NEEDS_GLOBAL)
+            cf_mark_global(hdrs, f, marked, n_marked);
         return;
     }
     constexpr int KEY_BITS = (int)sizeof(K) * 8 - 16;
@@ -205,6 +214,30 @@ __global__ __launch_bounds__(1024) void cf_downsample_kernel(const float2 *__res
     }
 }
 
+// frame_list == nullptr: one workgroup per frame (blockIdx.x).  Else the workgroups stride over the listed frames (the ones
+// that marked themselves for the HBM-scratch sort: rare -- a launch of one 1024-thread workgroup per frame that returns at
+// once cost 1.9 ms per 4096 frames, more than the whole filter stage; profiles/r06_final_bench_kernels.txt, first pass)
+template <bool IN_LDS, typename K>
+__global__ __launch_bounds__(1024) void cf_downsample_kernel(const float2 *__restrict__ p32, long long cap,
+                                                             CfHeader *__restrict__ hdrs, float2 *__restrict__ ds_out,
+                                                             int *__restrict__ seg_all, K *__restrict__ gkeys_all,
+                                                             long long n2cap, int only_marked,
+                                                             unsigned *__restrict__ leaf_keys_all, int *marked, int *n_marked,
+                                                             const int *__restrict__ frame_list)
+{
+    if (frame_list) {
+        const int nl = *n_marked;
+        for (int i = blockIdx.x; i < nl; i += gridDim.x) {
+            cf_downsample_frame<IN_LDS, K>(frame_list[i], blockIdx.x, p32, cap, hdrs, ds_out, seg_all, gkeys_all, n2cap, only_marked,
+                                           leaf_keys_all, nullptr, nullptr);
+            __syncthreads(); // (the next frame reuses the shared scan array and this workgroup's key slice)
+        }
+    } else {
+        cf_downsample_frame<IN_LDS, K>(blockIdx.x, blockIdx.x, p32, cap, hdrs, ds_out, seg_all, gkeys_all, n2cap, only_marked,
+                                       leaf_keys_all, marked, n_marked);
+    }
+}
+
 // exclusive prefix sum of one int per thread over the 1024-thread workgroup (wave scan by shuffles, then the 16 wave
 // totals by the first wave): two barriers instead of the twenty of a Hillis-Steele scan through LDS.  s_tmp: >= 17 ints.
 __device__ __forceinline__ int cf_block_excl_scan(int v, int *s_tmp, int *total)
@@ -266,7 +299,8 @@ __global__ __launch_bounds__(1024) void cf_downsample_radix_kernel(const float2 
                                                                    CfHeader *__restrict__ hdrs, float2 *__restrict__ ds_out,
                                                                    int *__restrict__ seg_all, int n2cap,
                                                                    unsigned *__restrict__ leaf_keys_all,
-                                                                   float2 *__restrict__ spts_all, int lds_bytes, int sort_cols)
+                                                                   float2 *__restrict__ spts_all, int lds_bytes, int sort_cols,
+                                                                   int *marked, int *n_marked)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[]; // ids[2][n2cap], key[n2cap], cnt[16][sort_cols]: u16
     __shared__ int s_scan[1024];
@@ -279,7 +313,7 @@ __global__ __launch_bounds__(1024) void cf_downsample_radix_kernel(const float2 
         return;
     if (n > n2cap) { // more points than the LDS of this launch holds: the HBM-scratch sort launched last takes the frame
         if (tid == 0)
-            hdrs[f].n_seg = CF_NEEDS_GLOBAL;
+            cf_mark_global(hdrs, f, marked, n_marked);
         return;
     }
     if (2 * h.levels > 16) { // deeper tree: the 64-bit bitonic instantiation launched behind takes the frame
@@ -718,6 +752,13 @@ int sfe_cf_run_staged(sfe_ctx *ctx, int n_frames, int64_t cap, float resolution,
             // 64-bit keys; a frame with more points (a capacity beyond CF_SORT_CAP allows them) marks itself and is sorted in HBM
             // scratch by the last launch.  (Rounds 2-5 chose by the batch's capacity: one dense ping sent all frames to HBM.)
             const size_t n2l = std::min<size_t>(n2, CF_SORT_CAP); // LDS slots of the first two launches
+            int *d_marked = nullptr; // capacities beyond the LDS sort: [n_frames] frames that want the HBM sort + [1] how many
+            if (cap > CF_SORT_CAP) {
+                d_marked = (int *)sfe_scratch(ctx, 52, sizeof(int) * ((size_t)n_frames + 1));
+                if (!d_marked)
+                    return SFE_ERR_HIP;
+                SFE_HIP(ctx, hipMemsetAsync(d_marked + n_frames, 0, sizeof(int), ctx->stream));
+            }
             {
                 // indices + keys + counters for the sort, then (same bytes) every point of the frame in sorted order.
                 // (The LDS is sized by the CAPACITY: 128 KB = one frame per CU at 16 384 points, 64 KB = two per CU at 8 192.
@@ -733,20 +774,22 @@ int sfe_cf_run_staged(sfe_ctx *ctx, int n_frames, int64_t cap, float resolution,
                 SFE_HIP(ctx, hipFuncSetAttribute((const void *)cf_downsample_radix_kernel,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)rdx_smem));
                 hipLaunchKernelGGL(cf_downsample_radix_kernel, dim3(n_frames), dim3(1024), rdx_smem, ctx->stream, d_p32,
-                                   (long long)cap, d_hdr, d_ds, d_seg, (int)n2l, d_lkeys, d_spts, (int)rdx_smem, sort_cols);
+                                   (long long)cap, d_hdr, d_ds, d_seg, (int)n2l, d_lkeys, d_spts, (int)rdx_smem, sort_cols, d_marked,
+                                   d_marked ? d_marked + n_frames : nullptr);
             }
             SFE_HIP(ctx, hipFuncSetAttribute((const void *)cf_downsample_kernel<true, unsigned long long>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(8 * n2l)));
             hipLaunchKernelGGL((cf_downsample_kernel<true, unsigned long long>), dim3(n_frames), dim3(1024), 8 * n2l,
                                ctx->stream, d_p32, (long long)cap, d_hdr, d_ds, d_seg, (unsigned long long *)nullptr, (long long)n2l, 1,
-                               (unsigned *)nullptr);
-            if (cap > CF_SORT_CAP) {
-                unsigned long long *d_gk = (unsigned long long *)sfe_scratch(ctx, 29, 8 * n2 * (size_t)n_frames);
+                               (unsigned *)nullptr, d_marked, d_marked ? d_marked + n_frames : nullptr, (const int *)nullptr);
+            if (cap > CF_SORT_CAP) { // the listed frames (> CF_SORT_CAP points): a few workgroups stride over the list
+                const int gw = std::min(n_frames, 256); // (one per CU: a batch whose frames ALL want this sort -- 2048 x 1024 pings -- keeps its parallelism)
+                unsigned long long *d_gk = (unsigned long long *)sfe_scratch(ctx, 29, 8 * n2 * (size_t)gw);
                 if (!d_gk)
                     return SFE_ERR_HIP;
-                hipLaunchKernelGGL((cf_downsample_kernel<false, unsigned long long>), dim3(n_frames), dim3(1024), 0,
+                hipLaunchKernelGGL((cf_downsample_kernel<false, unsigned long long>), dim3(gw), dim3(1024), 0,
                                    ctx->stream, d_p32, (long long)cap, d_hdr, d_ds, d_seg, d_gk, (long long)n2, 1,
-                                   (unsigned *)nullptr);
+                                   (unsigned *)nullptr, (int *)nullptr, d_marked + n_frames, (const int *)d_marked);
             }
         }
         stage = d_ds;

@@ -11,4 +11,4 @@ for it in 1 3 9 30; do
     echo "== max_iter $it, SFE_SW_WIDE=$wide"
     SFE_SW_WIDE=$wide timeout -s KILL 300 python tools/stage_times.py --batch 4096 --icp-variants 0 --p2plane-only --max-iter $it 2>&1 | grep "^icp" | cut -c1-200
   done
-done 2>&1 | tee gpurun_out/r6_phase_split_bound.txt
+done 2>&1 | tee gpurun_out/r06_phase_split_bound.txt

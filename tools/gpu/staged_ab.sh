@@ -9,4 +9,4 @@ for r in 1 2 3; do
     echo -n "staged=$v  "
     SONARFE_STAGED=$v timeout -s KILL 200 python tools/stage_times.py --batch 4096 --icp-variants 0 --p2plane-only 2>&1 | grep "^cfar\|^extract\|^filter" | tr '\n' ' '; echo
   done
-done 2>&1 | tee gpurun_out/r6_staged_ab.txt
+done 2>&1 | tee gpurun_out/r06_staged_ab.txt

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--icp-variants", default="0,4")  # 0 = sweep, 4 = brute force
     ap.add_argument("--p2plane-only", action="store_true", help="skip the shipped chain (counter passes)")
     ap.add_argument("--max-iter", type=int, default=30, help="iterations of the forced point-to-plane chain")
+    ap.add_argument("--max-points", type=int, default=32768, help="point capacity per frame (the bench's)")
     a = ap.parse_args()
     ctx = _lib.default_context()
     det = CFAR(40, 10, 0.1, 10)
@@ -40,7 +41,7 @@ def main():
                     ("reference", icp_config.shipped_params())):
         if a.p2plane_only and mode != "p2plane30":
             continue
-        kb = KeyframeBatch(ctx, fe.geometry, det.params["SOCA"], "SOCA", 65, p, a.batch)
+        kb = KeyframeBatch(ctx, fe.geometry, det.params["SOCA"], "SOCA", 65, p, a.batch, max_points=a.max_points)
         kb.upload_frames(frames)
         kb.upload_scan_pairs(srcs, tgts, guesses)
         if mode == "p2plane30":
