@@ -294,7 +294,13 @@ __device__ __forceinline__ int cf_block_excl_scan(int v, int *s_tmp, int *total)
 // pass, four passes of 4 bits for the 14 key bits of a sonar fan at 0.5 m.
 #define CF_RDX_BITS 4
 #define CF_RDX_DIGITS (1 << CF_RDX_BITS)
-#define CF_RDX_CHUNK 17 // elements per thread: (16384 / 1024) | 1
+// elements per sorting thread: CF_RDX_CHUNK = (16384 / 1024) | 1 for capacities up to CF_SORT_CAP; capacities beyond it take the
+// build with CF_RDX_CHUNK_BIG, whose LDS (152 of 160 KB) holds a ping of up to CF_LDS_PTS_BIG detections -- the dense pings of the
+// bench's synthetic frames (17 494 on rank 0, 19 122 on rank 3) sort in LDS instead of HBM scratch (0.87 ms per step there)
+#define CF_RDX_CHUNK 17
+#define CF_RDX_CHUNK_BIG 19
+#define CF_LDS_PTS_BIG (CF_RDX_CHUNK_BIG * 1024)
+template <int CHUNK>
 __global__ __launch_bounds__(1024) void cf_downsample_radix_kernel(const float2 *__restrict__ p32, long long cap,
                                                                    CfHeader *__restrict__ hdrs, float2 *__restrict__ ds_out,
                                                                    int *__restrict__ seg_all, int n2cap,
@@ -350,16 +356,16 @@ __global__ __launch_bounds__(1024) void cf_downsample_radix_kernel(const float2 
         const int shift = CF_RDX_BITS * pass;
         __syncthreads(); // idA complete (first pass: the identity and the keys; later: the previous scatter)
         // the chunk's indices and digits: independent LDS reads, in flight together
-        unsigned id[CF_RDX_CHUNK], dg[CF_RDX_CHUNK];
+        unsigned id[CHUNK], dg[CHUNK];
 #pragma unroll
-        for (int k = 0; k < CF_RDX_CHUNK; ++k)
+        for (int k = 0; k < CHUNK; ++k)
             id[k] = p0 + k < p1 ? idA[p0 + k] : 0u;
 #pragma unroll
-        for (int k = 0; k < CF_RDX_CHUNK; ++k)
+        for (int k = 0; k < CHUNK; ++k)
             dg[k] = p0 + k < p1 ? ((unsigned)skey[id[k]] >> shift) & (CF_RDX_DIGITS - 1) : 0u;
         // (the column's counters were zeroed behind the previous pass's scatter / before the first pass)
 #pragma unroll
-        for (int k = 0; k < CF_RDX_CHUNK; ++k) // count: the column is this thread's own, plain read-modify-write
+        for (int k = 0; k < CHUNK; ++k) // count: the column is this thread's own, plain read-modify-write
             if (p0 + k < p1)
                 cnt[slot(dg[k] * sort_cols + tid)] += 1;
         // (measured and dropped: the counts in registers -- two 64-bit words of eight 8-bit counters, the value before an
@@ -386,7 +392,7 @@ __global__ __launch_bounds__(1024) void cf_downsample_radix_kernel(const float2 
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < CF_RDX_CHUNK; ++k) // scatter in position order from the column's running offsets
+        for (int k = 0; k < CHUNK; ++k) // scatter in position order from the column's running offsets
             if (p0 + k < p1) {
                 const unsigned a = slot(dg[k] * sort_cols + tid);
                 const unsigned off = cnt[a];
@@ -442,16 +448,17 @@ __global__ __launch_bounds__(1024) void cf_downsample_radix_kernel(const float2 
             leaf_keys_all[(size_t)f * cap + sg] = (unsigned)skey[idA[s_seg[sg]]];
     }
     {
-        float2 v[16]; // n <= 16384
+        constexpr int NV = CHUNK == CF_RDX_CHUNK ? 16 : CHUNK; // n <= 16384, or <= CHUNK * 1024 in the build for larger capacities
+        float2 v[NV];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
+        for (int k = 0; k < NV; ++k) {
             const int r = tid + k * 1024;
             v[k] = r < n ? pts[idA[r]] : make_float2(0.0f, 0.0f);
         }
         __syncthreads(); // ids and keys have been read: their LDS is free
         float2 *dst = in_lds ? reinterpret_cast<float2 *>(lds_raw) : spts_g;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
+        for (int k = 0; k < NV; ++k) {
             const int r = tid + k * 1024;
             if (r < n)
                 dst[r] = v[k];
@@ -751,7 +758,8 @@ int sfe_cf_run_staged(sfe_ctx *ctx, int n_frames, int64_t cap, float resolution,
             // levels (every frame of a sonar fan at 0.5 m) by the radix sort of the indices, deeper ones by the bitonic sort with
             // 64-bit keys; a frame with more points (a capacity beyond CF_SORT_CAP allows them) marks itself and is sorted in HBM
             // scratch by the last launch.  (Rounds 2-5 chose by the batch's capacity: one dense ping sent all frames to HBM.)
-            const size_t n2l = std::min<size_t>(n2, CF_SORT_CAP); // LDS slots of the first two launches
+            const size_t n2l = std::min<size_t>(n2, CF_SORT_CAP); // LDS slots of the bitonic launch (a power of two)
+            const size_t n2r = cap <= CF_SORT_CAP ? n2 : (size_t)CF_LDS_PTS_BIG; // ... and of the radix launch
             int *d_marked = nullptr; // capacities beyond the LDS sort: [n_frames] frames that want the HBM sort + [1] how many
             if (cap > CF_SORT_CAP) {
                 d_marked = (int *)sfe_scratch(ctx, 52, sizeof(int) * ((size_t)n_frames + 1));
@@ -768,13 +776,16 @@ int sfe_cf_run_staged(sfe_ctx *ctx, int n_frames, int64_t cap, float resolution,
                 // whose pings are small passes a smaller capacity instead: chained.SessionBatch sizes it from its warm-up.)
                 // (digit counters: one column of 16 per sorting thread -- 1024 of them, 512 at capacities of <= 8192 points so
                 // that indices + keys + counters stay inside the 64 KB that let two frames share a CU)
-                const int sort_cols = n2l <= 8192 ? 512 : 1024;
+                const int sort_cols = n2r <= 8192 ? 512 : 1024;
                 const size_t n_cnt = CF_RDX_DIGITS * (size_t)sort_cols;
-                const size_t rdx_smem = std::max<size_t>(3 * 2 * n2l + 2 * (n_cnt + n_cnt / 16), sizeof(float2) * n2l);
-                SFE_HIP(ctx, hipFuncSetAttribute((const void *)cf_downsample_radix_kernel,
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)rdx_smem));
-                hipLaunchKernelGGL(cf_downsample_radix_kernel, dim3(n_frames), dim3(1024), rdx_smem, ctx->stream, d_p32,
-                                   (long long)cap, d_hdr, d_ds, d_seg, (int)n2l, d_lkeys, d_spts, (int)rdx_smem, sort_cols, d_marked,
+                const bool big = n2r > CF_SORT_CAP;
+                // (the sorted points take the same bytes when they fit, else their HBM scratch: the kernel looks at lds_bytes)
+                const size_t rdx_smem = big ? 3 * 2 * n2r + 2 * (n_cnt + n_cnt / 16)
+                                            : std::max<size_t>(3 * 2 * n2r + 2 * (n_cnt + n_cnt / 16), sizeof(float2) * n2r);
+                auto rk = big ? cf_downsample_radix_kernel<CF_RDX_CHUNK_BIG> : cf_downsample_radix_kernel<CF_RDX_CHUNK>;
+                SFE_HIP(ctx, hipFuncSetAttribute((const void *)rk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rdx_smem));
+                hipLaunchKernelGGL(rk, dim3(n_frames), dim3(1024), rdx_smem, ctx->stream, d_p32,
+                                   (long long)cap, d_hdr, d_ds, d_seg, (int)n2r, d_lkeys, d_spts, (int)rdx_smem, sort_cols, d_marked,
                                    d_marked ? d_marked + n_frames : nullptr);
             }
             SFE_HIP(ctx, hipFuncSetAttribute((const void *)cf_downsample_kernel<true, unsigned long long>,
