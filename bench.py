@@ -618,6 +618,10 @@ def main():
                                  "traffic_note": "bytes/launch from the committed PMC passes (profiles/extract_pmc.json: per-frame "
                                                  "FETCH_SIZE x 2 + WRITE_SIZE of the stage's kernels, scaled to this launch's frames)",
                                  "point_bytes": pt_bytes,
+                                 # (rounds 2-5 priced this stage on 16 B per point: the float64 pairs it wrote then.  Writing half the
+                                 #  bytes in about the same time LOWERS `frac`; the old pricing is kept next to it for comparison)
+                                 "frac_priced_with_float64_points": (float(args.batch) * ROWS * COLS / (8.0 if kb.bit_masks else 1.0) +
+                                                                     16.0 * float(res["counts"].sum())) / (ms_extract_b * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                  "note": "algorithmic bytes = the R*B detections (bits when CFAR hands over bit streams) + `point_bytes` per point per frame (16: float64 pairs; 8: the float32 pairs of the staged hand-over to the filters); the kernels are "
                                          "bound by gathers into the inverse remap table (10 MB of 4-byte entries, four candidates per 16-byte read), not "
                                          "by streaming"},
@@ -635,6 +639,9 @@ def main():
                 "frac": filters_bytes / (ms_filter_b * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": filters_bytes,
                 "ms_per_launch": ms_filter_b, "traffic": filters_traffic,
                 "bytes_note": "%d B per extracted point in + 8 B per filtered point out (SURVEY 8 f1 / pcl.cpp:128-141,54-74)" % (8 if kb.staged else 16),
+                # (as for the extraction: the stage reads half the bytes since round 6, which lowers `frac` at equal time)
+                "frac_priced_with_float64_points": (16.0 * float(res["counts"].sum()) + 8.0 * float(res["cloud_counts"].sum())) /
+                                                   (ms_filter_b * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "traffic_note": "bytes/launch from the committed PMC passes (profiles/filters_pmc.json), scaled to this launch's frames"}
         try:  # committed SQ counter pass of the ICP loop kernel (rocprofv3 cannot run inside the timed process)
             with open(os.path.join(ROOT, "profiles", "icp_sq.json")) as f:

@@ -271,14 +271,20 @@ struct SweepShared {
         }                                                                                        \
     } while (0)
 
-// PROF builds: clock stamps of ONE steady-state iteration (SW_STAMP_ITER) of workgroup 0 -> prof[85 ..]: where an iteration
-// that the clearance records settle spends its cycles (tools/stage_times.py prints the differences)
+// PROF builds compiled with -DSW_STAMPS: clock stamps of ONE steady-state iteration (SW_STAMP_ITER) of workgroup 0 -> prof[85 ..]:
+// where an iteration that the clearance records settle spends its cycles (tools/stage_times.py prints the differences).  Off by
+// default: the stamps change the profile build's register allocation (its sums phase reads 1.26 M cycles per job with them,
+// 0.76 M without: profiles/r06_icp_stamps_perturb_ab.txt), so the per-phase TOTALS are taken without them.
 #define SW_STAMP_ITER 25
+#ifndef SW_STAMPS
+#define SW_STAMP(k) do { } while (0)
+#else
 #define SW_STAMP(k)                                                                              \
     do {                                                                                         \
         if (PROF && threadIdx.x == 0 && blockIdx.x == 0 && it == SW_STAMP_ITER)                  \
             prof[85 + (k)] = clock64();                                                          \
     } while (0)
+#endif
 
 // debug watchdog: a loop that exceeds its bound records a code instead of hanging the device
 #define SW_WATCH(cnt, bound, code)                                                               \
