@@ -760,3 +760,22 @@ def test_two_real_farm_workers_on_one_device(ctx):
                 bad[1] = (np.zeros((0, 2), np.float32), pairs[1][1], [pairs[1][2]])      # job 1 -> worker 1
                 with pytest.raises(RuntimeError, match="empty source"):
                     f.run(bad)
+
+
+def test_eight_real_farm_workers_on_one_device(ctx):
+    """The farm at the target node's width with REAL HIP workers: eight worker processes, eight contexts
+    on this box's one GPU (devices=[0] * 8), fewer jobs than workers and more; results equal to single calls here."""
+    from sonar_slam_amd.farm import IcpFarm
+    p = icp_config.shipped_params()
+    pairs = [synth.scan_pair(seed=500 + i, n_src=260 + 31 * i, n_tgt=300 + 17 * i) for i in range(6)]
+    icp = _icp(p, ctx)
+    with IcpFarm(p, devices=[ctx.device] * 8, chunk=4) as f:
+        assert len(f._workers) == 8 and len(set(w.proc.pid for w in f._workers)) == 8
+        for n in (3, 19):
+            jobs = [(pairs[j % 6][0], pairs[j % 6][1], [pairs[j % 6][2]]) for j in range(n)]
+            out = f.run(jobs)
+            assert len(out) == n
+            for (s_, t_, gs), (m, Tf, itf) in zip(jobs, out):
+                mb, Tb, itb = icp.compute_batch(s_, t_, gs)
+                assert list(m) == list(mb) and np.array_equal(Tf, Tb) and np.array_equal(itf, itb)
+    assert f._workers == []
