@@ -3,9 +3,6 @@
 // definitions, the search's exactness argument and the overview: sfe_icp_sweep.h.
 #include "sfe_icp_sweep.h"
 
-#ifndef SW_SUMS_ONEPASS
-#define SW_SUMS_ONEPASS 1
-#endif
 
 // ties at the final best: lowest original index among the points at distance `best`, found by
 // searching the final window once more (rare)
@@ -1440,19 +1437,19 @@ __global__ __launch_bounds__(NT, MINW) __attribute__((amdgpu_waves_per_eu(MINW, 
         SW_PROF(3);
         SW_STAMP(6);
 
-#if SW_SUMS_ONEPASS
         // ---- D: error minimiser sums over the kept pairs: ONE pass over the results, nine fp64 accumulators per lane.
         // The tenth sum -- the number of kept pairs -- is an integer: counted per wave by ballot + popcount in an SGPR
         // (a sum of 1.0s is exact in any order, so the canonical fp64 total has these very bits).  Rounds 1-5 ran the
         // sums in two halves of five accumulators; each half gathered (source point, neighbour, normal) again -- ten
         // exposed memory round trips per iteration instead of five (profiles/r05_stage_times.txt: 34 k cycles).
+        // (The two-pass form left the source after the A/B of round 6: profiles/r06_icp_sums_ab.txt, 1.03 M -> 0.64 M cycles per job.)
         // The order of these sums is that of a 1024-thread workgroup whatever NT is: query i belongs to thread i mod 1024,
         // 64 consecutive threads are a wave (its fixed tree), the 16 wave totals are added left to right.  The smaller
         // builds play those waves one after the other.  (On a rank-deficient problem -- a target of three points -- the
         // sums are rounding noise that the solve amplifies without bound: only the same order gives the same result
         // as the other kernels; tools/icp_soak.py found such jobs at 6 in 100 000 before.)
         {
-            asm volatile("; SUMS_BEGIN");
+            asm volatile("; SUMS_BEGIN"); // (markers in the ISA, nothing else: tools/icp_isa.sh cuts the region between them)
             constexpr int NA = 9;
             // kept pair?  (called wave-uniformly; counts the kept pairs of the wave on the way)
             auto kept = [&](int i, bool in, int &id, unsigned &cnt) -> bool {
@@ -1537,95 +1534,6 @@ __global__ __launch_bounds__(NT, MINW) __attribute__((amdgpu_waves_per_eu(MINW, 
             __syncthreads();
             asm volatile("; SUMS_END");
         }
-#else
-        // ---- D: error minimiser sums over the kept pairs, in two halves of five accumulators: ten fp64
-        // accumulators per lane do not fit the 64-VGPR budget next to the loop state (they spilled) ----
-        // The order of these sums is that of a 1024-thread workgroup whatever NT is: query i belongs to thread i mod 1024,
-        // 64 consecutive threads are a wave (its fixed tree), the 16 wave totals are added left to right.  The smaller
-        // builds play those waves one after the other.  (On a rank-deficient problem -- a target of three points -- the
-        // sums are rounding noise that the solve amplifies without bound: only the same order gives the same result
-        // as the other kernels; tools/icp_soak.py found such jobs at 6 in 100 000 before.)
-        auto sums = [&](auto lo_tag) {
-            constexpr int LO = decltype(lo_tag)::value;
-            auto terms = [&](int i, double (&a5)[5]) {
-                const int id = Pz(i);
-                const float d = Dz(i);
-                const bool ok = id >= 0 && (!P.use_max_dist_filter || d <= r2_filter) &&
-                                (!P.use_trimmed_filter || d <= limit);
-                if (!ok)
-                    return;
-                const float2 p = xform(Ti, src[i]);
-                const double px = p.x, py = p.y;
-                const float2 q = T[id + 1];
-                const double qx = q.x, qy = q.y;
-                double t[10];
-                t[0] = 1.0;
-                if (P.minimizer == 0) {
-                    t[1] = px;
-                    t[2] = py;
-                    t[3] = qx;
-                    t[4] = qy;
-                    t[5] = qx * px;
-                    t[6] = qx * py;
-                    t[7] = qy * px;
-                    t[8] = qy * py;
-                    t[9] = 0.0;
-                } else {
-                    const float2 n = snrm[id];
-                    const double nx = n.x, ny = n.y;
-                    const double a0 = px * ny - py * nx;
-                    const double e = nx * (px - qx) + ny * (py - qy);
-                    t[1] = a0 * a0;
-                    t[2] = a0 * nx;
-                    t[3] = a0 * ny;
-                    t[4] = nx * nx;
-                    t[5] = nx * ny;
-                    t[6] = ny * ny;
-                    t[7] = -(a0 * e);
-                    t[8] = -(nx * e);
-                    t[9] = -(ny * e);
-                }
-#pragma unroll
-                for (int k = 0; k < 5; ++k)
-                    a5[k] += t[LO + k];
-            };
-            if constexpr (NT == 1024) {
-                double a5[5] = {0, 0, 0, 0, 0};
-                for (int i = tid; i < ns; i += NT)
-                    terms(i, a5);
-                block_sum<5, NT>(a5, S.red);
-                if (tid == 0) {
-#pragma unroll
-                    for (int k = 0; k < 5; ++k)
-                        S.acc[LO + k] = a5[k];
-                }
-            } else {
-                const int wave = tid >> 6;
-                const int roles = min(16, (ns + 63) >> 6); // (the waves beyond hold no query: their totals are 0.0)
-                for (int w0 = wave; w0 < roles; w0 += NT / 64) {
-                    double a5[5] = {0, 0, 0, 0, 0};
-                    for (int i = 64 * w0 + lane; i < ns; i += 1024)
-                        terms(i, a5);
-#pragma unroll
-                    for (int k = 0; k < 5; ++k) {
-                        const double sk = wave_sum(a5[k]);
-                        if (lane == 0)
-                            S.red[5 * w0 + k] = sk;
-                    }
-                }
-                __syncthreads();
-                if (tid < 5) {
-                    double sk = 0;
-                    for (int w = 0; w < roles; ++w)
-                        sk += S.red[5 * w + tid];
-                    S.acc[LO + tid] = sk;
-                }
-                __syncthreads();
-            }
-        };
-        sums(std::integral_constant<int, 0>());
-        sums(std::integral_constant<int, 5>());
-#endif
         if (MULTI)
             xreduce_acc(); // the sums over the queries of every share
         SW_PROF(4);
