@@ -574,30 +574,18 @@ __global__ __launch_bounds__(1024) void cf_radius_filter_kernel(const float2 *__
         for (int c = tid; c <= ncell; c += 1024)
             c_start[c] = (unsigned short)n; // "no leaf at or after this cell" until proven otherwise
         __syncthreads();
+        // the first leaf of a cell writes its index as the cell's start AND as the start of the empty cells between the
+        // previous occupied cell and its own ("the next occupied cell's start": starts grow with the cell index).  Round 6:
+        // one barrier instead of the 2 log2(ncell) of a suffix-minimum sweep over the cells (24 at the deepest level).
         for (int i = tid; i < n; i += 1024) {
             c_p[i] = pts[i];
             const unsigned c = keys[i] >> sh;
-            if (i == 0 || (keys[i - 1] >> sh) != c)
-                c_start[c] = (unsigned short)i; // first leaf of its cell (n <= 8192 fits 16 bits)
+            const unsigned cp = i == 0 ? 0xFFFFFFFFu : keys[i - 1] >> sh;
+            if (cp != c)
+                for (unsigned cc = cp + 1u; cc <= c; ++cc) // (cp + 1 wraps to 0 for the first leaf: the cells in front of it)
+                    c_start[cc] = (unsigned short)i;
         }
         __syncthreads();
-        // empty cells take the start of the next occupied one: suffix minimum (starts grow with the cell index)
-        for (int d = 1; d < ncell; d <<= 1) {
-            unsigned short v[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int c = tid + 1024 * k;
-                v[k] = (c < ncell) ? min(c_start[c], c_start[min(c + d, ncell)]) : (unsigned short)0;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int c = tid + 1024 * k;
-                if (c < ncell)
-                    c_start[c] = v[k];
-            }
-            __syncthreads();
-        }
     }
     int carry = 0; // kept points of the previous chunks of 1024
     for (int base = 0; base < n || base == 0; base += 1024) {
@@ -643,19 +631,11 @@ __global__ __launch_bounds__(1024) void cf_radius_filter_kernel(const float2 *__
             }
         }
         const int keep = (i < n) && (!do_filter || cnt > min_points);
-        __syncthreads();
-        s_scan[tid] = keep;
-        __syncthreads();
-        for (int d = 1; d < 1024; d <<= 1) {
-            const int v = (tid >= d) ? s_scan[tid - d] : 0;
-            __syncthreads();
-            s_scan[tid] += v;
-            __syncthreads();
-        }
+        int kept_here; // (wave scan + 16 wave totals: 3 barriers instead of the 20 of a Hillis-Steele scan through LDS: round 6)
+        const int at = cf_block_excl_scan(keep, s_scan, &kept_here);
         if (keep)
-            out[carry + s_scan[tid] - 1] = p;
-        carry += s_scan[1023];
-        __syncthreads();
+            out[carry + at] = p;
+        carry += kept_here;
         if (n == 0)
             break;
     }
